@@ -1,0 +1,119 @@
+"""ctypes binding of libavddpg_hip.so (C ABI: include/avddpg_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C avddpg_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libavddpg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avddpg_hip.h")
+AVD_MAX_L = 16
+
+
+class AvdError(RuntimeError):
+    pass
+
+
+class EnvConsts(C.Structure):
+    """avd_env_consts"""
+    _fields_ = [("L", C.c_int32), ("model_a", C.c_int32), ("can_terminate", C.c_int32), ("uniform_reset", C.c_int32),
+                ("max_ep", C.c_float), ("max_ev", C.c_float), ("abs_action_high", C.c_float),
+                ("two_max_a", C.c_float), ("T", C.c_float),
+                ("ca", C.c_float), ("cb", C.c_float), ("cc", C.c_float), ("cd", C.c_float),
+                ("re_scalar", C.c_float), ("terminal_reward", C.c_float),
+                ("stand_still", C.c_float), ("timegap", C.c_float),
+                ("reset_ep_max", C.c_float), ("reset_max_ev", C.c_float), ("reset_max_a", C.c_float),
+                ("reset_ep_eval", C.c_float), ("reset_ev_eval", C.c_float), ("reset_a_eval", C.c_float),
+                ("leader_reset_a", C.c_float),
+                ("A", (C.c_float * 16) * AVD_MAX_L), ("B", (C.c_float * 4) * AVD_MAX_L),
+                ("C", (C.c_float * 4) * AVD_MAX_L)]
+
+
+_LAYOUT_FIELDS = ["S", "A", "H1", "H2", "Ha", "B",
+                  "aW1", "ab1", "ag1", "abe1", "aW2", "ab2", "ag2", "abe2", "aW3", "ab3", "actor_size",
+                  "cWs", "cbs", "cgs", "cbes", "cWa", "cba", "cga", "cbea", "cW2", "cb2", "cg3", "cbe3", "cW3", "cb3",
+                  "theta_size",
+                  "amm1", "amv1", "amm2", "amv2", "cmms", "cmvs", "cmma", "cmva", "cmm3", "cmv3", "stats_size"]
+
+
+class MlpLayout(C.Structure):
+    """avd_mlp_layout"""
+    _fields_ = [(n, C.c_int32) for n in _LAYOUT_FIELDS]
+
+
+_P = C.c_void_p
+_i, _f, _d, _u64, _i64 = C.c_int, C.c_float, C.c_double, C.c_uint64, C.c_int64
+_LP = C.POINTER(MlpLayout)
+
+# name -> argtypes (every one of these returns int)
+_PROTOS = {
+    "avd_mlp_layout_init": [_LP, _i, _i, _i, _i, _i, _i],
+    "avd_env_step_f32": [_P, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "avd_env_reset_f32": [_P, _i, _i, _P, _P, _P, _P, _P, _i, _u64, _u64, _P, _P],
+    "avd_ou_step_f32": [_i, _P, _P, _f, _f, _f, _f, _u64, _u64, _P],
+    "avd_policy_f32": [_i, _P, _P, _f, _f, _P, _P],
+    "avd_normal_f32": [_i, _P, _f, _u64, _u64, _P],
+    "avd_replay_add_f32": [_i, _i, _i, _i, _P, _i64, _P, _P, _i, _P, _P, _P],
+    "avd_replay_indices": [_i, _i, _i, _u64, _u64, _P, _P],
+    "avd_replay_gather_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "avd_actor_forward_f32": [_LP, _i, _i, _P, _P, _P, _i, _f, _P, _P],
+    "avd_critic_forward_f32": [_LP, _i, _i, _P, _P, _P, _i, _P, _P, _P],
+    "avd_learn_f32": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P],
+    "avd_adam_polyak_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
+    "avd_polyak_f32": [_i64, _P, _P, _d, _P],
+    "avd_fed_sum_f32": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "avd_fed_finalize_f32": [_i, _i, _P, _f, _P, _P],
+    "avd_broadcast_sets_f32": [_i, _i, _i, _P, _P, _P],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises AvdError when it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AvdError(f"{LIB_PATH} not found: build the HIP extension first (__graft_entry__.build()); "
+                           "avddpg_amd has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.avd_last_error.restype = C.c_char_p
+        l.avd_last_error.argtypes = []
+        l.avd_version.restype = C.c_int
+        l.avd_version.argtypes = []
+        _lib = l
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise AvdError(f"{name} failed ({rc}): {lib().avd_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise AvdError("non-contiguous tensor passed to the C ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_layout(S, A, H1, H2, Ha, B):
+    lay = MlpLayout()
+    call("avd_mlp_layout_init", C.byref(lay), S, A, H1, H2, Ha, B)
+    return lay

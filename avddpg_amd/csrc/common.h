@@ -1,0 +1,82 @@
+// Shared helpers for the gfx950 hot-path kernels: error reporting, launch checks, Philox4x32-10.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/avddpg_hip.h"
+
+namespace avd {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return AVD_E_LAUNCH;
+    }
+    return AVD_OK;
+}
+
+#define AVD_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            avd::set_error(__VA_ARGS__); \
+            return AVD_E_INVALID;     \
+        }                             \
+    } while (0)
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: no state in HBM -------------------
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c.x;
+        uint64_t p1 = (uint64_t)M1 * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += W0;
+        k1 += W1;
+    }
+    return c;
+}
+
+// counter = (index, stream id, call counter lo, call counter hi); key = seed
+__device__ inline u32x4 philox_at(uint64_t seed, uint64_t counter, uint32_t index, uint32_t stream_id) {
+    u32x4 c = {index, stream_id, (uint32_t)counter, (uint32_t)(counter >> 32)};
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// Box-Muller on two 32-bit words: u1 in (0,1], u2 in [0,1). Returns n0 (cos branch); n1 via pointer.
+__device__ inline float box_muller(uint32_t a, uint32_t b, float* n1) {
+    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    if (n1) *n1 = rad * sinf(ang);
+    return rad * cosf(ang);
+}
+
+__device__ inline float uniform_pm1(uint32_t a) {  // U[-1, 1)
+    return (float)(a >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+enum PhiloxStream : uint32_t {
+    STREAM_RESET_A = 1,  // reset: words -> (x0, x1) normals
+    STREAM_RESET_B = 2,  // reset: x2 normal, front_accel
+    STREAM_OU = 3,
+    STREAM_NORMAL = 4,
+    STREAM_REPLAY = 5,
+};
+
+}  // namespace avd

@@ -1,0 +1,252 @@
+// Platoon environment kernels for gfx950: step (K1-K3), reset (K4), OU noise (K5), policy epilogue.
+//
+// HBM-bound byte work (48 B per vehicle-step + 5 B per platoon): one thread per vehicle, one
+// 16-byte load of x per lane, whole platoons per 256-thread block so the predecessor chain and
+// the per-platoon any-terminal / mean-reward reductions stay inside LDS.  All arithmetic is
+// written without FMA contraction in the reference's operation order so the float32 result is
+// bit-identical to the float32 oracle (oracle/platoon.py:batched_step).
+#include "common.h"
+
+namespace avd {
+
+constexpr int ENV_THREADS = 256;
+
+struct EnvLds {
+    float A[AVD_MAX_L][16];
+    float B[AVD_MAX_L][4];
+    float C[AVD_MAX_L][4];
+    float chain[ENV_THREADS];  // Model B: this step's action; Model A: post-step acceleration
+    float negr[ENV_THREADS];
+    int term[ENV_THREADS];
+};
+
+__global__ __launch_bounds__(ENV_THREADS) void env_step_kernel(const avd_env_consts* __restrict__ cst, int P, int L,
+                                                               const float4* __restrict__ x_in,
+                                                               float4* __restrict__ x_out, float* __restrict__ prev_a,
+                                                               float* __restrict__ cum_accel,
+                                                               const float* __restrict__ u,
+                                                               const float* __restrict__ leader_exog,
+                                                               float* __restrict__ reward, uint8_t* __restrict__ term,
+                                                               uint8_t* __restrict__ done,
+                                                               float* __restrict__ reward_mean,
+                                                               int32_t* __restrict__ any_done) {
+#pragma clang fp contract(off)
+    __shared__ EnvLds lds;
+    const int tid = threadIdx.x;
+    const int pb = ENV_THREADS / L;  // whole platoons per block
+    const int p0 = blockIdx.x * pb;
+    // stage the per-vehicle-index matrices once per block
+    for (int i = tid; i < L * 16; i += ENV_THREADS) lds.A[i >> 4][i & 15] = cst->A[i >> 4][i & 15];
+    for (int i = tid; i < L * 4; i += ENV_THREADS) {
+        lds.B[i >> 2][i & 3] = cst->B[i >> 2][i & 3];
+        lds.C[i >> 2][i & 3] = cst->C[i >> 2][i & 3];
+    }
+    const int lp = tid / L;
+    const int i = tid - lp * L;
+    const int p = p0 + lp;
+    const bool active = (lp < pb) && (p < P);
+    const long v = (long)p * L + i;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pa = 0.f, uu = 0.f;
+    if (active) {
+        xv = x_in[v];
+        pa = prev_a[v];
+        uu = u[v];
+    }
+    __syncthreads();
+    const float* Ai = lds.A[i];
+    const float* Bi = lds.B[i];
+    const float* Ci = lds.C[i];
+    // A.dot(x) row by row, left to right (environment.py:513)
+    float ax[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ax[r] = ((Ai[r * 4 + 0] * xv.x + Ai[r * 4 + 1] * xv.y) + Ai[r * 4 + 2] * xv.z) + Ai[r * 4 + 3] * xv.w;
+    const int model_a = cst->model_a;
+    // what the follower behind needs: Model B the action, Model A the post-step accel (C[2] == 0 by construction)
+    lds.chain[tid] = model_a ? (ax[2] + Bi[2] * uu) : uu;
+    __syncthreads();
+    float exog = 0.f;
+    if (active) exog = (i == 0) ? leader_exog[p] : lds.chain[tid - 1];
+    // reward from the PRE-update state (environment.py:473-476, 505-510)
+    const float norm_ep = fabsf(xv.x) / cst->max_ep;
+    const float norm_ev = fabsf(xv.y) / cst->max_ev;
+    const float norm_u = fabsf(uu) / cst->abs_action_high;
+    const float n_jerk = fabsf(xv.z - pa) / cst->two_max_a;
+    const bool is_term = ((fabsf(xv.x) > cst->max_ep) || (fabsf(xv.y) > cst->max_ev)) && (cst->can_terminate != 0);
+    float rew = (((cst->ca * norm_ep + cst->cb * norm_ev) + cst->cc * norm_u) + cst->cd * n_jerk) * cst->re_scalar;
+    if (is_term) rew = cst->terminal_reward * cst->re_scalar;
+    const float negr = -rew;
+    if (active) {
+        float4 xn;
+        xn.x = (ax[0] + Bi[0] * uu) + Ci[0] * exog;
+        xn.y = (ax[1] + Bi[1] * uu) + Ci[1] * exog;
+        xn.z = (ax[2] + Bi[2] * uu) + Ci[2] * exog;
+        xn.w = (ax[3] + Bi[3] * uu) + Ci[3] * exog;
+        x_out[v] = xn;      // state advances even when terminal (:512-513)
+        prev_a[v] = xv.z;   // prev_x <- x
+        if (cum_accel) cum_accel[v] = cum_accel[v] + xv.z;  // :500
+        reward[v] = negr;
+        if (term) term[v] = is_term ? 1 : 0;
+    }
+    lds.negr[tid] = negr;
+    lds.term[tid] = (active && is_term) ? 1 : 0;
+    __syncthreads();
+    if (active && i == 0) {
+        int any = 0;
+        float s = 0.f;
+        for (int k = 0; k < L; ++k) {
+            any |= lds.term[tid + k];
+            s = s + lds.negr[tid + k];
+        }
+        done[p] = (uint8_t)any;
+        if (reward_mean) reward_mean[p] = (1.0f / (float)L) * s;  // environment.py:281
+        if (any && any_done) atomicOr(any_done, 1);
+    }
+}
+
+__global__ __launch_bounds__(ENV_THREADS) void env_reset_kernel(const avd_env_consts* __restrict__ cst, int P, int L,
+                                                                float4* __restrict__ x, float* __restrict__ prev_a,
+                                                                float* __restrict__ cum_accel,
+                                                                const float* __restrict__ draws,
+                                                                const float* __restrict__ front_accel, int mode,
+                                                                uint64_t seed, uint64_t counter,
+                                                                const int32_t* __restrict__ cond) {
+#pragma clang fp contract(off)
+    __shared__ float x2s[ENV_THREADS];
+    if (cond && *cond == 0) return;  // uniform across the grid
+    const int tid = threadIdx.x;
+    const int pb = ENV_THREADS / L;
+    const int lp = tid / L;
+    const int i = tid - lp * L;
+    const int p = blockIdx.x * pb + lp;
+    const bool active = (lp < pb) && (p < P);
+    const long v = (long)p * L + i;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, fa = 0.f;
+    if (active) {
+        if (mode == 1) {  // evaluator constants (environment.py:534-539)
+            d0 = cst->reset_ep_eval, d1 = cst->reset_ev_eval, d2 = cst->reset_a_eval;
+        } else if (mode == 2) {  // rand_states=False (:552-555)
+            d0 = cst->reset_ep_max, d1 = cst->reset_max_ev, d2 = cst->reset_max_a;
+        } else if (draws) {  // host-RNG parity mode
+            d0 = draws[v * 3 + 0], d1 = draws[v * 3 + 1], d2 = draws[v * 3 + 2];
+        } else {  // device Philox (:547-549; util.py:67-70)
+            const u32x4 ra = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_A);
+            const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
+            if (cst->uniform_reset) {
+                d0 = uniform_pm1(ra.x) * cst->reset_ep_max;
+                d1 = uniform_pm1(ra.y) * cst->reset_max_ev;
+                d2 = uniform_pm1(rb.x) * cst->reset_max_a;
+            } else {
+                float n1;
+                const float n0 = box_muller(ra.x, ra.y, &n1);
+                d0 = n0 * cst->reset_ep_max;
+                d1 = n1 * cst->reset_max_ev;
+                d2 = box_muller(rb.x, rb.y, nullptr) * cst->reset_max_a;
+            }
+        }
+        if (i == 0) {
+            if (front_accel) {
+                fa = front_accel[p];
+            } else {
+                const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
+                fa = (cst->uniform_reset ? uniform_pm1(rb.z) : box_muller(rb.z, rb.w, nullptr)) * cst->leader_reset_a;
+            }
+        }
+    }
+    x2s[tid] = d2;
+    __syncthreads();
+    if (active) {
+        const float a_lead = (i == 0) ? fa : x2s[tid - 1];  // chain: predecessor's fresh x[2] (:291-294)
+        x[v] = make_float4(d0, d1, d2, a_lead);
+        prev_a[v] = d2;  // prev_x = x (:557)
+        if (cum_accel) cum_accel[v] = 0.f;
+    }
+}
+
+__global__ void ou_step_kernel(int n, float* __restrict__ st, const float* __restrict__ normals, float theta,
+                               float mean, float dt, float scale, uint64_t seed, uint64_t counter) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float nrm;
+    if (normals) {
+        nrm = normals[i];
+    } else {
+        const u32x4 r = philox_at(seed, counter, (uint32_t)i, STREAM_OU);
+        nrm = box_muller(r.x, r.y, nullptr);
+    }
+    const float x = st[i];
+    st[i] = (x + (theta * (mean - x)) * dt) + scale * nrm;  // noise.py:15-19
+}
+
+__global__ void policy_kernel(int n, const float* __restrict__ actor_out, const float* __restrict__ noise, float lo,
+                              float hi, float* __restrict__ action) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = actor_out[i];
+    if (noise) a = a + noise[i];
+    action[i] = fminf(fmaxf(a, lo), hi);  // np.clip (ddpgagent.py:27)
+}
+
+__global__ void normal_kernel(int n, float* __restrict__ out, float std_dev, uint64_t seed, uint64_t counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 r = philox_at(seed, counter, (uint32_t)i, STREAM_NORMAL);
+    out[i] = box_muller(r.x, r.y, nullptr) * std_dev;
+}
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_env_step_f32(const avd_env_consts* d_consts, int P, int L, const float* x_in, float* x_out,
+                                float* prev_a, float* cum_accel, const float* u, const float* leader_exog,
+                                float* reward, uint8_t* term, uint8_t* done, float* reward_mean, int32_t* any_done,
+                                void* stream) {
+    AVD_REQUIRE(P > 0 && L > 0 && L <= AVD_MAX_L, "avd_env_step_f32: P=%d L=%d (L must be 1..%d)", P, L, AVD_MAX_L);
+    AVD_REQUIRE(d_consts && x_in && x_out && prev_a && u && leader_exog && reward && done,
+                "avd_env_step_f32: null pointer");
+    const int pb = ENV_THREADS / L;
+    const int grid = (P + pb - 1) / pb;
+    hipLaunchKernelGGL(env_step_kernel, dim3(grid), dim3(ENV_THREADS), 0, (hipStream_t)stream, d_consts, P, L,
+                       (const float4*)x_in, (float4*)x_out, prev_a, cum_accel, u, leader_exog, reward, term, done,
+                       reward_mean, any_done);
+    return check_launch("avd_env_step_f32");
+}
+
+extern "C" int avd_env_reset_f32(const avd_env_consts* d_consts, int P, int L, float* x, float* prev_a,
+                                 float* cum_accel, const float* draws, const float* front_accel, int mode,
+                                 uint64_t seed, uint64_t counter, const int32_t* cond, void* stream) {
+    AVD_REQUIRE(P > 0 && L > 0 && L <= AVD_MAX_L, "avd_env_reset_f32: P=%d L=%d", P, L);
+    AVD_REQUIRE(d_consts && x && prev_a, "avd_env_reset_f32: null pointer");
+    AVD_REQUIRE(mode >= 0 && mode <= 2, "avd_env_reset_f32: mode %d", mode);
+    const int pb = ENV_THREADS / L;
+    const int grid = (P + pb - 1) / pb;
+    hipLaunchKernelGGL(env_reset_kernel, dim3(grid), dim3(ENV_THREADS), 0, (hipStream_t)stream, d_consts, P, L,
+                       (float4*)x, prev_a, cum_accel, draws, front_accel, mode, seed, counter, cond);
+    return check_launch("avd_env_reset_f32");
+}
+
+extern "C" int avd_ou_step_f32(int n, float* ou_state, const float* normals, float theta, float mean, float dt,
+                               float std_dev, uint64_t seed, uint64_t counter, void* stream) {
+    AVD_REQUIRE(n > 0 && ou_state, "avd_ou_step_f32: n=%d", n);
+    const float scale = std_dev * (float)sqrt((double)dt);  // float32(std_dev) * float32(sqrt(dt)), as the f32 oracle
+    hipLaunchKernelGGL(ou_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, ou_state, normals,
+                       theta, mean, dt, scale, seed, counter);
+    return check_launch("avd_ou_step_f32");
+}
+
+extern "C" int avd_policy_f32(int n, const float* actor_out, const float* noise, float lo, float hi, float* action,
+                              void* stream) {
+    AVD_REQUIRE(n > 0 && actor_out && action, "avd_policy_f32: n=%d", n);
+    hipLaunchKernelGGL(policy_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, actor_out, noise,
+                       lo, hi, action);
+    return check_launch("avd_policy_f32");
+}
+
+extern "C" int avd_normal_f32(int n, float* out, float std_dev, uint64_t seed, uint64_t counter, void* stream) {
+    AVD_REQUIRE(n > 0 && out, "avd_normal_f32: n=%d", n);
+    hipLaunchKernelGGL(normal_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, out, std_dev, seed,
+                       counter);
+    return check_launch("avd_normal_f32");
+}

@@ -1,0 +1,698 @@
+// Actor/critic MLP kernels for gfx950.
+//
+//  * mlp_rows_kernel  -- batch-1 actor / critic forward per agent (GEMV; weights streamed once).
+//  * learn_kernel     -- Trainer.learn (workers/trainer.py:472-508) for one agent's batch of 64 rows
+//                        per 256-thread workgroup: 5 forwards + 2 backwards fused, activations
+//                        resident in LDS (~150 KB, one workgroup per CU), the [64xK]x[KxN] products
+//                        on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), weights streamed
+//                        from HBM/L2 straight into MFMA B operands, gradients written once.
+//
+// BatchNormalization is always the inference form y = p*inv + (beta - mean*inv),
+// inv = rsqrt(var + 1e-3)*gamma (reference models are never called with training=True).  LDS holds
+// the post-ReLU value p; the affine is applied when p is fetched as an MFMA operand, and folded into
+// the weight-gradient epilogue (dW = inv*(p^T dz) + shift*(1^T dz)).
+#include "common.h"
+
+namespace avd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = 64;       // batch rows per workgroup (= batch_size 64, config.py:106)
+constexpr int NTHREADS = 256;  // 4 waves, one per SIMD
+constexpr float BN_EPS = 1e-3f;
+
+__host__ __device__ inline int ld_of(int k) { return k + 2; }  // (ld/2) odd -> conflict-free 16-row x 2-col b32 reads
+
+struct Net {  // pointers into one weight set
+    const float* th;
+    const float* st;
+};
+
+// ------------------------------------------------------------------------------------------
+// small building blocks (called by all 256 threads of the workgroup)
+// ------------------------------------------------------------------------------------------
+
+// inv/shift of a BN layer into LDS
+__device__ __forceinline__ void bn_coefs(const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv, int n,
+                                         float* inv, float* sh) {
+    for (int k = threadIdx.x; k < n; k += NTHREADS) {
+        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+        inv[k] = iv;
+        sh[k] = be[k] - mm[k] * iv;
+    }
+}
+
+// out[r][col0+k] = relu(sum_j X[r*xs + j] * W[j*H + k] + b[k]),  r < 64, k < H, tiny K (S or A)
+__device__ __forceinline__ void dense_in_relu(const float* X, int xs, int K, const float* __restrict__ W,
+                                              const float* __restrict__ b, int H, float* out, int ld, int col0) {
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (j < K) ? W[j * H + k] : 0.f;
+        const float bk = b[k];
+        for (int r = 0; r < TILE; ++r) {
+            float acc = bk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < K) acc = fmaf(X[r * xs + j], w[j], acc);
+            out[r * ld + col0 + k] = fmaxf(acc, 0.f);
+        }
+    }
+}
+
+// out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), 4 lanes per row
+__device__ __forceinline__ float out_layer_row(const float* P, int ld, const float* inv, const float* sh,
+                                               const float* __restrict__ w, float b, int K) {
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float acc = 0.f;
+    for (int k = part; k < K; k += 4) acc = fmaf(fmaf(P[r * ld + k], inv[k], sh[k]), w[k], acc);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    return acc + b;  // valid in all 4 lanes of row r
+}
+
+template <int MT, int NT, typename FA, typename FB>
+__device__ __forceinline__ void mfma_tiles(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB fb) {
+#pragma unroll 2
+    for (int ks = 0; ks < ksteps; ++ks) {
+        float a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = fa(m, ks);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = fb(n, ks);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+// Forward hidden layer: out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]); X,out in LDS, W global [K][N].
+__device__ __forceinline__ void gemm_fwd_relu(const float* X, int ldx, const float* inv, const float* sh, int K,
+                                              const float* __restrict__ W, const float* __restrict__ b, int N,
+                                              float* out, int ldo) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool two = (n0 + 16) < N;  // N multiple of 16; second 16-col tile may be absent
+        mfma_tiles<4, 2>(
+            acc, K / 4,
+            [&](int m, int ks) {
+                const int k = ks * 4 + lg;
+                return fmaf(X[(m * 16 + lr) * ldx + k], inv[k], sh[k]);
+            },
+            [&](int n, int ks) {
+                const int col = n0 + n * 16 + lr;
+                return (n == 0 || two) ? W[(ks * 4 + lg) * N + col] : 0.f;
+            });
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (n == 1 && !two) break;
+            const int col = n0 + n * 16 + lr;
+            const float bc = b[col];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[(m * 16 + lg * 4 + j) * ldo + col] = fmaxf(acc[m][n][j] + bc, 0.f);
+        }
+    }
+}
+
+// Weight gradient of a hidden layer fed by a BN output:
+//   dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n]   for k < K, n < N  -> global gW[k*N + n]
+__device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* inv, const float* sh, int K,
+                                        const float* DZ, int ldz, const float* db, int N, float* __restrict__ gW) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
+        const bool two = (n0 + 16) < N;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int mt = min(4, (K - k0) / 16);
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mfma_tiles<4, 2>(
+                acc, TILE / 4,
+                [&](int m, int ks) { return (m < mt) ? P[(ks * 4 + lg) * ldp + k0 + m * 16 + lr] : 0.f; },
+                [&](int n, int ks) { return (n == 0 || two) ? DZ[(ks * 4 + lg) * ldz + n0 + n * 16 + lr] : 0.f; });
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (n == 1 && !two) break;
+                const int col = n0 + n * 16 + lr;
+                const float dbc = db[col];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (m >= mt) break;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + m * 16 + lg * 4 + j;
+                        gW[k * N + col] = fmaf(inv[k], acc[m][n][j], sh[k] * dbc);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Input gradient of a hidden layer + BN/ReLU backward of the layer below, in place:
+//   dy[r][c] = sum_n DZ[r][n] * W[c][n]               (c in [c_begin, c_end), W global [K][N])
+//   dgamma[c] = sum_r dy*(p - mm[c])*rs[c];  dbeta[c] = sum_r dy;  P[r][c] <- dy * rs*g * (p > 0)
+// g/mm/mv/dg/dbe are indexed by (c - c_begin).  dg == nullptr skips the parameter gradients.
+__device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, const float* __restrict__ W, int c_begin,
+                                           int c_end, float* P, int ldp, const float* __restrict__ g,
+                                           const float* __restrict__ mm, const float* __restrict__ mv,
+                                           float* __restrict__ dg, float* __restrict__ dbe) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    for (int c0 = c_begin + wave * 16; c0 < c_end; c0 += 4 * 16) {
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wrow = W + (long)(c0 + lr) * N;
+        mfma_tiles<4, 1>(
+            acc, N / 4, [&](int m, int ks) { return DZ[(m * 16 + lr) * ldz + ks * 4 + lg]; },
+            [&](int, int ks) { return wrow[ks * 4 + lg]; });
+        const int c = c0 + lr;
+        const float rs = 1.0f / sqrtf(mv[c - c_begin] + BN_EPS);
+        const float gam = g[c - c_begin];
+        const float mean = mm[c - c_begin];
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = m * 16 + lg * 4 + j;
+                const float dy = acc[m][0][j];
+                const float p = P[r * ldp + c];
+                sg = fmaf(dy * (p - mean), rs, sg);
+                sb += dy;
+                P[r * ldp + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+            }
+        sg += __shfl_xor(sg, 16);
+        sg += __shfl_xor(sg, 32);
+        sb += __shfl_xor(sb, 16);
+        sb += __shfl_xor(sb, 32);
+        if (dg && lg == 0) {
+            dg[c - c_begin] = sg;
+            dbe[c - c_begin] = sb;
+        }
+    }
+}
+
+// Column sums db[n] = sum_r DZ[r][n] -> LDS db[] and global gdb[]
+__device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float* db, float* __restrict__ gdb) {
+    for (int n = threadIdx.x; n < N; n += NTHREADS) {
+        float s = 0.f;
+        for (int r = 0; r < TILE; ++r) s += DZ[r * ldz + n];
+        db[n] = s;
+        if (gdb) gdb[n] = s;
+    }
+}
+
+// First-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*xs+j]*dz[r][k], db[k] = sum_r dz[r][k]
+__device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, const float* DZ, int ldz, int c0, int H,
+                                               float* __restrict__ gW, float* __restrict__ gb) {
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        float sb = 0.f;
+        for (int r = 0; r < TILE; ++r) {
+            const float d = DZ[r * ldz + c0 + k];
+            sb += d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < K) acc[j] = fmaf(X[r * xs + j], d, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < K) gW[j * H + k] = acc[j];
+        gb[k] = sb;
+    }
+}
+
+// Output layer (width 1) backward through the BN below it, for column k < K (thread per k):
+//   dW3[k] = sum_r bn(p[r][k])*d[r]; dy = d[r]*w3[k]; dgamma, dbeta; DZ[r][k] = dy*inv*(p>0)
+__device__ __forceinline__ void out_layer_backward(const float* P, int ldp, const float* inv, const float* sh,
+                                                   const float* d, const float* __restrict__ w3,
+                                                   const float* __restrict__ g, const float* __restrict__ mm,
+                                                   const float* __restrict__ mv, int K, float* DZ, int ldz,
+                                                   float* __restrict__ gW3, float* __restrict__ gg,
+                                                   float* __restrict__ gbe) {
+    for (int k = threadIdx.x; k < K; k += NTHREADS) {
+        const float wk = w3[k], iv = inv[k], s = sh[k];
+        const float rs = 1.0f / sqrtf(mv[k] + BN_EPS), mean = mm[k];
+        float dw = 0.f, dgm = 0.f, dbt = 0.f;
+        for (int r = 0; r < TILE; ++r) {
+            const float p = P[r * ldp + k];
+            const float dr = d[r];
+            dw = fmaf(fmaf(p, iv, s), dr, dw);
+            const float dy = dr * wk;
+            dgm = fmaf(dy * (p - mean), rs, dgm);
+            dbt += dy;
+            DZ[r * ldz + k] = (p > 0.f) ? dy * iv : 0.f;
+        }
+        if (gW3) {
+            gW3[k] = dw;
+            gg[k] = dgm;
+            gbe[k] = dbt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused learn kernel: one agent (64-row batch) per workgroup
+// ------------------------------------------------------------------------------------------
+struct LearnLds {
+    float *bufA, *bufB, *bufC;  // [64][ldA], [64][ldB], [64][ldB]
+    float *invA, *shA;          // H1+Ha
+    float *invB, *shB;          // H2
+    float *db;                  // H2
+    float *sS, *sS2;            // [64][S]
+    float *sAct, *sR, *sY, *sQ, *sD, *sA1, *sT, *sDa;  // [64] each
+    float* red;                                         // [8]
+};
+
+__host__ __device__ inline size_t learn_lds_floats(const avd_mlp_layout& L) {
+    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
+    return (size_t)TILE * ldA + 2 * (size_t)TILE * ldB + 2 * (L.H1 + L.Ha) + 3 * L.H2 + 2 * TILE * L.S + 8 * TILE + 8;
+}
+
+__device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) {
+    LearnLds l;
+    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
+    float* p = smem;
+    l.bufA = p, p += TILE * ldA;
+    l.bufB = p, p += TILE * ldB;
+    l.bufC = p, p += TILE * ldB;
+    l.invA = p, p += L.H1 + L.Ha;
+    l.shA = p, p += L.H1 + L.Ha;
+    l.invB = p, p += L.H2;
+    l.shB = p, p += L.H2;
+    l.db = p, p += L.H2;
+    l.sS = p, p += TILE * L.S;
+    l.sS2 = p, p += TILE * L.S;
+    l.sAct = p, p += TILE;
+    l.sR = p, p += TILE;
+    l.sY = p, p += TILE;
+    l.sQ = p, p += TILE;
+    l.sD = p, p += TILE;
+    l.sA1 = p, p += TILE;
+    l.sT = p, p += TILE;
+    l.sDa = p, p += TILE;
+    l.red = p;
+    return l;
+}
+
+// actor forward over the 64 rows in X (LDS [64][S]); leaves p1 in bufA, p2 in bufB, coefs in invA/shA, invB/shB;
+// writes tanh to sT and action (tanh*high) to out.
+__device__ __forceinline__ void actor_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, float high,
+                                               LearnLds& l, float* out) {
+    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
+    const float* th = net.th;
+    dense_in_relu(X, L.S, L.S, th + L.aW1, th + L.ab1, L.H1, l.bufA, ldA, 0);
+    bn_coefs(th + L.ag1, th + L.abe1, net.st + L.amm1, net.st + L.amv1, L.H1, l.invA, l.shA);
+    bn_coefs(th + L.ag2, th + L.abe2, net.st + L.amm2, net.st + L.amv2, L.H2, l.invB, l.shB);
+    __syncthreads();
+    gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1, th + L.aW2, th + L.ab2, L.H2, l.bufB, ldB);
+    __syncthreads();
+    const float z = out_layer_row(l.bufB, ldB, l.invB, l.shB, th + L.aW3, th[L.ab3], L.H2);
+    if ((threadIdx.x & 3) == 0) {
+        const float t = tanhf(z);
+        l.sT[threadIdx.x >> 2] = t;
+        out[threadIdx.x >> 2] = t * high;
+    }
+    __syncthreads();
+}
+
+// critic forward over 64 rows: state X (LDS [64][S]), action act (LDS [64]); leaves concat p (state|action) in bufA,
+// p of layer 2 in bufB, coefs in invA/shA (H1+Ha) and invB/shB; q -> out[64].
+__device__ __forceinline__ void critic_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, const float* act,
+                                                LearnLds& l, float* out) {
+    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
+    const float* th = net.th + L.actor_size;
+    const float* st = net.st;
+    dense_in_relu(X, L.S, L.S, th + L.cWs, th + L.cbs, L.H1, l.bufA, ldA, 0);
+    dense_in_relu(act, 1, 1, th + L.cWa, th + L.cba, L.Ha, l.bufA, ldA, L.H1);
+    bn_coefs(th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, L.H1, l.invA, l.shA);
+    bn_coefs(th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, L.Ha, l.invA + L.H1, l.shA + L.H1);
+    bn_coefs(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, L.H2, l.invB, l.shB);
+    __syncthreads();
+    gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, th + L.cW2, th + L.cb2, L.H2, l.bufB, ldB);
+    __syncthreads();
+    const float q = out_layer_row(l.bufB, ldB, l.invB, l.shB, th + L.cW3, th[L.cb3], L.H2);
+    if ((threadIdx.x & 3) == 0) out[threadIdx.x >> 2] = q;
+    __syncthreads();
+}
+
+__device__ __forceinline__ float block_sum64(const float* v, float* red) {
+    // sum of 64 LDS values by wave 0; result broadcast through red[0]
+    if (threadIdx.x < 64) {
+        float s = v[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (threadIdx.x == 0) red[0] = s;
+    }
+    __syncthreads();
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int set_mod,
+                                                          const float* __restrict__ theta,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ theta_t,
+                                                          const float* __restrict__ stats_t,
+                                                          const float* __restrict__ s, const float* __restrict__ a,
+                                                          const float* __restrict__ r, const float* __restrict__ s2,
+                                                          float gamma, float high, float* __restrict__ grads,
+                                                          float* __restrict__ losses) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    LearnLds l = carve(smem, L);
+    const int agent = blockIdx.x;
+    const int set = set_mod > 0 ? agent % set_mod : agent;
+    const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
+    const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+    float* g = grads + (long)agent * L.theta_size;
+    float* ga = g;                 // actor block
+    float* gc = g + L.actor_size;  // critic block
+    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
+    const int tid = threadIdx.x;
+    const float invn = 1.0f / (float)(TILE * L.A);
+
+    // ---- stage the batch ----
+    for (int i = tid; i < TILE * L.S; i += NTHREADS) {
+        l.sS[i] = s[(long)agent * TILE * L.S + i];
+        l.sS2[i] = s2[(long)agent * TILE * L.S + i];
+    }
+    if (tid < TILE) {
+        l.sAct[tid] = a[(long)agent * TILE + tid];
+        l.sR[tid] = r[(long)agent * TILE + tid];
+    }
+    // zero the alignment padding of this agent's gradient slab (never written below)
+    if (tid == 0) {
+        for (int i = L.ab3 + L.A; i < L.actor_size; ++i) ga[i] = 0.f;
+        for (int i = L.cb3 + L.A; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- TD target: y = r + gamma * Q'(s2, mu'(s2))   (trainer.py:493-494) ----
+    actor_fwd_tile(L, tgt, l.sS2, high, l, l.sA1);
+    critic_fwd_tile(L, tgt, l.sS2, l.sA1, l, l.sQ);
+    if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
+    __syncthreads();
+
+    // ---- critic loss + gradient (trainer.py:495-498) ----
+    critic_fwd_tile(L, net, l.sS, l.sAct, l, l.sQ);
+    if (tid < TILE) {
+        const float e = l.sY[tid] - l.sQ[tid];
+        l.sD[tid] = -2.0f * e * invn;  // d mean((y-q)^2) / dq
+        l.sT[tid] = e * e;
+    }
+    __syncthreads();
+    {
+        const float lc = block_sum64(l.sT, l.red) * invn;
+        const float db3 = block_sum64(l.sD, l.red);
+        if (tid == 0) {
+            gc[L.cb3] = db3;
+            if (losses) losses[(long)agent * 2 + 0] = lc;
+        }
+    }
+    {
+        const float* cth = net.th + L.actor_size;
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, cth + L.cW3, cth + L.cg3, net.st + L.cmm3,
+                           net.st + L.cmv3, L.H2, l.bufC, ldB, gc + L.cW3, gc + L.cg3, gc + L.cbe3);
+        __syncthreads();
+        col_sums(l.bufC, ldB, L.H2, l.db, gc + L.cb2);
+        __syncthreads();
+        gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, l.bufC, ldB, l.db, L.H2, gc + L.cW2);
+        __syncthreads();
+        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, 0, L.H1, l.bufA, ldA, cth + L.cgs, net.st + L.cmms,
+                   net.st + L.cmvs, gc + L.cgs, gc + L.cbes);
+        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
+                   net.st + L.cmva, gc + L.cga, gc + L.cbea);
+        __syncthreads();
+        dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, gc + L.cWs, gc + L.cbs);
+        dense_in_grads(l.sAct, 1, 1, l.bufA, ldA, L.H1, L.Ha, gc + L.cWa, gc + L.cba);
+        __syncthreads();
+    }
+
+    // ---- actor loss: La = -mean(Q(s, mu(s)))   (trainer.py:501-506) ----
+    // pass 1: a1 = mu(s) (activations discarded), critic forward on (s, a1), gradient wrt the action input
+    actor_fwd_tile(L, net, l.sS, high, l, l.sA1);
+    critic_fwd_tile(L, net, l.sS, l.sA1, l, l.sQ);
+    {
+        const float la = -block_sum64(l.sQ, l.red) * invn;
+        if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
+        if (tid < TILE) l.sD[tid] = -invn;  // dLa/dq1
+        __syncthreads();
+        const float* cth = net.th + L.actor_size;
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, cth + L.cW3, cth + L.cg3, net.st + L.cmm3,
+                           net.st + L.cmv3, L.H2, l.bufC, ldB, nullptr, nullptr, nullptr);
+        __syncthreads();
+        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
+                   net.st + L.cmva, nullptr, nullptr);
+        __syncthreads();
+        // da1[r] = sum_j dza[r][j] * Wa[0][j]
+        {
+            const int rr = tid >> 2, part = tid & 3;
+            float acc = 0.f;
+            for (int j = part; j < L.Ha; j += 4) acc = fmaf(l.bufA[rr * ldA + L.H1 + j], cth[L.cWa + j], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) l.sDa[rr] = acc;
+        }
+        __syncthreads();
+    }
+    // pass 2: actor forward again keeping p1 (bufA), p2 (bufB), tanh (sT); then backward
+    actor_fwd_tile(L, net, l.sS, high, l, l.sA1);
+    if (tid < TILE) {
+        const float t = l.sT[tid];
+        l.sD[tid] = l.sDa[tid] * high * (1.0f - t * t);  // d/d(pre-tanh)
+    }
+    __syncthreads();
+    {
+        const float db3 = block_sum64(l.sD, l.red);
+        if (tid == 0) ga[L.ab3] = db3;
+        const float* ath = net.th;
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, ath + L.aW3, ath + L.ag2, net.st + L.amm2,
+                           net.st + L.amv2, L.H2, l.bufC, ldB, ga + L.aW3, ga + L.ag2, ga + L.abe2);
+        __syncthreads();
+        col_sums(l.bufC, ldB, L.H2, l.db, ga + L.ab2);
+        __syncthreads();
+        gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1, l.bufC, ldB, l.db, L.H2, ga + L.aW2);
+        __syncthreads();
+        gemm_dx_bn(l.bufC, ldB, L.H2, ath + L.aW2, 0, L.H1, l.bufA, ldA, ath + L.ag1, net.st + L.amm1,
+                   net.st + L.amv1, ga + L.ag1, ga + L.abe1);
+        __syncthreads();
+        dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, ga + L.aW1, ga + L.ab1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch-1 forward per agent (act / Q read-out): one workgroup per agent row, weights streamed once
+// ------------------------------------------------------------------------------------------
+// y[n] = relu(sum_k x[k]*W[k][n] + b[n]) for n < N with x in LDS (already BN'ed); 256 threads split K.
+__device__ __forceinline__ void gemv_relu(const float* x, int K, const float* __restrict__ W,
+                                          const float* __restrict__ b, int N, float* part, float* y) {
+    const int cols = N < NTHREADS ? N : NTHREADS;
+    const int ksplit = NTHREADS / cols;
+    for (int n0 = 0; n0 < N; n0 += cols) {
+        const int n = n0 + (threadIdx.x % cols);
+        const int kh = threadIdx.x / cols;
+        float acc = 0.f;
+        if (kh < ksplit && n < N) {
+            const int kb = (K * kh) / ksplit, ke = (K * (kh + 1)) / ksplit;
+#pragma unroll 8
+            for (int k = kb; k < ke; ++k) acc = fmaf(x[k], W[(long)k * N + n], acc);
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < cols && n < N) {
+            float sum = b[n];
+            for (int h = 0; h < ksplit; ++h) sum += part[h * cols + threadIdx.x];
+            y[n] = fmaxf(sum, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void bn_apply(float* y, int n, const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv) {
+    for (int k = threadIdx.x; k < n; k += NTHREADS) {
+        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+        y[k] = fmaf(y[k], iv, be[k] - mm[k] * iv);
+    }
+}
+
+__device__ __forceinline__ float block_dot(const float* x, const float* __restrict__ w, int n, float* part) {
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < n; k += NTHREADS) acc = fmaf(x[k], w[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float r = part[0] + part[1] + part[2] + part[3];
+    __syncthreads();
+    return r;
+}
+
+// mode 0: actor, out = tanh(.)*high ; mode 1: critic, out = q
+__global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, int mode, int set_mod,
+                                                             const float* __restrict__ theta,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ state, int x_stride,
+                                                             const float* __restrict__ action, float high,
+                                                             float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* h1 = smem;                    // H1 + Ha
+    float* h2 = h1 + L.H1 + L.Ha;        // H2
+    float* part = h2 + L.H2;             // 256
+    float* xin = part + NTHREADS;        // 8 + 8
+    const int agent = blockIdx.x;
+    const int set = set_mod > 0 ? agent % set_mod : agent;
+    const float* th = theta + (long)set * L.theta_size;
+    const float* st = stats + (long)set * L.stats_size;
+    if (threadIdx.x < L.S) xin[threadIdx.x] = state[(long)agent * x_stride + threadIdx.x];
+    if (mode == 1 && threadIdx.x == 0) xin[8] = action[agent];
+    __syncthreads();
+    if (mode == 0) {
+        gemv_relu(xin, L.S, th + L.aW1, th + L.ab1, L.H1, part, h1);
+        bn_apply(h1, L.H1, th + L.ag1, th + L.abe1, st + L.amm1, st + L.amv1);
+        __syncthreads();
+        gemv_relu(h1, L.H1, th + L.aW2, th + L.ab2, L.H2, part, h2);
+        bn_apply(h2, L.H2, th + L.ag2, th + L.abe2, st + L.amm2, st + L.amv2);
+        __syncthreads();
+        const float z = block_dot(h2, th + L.aW3, L.H2, part) + th[L.ab3];
+        if (threadIdx.x == 0) out[agent] = tanhf(z) * high;
+    } else {
+        const float* c = th + L.actor_size;
+        gemv_relu(xin, L.S, c + L.cWs, c + L.cbs, L.H1, part, h1);
+        gemv_relu(xin + 8, 1, c + L.cWa, c + L.cba, L.Ha, part, h1 + L.H1);
+        bn_apply(h1, L.H1, c + L.cgs, c + L.cbes, st + L.cmms, st + L.cmvs);
+        bn_apply(h1 + L.H1, L.Ha, c + L.cga, c + L.cbea, st + L.cmma, st + L.cmva);
+        __syncthreads();
+        gemv_relu(h1, L.H1 + L.Ha, c + L.cW2, c + L.cb2, L.H2, part, h2);
+        bn_apply(h2, L.H2, c + L.cg3, c + L.cbe3, st + L.cmm3, st + L.cmv3);
+        __syncthreads();
+        const float q = block_dot(h2, c + L.cW3, L.H2, part) + c[L.cb3];
+        if (threadIdx.x == 0) out[agent] = q;
+    }
+}
+
+static inline int round4(int x) { return (x + 3) & ~3; }
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_mlp_layout_init(avd_mlp_layout* o, int S, int A, int H1, int H2, int Ha, int B) {
+    AVD_REQUIRE(o, "avd_mlp_layout_init: null");
+    AVD_REQUIRE(S > 0 && A > 0 && H1 > 0 && H2 > 0 && Ha > 0 && B > 0, "avd_mlp_layout_init: non-positive dimension");
+    memset(o, 0, sizeof(*o));
+    o->S = S, o->A = A, o->H1 = H1, o->H2 = H2, o->Ha = Ha, o->B = B;
+    int p = 0;
+    auto take = [&](int n) {
+        const int at = p;
+        p += round4(n);
+        return at;
+    };
+    o->aW1 = take(S * H1), o->ab1 = take(H1), o->ag1 = take(H1), o->abe1 = take(H1);
+    o->aW2 = take(H1 * H2), o->ab2 = take(H2), o->ag2 = take(H2), o->abe2 = take(H2);
+    o->aW3 = take(H2 * A), o->ab3 = take(A);
+    o->actor_size = p;
+    p = 0;  // critic offsets are relative to the critic block
+    o->cWs = take(S * H1), o->cbs = take(H1), o->cgs = take(H1), o->cbes = take(H1);
+    o->cWa = take(A * Ha), o->cba = take(Ha), o->cga = take(Ha), o->cbea = take(Ha);
+    o->cW2 = take((H1 + Ha) * H2), o->cb2 = take(H2), o->cg3 = take(H2), o->cbe3 = take(H2);
+    o->cW3 = take(H2 * A), o->cb3 = take(A);
+    o->theta_size = o->actor_size + p;
+    p = 0;
+    o->amm1 = take(H1), o->amv1 = take(H1), o->amm2 = take(H2), o->amv2 = take(H2);
+    o->cmms = take(H1), o->cmvs = take(H1), o->cmma = take(Ha), o->cmva = take(Ha);
+    o->cmm3 = take(H2), o->cmv3 = take(H2);
+    o->stats_size = p;
+    return AVD_OK;
+}
+
+static int check_mlp_dims(const avd_mlp_layout* L, const char* who) {
+    AVD_REQUIRE(L, "%s: null layout", who);
+    if (L->A != 1) {
+        set_error("%s: num_actions=%d; only A == 1 (decentralized framework) is implemented", who, L->A);
+        return AVD_E_UNSUPPORTED;
+    }
+    if (L->S > 8 || (L->H1 % 16) || (L->H2 % 16) || (L->Ha % 16)) {
+        set_error("%s: need S <= 8 and H1,H2,Ha multiples of 16 (got S=%d H1=%d H2=%d Ha=%d)", who, L->S, L->H1, L->H2,
+                  L->Ha);
+        return AVD_E_UNSUPPORTED;
+    }
+    return AVD_OK;
+}
+
+static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int set_mod, const float* theta,
+                       const float* stats, const float* state, int x_stride, const float* action, float high,
+                       float* out, void* stream, const char* who) {
+    int rc = check_mlp_dims(lay, who);
+    if (rc) return rc;
+    AVD_REQUIRE(n_agents > 0 && set_mod >= 0 && x_stride >= lay->S, "%s: n_agents=%d set_mod=%d x_stride=%d", who,
+                n_agents, set_mod, x_stride);
+    AVD_REQUIRE(theta && stats && state && out && (mode == 0 || action), "%s: null pointer", who);
+    const size_t lds = sizeof(float) * (size_t)(lay->H1 + lay->Ha + lay->H2 + NTHREADS + 16);
+    if (lds > 160 * 1024) {
+        set_error("%s: hidden sizes need %zu B of LDS (> 160 KiB)", who, lds);
+        return AVD_E_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void*)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mlp_rows_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, mode, set_mod,
+                       theta, stats, state, x_stride, action, high, out);
+    return check_launch(who);
+}
+
+extern "C" int avd_actor_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                                     const float* stats, const float* state, int x_stride, float high, float* out,
+                                     void* stream) {
+    return launch_rows(lay, 0, n_agents, set_mod, theta, stats, state, x_stride, nullptr, high, out, stream,
+                       "avd_actor_forward_f32");
+}
+
+extern "C" int avd_critic_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                                      const float* stats, const float* state, int x_stride, const float* action,
+                                      float* q, void* stream) {
+    return launch_rows(lay, 1, n_agents, set_mod, theta, stats, state, x_stride, action, 0.f, q, stream,
+                       "avd_critic_forward_f32");
+}
+
+extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                             const float* stats, const float* theta_t, const float* stats_t, const float* s,
+                             const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
+                             float* losses, void* stream) {
+    int rc = check_mlp_dims(lay, "avd_learn_f32");
+    if (rc) return rc;
+    if (lay->B != TILE) {
+        set_error("avd_learn_f32: batch_size=%d; the tile kernel implements B == %d", lay->B, TILE);
+        return AVD_E_UNSUPPORTED;
+    }
+    AVD_REQUIRE(n_agents > 0 && set_mod >= 0, "avd_learn_f32: n_agents=%d set_mod=%d", n_agents, set_mod);
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads, "avd_learn_f32: null pointer");
+    const size_t lds = sizeof(float) * learn_lds_floats(*lay);
+    if (lds > 160 * 1024) {
+        set_error("avd_learn_f32: widths H1=%d H2=%d Ha=%d need %zu B of LDS per tile (> 160 KiB)", lay->H1, lay->H2,
+                  lay->Ha, lds);
+        return AVD_E_UNSUPPORTED;
+    }
+    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        return AVD_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(learn_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod, theta,
+                       stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
+    return check_launch("avd_learn_f32");
+}

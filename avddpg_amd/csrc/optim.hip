@@ -1,0 +1,165 @@
+// Optimiser / target-network / federation kernels for gfx950 (K11, K12, K13 local part).
+//
+// All of these are elementwise, HBM-bound streams over flat float32 slabs (16-byte accesses,
+// grid-stride).  Adam follows TF 2.4.1's ApplyAdam functor exactly and is compiled without FMA
+// contraction so the result is bit-identical to the float32 oracle (oracle/mlp.py:adam_update).
+#include "common.h"
+
+namespace avd {
+
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-7f;
+
+// grid: (blocks over theta_size/4, n_sets)
+__global__ __launch_bounds__(256) void adam_polyak_kernel(int theta_size, int actor_size, float4* __restrict__ theta,
+                                                          float4* __restrict__ theta_t, float4* __restrict__ m,
+                                                          float4* __restrict__ v, const float4* __restrict__ grads,
+                                                          const int32_t* __restrict__ step, float actor_lr,
+                                                          float critic_lr, float tau, float omt) {
+#pragma clang fp contract(off)
+    const int set = blockIdx.y;
+    const int t = step[set];
+    // beta^t as float32(pow) like the oracle / TF (math_ops.pow on float32 scalars)
+    const float b1p = (float)pow((double)ADAM_B1, (double)t);
+    const float b2p = (float)pow((double)ADAM_B2, (double)t);
+    const float root = sqrtf(1.0f - b2p);
+    const float alpha_a = (actor_lr * root) / (1.0f - b1p);
+    const float alpha_c = (critic_lr * root) / (1.0f - b1p);
+    const int n4 = theta_size / 4;
+    const long base = (long)set * n4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float alpha = (i * 4 < actor_size) ? alpha_a : alpha_c;  // blocks are 4-float aligned
+        float4 w = theta[base + i], wt = theta_t[base + i], mm = m[base + i], vv = v[base + i];
+        const float4 g = grads[base + i];
+        float* wp = &w.x;
+        float* tp = &wt.x;
+        float* mp = &mm.x;
+        float* vp = &vv.x;
+        const float* gp = &g.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mp[k] = mp[k] + (gp[k] - mp[k]) * (1.0f - ADAM_B1);
+            vp[k] = vp[k] + (gp[k] * gp[k] - vp[k]) * (1.0f - ADAM_B2);
+            wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
+            tp[k] = wp[k] * tau + tp[k] * omt;  // update_target on the freshly updated weight
+        }
+        theta[base + i] = w;
+        theta_t[base + i] = wt;
+        m[base + i] = mm;
+        v[base + i] = vv;
+    }
+}
+
+__global__ void polyak_kernel(long n, const float* __restrict__ w, float* __restrict__ t, float tau, float omt) {
+#pragma clang fp contract(off)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        t[i] = w[i] * tau + t[i] * omt;
+}
+
+// out[m][j] = sum_p (w[p][m]) * g[p][m][j]; one thread per (m, 4 j's), p in fixed order (reproducible)
+__global__ __launch_bounds__(256) void fed_sum_kernel(int P, int M, int n, const float4* __restrict__ g,
+                                                      const float* __restrict__ weights, float4* __restrict__ out,
+                                                      float* __restrict__ wsum) {
+    const int n4 = n / 4;
+    const int mset = blockIdx.y;
+    if (wsum && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += weights[p * M + mset];
+        wsum[mset] = s;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < P; ++p) {
+            const float4 x = g[((long)p * M + mset) * n4 + i];
+            const float w = weights ? weights[p * M + mset] : 1.0f;
+            acc.x += w * x.x, acc.y += w * x.y, acc.z += w * x.z, acc.w += w * x.w;
+        }
+        out[(long)mset * n4 + i] = acc;
+    }
+}
+
+__global__ void fed_finalize_kernel(int M, int n, float* __restrict__ out, float count,
+                                    const float* __restrict__ wsum) {
+#pragma clang fp contract(off)
+    const long total = (long)M * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (wsum)
+            out[i] = (1.0f / wsum[i / n]) * out[i];  // federated.py:110
+        else
+            out[i] = out[i] / count;  // reduce_mean (federated.py:62)
+    }
+}
+
+__global__ void broadcast_sets_kernel(int P, int M, int n, const float4* __restrict__ src, float4* __restrict__ dst) {
+    const long n4 = n / 4;
+    const long total = (long)P * M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pm = i / n4;
+        dst[i] = src[(pm % M) * n4 + (i - pm * n4)];
+    }
+}
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
+                                   float* stats_t, float* m, float* v, const float* grads, const int32_t* step,
+                                   float actor_lr, float critic_lr, double tau, void* stream) {
+    AVD_REQUIRE(lay && n_sets > 0, "avd_adam_polyak_f32: n_sets=%d", n_sets);
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && m && v && grads && step, "avd_adam_polyak_f32: null pointer");
+    AVD_REQUIRE(lay->theta_size % 4 == 0 && lay->actor_size % 4 == 0 && lay->stats_size % 4 == 0,
+                "avd_adam_polyak_f32: layout not 4-float aligned");
+    const float tauf = (float)tau, omt = (float)(1.0 - tau);  // Python doubles rounded to f32 (ddpgagent.py:47,53)
+    const int n4 = lay->theta_size / 4;
+    int gx = (n4 + 255) / 256;
+    if (n_sets >= 256 && gx > 8) gx = 8;  // many sets: fewer, longer-lived blocks per set
+    hipLaunchKernelGGL(adam_polyak_kernel, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size,
+                       lay->actor_size, (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v,
+                       (const float4*)grads, step, actor_lr, critic_lr, tauf, omt);
+    int rc = check_launch("avd_adam_polyak_f32");
+    if (rc) return rc;
+    // BN moving stats take part in the soft update too (ddpgagent.py:44-53 iterates .weights)
+    const long ns = (long)n_sets * lay->stats_size;
+    long blocks = (ns + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(polyak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ns, stats, stats_t,
+                       tauf, omt);
+    return check_launch("avd_adam_polyak_f32(stats)");
+}
+
+extern "C" int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream) {
+    AVD_REQUIRE(n > 0 && w && t, "avd_polyak_f32: n=%ld", (long)n);
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(polyak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, w, t,
+                       (float)tau, (float)(1.0 - tau));
+    return check_launch("avd_polyak_f32");
+}
+
+extern "C" int avd_fed_sum_f32(int P, int M, int n, const float* g, const float* weights, float* out, float* wsum,
+                               void* stream) {
+    AVD_REQUIRE(P > 0 && M > 0 && n > 0 && n % 4 == 0 && g && out, "avd_fed_sum_f32: P=%d M=%d n=%d", P, M, n);
+    AVD_REQUIRE(!wsum || weights, "avd_fed_sum_f32: wsum requested without weights");
+    int gx = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(fed_sum_kernel, dim3(gx, M), dim3(256), 0, (hipStream_t)stream, P, M, n, (const float4*)g,
+                       weights, (float4*)out, wsum);
+    return check_launch("avd_fed_sum_f32");
+}
+
+extern "C" int avd_fed_finalize_f32(int M, int n, float* out, float count, const float* wsum, void* stream) {
+    AVD_REQUIRE(M > 0 && n > 0 && out && (wsum || count > 0.f), "avd_fed_finalize_f32: M=%d n=%d", M, n);
+    long blocks = ((long)M * n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fed_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, n, out,
+                       count, wsum);
+    return check_launch("avd_fed_finalize_f32");
+}
+
+extern "C" int avd_broadcast_sets_f32(int P, int M, int n, const float* src, float* dst, void* stream) {
+    AVD_REQUIRE(P > 0 && M > 0 && n > 0 && n % 4 == 0 && src && dst, "avd_broadcast_sets_f32: P=%d M=%d n=%d", P, M, n);
+    long blocks = ((long)P * M * (n / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(broadcast_sets_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, M, n,
+                       (const float4*)src, (float4*)dst);
+    return check_launch("avd_broadcast_sets_f32");
+}

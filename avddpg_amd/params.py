@@ -1,0 +1,85 @@
+"""Parameter slab <-> Keras-ordered weight lists, and the reference initialisers.
+
+Slab layout comes from the C ABI (``avd_mlp_layout_init``); Keras orders follow reference
+``agent/model.py`` (``model.weights`` / ``model.trainable_variables`` of the functional
+models): actor 14 / 10 tensors, critic 20 / 14 tensors."""
+import numpy as np
+
+# (name in layout, shape fn) in Keras ``.weights`` order; 't' = in theta (trainable), 's' = in stats
+ACTOR_WEIGHTS = [("aW1", "t", lambda d: (d.S, d.H1)), ("ab1", "t", lambda d: (d.H1,)), ("ag1", "t", lambda d: (d.H1,)),
+                 ("abe1", "t", lambda d: (d.H1,)), ("amm1", "s", lambda d: (d.H1,)), ("amv1", "s", lambda d: (d.H1,)),
+                 ("aW2", "t", lambda d: (d.H1, d.H2)), ("ab2", "t", lambda d: (d.H2,)),
+                 ("ag2", "t", lambda d: (d.H2,)), ("abe2", "t", lambda d: (d.H2,)),
+                 ("amm2", "s", lambda d: (d.H2,)), ("amv2", "s", lambda d: (d.H2,)),
+                 ("aW3", "t", lambda d: (d.H2, d.A)), ("ab3", "t", lambda d: (d.A,))]
+CRITIC_WEIGHTS = [("cWs", "t", lambda d: (d.S, d.H1)), ("cbs", "t", lambda d: (d.H1,)),
+                  ("cWa", "t", lambda d: (d.A, d.Ha)), ("cba", "t", lambda d: (d.Ha,)),
+                  ("cgs", "t", lambda d: (d.H1,)), ("cbes", "t", lambda d: (d.H1,)),
+                  ("cmms", "s", lambda d: (d.H1,)), ("cmvs", "s", lambda d: (d.H1,)),
+                  ("cga", "t", lambda d: (d.Ha,)), ("cbea", "t", lambda d: (d.Ha,)),
+                  ("cmma", "s", lambda d: (d.Ha,)), ("cmva", "s", lambda d: (d.Ha,)),
+                  ("cW2", "t", lambda d: (d.H1 + d.Ha, d.H2)), ("cb2", "t", lambda d: (d.H2,)),
+                  ("cg3", "t", lambda d: (d.H2,)), ("cbe3", "t", lambda d: (d.H2,)),
+                  ("cmm3", "s", lambda d: (d.H2,)), ("cmv3", "s", lambda d: (d.H2,)),
+                  ("cW3", "t", lambda d: (d.H2, d.A)), ("cb3", "t", lambda d: (d.A,))]
+
+
+def _offset(lay, name, kind):
+    off = getattr(lay, name)
+    if kind == "t" and name.startswith("c"):
+        off += lay.actor_size  # critic offsets are relative to the critic block
+    return off
+
+
+def unpack(lay, theta, stats, which, trainable_only=False):
+    """theta[theta_size], stats[stats_size] (numpy) -> list of arrays in Keras order."""
+    spec = ACTOR_WEIGHTS if which == "actor" else CRITIC_WEIGHTS
+    out = []
+    for name, kind, shp in spec:
+        if trainable_only and kind == "s":
+            continue
+        shape = shp(lay)
+        n = int(np.prod(shape))
+        src = theta if kind == "t" else stats
+        off = _offset(lay, name, kind)
+        out.append(np.array(src[off:off + n]).reshape(shape))
+    return out
+
+
+def pack(lay, weights, theta, stats, which, trainable_only=False):
+    """Inverse of unpack: writes the list into theta/stats in place."""
+    spec = ACTOR_WEIGHTS if which == "actor" else CRITIC_WEIGHTS
+    spec = [s for s in spec if not (trainable_only and s[1] == "s")]
+    if len(weights) != len(spec):
+        raise ValueError(f"{which}: expected {len(spec)} tensors, got {len(weights)}")
+    for (name, kind, shp), w in zip(spec, weights):
+        shape = shp(lay)
+        w = np.asarray(w, dtype=np.float32)
+        if tuple(w.shape) != tuple(shape):
+            raise ValueError(f"{which}.{name}: shape {w.shape} != {shape}")
+        dst = theta if kind == "t" else stats
+        off = _offset(lay, name, kind)
+        dst[off:off + w.size] = w.reshape(-1)
+
+
+def init_weights(lay, rs, nominal=None):
+    """Fresh (theta, stats) float32 numpy slabs with the reference initialisers
+    (agent/model.py:17-24, 53-60): U(+-1/sqrt(nominal layer size)) -- the layer's OWN nominal
+    width, not fan-in; the critic action layer shares the layer-2 bound; last layers U(+-0.003)
+    / U(+-0.0003); biases 0; BatchNormalization gamma=1, beta=0, mean=0, var=1."""
+    H1n, H2n = nominal or (lay.H1, lay.H2)
+    b1, b2 = 1 / np.sqrt(H1n), 1 / np.sqrt(H2n)
+    theta = np.zeros(lay.theta_size, dtype=np.float32)
+    stats = np.zeros(lay.stats_size, dtype=np.float32)
+    d = lay
+    actor = [rs.uniform(-b1, b1, (d.S, d.H1)), np.zeros(d.H1), np.ones(d.H1), np.zeros(d.H1), np.zeros(d.H1),
+             np.ones(d.H1), rs.uniform(-b2, b2, (d.H1, d.H2)), np.zeros(d.H2), np.ones(d.H2), np.zeros(d.H2),
+             np.zeros(d.H2), np.ones(d.H2), rs.uniform(-0.003, 0.003, (d.H2, d.A)), np.zeros(d.A)]
+    critic = [rs.uniform(-b1, b1, (d.S, d.H1)), np.zeros(d.H1), rs.uniform(-b2, b2, (d.A, d.Ha)), np.zeros(d.Ha),
+              np.ones(d.H1), np.zeros(d.H1), np.zeros(d.H1), np.ones(d.H1),
+              np.ones(d.Ha), np.zeros(d.Ha), np.zeros(d.Ha), np.ones(d.Ha),
+              rs.uniform(-b2, b2, (d.H1 + d.Ha, d.H2)), np.zeros(d.H2), np.ones(d.H2), np.zeros(d.H2),
+              np.zeros(d.H2), np.ones(d.H2), rs.uniform(-0.0003, 0.0003, (d.H2, d.A)), np.zeros(d.A)]
+    pack(lay, actor, theta, stats, "actor")
+    pack(lay, critic, theta, stats, "critic")
+    return theta, stats

@@ -1,0 +1,326 @@
+"""Batched, device-resident host API over the C ABI (include/avddpg_hip.h).
+
+One instance of each class holds the state of P platoons x L vehicles in HBM and drives the
+gfx950 kernels; Python never touches per-platoon data in the loop.  The scalar classes that
+mirror the reference's object API (``environment.Platoon`` ...) are thin P = 1 views of these.
+
+Random numbers come from one of two sources:
+  * ``rng="host"``   -- the global legacy ``np.random`` stream, consumed in exactly the
+                        reference's order, uploaded to the kernels (fixed-seed parity mode);
+  * ``rng="device"`` -- counter-based Philox inside the kernels (throughput mode; same
+                        distributions, different stream).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip, dynamics, params
+from ._hip import call, ptr, stream_handle
+
+
+def _dev(device):
+    return torch.device(device if device is not None else "cuda")
+
+
+class VecPlatoon:
+    """P platoons of L vehicles. Batched ``Platoon`` (reference src/environment.py:8-301)."""
+
+    def __init__(self, num_platoons, length, config, device=None, rand_states=True, evaluator_states_enabled=False,
+                 rng="host", seed=1, track_aux=False):
+        self.P, self.L, self.config = int(num_platoons), int(length), config
+        self.length = self.L
+        self.device = _dev(device)
+        self.rng, self.seed = rng, int(seed)
+        self.rand_states, self.evaluator_states_enabled = rand_states, evaluator_states_enabled
+        centralized = config.framework == config.cntrl
+        # attributes read by callers (environment.py:35-54)
+        self.multiplier = self.L if centralized else 1
+        self.hidden_multiplier = config.centrl_hidd_mult if centralized else 1
+        self.num_models = 1 if centralized else self.L
+        self.def_num_actions = 1
+        self.num_actions = self.def_num_actions * self.multiplier
+        self.def_num_states = 3 if config.model == config.modelA else 4
+        self.num_states = self.def_num_states * self.multiplier
+        self.number_of_reward_components = 4
+        self.state_lbs = {0: "$e_{pi,k}$", 1: "$e_{vi,k}$", 2: "$a_{i,k}$", 3: "$a_{i-1,k}$"}
+        self.jerk_lb, self.exog_lbl = "jerk", "$u_{i,k}$"
+        self.obs_width = min(4, self.num_states)  # Vehicle.step returns x[0:num_states] (:518)
+
+        self.h_consts = dynamics.env_consts(config, self.L)
+        raw = np.frombuffer(bytes(self.h_consts), dtype=np.uint8).copy()
+        self.d_consts = torch.from_numpy(raw).to(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        P, L = self.P, self.L
+        self.x = torch.zeros(P, L, 4, **f32)
+        self.x_prev = torch.zeros(P, L, 4, **f32)  # state before the last step (= prev_states of the trainer)
+        self.prev_a = torch.zeros(P, L, **f32)
+        self.cum_accel = torch.zeros(P, L, **f32) if track_aux else None
+        self.reward = torch.zeros(P, L, **f32)
+        self.reward_mean = torch.zeros(P, **f32) if centralized else None
+        self.term = torch.zeros(P, L, dtype=torch.uint8, device=self.device)
+        self.done = torch.zeros(P, dtype=torch.uint8, device=self.device)
+        self.any_done = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.reset_count = 0
+        self.step_count = 0
+        if rng == "host":
+            # constructor draws of P reference Platoon objects: 2 + 3L each (environment.py:24,32,385)
+            self._host_ctor_draws()
+
+    # -- host RNG helpers: consume np.random exactly like the reference objects --------------
+    def _rand(self, val):
+        c = self.config
+        if c.rand_gen == c.uniform:
+            return np.random.uniform(-1 * val, val)
+        return np.random.normal(0, val)
+
+    def _mode(self):
+        if self.evaluator_states_enabled:
+            return 1 if self.rand_states else 2
+        return 0 if self.rand_states else 2
+
+    def _host_ctor_draws(self):
+        c = self.config
+        for _ in range(self.P):
+            self._rand(c.pl_leader_reset_a)
+            self._rand(c.reset_max_u)
+            if self._mode() == 0:
+                for _ in range(3 * self.L):
+                    self._rand(1.0)
+
+    def _host_reset_draws(self):
+        c, P, L = self.config, self.P, self.L
+        draws = np.zeros((P, L, 3), dtype=np.float64)
+        fa = np.zeros(P, dtype=np.float64)
+        train = self._mode() == 0
+        for p in range(P):  # Platoon.reset (:284-301): front_accel, then per vehicle front_u (+3 state draws)
+            fa[p] = self._rand(c.pl_leader_reset_a)
+            for i in range(L):
+                self._rand(c.reset_max_u)
+                if train:
+                    draws[p, i, 0] = self._rand(c.reset_ep_max)
+                    draws[p, i, 1] = self._rand(c.reset_max_ev)
+                    draws[p, i, 2] = self._rand(c.reset_max_a)
+        return draws, fa
+
+    # -- API ------------------------------------------------------------------------------------
+    def observations(self, x=None):
+        """[P, L, obs_width] view (decentralized) -- Model A hides x[3] (:518)."""
+        x = self.x if x is None else x
+        return x[..., : self.obs_width]
+
+    def reset(self, cond=None):
+        """All platoons reset together (workers/trainer.py:246-249). ``cond``: device int32 flag --
+        reset only if non-zero (device-RNG mode only)."""
+        draws = fa = None
+        if self.rng == "host":
+            if cond is not None:
+                raise ValueError("conditional reset needs rng='device'")
+            d, f = self._host_reset_draws()
+            draws = torch.from_numpy(d.astype(np.float32)).to(self.device)
+            fa = torch.from_numpy(f.astype(np.float32)).to(self.device)
+        call("avd_env_reset_f32", ptr(self.d_consts), self.P, self.L, ptr(self.x), ptr(self.prev_a),
+             ptr(self.cum_accel), ptr(draws), ptr(fa), self._mode(), self.seed, self.reset_count, ptr(cond),
+             stream_handle())
+        self.reset_count += 1
+        return self.observations()
+
+    def step(self, actions, leader_exog):
+        """actions [P, L] float32 (device), leader_exog [P]. Returns (obs, reward, done) device tensors;
+        ``self.x_prev`` then holds the pre-step state, ``self.any_done`` the any-terminal flag."""
+        self.x, self.x_prev = self.x_prev, self.x
+        call("avd_env_step_f32", ptr(self.d_consts), self.P, self.L, ptr(self.x_prev), ptr(self.x), ptr(self.prev_a),
+             ptr(self.cum_accel), ptr(actions), ptr(leader_exog), ptr(self.reward), ptr(self.term), ptr(self.done),
+             ptr(self.reward_mean), ptr(self.any_done), stream_handle())
+        self.step_count += 1
+        return self.observations(), self.reward, self.done
+
+    def get_jerk_from(self, x_before, prev_a_before):
+        """jerk of the step that consumed (x_before, prev_a_before) (environment.py:477)."""
+        return (x_before[..., 2] - prev_a_before) / self.config.sample_rate
+
+
+class VecOUNoise:
+    """n independent scalar OU processes (reference src/noise.py)."""
+
+    def __init__(self, n, config, device=None, rng="host", seed=1):
+        self.n, self.config, self.device = int(n), config, _dev(device)
+        self.rng, self.seed, self.calls = rng, int(seed), 0
+        self.state = torch.zeros(self.n, dtype=torch.float32, device=self.device)  # x_prev = 0 (noise.py:29)
+
+    def reset(self):
+        self.state.zero_()
+
+    def __call__(self, normals=None):
+        """Advance all processes; ``normals`` [n] host array of N(0,1) draws (host-RNG mode)."""
+        c = self.config
+        d_n = None
+        if self.rng == "host":
+            if normals is None:
+                normals = np.random.normal(0, 1.0, size=self.n)
+            d_n = torch.from_numpy(np.asarray(normals, dtype=np.float32).reshape(self.n)).to(self.device)
+        call("avd_ou_step_f32", self.n, ptr(self.state), ptr(d_n), c.theta, 0.0, c.ou_dt, c.std_dev, self.seed,
+             self.calls, stream_handle())
+        self.calls += 1
+        return self.state
+
+
+class VecReplay:
+    """One ring buffer per agent: ring[n_agents][cap][2S+A+1] float32 (reference src/replaybuffer.py)."""
+
+    def __init__(self, n_agents, buffer_capacity, batch_size, num_states, num_actions, device=None, rng="host",
+                 seed=1):
+        self.n, self.cap, self.B = int(n_agents), int(buffer_capacity), int(batch_size)
+        self.S, self.A = int(num_states), int(num_actions)
+        self.row = 2 * self.S + self.A + 1
+        self.device, self.rng, self.seed = _dev(device), rng, int(seed)
+        self.ring = torch.zeros(self.n, self.cap, self.row, dtype=torch.float32, device=self.device)
+        self.buffer_counter = 0  # identical for all agents: they are written in lock step
+        self.samples = 0
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.idx = torch.zeros(self.n, self.B, dtype=torch.int32, device=self.device)
+        self.s = torch.zeros(self.n, self.B, self.S, **f32)
+        self.a = torch.zeros(self.n, self.B, self.A, **f32)
+        self.r = torch.zeros(self.n, self.B, **f32)
+        self.s2 = torch.zeros(self.n, self.B, self.S, **f32)
+
+    def add(self, s_prev, action, reward, s_next, x_stride):
+        """s_prev / s_next: [n_agents, x_stride] device tensors (first S columns used)."""
+        call("avd_replay_add_f32", self.n, self.cap, self.S, self.A, ptr(self.ring), self.buffer_counter, ptr(s_prev),
+             ptr(s_next), x_stride, ptr(action), ptr(reward), stream_handle())
+        self.buffer_counter += 1
+
+    def sample_range(self):
+        return min(self.buffer_counter, self.cap)  # replaybuffer.py:52
+
+    def draw_indices(self, host_idx=None):
+        """host mode: np.random.choice(range, B) per agent in agent order (replaybuffer.py:54)."""
+        if self.rng == "host":
+            if host_idx is None:
+                rr = self.sample_range()
+                host_idx = np.stack([np.random.choice(rr, self.B) for _ in range(self.n)])
+            self.idx.copy_(torch.from_numpy(np.asarray(host_idx).astype(np.int32)))
+        else:
+            call("avd_replay_indices", self.n, self.B, self.sample_range(), self.seed, self.samples, ptr(self.idx),
+                 stream_handle())
+        self.samples += 1
+        return self.idx
+
+    def gather(self):
+        call("avd_replay_gather_f32", self.n, self.cap, self.S, self.A, self.B, ptr(self.ring), ptr(self.idx),
+             ptr(self.s), ptr(self.a), ptr(self.r), ptr(self.s2), stream_handle())
+        return self.s, self.a, self.r, self.s2
+
+    def sample(self, host_idx=None):
+        self.draw_indices(host_idx)
+        return self.gather()
+
+
+class AgentGroup:
+    """n_sets actor/critic/target/Adam weight sets in flat slabs (reference agent/model.py,
+    workers/trainer.py:100-139).  ``set_mod`` maps agent v to its weight set: 0 -> set v
+    (one per agent, reference nofrl), M -> set v % M (shared per vehicle index)."""
+
+    def __init__(self, n_sets, num_states, num_actions, config, device=None, hidd_mult=1, seed=None, high_bound=None):
+        c = config
+        self.config, self.device, self.n_sets = c, _dev(device), int(n_sets)
+        self.lay = _hip.make_layout(num_states, num_actions, int(c.actor_layer1_size * hidd_mult),
+                                    int(c.actor_layer2_size * hidd_mult), int(c.critic_act_layer_size * hidd_mult),
+                                    c.batch_size)
+        if (c.critic_layer1_size, c.critic_layer2_size) != (c.actor_layer1_size, c.actor_layer2_size):
+            raise _hip.AvdError("actor and critic layer1/layer2 sizes must match (reference defaults do)")
+        self.high = float(c.action_high if high_bound is None else high_bound)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        n, T, S = self.n_sets, self.lay.theta_size, self.lay.stats_size
+        self.theta = torch.zeros(n, T, **f32)
+        self.stats = torch.zeros(n, S, **f32)
+        self.theta_t = torch.zeros(n, T, **f32)
+        self.stats_t = torch.zeros(n, S, **f32)
+        self.m = torch.zeros(n, T, **f32)
+        self.v = torch.zeros(n, T, **f32)
+        self.step = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._layp = C.byref(self.lay)
+        rs = np.random.RandomState(c.random_seed if seed is None else seed)
+        th, st = params.init_weights(self.lay, rs, nominal=(c.actor_layer1_size, c.actor_layer2_size))
+        # every agent starts from agent (0,0)'s weights; targets copy their online nets (trainer.py:121-131)
+        self.theta.copy_(torch.from_numpy(th).to(self.device).expand(n, T))
+        self.stats.copy_(torch.from_numpy(st).to(self.device).expand(n, S))
+        self.theta_t.copy_(self.theta)
+        self.stats_t.copy_(self.stats)
+
+    # -- forward ----------------------------------------------------------------------------------
+    def actor(self, states, set_mod, x_stride=None, out=None, target=False):
+        """states [n_agents, x_stride] -> tanh(.)*high [n_agents] (agent/model.py:26-36)."""
+        n_agents = states.shape[0]
+        x_stride = states.shape[-1] if x_stride is None else x_stride
+        out = torch.empty(n_agents, dtype=torch.float32, device=self.device) if out is None else out
+        th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
+        call("avd_actor_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
+             self.high, ptr(out), stream_handle())
+        return out
+
+    def critic(self, states, actions, set_mod, x_stride=None, out=None, target=False):
+        n_agents = states.shape[0]
+        x_stride = states.shape[-1] if x_stride is None else x_stride
+        out = torch.empty(n_agents, dtype=torch.float32, device=self.device) if out is None else out
+        th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
+        call("avd_critic_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
+             ptr(actions), ptr(out), stream_handle())
+        return out
+
+    # -- learn / apply ----------------------------------------------------------------------------
+    def learn(self, s, a, r, s2, set_mod, grads=None, losses=None):
+        """Trainer.learn (workers/trainer.py:472-508) for n_agents batches -> grads [n_agents, theta_size]."""
+        n_agents = s.shape[0]
+        if grads is None:
+            grads = torch.empty(n_agents, self.lay.theta_size, dtype=torch.float32, device=self.device)
+        call("avd_learn_f32", self._layp, n_agents, set_mod, ptr(self.theta), ptr(self.stats), ptr(self.theta_t),
+             ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), self.config.gamma, self.high, ptr(grads),
+             ptr(losses), stream_handle())
+        return grads
+
+    def apply(self, grads):
+        """critic Adam, actor Adam, then Polyak (workers/trainer.py:348-356) for every weight set."""
+        c = self.config
+        self.step += 1
+        call("avd_adam_polyak_f32", self._layp, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(self.theta_t),
+             ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
+             float(c.tau), stream_handle())
+
+    # -- Keras-style weight access (host copies) ---------------------------------------------------
+    def get_weights(self, set_idx, which, target=False, trainable_only=False):
+        th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
+        return params.unpack(self.lay, th[set_idx].cpu().numpy(), st[set_idx].cpu().numpy(), which, trainable_only)
+
+    def set_weights(self, set_idx, which, weights, target=False):
+        th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
+        h_th, h_st = th[set_idx].cpu().numpy(), st[set_idx].cpu().numpy()
+        params.pack(self.lay, weights, h_th, h_st, which)
+        th[set_idx].copy_(torch.from_numpy(h_th))
+        st[set_idx].copy_(torch.from_numpy(h_st))
+
+    def grads_as_lists(self, grads_row):
+        """One row of a grads slab -> (critic_grad[14], actor_grad[10]) in trainable_variables order."""
+        g = grads_row.cpu().numpy()
+        dummy = np.zeros(self.lay.stats_size, dtype=np.float32)
+        return (params.unpack(self.lay, g, dummy, "critic", trainable_only=True),
+                params.unpack(self.lay, g, dummy, "actor", trainable_only=True))
+
+
+def fed_mean(grads, P, M, weights=None, group=None):
+    """Federated average over platoons of grads [P*M, n] (agent id v = p*M + m) -> [M, n]
+    (reference src/server/federated.py:47-63 / :99-118).  With a torch.distributed ``group`` of
+    ranks each holding P platoons, the local sums are all-reduced (RCCL) before the division."""
+    n = grads.shape[-1]
+    out = torch.empty(M, n, dtype=torch.float32, device=grads.device)
+    wsum = torch.empty(M, dtype=torch.float32, device=grads.device) if weights is not None else None
+    call("avd_fed_sum_f32", P, M, n, ptr(grads), ptr(weights), ptr(out), ptr(wsum), stream_handle())
+    count = float(P)
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        if wsum is not None:
+            dist.all_reduce(wsum, op=dist.ReduceOp.SUM, group=group)
+        count = float(P * dist.get_world_size(group))
+    call("avd_fed_finalize_f32", M, n, ptr(out), count, ptr(wsum), stream_handle())
+    return out

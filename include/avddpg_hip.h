@@ -1,0 +1,192 @@
+/*
+ * avddpg_hip.h -- C ABI of the MI355X (gfx950) hot-path library libavddpg_hip.so.
+ *
+ * The reference (cboin1996/avddpg) has no FFI: its hot path sits behind plain
+ * Python objects.  Each entry point below is the batched, device-resident
+ * replacement of one of those objects' methods; the reference interface it
+ * replaces is cited per function (file:line under the reference tree).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA tensor
+ *    data_ptr) unless it is named h_* or is an avd_* struct passed by pointer
+ *    from the host (those are read on the host at call time);
+ *  - sizes are explicit; nothing is allocated, nothing synchronises: the call
+ *    enqueues kernels on `stream` (a hipStream_t passed as void*) and returns;
+ *  - return value: 0 = ok, < 0 = error (AVD_E_*), message in avd_last_error();
+ *  - layouts: platoon-major; vehicle state x[P][L][4] float32 (one 16-byte
+ *    load per vehicle); per-agent vectors [P][L]; agent id v = p*L + m.
+ *  - thread-compatible: calls on different streams may run concurrently.
+ */
+#ifndef AVDDPG_HIP_H
+#define AVDDPG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVD_MAX_L 16 /* vehicles per platoon supported by the env kernels */
+
+#define AVD_OK 0
+#define AVD_E_INVALID (-1)     /* bad argument / unsupported dimension */
+#define AVD_E_LAUNCH (-2)      /* HIP launch or runtime error */
+#define AVD_E_UNSUPPORTED (-3) /* shape outside what the kernels implement */
+
+/* ---- environment constants (reference src/config.py:39-107 and the matrices of
+ *      src/environment.py:390-451, built on the host in float64 and rounded once) ---- */
+typedef struct avd_env_consts {
+    int32_t L;             /* pl_size */
+    int32_t model_a;       /* 1: Model A exogenous chain (predecessor's post-step accel, environment.py:263-267);
+                              0: Model B (predecessor's action this step, :257-261) */
+    int32_t can_terminate; /* config.py:75 */
+    int32_t uniform_reset; /* rand_gen == uniform (util.py:67-68), device-RNG reset only */
+    float max_ep, max_ev;  /* config.py:57-58 */
+    float abs_action_high; /* |action_high|, environment.py:475 */
+    float two_max_a;       /* 2*action_high, environment.py:476 */
+    float T;               /* sample_rate */
+    float ca, cb, cc, cd;  /* reward coefficients a,b,c,d config.py:52-55 */
+    float re_scalar, terminal_reward;
+    float stand_still, timegap;                              /* environment.py:343, 502 */
+    float reset_ep_max, reset_max_ev, reset_max_a;           /* config.py:60-62 */
+    float reset_ep_eval, reset_ev_eval, reset_a_eval;        /* config.py:64-66 */
+    float leader_reset_a;                                    /* config.py:41 */
+    float A[AVD_MAX_L][16]; /* row-major 4x4 per vehicle index */
+    float B[AVD_MAX_L][4];
+    float C[AVD_MAX_L][4];
+} avd_env_consts;
+
+/* ---- actor/critic parameter slab layout (agent/model.py:4-85) ----
+ * One weight set = theta[theta_size] (trainable: actor block then critic block,
+ * every tensor starting on a 4-float boundary, padding kept at zero) plus
+ * stats[stats_size] (the non-trainable BatchNormalization moving mean/var).
+ * Dense kernels are stored like Keras: W[in][out], row-major. */
+typedef struct avd_mlp_layout {
+    int32_t S, A, H1, H2, Ha, B;
+    /* actor trainables */
+    int32_t aW1, ab1, ag1, abe1, aW2, ab2, ag2, abe2, aW3, ab3;
+    int32_t actor_size; /* critic block starts here */
+    /* critic trainables */
+    int32_t cWs, cbs, cgs, cbes, cWa, cba, cga, cbea, cW2, cb2, cg3, cbe3, cW3, cb3;
+    int32_t theta_size;
+    /* non-trainable stats */
+    int32_t amm1, amv1, amm2, amv2, cmms, cmvs, cmma, cmva, cmm3, cmv3;
+    int32_t stats_size;
+} avd_mlp_layout;
+
+const char* avd_last_error(void);
+int avd_version(void);
+
+/* Fills `out` for the given network widths. S = num_states, A = num_actions (only
+ * A == 1, the decentralized framework, is implemented by the MLP kernels),
+ * H1/H2 = layer1/layer2 size, Ha = critic action layer size (config.py:112-117),
+ * B = batch_size (config.py:106). */
+int avd_mlp_layout_init(avd_mlp_layout* out, int S, int A, int H1, int H2, int Ha, int B);
+
+/* ---- environment ------------------------------------------------------------
+ * Replaces Platoon.step (src/environment.py:209-241) + Vehicle.step (:460-518)
+ * + get_exogenous_info (:253-269) + get_reward (:271-282) for P platoons at once.
+ *   x_in  [P][L][4]  state before the step      x_out [P][L][4] state after (may alias x_in)
+ *   prev_a[P][L]     prev_x[2], in/out           cum_accel [P][L] in/out or NULL (velocity/headway aux)
+ *   u     [P][L]     actions                     leader_exog [P]
+ *   reward[P][L]     NEGATED reward (as returned by Vehicle.step)   term [P][L] (0/1) or NULL
+ *   done  [P]        any(term) per platoon       reward_mean [P] centralized mean or NULL
+ *   any_done         single int32 OR-accumulated over all platoons (trainer.py:268) or NULL;
+ *                    the caller zeroes it. */
+int avd_env_step_f32(const avd_env_consts* d_consts, int P, int L, const float* x_in, float* x_out, float* prev_a,
+                     float* cum_accel, const float* u, const float* leader_exog, float* reward, uint8_t* term,
+                     uint8_t* done, float* reward_mean, int32_t* any_done, void* stream);
+
+/* Replaces Platoon.reset / Vehicle.reset (src/environment.py:284-301, 520-559).
+ *   mode 0 = training (random states), 1 = evaluator constants, 2 = rand_states=False constants.
+ *   draws [P][L][3] pre-drawn, already scaled values (host-RNG parity mode) or NULL = device Philox
+ *   front_accel [P] pre-drawn leader accel or NULL (device RNG: N(0, leader_reset_a)).
+ *   cond        device int32 or NULL: when given, the reset happens only if *cond != 0 (the
+ *               any-terminal episode break of workers/trainer.py:268-269 without a host sync). */
+int avd_env_reset_f32(const avd_env_consts* d_consts, int P, int L, float* x, float* prev_a, float* cum_accel,
+                      const float* draws, const float* front_accel, int mode, uint64_t seed, uint64_t counter,
+                      const int32_t* cond, void* stream);
+
+/* Aux read-outs used by the evaluator/renderer (environment.py:243-251, 477, 500-503), from the
+ * PRE-step state that produced them: jerk = (x2 - prev_a)/T is computed by the caller from the
+ * buffers; no kernel needed. */
+
+/* ---- exploration noise + policy ----------------------------------------------
+ * OUActionNoise.__call__ (src/noise.py:14-23) for n independent scalar processes.
+ *   normals [n] pre-drawn N(0,1) or NULL = device Philox (seed, counter). */
+int avd_ou_step_f32(int n, float* ou_state, const float* normals, float theta, float mean, float dt, float std_dev,
+                    uint64_t seed, uint64_t counter, void* stream);
+
+/* ddpgagent.policy (agent/ddpgagent.py:6-29): action = clip(actor_out + noise, lo, hi).
+ *   noise [n] or NULL (evaluator: no noise). */
+int avd_policy_f32(int n, const float* actor_out, const float* noise, float lo, float hi, float* action,
+                   void* stream);
+
+/* Leader exogenous input N(0, std) per platoon per step (workers/trainer.py:291-295), device Philox. */
+int avd_normal_f32(int n, float* out, float std_dev, uint64_t seed, uint64_t counter, void* stream);
+
+/* ---- replay buffer (src/replaybuffer.py:5-63) ----------------------------------
+ * ring [n_agents][cap][row] float32, row = [s(S) a(A) r(1) s2(S)], row = 2S+A+1.
+ * add: writes slot (counter % cap) of every agent (:40-47).
+ *   s_prev/s_next: [n_agents] rows of `x_stride` floats, first S used (Model A hides x[3], environment.py:518). */
+int avd_replay_add_f32(int n_agents, int cap, int S, int A, float* ring, int64_t counter, const float* s_prev,
+                       const float* s_next, int x_stride, const float* action, const float* reward, void* stream);
+
+/* Uniform indices with replacement in [0, range) (np.random.choice(range, B), :52-54) from device
+ * Philox: idx[a][b] = mulhi32(philox(seed, counter, a, b), range). Host-RNG parity mode uploads
+ * numpy's own indices instead. */
+int avd_replay_indices(int n_agents, int B, int range, uint64_t seed, uint64_t counter, int32_t* idx, void* stream);
+
+/* gather (:57-61): s[n][B][S], a[n][B][A], r[n][B], s2[n][B][S] <- ring rows idx[n][B]. */
+int avd_replay_gather_f32(int n_agents, int cap, int S, int A, int B, const float* ring, const int32_t* idx, float* s,
+                          float* a, float* r, float* s2, void* stream);
+
+/* ---- actor / critic -------------------------------------------------------------
+ * Weight-set addressing shared by the calls below: agent v uses set (set_mod > 0 ? v % set_mod : v)
+ * -- set_mod = 0: one weight set per agent (reference `nofrl`, workers/trainer.py:100-149);
+ *    set_mod = M: one set per vehicle index shared by all platoons (interfrl+gradients keeps
+ *    them bit-identical, workers/trainer.py:415-425). */
+
+/* actor(state) (agent/model.py:26-36, called at workers/trainer.py:287-289): out[v] = tanh(.)*high
+ * for n_agents rows of `x_stride` floats (first S used). */
+int avd_actor_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
+                          const float* state, int x_stride, float high, float* out, void* stream);
+
+/* critic([state, action]) -> q[n_agents] (agent/model.py:63-83); rows as above, batch 1 per agent. */
+int avd_critic_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                           const float* stats, const float* state, int x_stride, const float* action, float* q,
+                           void* stream);
+
+/* Trainer.learn (workers/trainer.py:472-508) for n_agents batches of B rows:
+ *   y = r + gamma*Q'(s2, mu'(s2)); Lc = mean((y-Q(s,a))^2); La = -mean(Q(s, mu(s)))
+ *   grads [n_agents][theta_size]: actor block = dLa/dactor, critic block = dLc/dcritic (pre-update weights)
+ *   losses [n_agents][2] = (Lc, La) or NULL. */
+int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
+                  const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                  const float* s2, float gamma, float high, float* grads, float* losses, void* stream);
+
+/* Adam x2 (critic then actor; tf.keras.optimizers.Adam defaults, workers/trainer.py:138-139, 348-349)
+ * followed by ddpgagent.update_target over ALL weights incl. BN stats (agent/ddpgagent.py:31-55;
+ * workers/trainer.py:352-356), fused per element, for n_sets weight sets.
+ *   grads [n_sets][theta_size]; step [n_sets] = Adam iteration count AFTER this update (>= 1). */
+int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
+                        float* stats_t, float* m, float* v, const float* grads, const int32_t* step, float actor_lr,
+                        float critic_lr, double tau, void* stream);
+
+/* update_target alone (agent/ddpgagent.py:31-55): t = w*tau + t*(1-tau) over n floats. */
+int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream);
+
+/* ---- federated averaging (src/server/federated.py:18-122; workers/trainer.py:400-431) ----
+ * out[m][j] = sum_p (w[p][m] or 1) * g[p][m][j]  -- the local partial sum a rank contributes to the
+ * RCCL all-reduce; g is [P][M][n]. weights [P][M] or NULL. wsum [M] (sum of weights) or NULL. */
+int avd_fed_sum_f32(int P, int M, int n, const float* g, const float* weights, float* out, float* wsum, void* stream);
+/* finalize: unweighted (wsum == NULL): out[m][j] /= count (tf.reduce_mean, federated.py:62);
+ * weighted: out[m][j] *= (1/wsum[m]) (federated.py:110). */
+int avd_fed_finalize_f32(int M, int n, float* out, float count, const float* wsum, void* stream);
+/* broadcast rows: dst[p][m][:] = src[m][:] (weights-aggregation mode, workers/trainer.py:448-456). */
+int avd_broadcast_sets_f32(int P, int M, int n, const float* src, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVDDPG_HIP_H */

@@ -1,0 +1,114 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports every symbol the header declares,
+and the host-side structs/layout agree with it. No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from avddpg_amd import _hip, config, dynamics, params
+
+
+def _declared():
+    text = open(_hip.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(avd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _hip.lib()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/avddpg_hip.h but not exported"
+    assert lib.avd_version() >= 1
+    # every int-returning entry point has a ctypes prototype in the binding
+    assert set(names) - {"avd_last_error", "avd_version"} == set(_hip._PROTOS)
+
+
+def test_error_reporting_without_gpu():
+    with pytest.raises(_hip.AvdError, match="non-positive"):
+        _hip.make_layout(4, 1, 0, 128, 48, 64)
+    # argument validation happens before any HIP call
+    with pytest.raises(_hip.AvdError, match="L must be"):
+        _hip.call("avd_env_step_f32", None, 4, 99, None, None, None, None, None, None, None, None, None, None, None, None)
+    lay = _hip.make_layout(12, 3, 307, 153, 57, 64)  # centralized widths: declared unsupported, loudly
+    with pytest.raises(_hip.AvdError, match="only A == 1"):
+        _hip.call("avd_learn_f32", ctypes.byref(lay), 1, 0, *([None] * 8), 0.99, 2.5, None, None, None)
+
+
+def test_layout_matches_reference_parameter_counts():
+    lay = _hip.make_layout(4, 1, 256, 128, 48, 64)
+    # SURVEY a-9/a-10: 35 073 actor + 41 409 critic trainables, 768 + 864 moving stats
+    a = sum(int(np.prod(shp(lay))) for _, k, shp in params.ACTOR_WEIGHTS if k == "t")
+    c = sum(int(np.prod(shp(lay))) for _, k, shp in params.CRITIC_WEIGHTS if k == "t")
+    assert (a, c) == (35073, 41409)
+    assert lay.actor_size == 35076 and lay.theta_size == 35076 + 41412 and lay.stats_size == 1632
+    assert len(params.ACTOR_WEIGHTS) == 14 and len(params.CRITIC_WEIGHTS) == 20
+    for f in _hip._LAYOUT_FIELDS[6:]:
+        assert getattr(lay, f) % 4 == 0
+
+
+def test_pack_unpack_roundtrip_and_init_bounds():
+    lay = _hip.make_layout(3, 1, 64, 32, 16, 64)
+    th, st = params.init_weights(lay, np.random.RandomState(0))
+    aw = params.unpack(lay, th, st, "actor")
+    cw = params.unpack(lay, th, st, "critic")
+    assert [w.shape for w in aw][:2] == [(3, 64), (64,)] and cw[12].shape == (64 + 16, 32)
+    assert np.abs(aw[0]).max() <= 1 / np.sqrt(64) and np.abs(aw[6]).max() <= 1 / np.sqrt(32)
+    assert np.abs(aw[12]).max() <= 0.003 and np.abs(cw[18]).max() <= 0.0003
+    assert np.abs(cw[2]).max() <= 1 / np.sqrt(32)  # action layer uses layer2_init (agent/model.py:70)
+    assert np.all(aw[2] == 1) and np.all(aw[5] == 1) and np.all(aw[4] == 0) and np.all(aw[1] == 0)
+    th2, st2 = np.zeros_like(th), np.zeros_like(st)
+    params.pack(lay, aw, th2, st2, "actor")
+    params.pack(lay, cw, th2, st2, "critic")
+    assert np.array_equal(th, th2) and np.array_equal(st, st2)
+    with pytest.raises(ValueError):
+        params.pack(lay, aw[:-1], th2, st2, "actor")
+
+
+def test_env_consts_match_oracle_matrices():
+    from oracle import platoon
+
+    for method in ("euler", "exact"):
+        conf = config.Config(method=method, dyn_coeff=0.25, pl_leader_tau=0.15, timegap=0.8, sample_rate=0.05)
+        c = dynamics.env_consts(conf, 5)
+        ep = platoon.EnvParams(method=method, dyn_coeff=0.25, pl_leader_tau=0.15, timegap=0.8, sample_rate=0.05)
+        A, B, Cm = platoon.platoon_matrices(ep, 5)
+        for i in range(5):
+            assert np.array_equal(np.array(list(c.A[i]), dtype=np.float32), A[i].astype(np.float32).ravel())
+            assert np.array_equal(np.array(list(c.B[i]), dtype=np.float32), B[i].astype(np.float32))
+            assert np.array_equal(np.array(list(c.C[i]), dtype=np.float32), Cm[i].astype(np.float32))
+    assert ctypes.sizeof(_hip.EnvConsts) == 4 * 4 + 20 * 4 + 16 * 24 * 4
+    with pytest.raises(ValueError):
+        dynamics.env_consts(config.Config(), 17)
+
+
+def test_config_defaults_and_derived_counts():
+    c = config.Config()
+    assert (c.steps_per_episode, c.number_of_episodes, c.fed_update_delay_steps) == (600, 1666, 1)
+    assert c.fed_enabled is False and config.Config(fed_method="interfrl").fed_enabled is True
+    with pytest.raises(AttributeError):
+        config.Config(not_a_field=1)
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "avddpg_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_philox_known_answers():
+    """Random123 Philox4x32-10 known-answer vectors for the oracle's restatement of the device RNG."""
+    from oracle import philox
+    z = np.array([0])
+    assert [int(v[0]) for v in philox.philox4x32_10(z, z, z, z, 0, 0)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    o = np.array([0xffffffff])
+    assert [int(v[0]) for v in philox.philox4x32_10(o, o, o, o, 0xffffffff, 0xffffffff)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    idx = philox.replay_indices(3, 64, 1000, seed=1, counter=0)
+    assert idx.shape == (3, 64) and idx.dtype == np.int32 and idx.min() >= 0 and idx.max() < 1000
