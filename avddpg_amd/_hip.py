@@ -64,9 +64,9 @@ _PROTOS = {
     "avd_learn_f32": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P],
     "avd_adam_polyak_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
     "avd_polyak_f32": [_i64, _P, _P, _d, _P],
-    "avd_fed_sum_f32": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],
     "avd_fed_finalize_f32": [_i, _i, _P, _f, _P, _P],
-    "avd_broadcast_sets_f32": [_i, _i, _i, _P, _P, _P],
+    "avd_fed_scatter_f32": [_i, _i, _i, _i, _i, _i, _P, _P, _P],
 }
 
 _lib = None

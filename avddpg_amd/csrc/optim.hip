@@ -55,32 +55,33 @@ __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __rest
         t[i] = w[i] * tau + t[i] * omt;
 }
 
-// out[m][j] = sum_p (w[p][m]) * g[p][m][j]; one thread per (m, 4 j's), p in fixed order (reproducible)
-__global__ __launch_bounds__(256) void fed_sum_kernel(int P, int M, int n, const float4* __restrict__ g,
+// out[o][j] = sum_i w[row(o,i)] * g[row(o,i)][j]; one thread per (o, 4 j's), i in fixed order (reproducible)
+__global__ __launch_bounds__(256) void fed_sum_kernel(int n_in, int so, int si, int n, const float4* __restrict__ g,
                                                       const float* __restrict__ weights, float4* __restrict__ out,
                                                       float* __restrict__ wsum) {
     const int n4 = n / 4;
-    const int mset = blockIdx.y;
+    const int o = blockIdx.y;
     if (wsum && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += weights[p * M + mset];
-        wsum[mset] = s;
+        for (int i = 0; i < n_in; ++i) s += weights[(long)o * so + (long)i * si];
+        wsum[o] = s;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += gridDim.x * blockDim.x) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = 0; p < P; ++p) {
-            const float4 x = g[((long)p * M + mset) * n4 + i];
-            const float w = weights ? weights[p * M + mset] : 1.0f;
+        for (int i = 0; i < n_in; ++i) {
+            const long row = (long)o * so + (long)i * si;
+            const float4 x = g[row * n4 + j];
+            const float w = weights ? weights[row] : 1.0f;
             acc.x += w * x.x, acc.y += w * x.y, acc.z += w * x.z, acc.w += w * x.w;
         }
-        out[(long)mset * n4 + i] = acc;
+        out[(long)o * n4 + j] = acc;
     }
 }
 
-__global__ void fed_finalize_kernel(int M, int n, float* __restrict__ out, float count,
+__global__ void fed_finalize_kernel(int n_out, int n, float* __restrict__ out, float count,
                                     const float* __restrict__ wsum) {
 #pragma clang fp contract(off)
-    const long total = (long)M * n;
+    const long total = (long)n_out * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         if (wsum)
             out[i] = (1.0f / wsum[i / n]) * out[i];  // federated.py:110
@@ -89,13 +90,14 @@ __global__ void fed_finalize_kernel(int M, int n, float* __restrict__ out, float
     }
 }
 
-__global__ void broadcast_sets_kernel(int P, int M, int n, const float4* __restrict__ src, float4* __restrict__ dst) {
-    const long n4 = n / 4;
-    const long total = (long)P * M * n4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pm = i / n4;
-        dst[i] = src[(pm % M) * n4 + (i - pm * n4)];
-    }
+// grid: (blocks over n/4, n_in - i_begin, n_out)
+__global__ void fed_scatter_kernel(int so, int si, int i_begin, int n, const float4* __restrict__ src,
+                                   float4* __restrict__ dst) {
+    const int n4 = n / 4;
+    const int o = blockIdx.z, i = blockIdx.y + i_begin;
+    const long row = (long)o * so + (long)i * si;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += gridDim.x * blockDim.x)
+        dst[row * n4 + j] = src[(long)o * n4 + j];
 }
 
 }  // namespace avd
@@ -136,30 +138,35 @@ extern "C" int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, v
     return check_launch("avd_polyak_f32");
 }
 
-extern "C" int avd_fed_sum_f32(int P, int M, int n, const float* g, const float* weights, float* out, float* wsum,
-                               void* stream) {
-    AVD_REQUIRE(P > 0 && M > 0 && n > 0 && n % 4 == 0 && g && out, "avd_fed_sum_f32: P=%d M=%d n=%d", P, M, n);
+extern "C" int avd_fed_sum_f32(int n_out, int n_in, int stride_out, int stride_in, int n, const float* g,
+                               const float* weights, float* out, float* wsum, void* stream) {
+    AVD_REQUIRE(n_out > 0 && n_in > 0 && n > 0 && n % 4 == 0 && g && out, "avd_fed_sum_f32: n_out=%d n_in=%d n=%d",
+                n_out, n_in, n);
+    AVD_REQUIRE(n_out <= 65535, "avd_fed_sum_f32: n_out=%d exceeds the grid limit", n_out);
     AVD_REQUIRE(!wsum || weights, "avd_fed_sum_f32: wsum requested without weights");
     int gx = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(fed_sum_kernel, dim3(gx, M), dim3(256), 0, (hipStream_t)stream, P, M, n, (const float4*)g,
-                       weights, (float4*)out, wsum);
+    hipLaunchKernelGGL(fed_sum_kernel, dim3(gx, n_out), dim3(256), 0, (hipStream_t)stream, n_in, stride_out,
+                       stride_in, n, (const float4*)g, weights, (float4*)out, wsum);
     return check_launch("avd_fed_sum_f32");
 }
 
-extern "C" int avd_fed_finalize_f32(int M, int n, float* out, float count, const float* wsum, void* stream) {
-    AVD_REQUIRE(M > 0 && n > 0 && out && (wsum || count > 0.f), "avd_fed_finalize_f32: M=%d n=%d", M, n);
-    long blocks = ((long)M * n + 255) / 256;
+extern "C" int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float* wsum, void* stream) {
+    AVD_REQUIRE(n_out > 0 && n > 0 && out && (wsum || count > 0.f), "avd_fed_finalize_f32: n_out=%d n=%d", n_out, n);
+    long blocks = ((long)n_out * n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fed_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, n, out,
+    hipLaunchKernelGGL(fed_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_out, n, out,
                        count, wsum);
     return check_launch("avd_fed_finalize_f32");
 }
 
-extern "C" int avd_broadcast_sets_f32(int P, int M, int n, const float* src, float* dst, void* stream) {
-    AVD_REQUIRE(P > 0 && M > 0 && n > 0 && n % 4 == 0 && src && dst, "avd_broadcast_sets_f32: P=%d M=%d n=%d", P, M, n);
-    long blocks = ((long)P * M * (n / 4) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(broadcast_sets_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, M, n,
-                       (const float4*)src, (float4*)dst);
-    return check_launch("avd_broadcast_sets_f32");
+extern "C" int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n,
+                                   const float* src, float* dst, void* stream) {
+    AVD_REQUIRE(n_out > 0 && n_in > 0 && i_begin >= 0 && i_begin < n_in && n > 0 && n % 4 == 0 && src && dst,
+                "avd_fed_scatter_f32: n_out=%d n_in=%d i_begin=%d n=%d", n_out, n_in, i_begin, n);
+    AVD_REQUIRE(n_out <= 65535 && n_in <= 65535, "avd_fed_scatter_f32: group counts exceed the grid limit");
+    int gx = (n / 4 + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(fed_scatter_kernel, dim3(gx, n_in - i_begin, n_out), dim3(256), 0, (hipStream_t)stream,
+                       stride_out, stride_in, i_begin, n, (const float4*)src, (float4*)dst);
+    return check_launch("avd_fed_scatter_f32");
 }

@@ -1,0 +1,296 @@
+"""Training loop over the HIP kernels: counterpart of reference ``workers/trainer.py``.
+
+``VecTrainer`` reproduces the control flow of ``Trainer.run`` (:223-280), ``advance_environment``
+(:282-302), ``train_all_models`` (:304-359) and the federated branches (:400-456) for P platoons at
+once: all state lives in HBM, one kernel launch per stage per step, no per-platoon Python.
+
+``Trainer`` keeps the reference's constructor / ``initialize()`` / ``run()`` / ``learn()`` names on top of
+it (reporting -- CSV, plots, model files -- is out of scope of this hot path).
+
+Weight-set regimes (the reference always holds P x M separate agents):
+  * per-agent  : one weight set per (platoon, vehicle)  -- nofrl, intrafrl, and any interfrl schedule
+                 in which agents can diverge between federated steps;
+  * shared     : one weight set per vehicle index -- interfrl + gradients when EVERY update is a
+                 federated one (fed_update_delay_steps == 1, fed_update_count == 1, no cutoff): the
+                 reference's P copies then stay bit-identical (same init :121-128, same averaged
+                 gradients through identical Adam states :415-425), so a single copy is exact.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import vec
+from ._hip import call, ptr, stream_handle
+
+log = logging.getLogger(__name__)
+
+
+# ---- schedule predicates, same names and semantics as workers/trainer.py:631-695 ------------------
+def is_fed_enabled(conf):
+    return (conf.fed_method == conf.interfrl or conf.fed_method == conf.intrafrl) and (conf.framework == conf.dcntrl)
+
+
+def is_gradient_updates_enabled(conf):
+    return conf.aggregation_method == conf.gradients
+
+
+def is_model_weight_updates_enabled(conf):
+    return conf.aggregation_method == conf.weights
+
+
+def is_weighted_fed_enabled(conf, training_episode):
+    return conf.weighted_average_enabled and training_episode >= conf.weighted_window
+
+
+def is_valid_update_episode(conf, training_episode):
+    return conf.fed_enabled and (training_episode % conf.fed_update_count) == 0 and \
+        training_episode <= conf.fed_cutoff_episode
+
+
+def is_valid_update_step(conf, training_step):
+    return (training_step % conf.fed_update_delay_steps) == 0
+
+
+def is_valid_step_for_federated_training_with_gradients(conf, training_episode, training_step):
+    return is_fed_enabled(conf) and is_valid_update_episode(conf, training_episode) and \
+        is_valid_update_step(conf, training_step) and is_gradient_updates_enabled(conf)
+
+
+def is_valid_step_for_federated_training_with_weights(conf, training_episode, training_step):
+    return is_fed_enabled(conf) and is_valid_update_episode(conf, training_episode) and \
+        is_valid_update_step(conf, training_step) and is_model_weight_updates_enabled(conf)
+
+
+class VecTrainer:
+    def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False):
+        """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
+        (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
+        sync per step); needs rng='device'."""
+        conf.refresh()
+        self.conf, self.rng, self.group = conf, rng, group
+        self.device = torch.device(device if device is not None else "cuda")
+        self.P, self.M = conf.num_platoons, conf.pl_size
+        if conf.framework != conf.dcntrl:
+            raise NotImplementedError("centralized framework: next-tier row of SURVEY section 8(f)")
+        seed = conf.random_seed if seed is None else seed
+        self.env = vec.VecPlatoon(self.P, self.M, conf, self.device, rand_states=conf.rand_states, rng=rng, seed=seed)
+        self.S, self.A = self.env.num_states, self.env.num_actions
+        n_agents = self.P * self.M
+        self.n_agents = n_agents
+        self.ou = vec.VecOUNoise(n_agents, conf, self.device, rng=rng, seed=seed)
+        fed = is_fed_enabled(conf)
+        can_share = (fed and conf.fed_method == conf.interfrl and is_gradient_updates_enabled(conf)
+                     and conf.fed_update_delay_steps == 1 and conf.fed_update_count == 1
+                     and conf.fed_cutoff_ratio >= 1.0)
+        self.shared = can_share if shared_sets is None else bool(shared_sets)
+        if self.shared and not can_share:
+            raise ValueError("shared weight sets are only exact for interfrl+gradients with every step federated")
+        self.set_mod = self.M if self.shared else 0
+        self.agents = vec.AgentGroup(self.M if self.shared else n_agents, self.S, self.A, conf, self.device, seed=seed)
+        self.replay = vec.VecReplay(n_agents, conf.buffer_size, conf.batch_size, self.S, self.A, self.device, rng=rng,
+                                    seed=seed)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.actor_out = torch.zeros(n_agents, **f32)
+        self.actions = torch.zeros(self.P, self.M, **f32)  # self.actions[p][m] (trainer.py:179)
+        self.leader_exog = torch.zeros(self.P, **f32)
+        self.grads = torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
+        self.losses = torch.zeros(n_agents, 2, **f32)
+        self.ep_reward = torch.zeros(self.P, self.M, **f32)  # float32 accumulators (trainer.py:249, 321)
+        self.all_ep_reward_lists = [[[] for _ in range(self.M)] for _ in range(self.P)]
+        self.all_avg_reward_lists = [[[] for _ in range(self.M)] for _ in range(self.P)]
+        self.fed_weights = None
+        self.exog_calls = 0
+        self.seed = seed
+        self.auto_reset = auto_reset
+        if auto_reset and rng != "device":
+            raise ValueError("auto_reset needs rng='device'")
+        self.episode, self.ep_step = 0, 0
+        self.updates = 0  # agent-updates (one agent's learn + Adam x2 + Polyak)
+        self.env_steps = 0  # platoon-steps
+
+    # ------------------------------------------------------------------------------------------
+    def reset_episode(self):
+        """trainer.py:244-249"""
+        self.env.reset()
+        self.ep_reward.zero_()
+        self.ep_step = 0
+
+    def _act(self):
+        """advance_environment (trainer.py:282-302): actor -> OU noise -> clip, leader exog, env step."""
+        conf, P, M = self.conf, self.P, self.M
+        states = self.env.x.view(P * M, 4)
+        self.agents.actor(states, self.set_mod, x_stride=4, out=self.actor_out)
+        if self.rng == "host":
+            # reference draw order per platoon: M OU normals, then the leader exog (trainer.py:286-295)
+            normals = np.empty((P, M))
+            exog = np.empty(P)
+            for p in range(P):
+                for m in range(M):
+                    normals[p, m] = np.random.normal(0, 1.0)
+                exog[p] = (np.random.uniform(-conf.reset_max_u, conf.reset_max_u) if conf.rand_gen == conf.uniform
+                           else np.random.normal(0, conf.reset_max_u))
+            noise = self.ou(normals.reshape(-1))
+            self.leader_exog.copy_(torch.from_numpy(exog.astype(np.float32)))
+        else:
+            noise = self.ou()
+            call("avd_normal_f32", P, ptr(self.leader_exog), conf.reset_max_u, self.seed, self.exog_calls,
+                 stream_handle())
+            self.exog_calls += 1
+        call("avd_policy_f32", self.n_agents, ptr(self.actor_out), ptr(noise), conf.action_low, conf.action_high,
+             ptr(self.actions), stream_handle())
+        self.env.any_done.zero_()
+        self.env.step(self.actions, self.leader_exog)
+
+    def _weights_for_fed(self, ep):
+        """trainer.py:385-398: w = |1 / mean(last `weighted_window` episodic rewards)| per agent."""
+        w = np.empty((self.P, self.M), dtype=np.float32)
+        for p in range(self.P):
+            for m in range(self.M):
+                w[p, m] = abs(1 / np.mean(self.all_ep_reward_lists[p][m][-self.conf.weighted_window:]))
+        return torch.from_numpy(w).to(self.device)
+
+    def _train(self, ep, i):
+        """train_all_models + federated branches (trainer.py:304-359, 400-456)."""
+        conf, P, M = self.conf, self.P, self.M
+        env = self.env
+        self.replay.add(env.x_prev.view(P * M, 4), self.actions.view(P * M, 1), env.reward.view(-1),
+                        env.x.view(P * M, 4), 4)
+        self.ep_reward += env.reward
+        if not self.replay.buffer_counter > conf.batch_size:  # strict gate: first update after the 65th add (:322)
+            return
+        s, a, r, s2 = self.replay.sample()
+        self.agents.learn(s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
+        self.updates += self.n_agents
+        fed = is_fed_enabled(conf)
+        if not fed or not is_valid_update_step(conf, i):
+            # local update (:345-356); note the gate tests the step only, not the episode (SURVEY 8a FRL quirk)
+            if self.shared:
+                raise RuntimeError("local update requested in shared-set mode")
+            self.agents.apply(self.grads)
+            return
+        weights = None
+        if is_weighted_fed_enabled(conf, ep):
+            if self.fed_weights is None or self.fed_weights[0] != ep:
+                self.fed_weights = (ep, self._weights_for_fed(ep))
+            weights = self.fed_weights[1]
+        method = conf.fed_method
+        if is_valid_step_for_federated_training_with_gradients(conf, ep, i):
+            avg = vec.fed_mean(self.grads, P, M, weights=weights, group=self.group, method=method)
+            if self.shared:
+                self.agents.apply(avg)
+            else:
+                i_begin = 1 if (method == conf.intrafrl and conf.intra_directional_averaging) else 0
+                if i_begin:
+                    # the lead vehicle gets no update at all on a federated step (:417-418): zero grads would
+                    # still move Adam moments, so it is handled by restoring its slabs after the apply
+                    raise NotImplementedError("intra_directional_averaging: next-tier (SURVEY 8f-2)")
+                vec.fed_scatter(avg, self.grads, P, M, method)
+                self.agents.apply(self.grads)
+        elif is_valid_step_for_federated_training_with_weights(conf, ep, i):
+            raise NotImplementedError("aggregation_method='weights': next-tier (SURVEY 8f-2)")
+        # else: FRL on, valid step, but not a valid update episode -> no parameter update at all
+
+    def step(self, ep=None, i=None, sync=True):
+        """One iteration of the loop at trainer.py:251-271. Returns the any-terminal flag (host bool)
+        when ``sync`` (parity mode); with auto_reset the episode bookkeeping stays on the device."""
+        ep = self.episode if ep is None else ep
+        i = self.ep_step if i is None else i
+        self._act()
+        self._train(ep, i)
+        self.env_steps += self.P
+        self.ep_step += 1
+        if self.auto_reset:
+            # any platoon terminal ends the episode for ALL platoons (:268-269); so does the step limit
+            if self.ep_step >= self.conf.steps_per_episode:
+                self.env.reset()
+                self.ep_step = 0
+                self.episode += 1
+            else:
+                self.env.reset(cond=self.env.any_done)
+            return None
+        if not sync:
+            return None
+        done = bool(self.env.any_done.item())
+        if self.group is not None:
+            import torch.distributed as dist
+            flag = self.env.any_done.clone()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            done = bool(flag.item())
+        return done
+
+    def update_reward_list(self, ep):
+        """trainer.py:510-517 (float32 counters, trailing mean over reward_averaging_window)."""
+        rew = self.ep_reward.cpu().numpy()
+        for p in range(self.P):
+            for m in range(self.M):
+                self.all_ep_reward_lists[p][m].append(rew[p, m])
+                self.all_avg_reward_lists[p][m].append(
+                    np.mean(self.all_ep_reward_lists[p][m][-self.conf.reward_averaging_window:]))
+
+    def run(self, number_of_episodes=None):
+        """trainer.py:232-273"""
+        conf = self.conf
+        n = conf.number_of_episodes if number_of_episodes is None else number_of_episodes
+        for ep in range(n):
+            self.episode = ep
+            self.reset_episode()
+            for i in range(conf.steps_per_episode):
+                if self.step(ep, i):
+                    break
+            self.update_reward_list(ep)
+        return self.all_ep_reward_lists, self.all_avg_reward_lists
+
+
+class Trainer:
+    """Reference-shaped facade (workers/trainer.py:18-61, 223): ``Trainer(base_dir, timestamp, debug_enabled,
+    conf)``, ``initialize()``, ``run()``. Host-RNG parity mode by default."""
+
+    def __init__(self, base_dir, timestamp, debug_enabled, conf, rng="host", device=None):
+        self.base_dir, self.timestamp, self.debug_enabled, self.conf = base_dir, timestamp, debug_enabled, conf
+        self.rng, self.device = rng, device
+        self.engine = None
+
+    def initialize(self):
+        self.conf.timestamp = str(self.timestamp)
+        self.conf.fed_enabled = is_fed_enabled(self.conf)
+        self.engine = VecTrainer(self.conf, device=self.device, rng=self.rng)
+        self.num_models, self.num_platoons = self.engine.M, self.engine.P
+        self.num_states, self.num_actions = self.engine.S, self.engine.A
+        self.all_ep_reward_lists = self.engine.all_ep_reward_lists
+        self.all_avg_reward_lists = self.engine.all_avg_reward_lists
+
+    def run(self, number_of_episodes=None):
+        return self.engine.run(number_of_episodes)
+
+
+def learn(rbuffer, actor_model, critic_model, target_actor, target_critic, gamma=0.99):
+    """``Trainer.learn`` (workers/trainer.py:472-508) on reference-shaped objects: samples ``rbuffer`` and
+    returns (critic_grad[14], actor_grad[10]) as lists in ``trainable_variables`` order. Pure w.r.t. the
+    model weights."""
+    from . import _hip, params
+
+    lay = actor_model.lay
+    s, a, r, s2 = rbuffer.sample()
+    A = lay.actor_size
+    theta = torch.cat([actor_model.theta[:, :A], critic_model.theta[:, A:]], dim=1).contiguous()
+    theta_t = torch.cat([target_actor.theta[:, :A], target_critic.theta[:, A:]], dim=1).contiguous()
+
+    def stats_of(act, cri):
+        st = act.stats.clone()
+        st[:, lay.cmms:] = cri.stats[:, lay.cmms:]
+        return st
+
+    stats, stats_t = stats_of(actor_model, critic_model), stats_of(target_actor, target_critic)
+    grads = torch.empty(1, lay.theta_size, dtype=torch.float32, device=theta.device)
+    call("avd_learn_f32", _hip.C.byref(lay), 1, 1, ptr(theta), ptr(stats), ptr(theta_t), ptr(stats_t),
+         ptr(s.reshape(1, lay.B, lay.S).contiguous()), ptr(a.reshape(1, lay.B, lay.A).contiguous()),
+         ptr(r.reshape(1, lay.B).contiguous()), ptr(s2.reshape(1, lay.B, lay.S).contiguous()), gamma,
+         actor_model.high, ptr(grads), None, stream_handle())
+    g = grads[0].cpu().numpy()
+    dummy = np.zeros(lay.stats_size, dtype=np.float32)
+    return (params.unpack(lay, g, dummy, "critic", trainable_only=True),
+            params.unpack(lay, g, dummy, "actor", trainable_only=True))
+
+
+Trainer.learn = staticmethod(learn)

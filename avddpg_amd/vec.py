@@ -80,13 +80,27 @@ class VecPlatoon:
         return 0 if self.rand_states else 2
 
     def _host_ctor_draws(self):
-        c = self.config
-        for _ in range(self.P):
-            self._rand(c.pl_leader_reset_a)
-            self._rand(c.reset_max_u)
+        """Platoon.__init__ (:24, :32) then Vehicle.__init__ -> reset (:385): front_accel, front_u, 3 per vehicle."""
+        c, P, L = self.config, self.P, self.L
+        self.front_accel = np.zeros(P)
+        self.front_u = np.zeros(P)
+        draws = np.zeros((P, L, 3), dtype=np.float64)
+        for p in range(P):
+            self.front_accel[p] = self._rand(c.pl_leader_reset_a)
+            self.front_u[p] = self._rand(c.reset_max_u)
             if self._mode() == 0:
-                for _ in range(3 * self.L):
-                    self._rand(1.0)
+                for i in range(L):
+                    draws[p, i, 0] = self._rand(c.reset_ep_max)
+                    draws[p, i, 1] = self._rand(c.reset_max_ev)
+                    draws[p, i, 2] = self._rand(c.reset_max_a)
+        self._upload_reset(draws, self.front_accel)
+
+    def _upload_reset(self, draws, fa, cond=None):
+        d = torch.from_numpy(draws.astype(np.float32)).to(self.device) if draws is not None else None
+        f = torch.from_numpy(np.asarray(fa, dtype=np.float32)).to(self.device) if fa is not None else None
+        call("avd_env_reset_f32", ptr(self.d_consts), self.P, self.L, ptr(self.x), ptr(self.prev_a),
+             ptr(self.cum_accel), ptr(d), ptr(f), self._mode(), self.seed, self.reset_count, ptr(cond),
+             stream_handle())
 
     def _host_reset_draws(self):
         c, P, L = self.config, self.P, self.L
@@ -96,11 +110,12 @@ class VecPlatoon:
         for p in range(P):  # Platoon.reset (:284-301): front_accel, then per vehicle front_u (+3 state draws)
             fa[p] = self._rand(c.pl_leader_reset_a)
             for i in range(L):
-                self._rand(c.reset_max_u)
+                self.front_u[p] = self._rand(c.reset_max_u)  # kept: Platoon.step(leader_exog=None) falls back to it
                 if train:
                     draws[p, i, 0] = self._rand(c.reset_ep_max)
                     draws[p, i, 1] = self._rand(c.reset_max_ev)
                     draws[p, i, 2] = self._rand(c.reset_max_a)
+        self.front_accel = fa.copy()
         return draws, fa
 
     # -- API ------------------------------------------------------------------------------------
@@ -116,12 +131,8 @@ class VecPlatoon:
         if self.rng == "host":
             if cond is not None:
                 raise ValueError("conditional reset needs rng='device'")
-            d, f = self._host_reset_draws()
-            draws = torch.from_numpy(d.astype(np.float32)).to(self.device)
-            fa = torch.from_numpy(f.astype(np.float32)).to(self.device)
-        call("avd_env_reset_f32", ptr(self.d_consts), self.P, self.L, ptr(self.x), ptr(self.prev_a),
-             ptr(self.cum_accel), ptr(draws), ptr(fa), self._mode(), self.seed, self.reset_count, ptr(cond),
-             stream_handle())
+            draws, fa = self._host_reset_draws()
+        self._upload_reset(draws, fa, cond)
         self.reset_count += 1
         return self.observations()
 
@@ -307,20 +318,36 @@ class AgentGroup:
                 params.unpack(self.lay, g, dummy, "actor", trainable_only=True))
 
 
-def fed_mean(grads, P, M, weights=None, group=None):
-    """Federated average over platoons of grads [P*M, n] (agent id v = p*M + m) -> [M, n]
-    (reference src/server/federated.py:47-63 / :99-118).  With a torch.distributed ``group`` of
-    ranks each holding P platoons, the local sums are all-reduced (RCCL) before the division."""
+def fed_mean(grads, P, M, weights=None, group=None, method="interfrl"):
+    """Federated average of per-agent rows grads[P*M, n] (agent id v = p*M + m)
+    (reference src/server/federated.py:47-63 / :99-118).
+      interfrl: mean over platoons  -> [M, n];  intrafrl: mean over a platoon's vehicles -> [P, n].
+    With a torch.distributed ``group`` whose ranks each hold P platoons, interfrl's local sums are
+    all-reduced (RCCL over xGMI) before the division; intrafrl never leaves the GPU."""
     n = grads.shape[-1]
-    out = torch.empty(M, n, dtype=torch.float32, device=grads.device)
-    wsum = torch.empty(M, dtype=torch.float32, device=grads.device) if weights is not None else None
-    call("avd_fed_sum_f32", P, M, n, ptr(grads), ptr(weights), ptr(out), ptr(wsum), stream_handle())
-    count = float(P)
-    if group is not None:
+    if method == "interfrl":
+        n_out, n_in, so, si = M, P, 1, M
+    elif method == "intrafrl":
+        n_out, n_in, so, si = P, M, M, 1
+    else:
+        raise ValueError(method)
+    out = torch.empty(n_out, n, dtype=torch.float32, device=grads.device)
+    wsum = torch.empty(n_out, dtype=torch.float32, device=grads.device) if weights is not None else None
+    call("avd_fed_sum_f32", n_out, n_in, so, si, n, ptr(grads), ptr(weights), ptr(out), ptr(wsum), stream_handle())
+    count = float(n_in)
+    if group is not None and method == "interfrl":
         import torch.distributed as dist
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
         if wsum is not None:
             dist.all_reduce(wsum, op=dist.ReduceOp.SUM, group=group)
-        count = float(P * dist.get_world_size(group))
-    call("avd_fed_finalize_f32", M, n, ptr(out), count, ptr(wsum), stream_handle())
+        count = float(n_in * dist.get_world_size(group))
+    call("avd_fed_finalize_f32", n_out, n, ptr(out), count, ptr(wsum), stream_handle())
     return out
+
+
+def fed_scatter(avg, dst, P, M, method="interfrl", i_begin=0):
+    """Write each group's average back to its member agents' rows of dst[P*M, n]."""
+    n = avg.shape[-1]
+    n_out, n_in, so, si = (M, P, 1, M) if method == "interfrl" else (P, M, M, 1)
+    call("avd_fed_scatter_f32", n_out, n_in, so, si, i_begin, n, ptr(avg), ptr(dst), stream_handle())
+    return dst

@@ -176,15 +176,22 @@ int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, flo
 /* update_target alone (agent/ddpgagent.py:31-55): t = w*tau + t*(1-tau) over n floats. */
 int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream);
 
-/* ---- federated averaging (src/server/federated.py:18-122; workers/trainer.py:400-431) ----
- * out[m][j] = sum_p (w[p][m] or 1) * g[p][m][j]  -- the local partial sum a rank contributes to the
- * RCCL all-reduce; g is [P][M][n]. weights [P][M] or NULL. wsum [M] (sum of weights) or NULL. */
-int avd_fed_sum_f32(int P, int M, int n, const float* g, const float* weights, float* out, float* wsum, void* stream);
-/* finalize: unweighted (wsum == NULL): out[m][j] /= count (tf.reduce_mean, federated.py:62);
- * weighted: out[m][j] *= (1/wsum[m]) (federated.py:110). */
-int avd_fed_finalize_f32(int M, int n, float* out, float count, const float* wsum, void* stream);
-/* broadcast rows: dst[p][m][:] = src[m][:] (weights-aggregation mode, workers/trainer.py:448-456). */
-int avd_broadcast_sets_f32(int P, int M, int n, const float* src, float* dst, void* stream);
+/* ---- federated averaging (src/server/federated.py:18-122; workers/trainer.py:400-456) ----
+ * Agents are rows of g[n_out*n_in][n]; row of (o, i) = o*stride_out + i*stride_in.
+ *   interfrl (average vehicle m over platoons, trainer.py:186-187): n_out=M, n_in=P, stride_out=1, stride_in=M
+ *   intrafrl (average the vehicles inside platoon p, :189-190):    n_out=P, n_in=M, stride_out=M, stride_in=1
+ * out[o][j] = sum_i (w[row(o,i)] or 1) * g[row(o,i)][j], i ascending (reproducible) -- the local partial
+ * sum a rank contributes to the RCCL all-reduce. weights [n_out*n_in] or NULL; wsum [n_out] or NULL. */
+int avd_fed_sum_f32(int n_out, int n_in, int stride_out, int stride_in, int n, const float* g, const float* weights,
+                    float* out, float* wsum, void* stream);
+/* finalize: unweighted (wsum == NULL): out[o][j] /= count (tf.reduce_mean, federated.py:62);
+ * weighted: out[o][j] *= (1/wsum[o]) (federated.py:110). */
+int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float* wsum, void* stream);
+/* scatter group rows back to agents: dst[row(o,i)][:] = src[o][:] for i >= i_begin
+ * (each agent receives its group's average, trainer.py:415-425, 448-456; i_begin = 1 skips the lead
+ * vehicle under intra_directional_averaging, :417-418). */
+int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n, const float* src,
+                        float* dst, void* stream);
 
 #ifdef __cplusplus
 }

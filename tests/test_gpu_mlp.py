@@ -101,14 +101,17 @@ def test_learn_gradients_match_oracle(S, set_mod):
         k = v % set_mod if set_mod else v
         nets64 = _nets(grp, k, np.float64)
         cg, ag, aux = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *nets64, gamma=conf.gamma, high=2.5)
+        cg32, ag32, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp, k, np.float32), gamma=conf.gamma, high=2.5)
         gcg, gag = grp.grads_as_lists(grads[v])
         assert abs(losses[v, 0].item() - aux["critic_loss"]) <= 1e-4 * max(1.0, abs(aux["critic_loss"]))
         assert abs(losses[v, 1].item() - aux["actor_loss"]) <= 1e-4 * max(1.0, abs(aux["actor_loss"]))
-        for i, (got, ref) in enumerate(zip(gcg, cg)):
+        # tolerance: GRAD_TOL of the tensor's max, or -- for cancellation-prone sums such as
+        # dbeta3 = W3 * sum_r dq[r] -- 4x the error a float32 CPU implementation (the f32 oracle) makes
+        for i, (got, ref, r32) in enumerate(zip(gcg, cg, cg32)):
             assert got.shape == ref.shape
-            assert _relerr(got, ref) <= GRAD_TOL, ("critic", v, i, _relerr(got, ref))
-        for i, (got, ref) in enumerate(zip(gag, ag)):
-            assert _relerr(got, ref) <= GRAD_TOL, ("actor", v, i, _relerr(got, ref))
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref)), ("critic", v, i, _relerr(got, ref))
+        for i, (got, ref, r32) in enumerate(zip(gag, ag, ag32)):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref)), ("actor", v, i, _relerr(got, ref))
         assert np.max(np.abs(ag[0])) > 1e-8 and np.max(np.abs(cg[0])) > 1e-8  # non-degenerate case
     # alignment padding of the slab stays zero
     lay = grp.lay
@@ -198,12 +201,17 @@ def test_federated_mean_unweighted_and_weighted():
     ww = np.array([[2.0], [1.0]], np.float32)
     o = vec.fed_mean(t(tab).reshape(2, 4), 2, 1, weights=t(ww)).cpu().numpy()
     assert np.allclose(o[0, :3], (2 * np.array([1, 2, 3.]) + np.array([10, 11, 12.])) / 3)
-    # broadcast (weights-aggregation mode)
-    from avddpg_amd._hip import call, ptr, stream_handle
-    dst = torch.empty(P * M, n, device="cuda")
-    src = t(out)
-    call("avd_broadcast_sets_f32", P, M, n, ptr(src), ptr(dst), stream_handle())
-    assert torch.equal(dst.reshape(P, M, n)[11], src)
+    # intrafrl: mean over the vehicles of each platoon
+    outi = vec.fed_mean(t(g).reshape(P * M, n), P, M, method="intrafrl").cpu().numpy()
+    assert np.allclose(outi, g.mean(axis=1), rtol=1e-5, atol=1e-6)
+    # scatter each group's average back to its members (directional: skip the lead vehicle)
+    dst = torch.zeros(P * M, n, device="cuda")
+    vec.fed_scatter(t(out), dst, P, M, "interfrl")
+    assert torch.equal(dst.reshape(P, M, n)[11], t(out))
+    dst.zero_()
+    vec.fed_scatter(t(outi), dst, P, M, "intrafrl", i_begin=1)
+    d = dst.reshape(P, M, n).cpu().numpy()
+    assert np.all(d[:, 0] == 0) and np.array_equal(d[:, 3], outi)
 
 
 def test_unsupported_shapes_fail_loudly():

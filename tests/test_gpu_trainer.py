@@ -1,0 +1,177 @@
+"""GPU parity of the whole loop: the vectorised trainer vs the oracle's reference-shaped Python loop
+(same global legacy RNG stream, same initial weights), the shared-vs-per-agent interfrl equivalence,
+and the reference-shaped object API (Platoon / OUActionNoise / ReplayBuffer / get_actor / policy /
+update_target / Trainer.learn)."""
+import numpy as np
+import pytest
+import torch
+
+from avddpg_amd import config, ddpgagent, environment, model, noise, replaybuffer, trainer
+from oracle import mlp as omlp
+from oracle import platoon as oplatoon
+from oracle import trainer as otrainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _copy_weights_to_oracle(vt, ref):
+    for p in range(vt.P):
+        for m in range(vt.M):
+            k = m if vt.shared else p * vt.M + m
+            ref.actors[p][m] = vt.agents.get_weights(k, "actor")
+            ref.critics[p][m] = vt.agents.get_weights(k, "critic")
+            ref.t_actors[p][m] = vt.agents.get_weights(k, "actor", target=True)
+            ref.t_critics[p][m] = vt.agents.get_weights(k, "critic", target=True)
+
+
+@pytest.mark.parametrize("fed_method", ["normal", "interfrl"])
+def test_vectorised_loop_matches_reference_shaped_oracle_loop(fed_method):
+    P, L, steps = 2, 3, 72
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, fed_method=fed_method,
+                         weighted_average_enabled=False)
+    # --- oracle run (records the trajectory) ---
+    np.random.seed(1)
+    vt0 = trainer.VecTrainer(conf, rng="host", shared_sets=False)  # only to obtain identical initial weights
+    ref = otrainer.RefTrainer(oplatoon.EnvParams(), P, L, seed=1, buffer_size=128, fed_method=fed_method)
+    _copy_weights_to_oracle(vt0, ref)
+    ref.reset_episode()
+    traj = []
+    for i in range(steps):
+        done = ref.step()
+        traj.append((ref.actions.copy(), np.array([[np.asarray(s) for s in ref.prev_states[p]] for p in range(P)]), done))
+        assert not done
+    next_draw_ref = np.random.normal(0, 1)
+    # --- product run on the GPU, same seed ---
+    np.random.seed(1)
+    vt = trainer.VecTrainer(conf, rng="host", shared_sets=False)
+    assert torch.equal(vt.agents.theta, vt0.agents.theta)
+    vt.reset_episode()
+    for i in range(steps):
+        done = vt.step(0, i)
+        act = vt.actions.cpu().numpy()
+        x = vt.env.x.cpu().numpy()
+        tol = 1e-5 if i < 65 else 2e-3  # after the first Adam steps f32 rounding is amplified by m/sqrt(v)
+        assert np.allclose(act, traj[i][0][..., 0], rtol=0, atol=tol * 2.5), (i, np.abs(act - traj[i][0][..., 0]).max())
+        assert np.allclose(x, traj[i][1], rtol=0, atol=tol * np.maximum(1.0, np.abs(traj[i][1]))), i
+        assert done == traj[i][2]
+    assert np.random.normal(0, 1) == next_draw_ref  # identical consumption of the global RNG stream
+    assert vt.replay.buffer_counter == steps and vt.updates == (steps - 64) * P * L == ref.updates
+    assert np.allclose(vt.ep_reward.cpu().numpy(), np.array(ref.ep_reward), rtol=1e-4)
+    # weights after 8 updates: close to the oracle's (Adam turns 1e-4 gradient differences on tiny-gradient
+    # elements into O(lr) differences, hence the two-level bound)
+    for p in range(P):
+        for m in range(L):
+            k = p * L + m
+            for which, refw, lr in (("actor", ref.actors[p][m], conf.actor_lr), ("critic", ref.critics[p][m], conf.critic_lr)):
+                for got, want in zip(vt.agents.get_weights(k, which), refw):
+                    d = np.abs(got - want)
+                    assert d.max() <= 2 * lr * (steps - 64) and d.mean() <= 0.05 * lr * (steps - 64), (which, d.max(), d.mean())
+    if fed_method == "interfrl":  # every platoon's vehicle-m agent stays bit-identical
+        th = vt.agents.theta.reshape(P, L, -1)
+        assert torch.equal(th[0], th[1])
+        assert not torch.equal(th[0, 0], th[0, 1])
+
+
+def test_shared_sets_equal_per_agent_sets_under_interfrl():
+    """interfrl + gradients with every step federated: ONE weight set per vehicle index gives bit-identical
+    weights and trajectories to the reference's P x M separate agents."""
+    P, L, steps = 4, 3, 70
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+    runs = []
+    for shared in (False, True):
+        np.random.seed(3)
+        vt = trainer.VecTrainer(conf, rng="host", shared_sets=shared)
+        vt.reset_episode()
+        for i in range(steps):
+            vt.step(0, i)
+        runs.append(vt)
+    a, b = runs
+    assert b.agents.n_sets == L and a.agents.n_sets == P * L
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.actions, b.actions)
+    assert torch.equal(a.agents.theta.reshape(P, L, -1)[2], b.agents.theta)
+    assert torch.equal(a.agents.theta_t.reshape(P, L, -1)[0], b.agents.theta_t)
+    assert int(b.agents.step[0]) == steps - 64
+
+
+def test_device_rng_throughput_mode_runs_and_learns_shapes():
+    conf = config.Config(num_platoons=64, pl_size=5, buffer_size=256)
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=True)
+    vt.reset_episode()
+    for _ in range(80):
+        vt.step()
+    torch.cuda.synchronize()
+    assert vt.updates == (80 - 64) * 64 * 5 and vt.env_steps == 80 * 64
+    assert torch.isfinite(vt.agents.theta).all() and torch.isfinite(vt.env.x).all()
+    assert not torch.equal(vt.agents.theta[0], vt.agents.theta[1])  # independent agents diverge
+    assert (vt.losses[:, 0] >= 0).all()
+
+
+def test_reference_object_api_roundtrip():
+    """A trainer written against the reference's object API (workers/trainer.py:71-171, 282-356) runs
+    unchanged against the avddpg_amd objects, and matches the oracle objects step by step."""
+    conf = config.Config(pl_size=3, buffer_size=100)
+    ep = oplatoon.EnvParams()
+    np.random.seed(5)
+    env = environment.Platoon(conf.pl_size, conf, 0, rand_states=conf.rand_states)
+    ou = [noise.OUActionNoise(mean=np.zeros(1), config=conf) for _ in range(env.num_models)]
+    actor = model.get_actor(env.num_states, env.num_actions, conf.action_high, seed_int=conf.random_seed,
+                            hidd_mult=env.hidden_multiplier, layer1_size=conf.actor_layer1_size,
+                            layer2_size=conf.actor_layer2_size)
+    critic = model.get_critic(env.num_states, env.num_actions, hidd_mult=env.hidden_multiplier,
+                              layer1_size=conf.critic_layer1_size, layer2_size=conf.critic_layer2_size,
+                              action_layer_size=conf.critic_act_layer_size)
+    t_actor = model.get_actor(env.num_states, env.num_actions, conf.action_high, seed_int=conf.random_seed,
+                              layer1_size=conf.actor_layer1_size, layer2_size=conf.actor_layer2_size)
+    t_critic = model.get_critic(env.num_states, env.num_actions, layer1_size=conf.critic_layer1_size,
+                                layer2_size=conf.critic_layer2_size, action_layer_size=conf.critic_act_layer_size)
+    t_actor.set_weights(actor.get_weights())
+    t_critic.set_weights(critic.get_weights())
+    assert [w.shape for w in actor.get_weights()] == [(4, 256), (256,), (256,), (256,), (256,), (256,), (256, 128),
+                                                      (128,), (128,), (128,), (128,), (128,), (128, 1), (1,)]
+    assert len(critic.weights) == 20 and len(critic.trainable_variables) == 14 and len(actor.trainable_variables) == 10
+    rb = replaybuffer.ReplayBuffer(conf.buffer_size, conf.batch_size, env.num_states, env.num_actions, conf.pl_size)
+    # oracle twins on the same RNG stream
+    st = np.random.get_state()
+    np.random.seed(5)
+    oenv = oplatoon.RefPlatoon(conf.pl_size, ep)
+    np.random.set_state(st)
+    prev = env.reset()
+    np.random.set_state(st)
+    oprev = oenv.reset()
+    assert np.allclose(np.array(prev), np.array(oprev), rtol=1e-6)
+    aw = [w.astype(np.float64) for w in actor.get_weights()]
+    actions = np.zeros((env.num_models, env.num_actions))
+    for step in range(70):
+        for m in range(env.num_models):
+            st = np.random.get_state()
+            actions[m] = ddpgagent.policy(actor(np.asarray(prev[m])[None]), ou[m], conf.action_low, conf.action_high)[0]
+            np.random.set_state(st)
+            nz = np.random.normal(0, 1.0, size=1)  # the draw OUActionNoise made
+            assert abs(actions[m, 0]) <= 2.5
+        ex = np.random.normal(0, conf.reset_max_u)
+        states, rewards, done = env.step(actions.flatten(), ex)
+        ostates, orewards, odone = oenv.step(actions.flatten(), ex)
+        assert np.allclose(np.array(states), np.array(ostates), rtol=1e-5, atol=1e-5) and done == odone
+        assert np.allclose(rewards, orewards, rtol=1e-5, atol=1e-7)
+        assert np.allclose(np.array(env.get_jerk()), np.array(oenv.get_jerk()), rtol=1e-3, atol=1e-4)
+        rb.add((prev[0], actions[0], rewards[0], states[0]))
+        prev = states
+    assert rb.buffer_counter == 70 > conf.batch_size
+    np.random.seed(11)
+    cg, ag = trainer.Trainer.learn(rb, actor, critic, t_actor, t_critic)
+    np.random.seed(11)
+    idx = np.random.choice(70, 64)
+    ring = rb._v.ring.cpu().numpy()[0]
+    batch = (ring[idx, 0:4], ring[idx, 4:5], ring[idx, 5:6], ring[idx, 6:10])
+    nets = [[w.astype(np.float64) for w in n.get_weights()] for n in (actor, critic, t_actor, t_critic)]
+    ocg, oag, _ = omlp.learn(batch, *nets)
+    for got, ref in zip(cg + ag, ocg + oag):
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-4 * max(1e-12, np.max(np.abs(ref)))
+    tc, ta = ddpgagent.update_target(conf.tau, t_critic.weights, critic.weights, t_actor.weights, actor.weights)
+    otc, ota = omlp.update_target(conf.tau, t_critic.weights, critic.weights, t_actor.weights, actor.weights)
+    for got, ref in zip(tc + ta, otc + ota):
+        assert np.array_equal(got, ref)
+    t_critic.set_weights(tc)
+    assert np.array_equal(t_critic.get_weights()[0], tc[0])
+    with pytest.raises(ValueError):  # reference refuses platoons longer than its colour table, after construction
+        environment.Platoon(7, conf, 0)
