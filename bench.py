@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s + DDPG updates/s of the avddpg hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic platoons on each GPU:
+  actor forward -> OU noise -> clip -> leader exog -> platoon step -> replay add -> replay sample
+  -> Trainer.learn (5 forwards, 2 backwards, B=64 per agent) -> Adam x2 + Polyak -> episode reset.
+Workload (BASELINE.json configs[1]): 4096 platoons x 5 vehicles per GPU, reference `nofrl` DDPG = one
+independent actor/critic/target/Adam/replay set per (platoon, vehicle) = 20480 agents, f32, replay at its
+steady state (capacity 100000 rows per agent, full).  `--mode interfrl` runs configs[3]'s federated variant
+(one weight set per vehicle index, gradients averaged over platoons and all-reduced across ranks with RCCL).
+
+Launch: python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run, one rank per GPU)
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
+LEARN_FLOP_PER_SAMPLE = 0.751e6  # 5 forwards + 2 backwards per replay sample
+ADAM_BYTES_PER_AGENT = 2.47e6  # r/w of W, W_target, m, v per agent-update
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--platoons", type=int, default=4096, help="platoons per GPU")
+    ap.add_argument("--pl-size", type=int, default=5)
+    ap.add_argument("--buffer-size", type=int, default=100000)
+    ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds, pl_size):
+    """The oracle's reference-shaped Python loop (oracle/trainer.py, kind "port": TensorFlow is not installable,
+    so the NN arithmetic is NumPy float32) on ONE host thread -- the reference's own setting (src/rand.py:14-15)."""
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+
+    from oracle import platoon, trainer
+
+    P = 2
+    with threadpool_limits(limits=1):
+        tr = trainer.RefTrainer(platoon.EnvParams(), P, pl_size, seed=1, buffer_size=4096)
+        tr.reset_episode()
+        for _ in range(65):  # replay warm-up: updates start at the 65th add
+            if tr.step():
+                tr.reset_episode()
+        n, t0, u0 = 0, time.perf_counter(), tr.updates
+        while time.perf_counter() - t0 < seconds:
+            if tr.step():
+                tr.reset_episode()
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": P * n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "updates_per_s": (tr.updates - u0) / dt,
+            "sample": f"{P} platoons x {pl_size} vehicles (={P * pl_size} agents), nofrl, {n} training steps after a "
+                      f"65-step replay warm-up, {dt:.1f} s on 1 thread; the per-platoon cost of the reference loop "
+                      "does not depend on the number of platoons"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    from avddpg_amd import config, trainer
+
+    P, L = args.platoons, args.pl_size
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
+                         fed_method="interfrl" if args.mode == "interfrl" else "normal",
+                         weighted_average_enabled=False, random_seed=1 + rank)
+    vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
+                            seed=1 + rank)
+    # synthetic steady state: replay rings full of random-init-platoon-like rows
+    ring = vt.replay.ring
+    chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
+    for a0 in range(0, ring.shape[0], chunk):
+        ring[a0:a0 + chunk].normal_(0.0, 1.0)
+    vt.replay.buffer_counter = args.buffer_size
+    vt.reset_episode()
+
+    # per-stage HIP events on the launch stream (torch's current stream is the one handed to the C ABI)
+    names = ("act+env", "replay", "learn", "update")
+    ev = {n: [] for n in names}
+
+    def timed(stage, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        ev[stage].append((e0, e1))
+
+    def one_step(record):
+        if not record:
+            vt.step()
+            return
+        ep, i = vt.episode, vt.ep_step
+        timed("act+env", vt._act)
+        split = {}
+
+        def replay_part():
+            env = vt.env
+            vt.replay.add(env.x_prev.view(P * L, 4), vt.actions.view(P * L, 1), env.reward.view(-1),
+                          env.x.view(P * L, 4), 4)
+            vt.ep_reward += env.reward
+            split["batch"] = vt.replay.sample()
+
+        timed("replay", replay_part)
+        timed("learn", lambda: vt.agents.learn(*split["batch"], vt.set_mod, grads=vt.grads, losses=vt.losses))
+
+        def update_part():
+            if vt.shared:
+                from avddpg_amd import vec
+                vt.agents.apply(vec.fed_mean(vt.grads, P, L, group=vt.group))
+            else:
+                vt.agents.apply(vt.grads)
+
+        timed("update", update_part)
+        vt.updates += vt.n_agents
+        vt.env_steps += P
+        vt.ep_step += 1
+        if vt.ep_step >= conf.steps_per_episode:
+            vt.env.reset()
+            vt.ep_step = 0
+            vt.episode += 1
+        else:
+            vt.env.reset(cond=vt.env.any_done)
+
+    for _ in range(args.warmup):
+        one_step(False)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stage_ms = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / max(1, len(ev[n])) for n in names}
+    n_agents = P * L
+    env_steps_per_s = world * P * args.steps / elapsed
+    updates_per_s = world * n_agents * args.steps / elapsed
+    learn_s = stage_ms["learn"] / 1e3
+    upd_s = stage_ms["update"] / 1e3
+    roof_learn = {"kernel": "learn_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / learn_s / 1e12,
+                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+    if args.mode == "nofrl":
+        roof_upd = {"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / upd_s / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+    else:
+        roof_upd = None
+    for r in (roof_learn, roof_upd):
+        if r:
+            r["frac"] = r["achieved"] / r["peak"]
+    dominant = roof_learn if (roof_upd is None or learn_s >= upd_s) else roof_upd
+
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec + DDPG updates/sec, 4096x5-vehicle platoons",
+            "value": env_steps_per_s,
+            "unit": "env-steps/s",
+            "updates_per_s": updates_per_s,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
+                                   + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
+                                      if args.mode == "nofrl" else
+                                      "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads")
+                                   + f", B=64, replay capacity {args.buffer_size} (full), 1 update per env step",
+                       "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": args.mode,
+                       "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
+            "stages_ms": stage_ms,
+            "kernels": [r for r in (roof_learn, roof_upd) if r],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
