@@ -21,7 +21,9 @@ constexpr int TILE = 64;       // batch rows per workgroup (= batch_size 64, con
 constexpr int NTHREADS = 256;  // 4 waves, one per SIMD
 constexpr float BN_EPS = 1e-3f;
 
-__host__ __device__ inline int ld_of(int k) { return k + 2; }  // (ld/2) odd -> conflict-free 16-row x 2-col b32 reads
+// LDS row stride: a multiple of 4 floats (16-byte rows for b128 reads) with (ld/4) odd so that 16 consecutive rows
+// start on 16 different 4-bank slots
+__host__ __device__ inline int ld_of(int k) { return ((k >> 2) & 1) ? k : k + 4; }
 
 struct Net {  // pointers into one weight set
     const float* th;
@@ -72,87 +74,115 @@ __device__ __forceinline__ float out_layer_row(const float* P, int ld, const flo
     return acc + b;  // valid in all 4 lanes of row r
 }
 
-template <int MT, int NT, typename FA, typename FB>
-__device__ __forceinline__ void mfma_tiles(f32x4 (&acc)[MT][NT], int ksteps, FA fa, FB fb) {
-#pragma unroll 2
-    for (int ks = 0; ks < ksteps; ++ks) {
-        float a[MT], b[NT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = fa(m, ks);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = fb(n, ks);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// MFMA operand conventions used below (v_mfma_f32_16x16x4_f32, lane = 16*lg + lr):
+//   A[i = lr][kk = lg], B[kk = lg][j = lr], D[i = 4*lg + reg][j = lr].
+// The reduction index kk and the tile column j may be permuted freely as long as A and B agree, so every
+// routine picks the permutation that turns its operand fetches into 8/16-byte accesses:
+//   * reduction permuted: the 4 MFMAs of a 16-deep block take kk = 4*lg + jj (jj = 0..3) -> one b128 per block;
+//   * columns permuted:   n-tile t holds columns base + NT*lr + t -> one NT-float load feeds NT tiles.
+
+constexpr int FWD_RING = 4;  // B-operand register ring: blocks of 16 k in flight ahead of the MFMAs
 
 // Forward hidden layer: out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]); X,out in LDS, W global [K][N].
+// K % 16 == 0, N % 32 == 0. Wave w owns columns [32w, 32w+32) (+128 per pass).
 __device__ __forceinline__ void gemm_fwd_relu(const float* X, int ldx, const float* inv, const float* sh, int K,
                                               const float* __restrict__ W, const float* __restrict__ b, int N,
                                               float* out, int ldo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int nblk = K >> 4;
     for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
         f32x4 acc[4][2];
 #pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wp = W + (long)(4 * lg) * N + n0 + 2 * lr;  // row k = 16*blk + 4*lg + jj, columns n0+2lr, +1
+        f32x2 ring[FWD_RING][4];
+#pragma unroll
+        for (int d = 0; d < FWD_RING - 1; ++d)
+            if (d < nblk)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) ring[d][jj] = *(const f32x2*)(wp + (long)(16 * d + jj) * N);
+        for (int kb = 0; kb < nblk; kb += FWD_RING) {
+#pragma unroll
+            for (int d = 0; d < FWD_RING; ++d) {
+                const int blk = kb + d;
+                if (blk < nblk) {
+                    const int pre = blk + FWD_RING - 1;
+                    if (pre < nblk)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            ring[(d + FWD_RING - 1) % FWD_RING][jj] = *(const f32x2*)(wp + (long)(16 * pre + jj) * N);
+                    const int k4 = 16 * blk + 4 * lg;
+                    const f32x4 iv = *(const f32x4*)(inv + k4);
+                    const f32x4 sf = *(const f32x4*)(sh + k4);
+                    f32x4 a[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x4 xv = *(const f32x4*)(X + (m * 16 + lr) * ldx + k4);
+                        a[m] = xv * iv + sf;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            acc[m][0] = MFMA16(a[m][jj], ring[d][jj][0], acc[m][0]);
+                            acc[m][1] = MFMA16(a[m][jj], ring[d][jj][1], acc[m][1]);
+                        }
+                }
+            }
+        }
+        const f32x2 bc = *(const f32x2*)(b + n0 + 2 * lr);
+#pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool two = (n0 + 16) < N;  // N multiple of 16; second 16-col tile may be absent
-        mfma_tiles<4, 2>(
-            acc, K / 4,
-            [&](int m, int ks) {
-                const int k = ks * 4 + lg;
-                return fmaf(X[(m * 16 + lr) * ldx + k], inv[k], sh[k]);
-            },
-            [&](int n, int ks) {
-                const int col = n0 + n * 16 + lr;
-                return (n == 0 || two) ? W[(ks * 4 + lg) * N + col] : 0.f;
-            });
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (n == 1 && !two) break;
-            const int col = n0 + n * 16 + lr;
-            const float bc = b[col];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) out[(m * 16 + lg * 4 + j) * ldo + col] = fmaxf(acc[m][n][j] + bc, 0.f);
-        }
+            for (int j = 0; j < 4; ++j) {
+                f32x2 o;
+                o[0] = fmaxf(acc[m][0][j] + bc[0], 0.f);
+                o[1] = fmaxf(acc[m][1][j] + bc[1], 0.f);
+                *(f32x2*)(out + (m * 16 + lg * 4 + j) * ldo + n0 + 2 * lr) = o;
+            }
     }
 }
 
-// Weight gradient of a hidden layer fed by a BN output:
+// Weight gradient of a hidden layer fed by a BN output (all operands in LDS):
 //   dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n]   for k < K, n < N  -> global gW[k*N + n]
+// Output tile (ta, tb) of a 64x32 block holds rows k0 + 4*i + ta (i = 4*lg + reg) and columns n0 + 2*lr + tb.
 __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* inv, const float* sh, int K,
                                         const float* DZ, int ldz, const float* db, int N, float* __restrict__ gW) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
-        const bool two = (n0 + 16) < N;
+        const f32x2 dbc = *(const f32x2*)(db + n0 + 2 * lr);
         for (int k0 = 0; k0 < K; k0 += 64) {
-            const int mt = min(4, (K - k0) / 16);
             f32x4 acc[4][2];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* pp = P + lg * ldp + k0 + 4 * lr;  // may read past K in the last block: those rows are not stored
+            const float* dp = DZ + lg * ldz + n0 + 2 * lr;
+#pragma unroll 4
+            for (int r = 0; r < TILE; r += 4) {
+                const f32x4 pa = *(const f32x4*)(pp + r * ldp);
+                const f32x2 dz = *(const f32x2*)(dp + r * ldz);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mfma_tiles<4, 2>(
-                acc, TILE / 4,
-                [&](int m, int ks) { return (m < mt) ? P[(ks * 4 + lg) * ldp + k0 + m * 16 + lr] : 0.f; },
-                [&](int n, int ks) { return (n == 0 || two) ? DZ[(ks * 4 + lg) * ldz + n0 + n * 16 + lr] : 0.f; });
+                for (int ta = 0; ta < 4; ++ta) {
+                    acc[ta][0] = MFMA16(pa[ta], dz[0], acc[ta][0]);
+                    acc[ta][1] = MFMA16(pa[ta], dz[1], acc[ta][1]);
+                }
+            }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                if (n == 1 && !two) break;
-                const int col = n0 + n * 16 + lr;
-                const float dbc = db[col];
+            for (int j = 0; j < 4; ++j) {
+                const int kbase = k0 + 4 * (lg * 4 + j);
+                if (kbase < K) {  // K % 4 == 0: the four ta rows are valid together
+                    const f32x4 iv = *(const f32x4*)(inv + kbase);
+                    const f32x4 sf = *(const f32x4*)(sh + kbase);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (m >= mt) break;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = k0 + m * 16 + lg * 4 + j;
-                        gW[k * N + col] = fmaf(inv[k], acc[m][n][j], sh[k] * dbc);
+                    for (int ta = 0; ta < 4; ++ta) {
+                        f32x2 o;
+                        o[0] = fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]);
+                        o[1] = fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1]);
+                        *(f32x2*)(gW + (long)(kbase + ta) * N + n0 + 2 * lr) = o;
                     }
                 }
             }
@@ -160,46 +190,79 @@ __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* in
     }
 }
 
+constexpr int DX_NB = 8;  // reduction blocks of 16 held in registers per tile (N <= 128 per pass)
+
 // Input gradient of a hidden layer + BN/ReLU backward of the layer below, in place:
 //   dy[r][c] = sum_n DZ[r][n] * W[c][n]               (c in [c_begin, c_end), W global [K][N])
 //   dgamma[c] = sum_r dy*(p - mm[c])*rs[c];  dbeta[c] = sum_r dy;  P[r][c] <- dy * rs*g * (p > 0)
 // g/mm/mv/dg/dbe are indexed by (c - c_begin).  dg == nullptr skips the parameter gradients.
+// 16-column tiles round-robin over the waves; a tile's whole W slice (16 x N) is fetched with N/16 16-byte
+// loads per lane, the NEXT tile's slice being requested before the current tile's MFMAs start.
 __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, const float* __restrict__ W, int c_begin,
                                            int c_end, float* P, int ldp, const float* __restrict__ g,
                                            const float* __restrict__ mm, const float* __restrict__ mv,
                                            float* __restrict__ dg, float* __restrict__ dbe) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    for (int c0 = c_begin + wave * 16; c0 < c_end; c0 += 4 * 16) {
-        f32x4 acc[4][1];
+    {
+        const int nb0 = 0;  // single reduction pass: N <= 16*DX_NB (checked on the host)
+        const int nblk = N >> 4;
+        f32x4 wc[DX_NB], wn[DX_NB];
+        int c0 = c_begin + wave * 16;
+        if (c0 < c_end) {
+            const float* wrow = W + (long)(c0 + lr) * N + nb0 + 4 * lg;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wrow = W + (long)(c0 + lr) * N;
-        mfma_tiles<4, 1>(
-            acc, N / 4, [&](int m, int ks) { return DZ[(m * 16 + lr) * ldz + ks * 4 + lg]; },
-            [&](int, int ks) { return wrow[ks * 4 + lg]; });
-        const int c = c0 + lr;
-        const float rs = 1.0f / sqrtf(mv[c - c_begin] + BN_EPS);
-        const float gam = g[c - c_begin];
-        const float mean = mm[c - c_begin];
-        float sg = 0.f, sb = 0.f;
+            for (int q = 0; q < DX_NB; ++q)
+                if (q < nblk) wc[q] = *(const f32x4*)(wrow + 16 * q);
+        }
+        for (; c0 < c_end; c0 += 4 * 16) {
+            const int cn = c0 + 4 * 16;
+            if (cn < c_end) {
+                const float* wrow = W + (long)(cn + lr) * N + nb0 + 4 * lg;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = m * 16 + lg * 4 + j;
-                const float dy = acc[m][0][j];
-                const float p = P[r * ldp + c];
-                sg = fmaf(dy * (p - mean), rs, sg);
-                sb += dy;
-                P[r * ldp + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+                for (int q = 0; q < DX_NB; ++q)
+                    if (q < nblk) wn[q] = *(const f32x4*)(wrow + 16 * q);
             }
-        sg += __shfl_xor(sg, 16);
-        sg += __shfl_xor(sg, 32);
-        sb += __shfl_xor(sb, 16);
-        sb += __shfl_xor(sb, 32);
-        if (dg && lg == 0) {
-            dg[c - c_begin] = sg;
-            dbe[c - c_begin] = sb;
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < DX_NB; ++q) {
+                if (q < nblk) {
+                    f32x4 a[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[m] = *(const f32x4*)(DZ + (m * 16 + lr) * ldz + nb0 + 16 * q + 4 * lg);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[m][jj], wc[q][jj], acc[m]);
+                }
+            }
+            const int c = c0 + lr;
+            const float rs = 1.0f / sqrtf(mv[c - c_begin] + BN_EPS);
+            const float gam = g[c - c_begin];
+            const float mean = mm[c - c_begin];
+            float sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = m * 16 + lg * 4 + j;
+                    const float dy = acc[m][j];
+                    const float p = P[r * ldp + c];
+                    sg = fmaf(dy * (p - mean), rs, sg);
+                    sb += dy;
+                    P[r * ldp + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+                }
+            sg += __shfl_xor(sg, 16);
+            sg += __shfl_xor(sg, 32);
+            sb += __shfl_xor(sb, 16);
+            sb += __shfl_xor(sb, 32);
+            if (dg && lg == 0) {
+                dg[c - c_begin] = sg;
+                dbe[c - c_begin] = sb;
+            }
+#pragma unroll
+            for (int q = 0; q < DX_NB; ++q) wc[q] = wn[q];
         }
     }
 }
@@ -675,6 +738,11 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
                              float* losses, void* stream) {
     int rc = check_mlp_dims(lay, "avd_learn_f32");
     if (rc) return rc;
+    if (lay->H2 % 32 || lay->H2 > 16 * DX_NB) {
+        set_error("avd_learn_f32: layer2 size %d; the tile kernel implements H2 %% 32 == 0 and H2 <= %d", lay->H2,
+                  16 * DX_NB);
+        return AVD_E_UNSUPPORTED;
+    }
     if (lay->B != TILE) {
         set_error("avd_learn_f32: batch_size=%d; the tile kernel implements B == %d", lay->B, TILE);
         return AVD_E_UNSUPPORTED;
