@@ -25,6 +25,31 @@ constexpr float BN_EPS = 1e-3f;
 // start on 16 different 4-bank slots
 __host__ __device__ inline int ld_of(int k) { return ((k >> 2) & 1) ? k : k + 4; }
 
+#ifdef AVD_PHASE_TIMING
+// Diagnostic build only (tools/phase_profile.py): per-phase shader-cycle sums of workgroup thread 0.
+__device__ unsigned long long g_phase_cycles[32];
+#define PH_INIT() unsigned long long ph_last = clock64()
+#define PH(id)                                                                  \
+    do {                                                                        \
+        if (threadIdx.x == 0) {                                                 \
+            const unsigned long long ph_now = clock64();                        \
+            atomicAdd(&g_phase_cycles[id], ph_now - ph_last);                   \
+            ph_last = ph_now;                                                   \
+        }                                                                       \
+    } while (0)
+#define PH_ARG , unsigned long long& ph_last
+#define PH_PASS , ph_last
+#else
+#define PH_INIT()
+#define PH(id)
+#define PH_ARG
+#define PH_PASS
+#endif
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, i.e. waits for every
+// outstanding gradient STORE to be acknowledged by HBM; nothing in learn_kernel re-reads what it stored.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct Net {  // pointers into one weight set
     const float* th;
     const float* st;
@@ -34,41 +59,62 @@ struct Net {  // pointers into one weight set
 // small building blocks (called by all 256 threads of the workgroup)
 // ------------------------------------------------------------------------------------------
 
-// inv/shift of a BN layer into LDS
-__device__ __forceinline__ void bn_coefs(const float* __restrict__ g, const float* __restrict__ be,
-                                         const float* __restrict__ mm, const float* __restrict__ mv, int n,
-                                         float* inv, float* sh) {
-    for (int k = threadIdx.x; k < n; k += NTHREADS) {
-        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
-        inv[k] = iv;
-        sh[k] = be[k] - mm[k] * iv;
+// First layer of a branch + the BatchNormalization coefficients of its output, for column k = threadIdx.x < H:
+//   out[r][col0+k] = relu(sum_j X[r*xs + j] * W[j*H + k] + b[k]),  inv/sh[col0+k] = BN coefficients.
+// Every global load of the phase (weight column, bias, gamma, beta, mean, var) is issued before the first use,
+// so the phase pays ONE memory latency instead of one per tensor (one wave per SIMD: nothing else hides it).
+struct L1Col {
+    float w[8], b, g, be, mm, mv;
+};
+__device__ __forceinline__ L1Col l1_load(int K, const float* __restrict__ W, const float* __restrict__ b,
+                                         const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv, int H, int k) {
+    L1Col c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.w[j] = (j < K && k < H) ? W[j * H + k] : 0.f;
+    const bool on = k < H;
+    c.b = on ? b[k] : 0.f, c.g = on ? g[k] : 0.f, c.be = on ? be[k] : 0.f, c.mm = on ? mm[k] : 0.f,
+    c.mv = on ? mv[k] : 1.f;
+    return c;
+}
+template <int K>
+__device__ __forceinline__ void l1_rows_k(const L1Col& c, const float* X, int xs, float* out, int ld, int col, int r0,
+                                          int rstep) {
+#pragma unroll 8
+    for (int r = r0; r < TILE; r += rstep) {
+        float acc = c.b;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc = fmaf(X[r * xs + j], c.w[j], acc);
+        out[r * ld + col] = fmaxf(acc, 0.f);
     }
 }
-
-// out[r][col0+k] = relu(sum_j X[r*xs + j] * W[j*H + k] + b[k]),  r < 64, k < H, tiny K (S or A)
-__device__ __forceinline__ void dense_in_relu(const float* X, int xs, int K, const float* __restrict__ W,
-                                              const float* __restrict__ b, int H, float* out, int ld, int col0) {
-    for (int k = threadIdx.x; k < H; k += NTHREADS) {
-        float w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = (j < K) ? W[j * H + k] : 0.f;
-        const float bk = b[k];
-        for (int r = 0; r < TILE; ++r) {
-            float acc = bk;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < K) acc = fmaf(X[r * xs + j], w[j], acc);
-            out[r * ld + col0 + k] = fmaxf(acc, 0.f);
-        }
+__device__ __forceinline__ void l1_rows(const L1Col& c, int K, const float* X, int xs, float* out, int ld, int col,
+                                        int r0, int rstep) {
+    switch (K) {
+        case 1: l1_rows_k<1>(c, X, xs, out, ld, col, r0, rstep); break;
+        case 3: l1_rows_k<3>(c, X, xs, out, ld, col, r0, rstep); break;
+        case 4: l1_rows_k<4>(c, X, xs, out, ld, col, r0, rstep); break;
+        default: l1_rows_k<8>(c, X, xs, out, ld, col, r0, rstep); break;  // w[j >= K] == 0, X padded reads stay in LDS
     }
 }
+__device__ __forceinline__ void l1_coefs(const L1Col& c, float* inv, float* sh, int idx) {
+    const float iv = (1.0f / sqrtf(c.mv + BN_EPS)) * c.g;
+    inv[idx] = iv;
+    sh[idx] = c.be - c.mm * iv;
+}
 
-// out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), 4 lanes per row
+// out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), 4 lanes per row, 16-byte LDS reads
 __device__ __forceinline__ float out_layer_row(const float* P, int ld, const float* inv, const float* sh,
-                                               const float* __restrict__ w, float b, int K) {
+                                               const float* w, float b, int K) {
     const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
     float acc = 0.f;
-    for (int k = part; k < K; k += 4) acc = fmaf(fmaf(P[r * ld + k], inv[k], sh[k]), w[k], acc);
+    for (int k = 4 * part; k < K; k += 16) {
+        const f32x4 p = *(const f32x4*)(P + r * ld + k);
+        const f32x4 y = p * *(const f32x4*)(inv + k) + *(const f32x4*)(sh + k);
+        const f32x4 wk = *(const f32x4*)(w + k);
+        acc = fmaf(y[0], wk[0], acc), acc = fmaf(y[1], wk[1], acc), acc = fmaf(y[2], wk[2], acc),
+        acc = fmaf(y[3], wk[3], acc);
+    }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     return acc + b;  // valid in all 4 lanes of row r
@@ -207,12 +253,14 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
         const int nb0 = 0;  // single reduction pass: N <= 16*DX_NB (checked on the host)
         const int nblk = N >> 4;
         f32x4 wc[DX_NB], wn[DX_NB];
+        float bnc[3] = {0.f, 0.f, 1.f}, bnn[3] = {0.f, 0.f, 1.f};  // gamma, mean, var of column c0 + lr
         int c0 = c_begin + wave * 16;
         if (c0 < c_end) {
             const float* wrow = W + (long)(c0 + lr) * N + nb0 + 4 * lg;
 #pragma unroll
             for (int q = 0; q < DX_NB; ++q)
                 if (q < nblk) wc[q] = *(const f32x4*)(wrow + 16 * q);
+            bnc[0] = g[c0 + lr - c_begin], bnc[1] = mm[c0 + lr - c_begin], bnc[2] = mv[c0 + lr - c_begin];
         }
         for (; c0 < c_end; c0 += 4 * 16) {
             const int cn = c0 + 4 * 16;
@@ -221,6 +269,7 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
 #pragma unroll
                 for (int q = 0; q < DX_NB; ++q)
                     if (q < nblk) wn[q] = *(const f32x4*)(wrow + 16 * q);
+                bnn[0] = g[cn + lr - c_begin], bnn[1] = mm[cn + lr - c_begin], bnn[2] = mv[cn + lr - c_begin];
             }
             f32x4 acc[4];
 #pragma unroll
@@ -238,9 +287,9 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
                 }
             }
             const int c = c0 + lr;
-            const float rs = 1.0f / sqrtf(mv[c - c_begin] + BN_EPS);
-            const float gam = g[c - c_begin];
-            const float mean = mm[c - c_begin];
+            const float rs = 1.0f / sqrtf(bnc[2] + BN_EPS);
+            const float gam = bnc[0];
+            const float mean = bnc[1];
             float sg = 0.f, sb = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -263,6 +312,7 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
             }
 #pragma unroll
             for (int q = 0; q < DX_NB; ++q) wc[q] = wn[q];
+            bnc[0] = bnn[0], bnc[1] = bnn[1], bnc[2] = bnn[2];
         }
     }
 }
@@ -278,40 +328,58 @@ __device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float*
 }
 
 // First-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*xs+j]*dz[r][k], db[k] = sum_r dz[r][k]
-__device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, const float* DZ, int ldz, int c0, int H,
-                                               float* __restrict__ gW, float* __restrict__ gb) {
+template <int K>
+__device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const float* DZ, int ldz, int c0, int H,
+                                                 float* __restrict__ gW, float* __restrict__ gb) {
     for (int k = threadIdx.x; k < H; k += NTHREADS) {
-        float acc[8];
+        float acc[K];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int j = 0; j < K; ++j) acc[j] = 0.f;
         float sb = 0.f;
+#pragma unroll 8
         for (int r = 0; r < TILE; ++r) {
             const float d = DZ[r * ldz + c0 + k];
             sb += d;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < K) acc[j] = fmaf(X[r * xs + j], d, acc[j]);
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(X[r * xs + j], d, acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < K) gW[j * H + k] = acc[j];
+        for (int j = 0; j < K; ++j) gW[j * H + k] = acc[j];
         gb[k] = sb;
     }
 }
+__device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, const float* DZ, int ldz, int c0, int H,
+                                               float* __restrict__ gW, float* __restrict__ gb) {
+    switch (K) {
+        case 1: dense_in_grads_k<1>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 2: dense_in_grads_k<2>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 3: dense_in_grads_k<3>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 4: dense_in_grads_k<4>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 5: dense_in_grads_k<5>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 6: dense_in_grads_k<6>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        case 7: dense_in_grads_k<7>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+        default: dense_in_grads_k<8>(X, xs, DZ, ldz, c0, H, gW, gb); break;
+    }
+}
 
-// Output layer (width 1) backward through the BN below it, for column k < K (thread per k):
+// Output layer (width 1) backward through the BN below it, for column k < K (K <= 256):
 //   dW3[k] = sum_r bn(p[r][k])*d[r]; dy = d[r]*w3[k]; dgamma, dbeta; DZ[r][k] = dy*inv*(p>0)
+// The 64 rows are split over NTHREADS/K thread groups; partial sums meet in LDS scratch scr[3*NTHREADS].
+// rs/mean come from LDS tables (rsl, mml) filled when the layer's coefficients were built. Ends with a barrier.
 __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, const float* inv, const float* sh,
-                                                   const float* d, const float* __restrict__ w3,
-                                                   const float* __restrict__ g, const float* __restrict__ mm,
-                                                   const float* __restrict__ mv, int K, float* DZ, int ldz,
+                                                   const float* d, const float* w3, const float* rsl,
+                                                   const float* mml, int K, float* DZ, int ldz, float* scr,
                                                    float* __restrict__ gW3, float* __restrict__ gg,
                                                    float* __restrict__ gbe) {
-    for (int k = threadIdx.x; k < K; k += NTHREADS) {
-        const float wk = w3[k], iv = inv[k], s = sh[k];
-        const float rs = 1.0f / sqrtf(mv[k] + BN_EPS), mean = mm[k];
-        float dw = 0.f, dgm = 0.f, dbt = 0.f;
-        for (int r = 0; r < TILE; ++r) {
+    int parts = 1;
+    while (parts * 2 * K <= NTHREADS && parts < 8) parts *= 2;
+    const int part = threadIdx.x / K, k = threadIdx.x - part * K;
+    const int rows = TILE / parts;
+    float dw = 0.f, dgm = 0.f, dbt = 0.f;
+    if (part < parts) {
+        const float wk = w3[k], iv = inv[k], s = sh[k], rs = rsl[k], mean = mml[k];
+#pragma unroll 8
+        for (int r = part * rows; r < (part + 1) * rows; ++r) {
             const float p = P[r * ldp + k];
             const float dr = d[r];
             dw = fmaf(fmaf(p, iv, s), dr, dw);
@@ -320,12 +388,18 @@ __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, cons
             dbt += dy;
             DZ[r * ldz + k] = (p > 0.f) ? dy * iv : 0.f;
         }
-        if (gW3) {
-            gW3[k] = dw;
-            gg[k] = dgm;
-            gbe[k] = dbt;
+    }
+    if (gW3) {
+        scr[threadIdx.x] = dw, scr[NTHREADS + threadIdx.x] = dgm, scr[2 * NTHREADS + threadIdx.x] = dbt;
+        lds_barrier();
+        if (threadIdx.x < K) {
+            float a = 0.f, b2 = 0.f, c = 0.f;
+            for (int q = 0; q < parts; ++q)
+                a += scr[q * K + k], b2 += scr[NTHREADS + q * K + k], c += scr[2 * NTHREADS + q * K + k];
+            gW3[k] = a, gg[k] = b2, gbe[k] = c;
         }
     }
+    lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,9 +407,11 @@ __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, cons
 // ------------------------------------------------------------------------------------------
 struct LearnLds {
     float *bufA, *bufB, *bufC;  // [64][ldA], [64][ldB], [64][ldB]
-    float *invA, *shA;          // H1+Ha
-    float *invB, *shB;          // H2
+    float *invA, *shA;          // H1+Ha: BN coefficients of the features held in bufA
+    float *invB, *shB;          // H2:    BN coefficients of the features held in bufB
+    float *w3B, *rsB, *mmB;     // H2:    output-layer weights, rsqrt(var+eps) and mean of that BN layer
     float *db;                  // H2
+    float *scr;                 // 3*NTHREADS reduction scratch
     float *sS, *sS2;            // [64][S]
     float *sAct, *sR, *sY, *sQ, *sD, *sA1, *sT, *sDa;  // [64] each
     float* red;                                         // [8]
@@ -343,7 +419,8 @@ struct LearnLds {
 
 __host__ __device__ inline size_t learn_lds_floats(const avd_mlp_layout& L) {
     const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
-    return (size_t)TILE * ldA + 2 * (size_t)TILE * ldB + 2 * (L.H1 + L.Ha) + 3 * L.H2 + 2 * TILE * L.S + 8 * TILE + 8;
+    return (size_t)TILE * ldA + 2 * (size_t)TILE * ldB + 2 * (L.H1 + L.Ha) + 6 * L.H2 + 3 * NTHREADS +
+           2 * TILE * L.S + 8 * TILE + 8;
 }
 
 __device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) {
@@ -357,7 +434,11 @@ __device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) 
     l.shA = p, p += L.H1 + L.Ha;
     l.invB = p, p += L.H2;
     l.shB = p, p += L.H2;
+    l.w3B = p, p += L.H2;
+    l.rsB = p, p += L.H2;
+    l.mmB = p, p += L.H2;
     l.db = p, p += L.H2;
+    l.scr = p, p += 3 * NTHREADS;
     l.sS = p, p += TILE * L.S;
     l.sS2 = p, p += TILE * L.S;
     l.sAct = p, p += TILE;
@@ -372,45 +453,90 @@ __device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) 
     return l;
 }
 
-// actor forward over the 64 rows in X (LDS [64][S]); leaves p1 in bufA, p2 in bufB, coefs in invA/shA, invB/shB;
-// writes tanh to sT and action (tanh*high) to out.
+// coefficients of the BN layer in front of a width-1 output layer + that layer's weights -> LDS (thread k < H2)
+struct L2Col {
+    float g, be, mm, mv, w3;
+};
+__device__ __forceinline__ L2Col l2_load(const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv,
+                                         const float* __restrict__ w3, int H2, int k) {
+    L2Col c = {0.f, 0.f, 0.f, 1.f, 0.f};
+    if (k < H2) c.g = g[k], c.be = be[k], c.mm = mm[k], c.mv = mv[k], c.w3 = w3[k];
+    return c;
+}
+__device__ __forceinline__ void l2_store(const L2Col& c, LearnLds& l, int H2, int k) {
+    if (k < H2) {
+        const float rs = 1.0f / sqrtf(c.mv + BN_EPS);
+        const float iv = rs * c.g;
+        l.invB[k] = iv, l.shB[k] = c.be - c.mm * iv, l.w3B[k] = c.w3, l.rsB[k] = rs, l.mmB[k] = c.mm;
+    }
+}
+
+// actor forward over the 64 rows in X (LDS [64][S]); leaves p1 in bufA, p2 in bufB, coefs in invA/shA, invB/shB..;
+// writes tanh to sT and action (tanh*high) to out.  (H1, H2 <= NTHREADS)
 __device__ __forceinline__ void actor_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, float high,
-                                               LearnLds& l, float* out) {
+                                               LearnLds& l, float* out PH_ARG) {
     const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
     const float* th = net.th;
-    dense_in_relu(X, L.S, L.S, th + L.aW1, th + L.ab1, L.H1, l.bufA, ldA, 0);
-    bn_coefs(th + L.ag1, th + L.abe1, net.st + L.amm1, net.st + L.amv1, L.H1, l.invA, l.shA);
-    bn_coefs(th + L.ag2, th + L.abe2, net.st + L.amm2, net.st + L.amv2, L.H2, l.invB, l.shB);
-    __syncthreads();
+    const int k = threadIdx.x;
+    const float b3 = th[L.ab3];
+    const L1Col c1 = l1_load(L.S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, net.st + L.amm1, net.st + L.amv1,
+                             L.H1, k);
+    const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, net.st + L.amm2, net.st + L.amv2, th + L.aW3, L.H2, k);
+    if (k < L.H1) {
+        l1_coefs(c1, l.invA, l.shA, k);
+        l1_rows(c1, L.S, X, L.S, l.bufA, ldA, k, 0, 1);
+    }
+    l2_store(c2, l, L.H2, k);
+    lds_barrier();
+    PH(1);
     gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1, th + L.aW2, th + L.ab2, L.H2, l.bufB, ldB);
-    __syncthreads();
-    const float z = out_layer_row(l.bufB, ldB, l.invB, l.shB, th + L.aW3, th[L.ab3], L.H2);
+    lds_barrier();
+    PH(2);
+    const float z = out_layer_row(l.bufB, ldB, l.invB, l.shB, l.w3B, b3, L.H2);
     if ((threadIdx.x & 3) == 0) {
         const float t = tanhf(z);
         l.sT[threadIdx.x >> 2] = t;
         out[threadIdx.x >> 2] = t * high;
     }
-    __syncthreads();
+    lds_barrier();
+    PH(3);
 }
 
 // critic forward over 64 rows: state X (LDS [64][S]), action act (LDS [64]); leaves concat p (state|action) in bufA,
-// p of layer 2 in bufB, coefs in invA/shA (H1+Ha) and invB/shB; q -> out[64].
+// p of layer 2 in bufB, coefs in invA/shA (H1+Ha) and invB/shB..; q -> out[64].  (H1, Ha, H2 <= NTHREADS)
 __device__ __forceinline__ void critic_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, const float* act,
-                                                LearnLds& l, float* out) {
+                                                LearnLds& l, float* out PH_ARG) {
     const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
     const float* th = net.th + L.actor_size;
     const float* st = net.st;
-    dense_in_relu(X, L.S, L.S, th + L.cWs, th + L.cbs, L.H1, l.bufA, ldA, 0);
-    dense_in_relu(act, 1, 1, th + L.cWa, th + L.cba, L.Ha, l.bufA, ldA, L.H1);
-    bn_coefs(th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, L.H1, l.invA, l.shA);
-    bn_coefs(th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, L.Ha, l.invA + L.H1, l.shA + L.H1);
-    bn_coefs(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, L.H2, l.invB, l.shB);
-    __syncthreads();
+    const int k = threadIdx.x;
+    // action branch: Ha columns x row groups so that (almost) every thread works
+    const int agroups = NTHREADS / L.Ha;
+    const int ka = k % L.Ha, ra = k / L.Ha;
+    const float b3 = th[L.cb3];
+    const L1Col cs = l1_load(L.S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, L.H1, k);
+    const L1Col ca = l1_load(1, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, L.Ha,
+                             ra < agroups ? ka : L.Ha);
+    const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, L.H2, k);
+    if (k < L.H1) {
+        l1_coefs(cs, l.invA, l.shA, k);
+        l1_rows(cs, L.S, X, L.S, l.bufA, ldA, k, 0, 1);
+    }
+    if (ra < agroups) {
+        if (ra == 0) l1_coefs(ca, l.invA, l.shA, L.H1 + ka);
+        l1_rows(ca, 1, act, 1, l.bufA, ldA, L.H1 + ka, ra, agroups);
+    }
+    l2_store(c2, l, L.H2, k);
+    lds_barrier();
+    PH(4);
     gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, th + L.cW2, th + L.cb2, L.H2, l.bufB, ldB);
-    __syncthreads();
-    const float q = out_layer_row(l.bufB, ldB, l.invB, l.shB, th + L.cW3, th[L.cb3], L.H2);
+    lds_barrier();
+    PH(5);
+    const float q = out_layer_row(l.bufB, ldB, l.invB, l.shB, l.w3B, b3, L.H2);
     if ((threadIdx.x & 3) == 0) out[threadIdx.x >> 2] = q;
-    __syncthreads();
+    lds_barrier();
+    PH(6);
 }
 
 __device__ __forceinline__ float block_sum64(const float* v, float* red) {
@@ -421,9 +547,9 @@ __device__ __forceinline__ float block_sum64(const float* v, float* red) {
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (threadIdx.x == 0) red[0] = s;
     }
-    __syncthreads();
+    lds_barrier();
     const float r = red[0];
-    __syncthreads();
+    lds_barrier();
     return r;
 }
 
@@ -463,22 +589,24 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
         for (int i = L.ab3 + L.A; i < L.actor_size; ++i) ga[i] = 0.f;
         for (int i = L.cb3 + L.A; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
+    PH_INIT();
+    PH(0);
 
     // ---- TD target: y = r + gamma * Q'(s2, mu'(s2))   (trainer.py:493-494) ----
-    actor_fwd_tile(L, tgt, l.sS2, high, l, l.sA1);
-    critic_fwd_tile(L, tgt, l.sS2, l.sA1, l, l.sQ);
+    actor_fwd_tile(L, tgt, l.sS2, high, l, l.sA1 PH_PASS);
+    critic_fwd_tile(L, tgt, l.sS2, l.sA1, l, l.sQ PH_PASS);
     if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
-    __syncthreads();
+    lds_barrier();
 
     // ---- critic loss + gradient (trainer.py:495-498) ----
-    critic_fwd_tile(L, net, l.sS, l.sAct, l, l.sQ);
+    critic_fwd_tile(L, net, l.sS, l.sAct, l, l.sQ PH_PASS);
     if (tid < TILE) {
         const float e = l.sY[tid] - l.sQ[tid];
         l.sD[tid] = -2.0f * e * invn;  // d mean((y-q)^2) / dq
         l.sT[tid] = e * e;
     }
-    __syncthreads();
+    lds_barrier();
     {
         const float lc = block_sum64(l.sT, l.red) * invn;
         const float db3 = block_sum64(l.sD, l.red);
@@ -489,39 +617,44 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
     }
     {
         const float* cth = net.th + L.actor_size;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, cth + L.cW3, cth + L.cg3, net.st + L.cmm3,
-                           net.st + L.cmv3, L.H2, l.bufC, ldB, gc + L.cW3, gc + L.cg3, gc + L.cbe3);
-        __syncthreads();
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr,
+                           gc + L.cW3, gc + L.cg3, gc + L.cbe3);
+        PH(7);
         col_sums(l.bufC, ldB, L.H2, l.db, gc + L.cb2);
-        __syncthreads();
+        lds_barrier();
+        PH(8);
         gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, l.bufC, ldB, l.db, L.H2, gc + L.cW2);
-        __syncthreads();
+        lds_barrier();
+        PH(9);
         gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, 0, L.H1, l.bufA, ldA, cth + L.cgs, net.st + L.cmms,
                    net.st + L.cmvs, gc + L.cgs, gc + L.cbes);
         gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
                    net.st + L.cmva, gc + L.cga, gc + L.cbea);
-        __syncthreads();
+        lds_barrier();
+        PH(10);
         dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, gc + L.cWs, gc + L.cbs);
         dense_in_grads(l.sAct, 1, 1, l.bufA, ldA, L.H1, L.Ha, gc + L.cWa, gc + L.cba);
-        __syncthreads();
+        lds_barrier();
+        PH(11);
     }
 
     // ---- actor loss: La = -mean(Q(s, mu(s)))   (trainer.py:501-506) ----
     // pass 1: a1 = mu(s) (activations discarded), critic forward on (s, a1), gradient wrt the action input
-    actor_fwd_tile(L, net, l.sS, high, l, l.sA1);
-    critic_fwd_tile(L, net, l.sS, l.sA1, l, l.sQ);
+    actor_fwd_tile(L, net, l.sS, high, l, l.sA1 PH_PASS);
+    critic_fwd_tile(L, net, l.sS, l.sA1, l, l.sQ PH_PASS);
     {
         const float la = -block_sum64(l.sQ, l.red) * invn;
         if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
         if (tid < TILE) l.sD[tid] = -invn;  // dLa/dq1
-        __syncthreads();
+        lds_barrier();
         const float* cth = net.th + L.actor_size;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, cth + L.cW3, cth + L.cg3, net.st + L.cmm3,
-                           net.st + L.cmv3, L.H2, l.bufC, ldB, nullptr, nullptr, nullptr);
-        __syncthreads();
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr, nullptr,
+                           nullptr, nullptr);
+        PH(12);
         gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
                    net.st + L.cmva, nullptr, nullptr);
-        __syncthreads();
+        lds_barrier();
+        PH(13);
         // da1[r] = sum_j dza[r][j] * Wa[0][j]
         {
             const int rr = tid >> 2, part = tid & 3;
@@ -531,30 +664,35 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
             acc += __shfl_xor(acc, 2);
             if (part == 0) l.sDa[rr] = acc;
         }
-        __syncthreads();
+        lds_barrier();
+        PH(14);
     }
     // pass 2: actor forward again keeping p1 (bufA), p2 (bufB), tanh (sT); then backward
-    actor_fwd_tile(L, net, l.sS, high, l, l.sA1);
+    actor_fwd_tile(L, net, l.sS, high, l, l.sA1 PH_PASS);
     if (tid < TILE) {
         const float t = l.sT[tid];
         l.sD[tid] = l.sDa[tid] * high * (1.0f - t * t);  // d/d(pre-tanh)
     }
-    __syncthreads();
+    lds_barrier();
     {
         const float db3 = block_sum64(l.sD, l.red);
         if (tid == 0) ga[L.ab3] = db3;
         const float* ath = net.th;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, ath + L.aW3, ath + L.ag2, net.st + L.amm2,
-                           net.st + L.amv2, L.H2, l.bufC, ldB, ga + L.aW3, ga + L.ag2, ga + L.abe2);
-        __syncthreads();
+        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr,
+                           ga + L.aW3, ga + L.ag2, ga + L.abe2);
+        PH(15);
         col_sums(l.bufC, ldB, L.H2, l.db, ga + L.ab2);
-        __syncthreads();
+        lds_barrier();
+        PH(16);
         gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1, l.bufC, ldB, l.db, L.H2, ga + L.aW2);
-        __syncthreads();
+        lds_barrier();
+        PH(17);
         gemm_dx_bn(l.bufC, ldB, L.H2, ath + L.aW2, 0, L.H1, l.bufA, ldA, ath + L.ag1, net.st + L.amm1,
                    net.st + L.amv1, ga + L.ag1, ga + L.abe1);
-        __syncthreads();
+        lds_barrier();
+        PH(18);
         dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, ga + L.aW1, ga + L.ab1);
+        PH(19);
     }
 }
 
@@ -649,6 +787,19 @@ __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, in
     }
 }
 
+#ifdef AVD_PHASE_TIMING
+}  // namespace avd
+extern "C" int avd_debug_phase_cycles(unsigned long long* h_out, int reset) {
+    if (h_out) hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
+    if (reset) {
+        unsigned long long z[32] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(avd::g_phase_cycles), z, sizeof(z));
+    }
+    return 0;
+}
+namespace avd {
+#endif
+
 static inline int round4(int x) { return (x + 3) & ~3; }
 
 }  // namespace avd
@@ -738,6 +889,11 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
                              float* losses, void* stream) {
     int rc = check_mlp_dims(lay, "avd_learn_f32");
     if (rc) return rc;
+    if (lay->H1 > NTHREADS || lay->Ha > NTHREADS) {
+        set_error("avd_learn_f32: layer1/action-layer size %d/%d; the tile kernel implements widths <= %d", lay->H1,
+                  lay->Ha, NTHREADS);
+        return AVD_E_UNSUPPORTED;
+    }
     if (lay->H2 % 32 || lay->H2 > 16 * DX_NB) {
         set_error("avd_learn_f32: layer2 size %d; the tile kernel implements H2 %% 32 == 0 and H2 <= %d", lay->H2,
                   16 * DX_NB);

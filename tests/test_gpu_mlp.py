@@ -220,5 +220,5 @@ def test_unsupported_shapes_fail_loudly():
     conf = config.Config(actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024, critic_layer2_size=1024)
     grp = vec.AgentGroup(1, 4, 1, conf)
     z = torch.zeros(1, 64, 4, device="cuda")
-    with pytest.raises(AvdError, match="LDS|layer2 size"):
+    with pytest.raises(AvdError, match="LDS|layer2 size|layer1"):
         grp.learn(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 0)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostic: where learn_kernel spends its cycles. Builds/loads the -DAVD_PHASE_TIMING library
+(avddpg_amd/lib/libavddpg_hip_diag.so, `make -C avddpg_amd/csrc diag`), runs the kernel on synthetic
+batches and prints the share of workgroup-thread-0 shader cycles per phase. Not part of the product."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from avddpg_amd import _hip
+
+_hip.LIB_PATH = os.path.join(ROOT, "avddpg_amd", "lib", "libavddpg_hip_diag.so")
+from avddpg_amd import config, vec
+
+NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fwd", 3: "actor out layer",
+         4: "critic L1 (VALU) + bn coefs", 5: "critic L2 GEMM fwd", 6: "critic out layer",
+         7: "critic out-layer bwd (+glue)", 8: "critic col sums", 9: "critic dW2 GEMM", 10: "critic dX GEMM + BN bwd",
+         11: "critic L1 grads", 12: "actor-path critic out bwd (+glue)", 13: "actor-path dX (action cols)",
+         14: "da reduction", 15: "actor out-layer bwd (+glue)", 16: "actor col sums", 17: "actor dW2 GEMM",
+         18: "actor dX GEMM + BN bwd", 19: "actor L1 grads"}
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+conf = config.Config()
+grp = vec.AgentGroup(n, 4, 1, conf)
+f = lambda *s: torch.randn(*s, device="cuda")
+s, a, r, s2 = f(n, 64, 4), f(n, 64, 1), f(n, 64), f(n, 64, 4)
+lib = _hip.lib()
+lib.avd_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+grp.learn(s, a, r, s2, 0)
+torch.cuda.synchronize()
+lib.avd_debug_phase_cycles(None, 1)
+for _ in range(3):
+    grp.learn(s, a, r, s2, 0)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 32)()
+lib.avd_debug_phase_cycles(buf, 0)
+tot = sum(buf)
+print(f"tiles={3 * n}  cycles/tile={tot / (3 * n):.0f}")
+for i in range(20):
+    print(f"{i:2d} {NAMES[i]:38s} {buf[i] / (3 * n):9.0f} cyc/tile  {100 * buf[i] / tot:5.1f}%")
