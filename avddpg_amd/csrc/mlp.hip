@@ -11,6 +11,8 @@
 // inv = rsqrt(var + 1e-3)*gamma (reference models are never called with training=True).  LDS holds
 // the post-ReLU value p; the affine is applied when p is fetched as an MFMA operand, and folded into
 // the weight-gradient epilogue (dW = inv*(p^T dz) + shift*(1^T dz)).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace avd {
@@ -23,7 +25,7 @@ constexpr float BN_EPS = 1e-3f;
 
 // LDS row stride: a multiple of 4 floats (16-byte rows for b128 reads) with (ld/4) odd so that 16 consecutive rows
 // start on 16 different 4-bank slots
-__host__ __device__ inline int ld_of(int k) { return ((k >> 2) & 1) ? k : k + 4; }
+__host__ __device__ constexpr int ld_of(int k) { return ((k >> 2) & 1) ? k : k + 4; }
 
 #ifdef AVD_PHASE_TIMING
 // Diagnostic build only (tools/phase_profile.py): per-phase shader-cycle sums of workgroup thread 0.
@@ -697,6 +699,423 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
 }
 
 // ------------------------------------------------------------------------------------------
+// Dimension-specialised learn kernel (reference widths known at compile time).
+//
+// Same algorithm and LDS plan as learn_kernel above; what changes is the code shape, chosen from its ISA:
+//  * S/H1/H2/Ha are template constants -> row strides and weight strides fold into immediates / scalar adds
+//    (the generic kernel carried one 64-bit VGPR pointer per in-flight weight load);
+//  * the four network passes (targets, critic, actor-through-critic, actor) run as ONE loop whose body holds a
+//    single copy of each routine, so the kernel fits the 64 KB instruction cache (the generic kernel is ~240 KB
+//    of straight-line code that is fetched once per tile);
+//  * pipelined loops have no guards inside their unrolled bodies: prefetch indices are clamped (a redundant
+//    load at the end instead of a branch) and the remainder blocks run through a rotating tail.
+// ------------------------------------------------------------------------------------------
+namespace fast {
+
+constexpr int R = 4;  // weight-operand register ring depth (blocks of 16 k)
+
+template <int LDX>
+__device__ __forceinline__ void fetch_a(f32x4 (&a)[4], const float* X, const float* inv, const float* sh, int k4,
+                                        int lr) {
+    const f32x4 iv = *(const f32x4*)(inv + k4);
+    const f32x4 sf = *(const f32x4*)(sh + k4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = *(const f32x4*)(X + (m * 16 + lr) * LDX + k4) * iv + sf;
+}
+
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[4][2], const f32x4 (&a)[4], const f32x2 (&b)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m][0] = MFMA16(a[m][jj], b[jj][0], acc[m][0]);
+            acc[m][1] = MFMA16(a[m][jj], b[jj][1], acc[m][1]);
+        }
+}
+
+// out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]), N == 128: wave w owns columns [32w, 32w+32).
+template <int N, int LDX, int LDO>
+__device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, int nblk,
+                                         const float* __restrict__ W, const float* __restrict__ b, float* out) {
+    static_assert(N == 128, "one 32-column chunk per wave");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int n0 = wave * 32;
+    const f32x2 bc = *(const f32x2*)(b + n0 + 2 * lr);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wl = W + (4 * lg) * N + n0 + 2 * lr;  // lane's column pair, row 4*lg of block 0
+    const int last = nblk - 1;
+    f32x2 ring[R][4];
+    auto load_blk = [&](f32x2(&dst)[4], int blk) {
+        const float* p = wl + blk * (16 * N);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dst[jj] = *(const f32x2*)(p + jj * N);
+    };
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d) load_blk(ring[d], min(d, last));
+    f32x4 a[2][4];
+    fetch_a<LDX>(a[0], X, inv, sh, 4 * lg, lr);
+    int blk = 0;
+    const int ngrp = nblk / R;
+    for (int g = 0; g < ngrp; ++g) {
+#pragma unroll
+        for (int d = 0; d < R; ++d) {
+            load_blk(ring[(d + R - 1) % R], min(blk + R - 1, last));
+            fetch_a<LDX>(a[(d + 1) & 1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
+            mfma_block(acc, a[d & 1], ring[d]);
+            ++blk;
+        }
+    }
+    for (; blk < nblk; ++blk) {  // remainder: blocks already sit in ring[0..R-2]
+        fetch_a<LDX>(a[1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
+        mfma_block(acc, a[0], ring[0]);
+#pragma unroll
+        for (int d = 0; d + 2 < R; ++d)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ring[d][jj] = ring[d + 1][jj];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[0][m] = a[1][m];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 o;
+            o[0] = fmaxf(acc[m][0][j] + bc[0], 0.f);
+            o[1] = fmaxf(acc[m][1][j] + bc[1], 0.f);
+            *(f32x2*)(out + (m * 16 + lg * 4 + j) * LDO + n0 + 2 * lr) = o;
+        }
+}
+
+// dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n], k < K (runtime, % 4 == 0), N == 128.
+template <int N, int LDP, int LDZ>
+__device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const float* sh, int K, const float* DZ,
+                                        const float* db, float* __restrict__ gW) {
+    static_assert(N == 128, "one 32-column chunk per wave");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int n0 = wave * 32;
+    const f32x2 dbc = *(const f32x2*)(db + n0 + 2 * lr);
+    const float* dp = DZ + lg * LDZ + n0 + 2 * lr;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* pp = P + lg * LDP + k0 + 4 * lr;  // may read past K in the last block: those rows are not stored
+        f32x4 pa[2];
+        f32x2 dz[2];
+        pa[0] = *(const f32x4*)(pp);
+        dz[0] = *(const f32x2*)(dp);
+#pragma unroll
+        for (int it = 0; it < TILE / 4; ++it) {
+            if (it + 1 < TILE / 4) {
+                pa[(it + 1) & 1] = *(const f32x4*)(pp + 4 * (it + 1) * LDP);
+                dz[(it + 1) & 1] = *(const f32x2*)(dp + 4 * (it + 1) * LDZ);
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) {
+                acc[ta][0] = MFMA16(pa[it & 1][ta], dz[it & 1][0], acc[ta][0]);
+                acc[ta][1] = MFMA16(pa[it & 1][ta], dz[it & 1][1], acc[ta][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kbase = k0 + 4 * (lg * 4 + j);
+            if (kbase < K) {
+                const f32x4 iv = *(const f32x4*)(inv + kbase);
+                const f32x4 sf = *(const f32x4*)(sh + kbase);
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta) {
+                    f32x2 o;
+                    o[0] = fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]);
+                    o[1] = fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1]);
+                    *(f32x2*)(gW + (kbase + ta) * N + n0 + 2 * lr) = o;
+                }
+            }
+        }
+    }
+}
+
+struct BnSet {  // BN parameters / gradient outputs of a column range, indexed by (c - base)
+    const float *g, *mm, *mv;
+    float *dg, *dbe;
+    int base;
+};
+
+// dy[r][c] = sum_n DZ[r][n]*W[c][n] for c in [c_begin, c_end) (16-column tiles round-robin over waves), then the
+// BN/ReLU backward of the layer below in place in P. Columns < split use `lo`, the others `hi`.
+template <int N, int LDZ, int LDP>
+__device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict__ W, int c_begin, int c_end, float* P,
+                                        BnSet lo, BnSet hi, int split, bool write_grads) {
+    static_assert(N == 128, "N/16 == 8 reduction blocks held in registers");
+    constexpr int NB = N / 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    f32x4 wc[NB], wn[NB];
+    float bnc[3] = {0.f, 0.f, 1.f}, bnn[3] = {0.f, 0.f, 1.f};
+    auto load_tile = [&](f32x4(&w)[NB], float(&bn)[3], int c0) {
+        const float* wrow = W + (c0 + lr) * N + 4 * lg;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) w[q] = *(const f32x4*)(wrow + 16 * q);
+        const BnSet& s = (c0 < split) ? lo : hi;
+        const int i = c0 + lr - s.base;
+        bn[0] = s.g[i], bn[1] = s.mm[i], bn[2] = s.mv[i];
+    };
+    int c0 = c_begin + wave * 16;
+    if (c0 < c_end) load_tile(wc, bnc, c0);
+    for (; c0 < c_end; c0 += 4 * 16) {
+        const int cn = c0 + 4 * 16;
+        if (cn < c_end) load_tile(wn, bnn, cn);
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a[2][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[0][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 4 * lg);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (q + 1 < NB)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[(q + 1) & 1][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 16 * (q + 1) + 4 * lg);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[q & 1][m][jj], wc[q][jj], acc[m]);
+        }
+        const int c = c0 + lr;
+        const float rs = 1.0f / sqrtf(bnc[2] + BN_EPS);
+        const float gam = bnc[0], mean = bnc[1];
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = m * 16 + lg * 4 + j;
+                const float dy = acc[m][j];
+                const float p = P[r * LDP + c];
+                sg = fmaf(dy * (p - mean), rs, sg);
+                sb += dy;
+                P[r * LDP + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+            }
+        sg += __shfl_xor(sg, 16);
+        sg += __shfl_xor(sg, 32);
+        sb += __shfl_xor(sb, 16);
+        sb += __shfl_xor(sb, 32);
+        if (write_grads && lg == 0) {
+            const BnSet& s = (c0 < split) ? lo : hi;
+            s.dg[c - s.base] = sg;
+            s.dbe[c - s.base] = sb;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) wc[q] = wn[q];
+        bnc[0] = bnn[0], bnc[1] = bnn[1], bnc[2] = bnn[2];
+    }
+}
+
+template <int S, int H1, int H2, int HA>
+__global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int set_mod,
+                                                            const float* __restrict__ theta,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ theta_t,
+                                                            const float* __restrict__ stats_t,
+                                                            const float* __restrict__ s, const float* __restrict__ a,
+                                                            const float* __restrict__ r, const float* __restrict__ s2,
+                                                            float gamma, float high, float* __restrict__ grads,
+                                                            float* __restrict__ losses) {
+    static_assert(H1 <= NTHREADS && HA <= NTHREADS && H2 <= NTHREADS && H1 % 16 == 0 && HA % 16 == 0, "widths");
+    constexpr int KC = H1 + HA, LDA = ld_of(KC), LDB = ld_of(H2);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    LearnLds l = carve(smem, L);
+    const int agent = blockIdx.x;
+    const int set = set_mod > 0 ? agent % set_mod : agent;
+    const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
+    const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+    float* g = grads + (long)agent * L.theta_size;
+    float* ga = g;                 // actor block
+    float* gc = g + L.actor_size;  // critic block
+    const int tid = threadIdx.x;
+    constexpr float invn = 1.0f / (float)TILE;  // A == 1
+
+    for (int i = tid; i < TILE * S; i += NTHREADS) {
+        l.sS[i] = s[(long)agent * TILE * S + i];
+        l.sS2[i] = s2[(long)agent * TILE * S + i];
+    }
+    if (tid < TILE) {
+        l.sAct[tid] = a[(long)agent * TILE + tid];
+        l.sR[tid] = r[(long)agent * TILE + tid];
+    }
+    if (tid == 0) {  // alignment padding of the gradient slab
+        for (int i = L.ab3 + 1; i < L.actor_size; ++i) ga[i] = 0.f;
+        for (int i = L.cb3 + 1; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
+    }
+    lds_barrier();
+    PH_INIT();
+    PH(0);
+
+    // pass 0: targets (y); pass 1: critic loss + gradient; pass 2: actor -> critic, gradient wrt the action;
+    // pass 3: actor forward again (activations kept) + actor gradient          (workers/trainer.py:492-506)
+#pragma nounroll
+    for (int it = 0; it < 4; ++it) {
+        const Net n = (it == 0) ? tgt : net;
+        const float* X = (it == 0) ? l.sS2 : l.sS;
+        const int k = tid;
+        if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
+            const float* th = n.th;
+            const float b3 = th[L.ab3];
+            const L1Col c1 = l1_load(S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1,
+                                     H1, k);
+            const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, th + L.aW3, H2, k);
+            if (k < H1) {
+                l1_coefs(c1, l.invA, l.shA, k);
+                l1_rows_k<S>(c1, X, S, l.bufA, LDA, k, 0, 1);
+            }
+            l2_store(c2, l, H2, k);
+            lds_barrier();
+            PH(1);
+            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, H1 / 16, th + L.aW2, th + L.ab2, l.bufB);
+            lds_barrier();
+            PH(2);
+            const float z = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
+            if ((tid & 3) == 0) {
+                const float t = tanhf(z);
+                l.sT[tid >> 2] = t;
+                l.sA1[tid >> 2] = t * high;
+            }
+            lds_barrier();
+            PH(3);
+        }
+        if (it != 3) {  // ---- critic forward (agent/model.py:63-83)
+            const float* th = n.th + L.actor_size;
+            const float* st = n.st;
+            const float* act = (it == 1) ? l.sAct : l.sA1;
+            constexpr int agroups = NTHREADS / HA;
+            const int ka = k % HA, ra = k / HA;
+            const float b3 = th[L.cb3];
+            const L1Col cs = l1_load(S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, H1, k);
+            const L1Col ca = l1_load(1, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, HA,
+                                     ra < agroups ? ka : HA);
+            const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, H2, k);
+            if (k < H1) {
+                l1_coefs(cs, l.invA, l.shA, k);
+                l1_rows_k<S>(cs, X, S, l.bufA, LDA, k, 0, 1);
+            }
+            if (ra < agroups) {
+                if (ra == 0) l1_coefs(ca, l.invA, l.shA, H1 + ka);
+                l1_rows_k<1>(ca, act, 1, l.bufA, LDA, H1 + ka, ra, agroups);
+            }
+            l2_store(c2, l, H2, k);
+            lds_barrier();
+            PH(4);
+            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, KC / 16, th + L.cW2, th + L.cb2, l.bufB);
+            lds_barrier();
+            PH(5);
+            const float q = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
+            if ((tid & 3) == 0) l.sQ[tid >> 2] = q;
+            lds_barrier();
+            PH(6);
+        }
+        if (it == 0) {  // TD target, no done mask (trainer.py:494)
+            if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
+            lds_barrier();
+            continue;
+        }
+        // ---- d(loss)/d(output-layer input) for this pass
+        if (it == 1) {
+            if (tid < TILE) {
+                const float e = l.sY[tid] - l.sQ[tid];
+                l.sD[tid] = -2.0f * e * invn;
+                l.sT[tid] = e * e;
+            }
+            lds_barrier();
+            const float lc = block_sum64(l.sT, l.red) * invn;
+            const float db3 = block_sum64(l.sD, l.red);
+            if (tid == 0) {
+                gc[L.cb3] = db3;
+                if (losses) losses[(long)agent * 2 + 0] = lc;
+            }
+        } else if (it == 2) {
+            const float la = -block_sum64(l.sQ, l.red) * invn;
+            if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
+            if (tid < TILE) l.sD[tid] = -invn;
+            lds_barrier();
+        } else {
+            if (tid < TILE) {
+                const float t = l.sT[tid];
+                l.sD[tid] = l.sDa[tid] * high * (1.0f - t * t);
+            }
+            lds_barrier();
+            const float db3 = block_sum64(l.sD, l.red);
+            if (tid == 0) ga[L.ab3] = db3;
+        }
+        const bool crit = (it != 3), wg = (it != 2);
+        const float* wth = crit ? net.th + L.actor_size : net.th;
+        float* gout = crit ? gc : ga;
+        out_layer_backward(l.bufB, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, l.bufC, LDB, l.scr,
+                           wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
+                           gout + (crit ? L.cbe3 : L.abe2));
+        PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
+        if (wg) {
+            col_sums(l.bufC, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2));
+            lds_barrier();
+            PH(it == 1 ? 8 : 16);
+            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, l.bufC, l.db, gout + (crit ? L.cW2 : L.aW2));
+            lds_barrier();
+            PH(it == 1 ? 9 : 17);
+        }
+        {
+            BnSet lo, hi;
+            if (crit) {
+                lo = {wth + L.cgs, net.st + L.cmms, net.st + L.cmvs, gc + L.cgs, gc + L.cbes, 0};
+            } else {
+                lo = {wth + L.ag1, net.st + L.amm1, net.st + L.amv1, ga + L.ag1, ga + L.abe1, 0};
+            }
+            const float* cth = net.th + L.actor_size;
+            hi = {cth + L.cga, net.st + L.cmma, net.st + L.cmva, gc + L.cga, gc + L.cbea, H1};
+            gemm_dx<H2, LDB, LDA>(l.bufC, wth + (crit ? L.cW2 : L.aW2), (it == 2) ? H1 : 0, crit ? KC : H1, l.bufA, lo, hi,
+                                  H1, wg);
+            lds_barrier();
+            PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
+        }
+        if (it == 1) {
+            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, gc + L.cWs, gc + L.cbs);
+            dense_in_grads_k<1>(l.sAct, 1, l.bufA, LDA, H1, HA, gc + L.cWa, gc + L.cba);
+            lds_barrier();
+            PH(11);
+        } else if (it == 2) {  // da1[r] = sum_j dza[r][j] * Wa[0][j]
+            const float* cth = net.th + L.actor_size;
+            const int rr = tid >> 2, part = tid & 3;
+            float acc = 0.f;
+            for (int j = part; j < HA; j += 4) acc = fmaf(l.bufA[rr * LDA + H1 + j], cth[L.cWa + j], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) l.sDa[rr] = acc;
+            lds_barrier();
+            PH(14);
+        } else {
+            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, ga + L.aW1, ga + L.ab1);
+            PH(19);
+        }
+    }
+}
+
+template <int S, int H1, int H2, int HA>
+static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
+                  const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                  const float* s2, float gamma, float high, float* grads, float* losses, void* stream) {
+    const size_t lds = sizeof(float) * learn_lds_floats(*lay);
+    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_t<S, H1, H2, HA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        return AVD_E_LAUNCH;
+    }
+    hipLaunchKernelGGL((learn_kernel_t<S, H1, H2, HA>), dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay,
+                       set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
+    return check_launch("avd_learn_f32");
+}
+
+}  // namespace fast
+
+// ------------------------------------------------------------------------------------------
 // batch-1 forward per agent (act / Q read-out): one workgroup per agent row, weights streamed once
 // ------------------------------------------------------------------------------------------
 // y[n] = relu(sum_k x[k]*W[k][n] + b[n]) for n < N with x in LDS (already BN'ed); 256 threads split K.
@@ -905,6 +1324,15 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
     }
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0, "avd_learn_f32: n_agents=%d set_mod=%d", n_agents, set_mod);
     AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads, "avd_learn_f32: null pointer");
+    // reference widths (src/config.py:112-117) take the dimension-specialised kernel; anything else the generic one
+    if (lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && !getenv("AVD_LEARN_GENERIC")) {
+        if (lay->S == 4)
+            return fast::launch<4, 256, 128, 48>(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2,
+                                                 gamma, high, grads, losses, stream);
+        if (lay->S == 3)
+            return fast::launch<3, 256, 128, 48>(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2,
+                                                 gamma, high, grads, losses, stream);
+    }
     const size_t lds = sizeof(float) * learn_lds_floats(*lay);
     if (lds > 160 * 1024) {
         set_error("avd_learn_f32: widths H1=%d H2=%d Ha=%d need %zu B of LDS per tile (> 160 KiB)", lay->H1, lay->H2,

@@ -222,3 +222,32 @@ def test_unsupported_shapes_fail_loudly():
     z = torch.zeros(1, 64, 4, device="cuda")
     with pytest.raises(AvdError, match="LDS|layer2 size|layer1"):
         grp.learn(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 0)
+
+
+def test_generic_and_specialised_learn_kernels_agree(monkeypatch):
+    """Reference widths run the dimension-specialised kernel, other widths the generic one: both against the
+    oracle, and against each other on the same inputs."""
+    need_gpu()
+    n_agents = 4
+    conf, grp = _perturbed_group(n_agents, S=4, seed=21)
+    rs = np.random.RandomState(22)
+    s = rs.normal(0, 1.5, size=(n_agents, 64, 4)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n_agents, 64, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n_agents, 64))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n_agents, 64, 4)).astype(np.float32)
+    fast = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()
+    monkeypatch.setenv("AVD_LEARN_GENERIC", "1")
+    gen = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()
+    monkeypatch.delenv("AVD_LEARN_GENERIC")
+    assert not np.array_equal(fast, gen) or True  # summation orders may differ; values must agree closely
+    assert np.max(np.abs(fast - gen)) <= 2e-5 * np.max(np.abs(gen))
+    # non-reference widths -> generic kernel, checked against the oracle
+    conf2, grp2 = _perturbed_group(3, S=4, seed=23, actor_layer1_size=128, actor_layer2_size=64, critic_layer1_size=128,
+                                   critic_layer2_size=64, critic_act_layer_size=32)
+    g2 = grp2.learn(t(s[:3]), t(a[:3]), t(r[:3]), t(s2[:3]), 0)
+    for v in range(3):
+        cg, ag, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp2, v, np.float64))
+        cg32, ag32, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp2, v, np.float32))
+        gcg, gag = grp2.grads_as_lists(g2[v])
+        for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref))
