@@ -39,10 +39,21 @@ __device__ unsigned long long g_phase_cycles[32];
             ph_last = ph_now;                                                   \
         }                                                                       \
     } while (0)
+#define PHX_T0() unsigned long long phx_t = clock64()
+#define PHX(id)                                                                 \
+    do {                                                                        \
+        if (threadIdx.x == 0) {                                                 \
+            const unsigned long long phx_n = clock64();                         \
+            atomicAdd(&g_phase_cycles[id], phx_n - phx_t);                      \
+            phx_t = phx_n;                                                      \
+        }                                                                       \
+    } while (0)
 #define PH_ARG , unsigned long long& ph_last
 #define PH_PASS , ph_last
 #else
 #define PH_INIT()
+#define PHX_T0()
+#define PHX(id)
 #define PH(id)
 #define PH_ARG
 #define PH_PASS
@@ -105,12 +116,13 @@ __device__ __forceinline__ void l1_coefs(const L1Col& c, float* inv, float* sh, 
     sh[idx] = c.be - c.mm * iv;
 }
 
-// out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), 4 lanes per row, 16-byte LDS reads
+// out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), blockDim/64 lanes per row, 16-byte LDS reads
 __device__ __forceinline__ float out_layer_row(const float* P, int ld, const float* inv, const float* sh,
                                                const float* w, float b, int K) {
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int lpr = blockDim.x >> 6;  // lanes per row: 4 (256 threads) or 8 (512 threads)
+    const int r = threadIdx.x / lpr, part = threadIdx.x % lpr;
     float acc = 0.f;
-    for (int k = 4 * part; k < K; k += 16) {
+    for (int k = 4 * part; k < K; k += 4 * lpr) {
         const f32x4 p = *(const f32x4*)(P + r * ld + k);
         const f32x4 y = p * *(const f32x4*)(inv + k) + *(const f32x4*)(sh + k);
         const f32x4 wk = *(const f32x4*)(w + k);
@@ -119,7 +131,8 @@ __device__ __forceinline__ float out_layer_row(const float* P, int ld, const flo
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
-    return acc + b;  // valid in all 4 lanes of row r
+    if (lpr == 8) acc += __shfl_xor(acc, 4);
+    return acc + b;  // valid in all lanes of row r
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -321,7 +334,7 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
 
 // Column sums db[n] = sum_r DZ[r][n] -> LDS db[] and global gdb[]
 __device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float* db, float* __restrict__ gdb) {
-    for (int n = threadIdx.x; n < N; n += NTHREADS) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
         for (int r = 0; r < TILE; ++r) s += DZ[r * ldz + n];
         db[n] = s;
@@ -333,7 +346,7 @@ __device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float*
 template <int K>
 __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const float* DZ, int ldz, int c0, int H,
                                                  float* __restrict__ gW, float* __restrict__ gb) {
-    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
         float acc[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[j] = 0.f;
@@ -366,15 +379,16 @@ __device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, co
 
 // Output layer (width 1) backward through the BN below it, for column k < K (K <= 256):
 //   dW3[k] = sum_r bn(p[r][k])*d[r]; dy = d[r]*w3[k]; dgamma, dbeta; DZ[r][k] = dy*inv*(p>0)
-// The 64 rows are split over NTHREADS/K thread groups; partial sums meet in LDS scratch scr[3*NTHREADS].
+// The 64 rows are split over blockDim/K thread groups; partial sums meet in LDS scratch scr[3*blockDim].
 // rs/mean come from LDS tables (rsl, mml) filled when the layer's coefficients were built. Ends with a barrier.
 __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, const float* inv, const float* sh,
                                                    const float* d, const float* w3, const float* rsl,
                                                    const float* mml, int K, float* DZ, int ldz, float* scr,
                                                    float* __restrict__ gW3, float* __restrict__ gg,
                                                    float* __restrict__ gbe) {
+    const int nth = blockDim.x;
     int parts = 1;
-    while (parts * 2 * K <= NTHREADS && parts < 8) parts *= 2;
+    while (parts * 2 * K <= nth && parts < 8) parts *= 2;
     const int part = threadIdx.x / K, k = threadIdx.x - part * K;
     const int rows = TILE / parts;
     float dw = 0.f, dgm = 0.f, dbt = 0.f;
@@ -392,12 +406,12 @@ __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, cons
         }
     }
     if (gW3) {
-        scr[threadIdx.x] = dw, scr[NTHREADS + threadIdx.x] = dgm, scr[2 * NTHREADS + threadIdx.x] = dbt;
+        scr[threadIdx.x] = dw, scr[nth + threadIdx.x] = dgm, scr[2 * nth + threadIdx.x] = dbt;
         lds_barrier();
         if (threadIdx.x < K) {
             float a = 0.f, b2 = 0.f, c = 0.f;
             for (int q = 0; q < parts; ++q)
-                a += scr[q * K + k], b2 += scr[NTHREADS + q * K + k], c += scr[2 * NTHREADS + q * K + k];
+                a += scr[q * K + k], b2 += scr[nth + q * K + k], c += scr[2 * nth + q * K + k];
             gW3[k] = a, gg[k] = b2, gbe[k] = c;
         }
     }
@@ -413,19 +427,19 @@ struct LearnLds {
     float *invB, *shB;          // H2:    BN coefficients of the features held in bufB
     float *w3B, *rsB, *mmB;     // H2:    output-layer weights, rsqrt(var+eps) and mean of that BN layer
     float *db;                  // H2
-    float *scr;                 // 3*NTHREADS reduction scratch
+    float *scr;                 // 3*blockDim reduction scratch
     float *sS, *sS2;            // [64][S]
     float *sAct, *sR, *sY, *sQ, *sD, *sA1, *sT, *sDa;  // [64] each
     float* red;                                         // [8]
 };
 
-__host__ __device__ inline size_t learn_lds_floats(const avd_mlp_layout& L) {
+__host__ __device__ inline size_t learn_lds_floats(const avd_mlp_layout& L, int nth = NTHREADS) {
     const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
-    return (size_t)TILE * ldA + 2 * (size_t)TILE * ldB + 2 * (L.H1 + L.Ha) + 6 * L.H2 + 3 * NTHREADS +
+    return (size_t)TILE * ldA + 2 * (size_t)TILE * ldB + 2 * (L.H1 + L.Ha) + 6 * L.H2 + 3 * nth +
            2 * TILE * L.S + 8 * TILE + 8;
 }
 
-__device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) {
+__device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L, int nth = NTHREADS) {
     LearnLds l;
     const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
     float* p = smem;
@@ -440,7 +454,7 @@ __device__ __forceinline__ LearnLds carve(float* smem, const avd_mlp_layout& L) 
     l.rsB = p, p += L.H2;
     l.mmB = p, p += L.H2;
     l.db = p, p += L.H2;
-    l.scr = p, p += 3 * NTHREADS;
+    l.scr = p, p += 3 * nth;
     l.sS = p, p += TILE * L.S;
     l.sS2 = p, p += TILE * L.S;
     l.sAct = p, p += TILE;
@@ -712,111 +726,128 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
 // ------------------------------------------------------------------------------------------
 namespace fast {
 
-constexpr int R = 4;  // weight-operand register ring depth (blocks of 16 k)
+constexpr int FT = 512;  // 8 waves: two per SIMD, so one wave's LDS/VALU/latency phases run under its partner's MFMAs
+constexpr int R = 4;     // weight-operand register ring depth (blocks of 16 k)
 
+struct RawA {  // LDS operands of one 16-deep block: post-ReLU activations of 4 row tiles + the block's BN coefficients
+    f32x4 x[4], iv, sf;
+};
 template <int LDX>
-__device__ __forceinline__ void fetch_a(f32x4 (&a)[4], const float* X, const float* inv, const float* sh, int k4,
-                                        int lr) {
-    const f32x4 iv = *(const f32x4*)(inv + k4);
-    const f32x4 sf = *(const f32x4*)(sh + k4);
+__device__ __forceinline__ void read_a(RawA& q, const float* X, const float* inv, const float* sh, int k4, int lr) {
+    q.iv = *(const f32x4*)(inv + k4);
+    q.sf = *(const f32x4*)(sh + k4);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = *(const f32x4*)(X + (m * 16 + lr) * LDX + k4) * iv + sf;
+    for (int m = 0; m < 4; ++m) q.x[m] = *(const f32x4*)(X + (m * 16 + lr) * LDX + k4);
 }
 
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[4][2], const f32x4 (&a)[4], const f32x2 (&b)[4]) {
+// One 16-deep block: sum_k (p*inv + sh)[r][k] * W[k][n] is evaluated as  p @ (inv (.) W)  +  (sh . W[:, n]):
+// the BN scale goes onto the prefetched weight operand (4 v_mul), the shift into a per-column constant (4 v_fma),
+// so the A operand is the raw LDS value and no VALU result sits between an LDS read and an MFMA.
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[4], float& cs, const RawA& q, const float (&w)[4]) {
+    float bs[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        bs[jj] = w[jj] * q.iv[jj];
+        cs = fmaf(w[jj], q.sf[jj], cs);
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[m][0] = MFMA16(a[m][jj], b[jj][0], acc[m][0]);
-            acc[m][1] = MFMA16(a[m][jj], b[jj][1], acc[m][1]);
-        }
+        for (int m = 0; m < 4; ++m) acc[m] = MFMA16(q.x[m][jj], bs[jj], acc[m]);
 }
 
-// out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]), N == 128: wave w owns columns [32w, 32w+32).
+// out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]), N == 128: wave w owns columns [16w, 16w+16).
+// Per 16-deep block: [issue weight loads R-1 blocks ahead + LDS reads one block ahead] | [16 MFMAs].
+// sched_barrier(0) pins the two stages: hipcc's scheduler otherwise sinks every load down to its first use and
+// neither the register ring nor the LDS double buffer prefetches anything.
 template <int N, int LDX, int LDO>
 __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, int nblk,
                                          const float* __restrict__ W, const float* __restrict__ b, float* out) {
-    static_assert(N == 128, "one 32-column chunk per wave");
+    static_assert(N == 16 * (FT / 64), "one 16-column tile per wave");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    const int n0 = wave * 32;
-    const f32x2 bc = *(const f32x2*)(b + n0 + 2 * lr);
-    f32x4 acc[4][2];
+    const int col = wave * 16 + lr;
+    const float bc = b[col];
+    f32x4 acc[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wl = W + (4 * lg) * N + n0 + 2 * lr;  // lane's column pair, row 4*lg of block 0
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;                            // this lane's share (its k's) of sum_k sh[k]*W[k][col]
+    const float* wl = W + (4 * lg) * N + col;  // lane's column, row 4*lg of block 0
     const int last = nblk - 1;
-    f32x2 ring[R][4];
-    auto load_blk = [&](f32x2(&dst)[4], int blk) {
+    float ring[R][4];
+    auto load_blk = [&](float(&dst)[4], int blk) {
         const float* p = wl + blk * (16 * N);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dst[jj] = *(const f32x2*)(p + jj * N);
+        for (int jj = 0; jj < 4; ++jj) dst[jj] = p[jj * N];
     };
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) load_blk(ring[d], min(d, last));
-    f32x4 a[2][4];
-    fetch_a<LDX>(a[0], X, inv, sh, 4 * lg, lr);
+    RawA raw[2];
+    read_a<LDX>(raw[0], X, inv, sh, 4 * lg, lr);
     int blk = 0;
     const int ngrp = nblk / R;
+#pragma nounroll
     for (int g = 0; g < ngrp; ++g) {
 #pragma unroll
         for (int d = 0; d < R; ++d) {
             load_blk(ring[(d + R - 1) % R], min(blk + R - 1, last));
-            fetch_a<LDX>(a[(d + 1) & 1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
-            mfma_block(acc, a[d & 1], ring[d]);
+            read_a<LDX>(raw[(d + 1) & 1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(acc, cs, raw[d & 1], ring[d]);
+            __builtin_amdgcn_sched_barrier(0);
             ++blk;
         }
     }
+#pragma nounroll
     for (; blk < nblk; ++blk) {  // remainder: blocks already sit in ring[0..R-2]
-        fetch_a<LDX>(a[1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
-        mfma_block(acc, a[0], ring[0]);
+        read_a<LDX>(raw[1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(acc, cs, raw[0], ring[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d + 2 < R; ++d)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ring[d][jj] = ring[d + 1][jj];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) a[0][m] = a[1][m];
+        raw[0] = raw[1];
     }
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 32);
+    cs += bc;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2 o;
-            o[0] = fmaxf(acc[m][0][j] + bc[0], 0.f);
-            o[1] = fmaxf(acc[m][1][j] + bc[1], 0.f);
-            *(f32x2*)(out + (m * 16 + lg * 4 + j) * LDO + n0 + 2 * lr) = o;
-        }
+        for (int j = 0; j < 4; ++j) out[(m * 16 + lg * 4 + j) * LDO + col] = fmaxf(acc[m][j] + cs, 0.f);
 }
 
 // dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n], k < K (runtime, % 4 == 0), N == 128.
+// Wave w owns columns [16w, 16w+16); output tile ta of a 64-row block holds rows k0 + 4*i + ta (i = 4*lg + reg).
 template <int N, int LDP, int LDZ>
 __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const float* sh, int K, const float* DZ,
                                         const float* db, float* __restrict__ gW) {
-    static_assert(N == 128, "one 32-column chunk per wave");
+    static_assert(N == 16 * (FT / 64), "one 16-column tile per wave");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    const int n0 = wave * 32;
-    const f32x2 dbc = *(const f32x2*)(db + n0 + 2 * lr);
-    const float* dp = DZ + lg * LDZ + n0 + 2 * lr;
+    const int col = wave * 16 + lr;
+    const float dbc = db[col];
+    const float* dp = DZ + lg * LDZ + col;
+#pragma nounroll
     for (int k0 = 0; k0 < K; k0 += 64) {
-        f32x4 acc[4][2];
+        f32x4 acc[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* pp = P + lg * LDP + k0 + 4 * lr;  // may read past K in the last block: those rows are not stored
         f32x4 pa[2];
-        f32x2 dz[2];
+        float dz[2];
         pa[0] = *(const f32x4*)(pp);
-        dz[0] = *(const f32x2*)(dp);
+        dz[0] = dp[0];
 #pragma unroll
         for (int it = 0; it < TILE / 4; ++it) {
             if (it + 1 < TILE / 4) {
                 pa[(it + 1) & 1] = *(const f32x4*)(pp + 4 * (it + 1) * LDP);
-                dz[(it + 1) & 1] = *(const f32x2*)(dp + 4 * (it + 1) * LDZ);
+                dz[(it + 1) & 1] = dp[4 * (it + 1) * LDZ];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ta = 0; ta < 4; ++ta) {
-                acc[ta][0] = MFMA16(pa[it & 1][ta], dz[it & 1][0], acc[ta][0]);
-                acc[ta][1] = MFMA16(pa[it & 1][ta], dz[it & 1][1], acc[ta][1]);
-            }
+            for (int ta = 0; ta < 4; ++ta) acc[ta] = MFMA16(pa[it & 1][ta], dz[it & 1], acc[ta]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -825,12 +856,7 @@ __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const 
                 const f32x4 iv = *(const f32x4*)(inv + kbase);
                 const f32x4 sf = *(const f32x4*)(sh + kbase);
 #pragma unroll
-                for (int ta = 0; ta < 4; ++ta) {
-                    f32x2 o;
-                    o[0] = fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]);
-                    o[1] = fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1]);
-                    *(f32x2*)(gW + (kbase + ta) * N + n0 + 2 * lr) = o;
-                }
+                for (int ta = 0; ta < 4; ++ta) gW[(kbase + ta) * N + col] = fmaf(iv[ta], acc[ta][j], sf[ta] * dbc);
             }
         }
     }
@@ -842,13 +868,13 @@ struct BnSet {  // BN parameters / gradient outputs of a column range, indexed b
     int base;
 };
 
-// dy[r][c] = sum_n DZ[r][n]*W[c][n] for c in [c_begin, c_end) (16-column tiles round-robin over waves), then the
-// BN/ReLU backward of the layer below in place in P. Columns < split use `lo`, the others `hi`.
+// dy[r][c] = sum_n DZ[r][n]*W[c][n] for c in [c_begin, c_end) (16-column tiles round-robin over the 8 waves), then
+// the BN/ReLU backward of the layer below in place in P. Columns < split use `lo`, the others `hi`.
 template <int N, int LDZ, int LDP>
 __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict__ W, int c_begin, int c_end, float* P,
                                         BnSet lo, BnSet hi, int split, bool write_grads) {
     static_assert(N == 128, "N/16 == 8 reduction blocks held in registers");
-    constexpr int NB = N / 16;
+    constexpr int NB = N / 16, NW = FT / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     f32x4 wc[NB], wn[NB];
     float bnc[3] = {0.f, 0.f, 1.f}, bnn[3] = {0.f, 0.f, 1.f};
@@ -862,9 +888,19 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
     };
     int c0 = c_begin + wave * 16;
     if (c0 < c_end) load_tile(wc, bnc, c0);
-    for (; c0 < c_end; c0 += 4 * 16) {
-        const int cn = c0 + 4 * 16;
+#pragma nounroll
+    for (; c0 < c_end; c0 += NW * 16) {
+        PHX_T0();
+        const int cn = c0 + NW * 16;
         if (cn < c_end) load_tile(wn, bnn, cn);
+        // this tile's P values (the BN backward needs them): read now, consumed after the MFMAs
+        float pv[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[m][j] = P[(m * 16 + lg * 4 + j) * LDP + c0 + lr];
+        __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads ahead of this tile's MFMAs
+        PHX(20);
         f32x4 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -876,11 +912,14 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
             if (q + 1 < NB)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) a[(q + 1) & 1][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 16 * (q + 1) + 4 * lg);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[q & 1][m][jj], wc[q][jj], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        PHX(21);
         const int c = c0 + lr;
         const float rs = 1.0f / sqrtf(bnc[2] + BN_EPS);
         const float gam = bnc[0], mean = bnc[1];
@@ -889,12 +928,11 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r = m * 16 + lg * 4 + j;
                 const float dy = acc[m][j];
-                const float p = P[r * LDP + c];
+                const float p = pv[m][j];
                 sg = fmaf(dy * (p - mean), rs, sg);
                 sb += dy;
-                P[r * LDP + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+                P[(m * 16 + lg * 4 + j) * LDP + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
             }
         sg += __shfl_xor(sg, 16);
         sg += __shfl_xor(sg, 32);
@@ -905,26 +943,27 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
             s.dg[c - s.base] = sg;
             s.dbe[c - s.base] = sb;
         }
+        PHX(22);
 #pragma unroll
         for (int q = 0; q < NB; ++q) wc[q] = wn[q];
         bnc[0] = bnn[0], bnc[1] = bnn[1], bnc[2] = bnn[2];
+        PHX(23);
     }
 }
 
 template <int S, int H1, int H2, int HA>
-__global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int set_mod,
-                                                            const float* __restrict__ theta,
-                                                            const float* __restrict__ stats,
-                                                            const float* __restrict__ theta_t,
-                                                            const float* __restrict__ stats_t,
-                                                            const float* __restrict__ s, const float* __restrict__ a,
-                                                            const float* __restrict__ r, const float* __restrict__ s2,
-                                                            float gamma, float high, float* __restrict__ grads,
-                                                            float* __restrict__ losses) {
-    static_assert(H1 <= NTHREADS && HA <= NTHREADS && H2 <= NTHREADS && H1 % 16 == 0 && HA % 16 == 0, "widths");
+__global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_mod, const float* __restrict__ theta,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ theta_t,
+                                                      const float* __restrict__ stats_t,
+                                                      const float* __restrict__ s, const float* __restrict__ a,
+                                                      const float* __restrict__ r, const float* __restrict__ s2,
+                                                      float gamma, float high, float* __restrict__ grads,
+                                                      float* __restrict__ losses) {
+    static_assert(H1 <= FT && HA <= FT && H2 <= FT && FT % H1 == 0 && H1 % 16 == 0 && HA % 16 == 0, "widths");
     constexpr int KC = H1 + HA, LDA = ld_of(KC), LDB = ld_of(H2);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    LearnLds l = carve(smem, L);
+    LearnLds l = carve(smem, L, FT);
     const int agent = blockIdx.x;
     const int set = set_mod > 0 ? agent % set_mod : agent;
     const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
@@ -934,8 +973,12 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int
     float* gc = g + L.actor_size;  // critic block
     const int tid = threadIdx.x;
     constexpr float invn = 1.0f / (float)TILE;  // A == 1
+    // thread -> (column, row phase) maps of the first-layer phases
+    constexpr int sgroups = FT / H1, agroups = FT / HA;
+    const int ks = tid % H1, rs0 = tid / H1;
+    const int ka = tid % HA, ra = tid / HA;
 
-    for (int i = tid; i < TILE * S; i += NTHREADS) {
+    for (int i = tid; i < TILE * S; i += FT) {
         l.sS[i] = s[(long)agent * TILE * S + i];
         l.sS2[i] = s2[(long)agent * TILE * S + i];
     }
@@ -957,28 +1000,25 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int
     for (int it = 0; it < 4; ++it) {
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.sS2 : l.sS;
-        const int k = tid;
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
             const float* th = n.th;
             const float b3 = th[L.ab3];
             const L1Col c1 = l1_load(S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1,
-                                     H1, k);
-            const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, th + L.aW3, H2, k);
-            if (k < H1) {
-                l1_coefs(c1, l.invA, l.shA, k);
-                l1_rows_k<S>(c1, X, S, l.bufA, LDA, k, 0, 1);
-            }
-            l2_store(c2, l, H2, k);
+                                     H1, ks);
+            const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, th + L.aW3, H2, tid);
+            if (rs0 == 0) l1_coefs(c1, l.invA, l.shA, ks);
+            l1_rows_k<S>(c1, X, S, l.bufA, LDA, ks, rs0, sgroups);
+            l2_store(c2, l, H2, tid);
             lds_barrier();
             PH(1);
             gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, H1 / 16, th + L.aW2, th + L.ab2, l.bufB);
             lds_barrier();
             PH(2);
             const float z = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
-            if ((tid & 3) == 0) {
+            if ((tid & 7) == 0) {
                 const float t = tanhf(z);
-                l.sT[tid >> 2] = t;
-                l.sA1[tid >> 2] = t * high;
+                l.sT[tid >> 3] = t;
+                l.sA1[tid >> 3] = t * high;
             }
             lds_barrier();
             PH(3);
@@ -987,29 +1027,25 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int
             const float* th = n.th + L.actor_size;
             const float* st = n.st;
             const float* act = (it == 1) ? l.sAct : l.sA1;
-            constexpr int agroups = NTHREADS / HA;
-            const int ka = k % HA, ra = k / HA;
             const float b3 = th[L.cb3];
-            const L1Col cs = l1_load(S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, H1, k);
+            const L1Col cs = l1_load(S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, H1, ks);
             const L1Col ca = l1_load(1, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, HA,
                                      ra < agroups ? ka : HA);
-            const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, H2, k);
-            if (k < H1) {
-                l1_coefs(cs, l.invA, l.shA, k);
-                l1_rows_k<S>(cs, X, S, l.bufA, LDA, k, 0, 1);
-            }
+            const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, H2, tid);
+            if (rs0 == 0) l1_coefs(cs, l.invA, l.shA, ks);
+            l1_rows_k<S>(cs, X, S, l.bufA, LDA, ks, rs0, sgroups);
             if (ra < agroups) {
                 if (ra == 0) l1_coefs(ca, l.invA, l.shA, H1 + ka);
                 l1_rows_k<1>(ca, act, 1, l.bufA, LDA, H1 + ka, ra, agroups);
             }
-            l2_store(c2, l, H2, k);
+            l2_store(c2, l, H2, tid);
             lds_barrier();
             PH(4);
             gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, KC / 16, th + L.cW2, th + L.cb2, l.bufB);
             lds_barrier();
             PH(5);
             const float q = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
-            if ((tid & 3) == 0) l.sQ[tid >> 2] = q;
+            if ((tid & 7) == 0) l.sQ[tid >> 3] = q;
             lds_barrier();
             PH(6);
         }
@@ -1082,11 +1118,12 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_t(avd_mlp_layout L, int
             PH(11);
         } else if (it == 2) {  // da1[r] = sum_j dza[r][j] * Wa[0][j]
             const float* cth = net.th + L.actor_size;
-            const int rr = tid >> 2, part = tid & 3;
+            const int rr = tid >> 3, part = tid & 7;
             float acc = 0.f;
-            for (int j = part; j < HA; j += 4) acc = fmaf(l.bufA[rr * LDA + H1 + j], cth[L.cWa + j], acc);
+            for (int j = part; j < HA; j += 8) acc = fmaf(l.bufA[rr * LDA + H1 + j], cth[L.cWa + j], acc);
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
             if (part == 0) l.sDa[rr] = acc;
             lds_barrier();
             PH(14);
@@ -1101,14 +1138,14 @@ template <int S, int H1, int H2, int HA>
 static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
                   const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
                   const float* s2, float gamma, float high, float* grads, float* losses, void* stream) {
-    const size_t lds = sizeof(float) * learn_lds_floats(*lay);
+    const size_t lds = sizeof(float) * learn_lds_floats(*lay, FT);
     hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_t<S, H1, H2, HA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         return AVD_E_LAUNCH;
     }
-    hipLaunchKernelGGL((learn_kernel_t<S, H1, H2, HA>), dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay,
+    hipLaunchKernelGGL((learn_kernel_t<S, H1, H2, HA>), dim3(n_agents), dim3(FT), lds, (hipStream_t)stream, *lay,
                        set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
     return check_launch("avd_learn_f32");
 }
@@ -1209,10 +1246,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, in
 #ifdef AVD_PHASE_TIMING
 }  // namespace avd
 extern "C" int avd_debug_phase_cycles(unsigned long long* h_out, int reset) {
-    if (h_out) hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
+    if (h_out) (void)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
     if (reset) {
         unsigned long long z[32] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(avd::g_phase_cycles), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(avd::g_phase_cycles), z, sizeof(z));
     }
     return 0;
 }
@@ -1282,7 +1319,7 @@ static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int se
         return AVD_E_UNSUPPORTED;
     }
     if (lds > 48 * 1024)
-        hipFuncSetAttribute((const void*)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mlp_rows_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, mode, set_mod,
                        theta, stats, state, x_stride, action, high, out);
     return check_launch(who);

@@ -63,7 +63,8 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 
 class VecTrainer:
-    def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False):
+    def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
+                 pipeline_chunks=1):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'."""
@@ -105,11 +106,24 @@ class VecTrainer:
         self.auto_reset = auto_reset
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
+        self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
+        self.timers = None
         self.episode, self.ep_step = 0, 0
         self.updates = 0  # agent-updates (one agent's learn + Adam x2 + Polyak)
         self.env_steps = 0  # platoon-steps
 
     # ------------------------------------------------------------------------------------------
+    def _timed(self, name, fn, *args, **kw):
+        """Run fn; when self.timers is a dict, bracket it with HIP events on the launch stream."""
+        if self.timers is None:
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kw)
+        e1.record()
+        self.timers.setdefault(name, []).append((e0, e1))
+        return out
+
     def reset_episode(self):
         """trainer.py:244-249"""
         self.env.reset()
@@ -154,15 +168,31 @@ class VecTrainer:
         """train_all_models + federated branches (trainer.py:304-359, 400-456)."""
         conf, P, M = self.conf, self.P, self.M
         env = self.env
-        self.replay.add(env.x_prev.view(P * M, 4), self.actions.view(P * M, 1), env.reward.view(-1),
-                        env.x.view(P * M, 4), 4)
-        self.ep_reward += env.reward
-        if not self.replay.buffer_counter > conf.batch_size:  # strict gate: first update after the 65th add (:322)
+
+        def replay_part():
+            self.replay.add(env.x_prev.view(P * M, 4), self.actions.view(P * M, 1), env.reward.view(-1),
+                            env.x.view(P * M, 4), 4)
+            self.ep_reward += env.reward
+            if not self.replay.buffer_counter > conf.batch_size:  # strict gate: first update after the 65th add (:322)
+                return None
+            return self.replay.sample()
+
+        batch = self._timed("replay", replay_part)
+        if batch is None:
             return
-        s, a, r, s2 = self.replay.sample()
-        self.agents.learn(s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
-        self.updates += self.n_agents
+        s, a, r, s2 = batch
         fed = is_fed_enabled(conf)
+        self.updates += self.n_agents
+        if not fed and self.pipeline_chunks > 1:
+            # nofrl: every agent learns and updates locally -> software-pipeline the two kernels over agent slices
+            self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,
+                                    timers=self.timers)
+            return
+        self._timed("learn", self.agents.learn, s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
+        self._timed("update", self._update, ep, i, fed)
+
+    def _update(self, ep, i, fed):
+        conf, P, M = self.conf, self.P, self.M
         if not fed or not is_valid_update_step(conf, i):
             # local update (:345-356); note the gate tests the step only, not the episode (SURVEY 8a FRL quirk)
             if self.shared:
@@ -196,7 +226,7 @@ class VecTrainer:
         when ``sync`` (parity mode); with auto_reset the episode bookkeeping stays on the device."""
         ep = self.episode if ep is None else ep
         i = self.ep_step if i is None else i
-        self._act()
+        self._timed("act+env", self._act)
         self._train(ep, i)
         self.env_steps += self.P
         self.ep_step += 1

@@ -298,6 +298,52 @@ class AgentGroup:
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())
 
+    def learn_apply(self, s, a, r, s2, grads, losses=None, chunks=4, timers=None):
+        """learn + local update for per-agent weight sets (reference nofrl, workers/trainer.py:325-356).
+        Agents are independent, so they are processed in `chunks` slices: the Adam/Polyak kernel of slice c
+        (an HBM stream) runs on a side HIP stream underneath the learn kernel of slice c+1 (matrix-core
+        bound, ~1/5 of HBM bandwidth). Results are identical to learn() followed by apply().
+        timers: optional dict of lists collecting (start, end) event pairs per kernel ("learn", "update")."""
+        n = self.n_sets
+        if s.shape[0] != n:
+            raise _hip.AvdError("learn_apply needs one weight set per agent (set_mod == 0)")
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        c = self.config
+        self.step += 1
+        chunks = max(1, min(chunks, n))
+        bounds = [(n * i) // chunks for i in range(chunks + 1)]
+        T = lambda: torch.cuda.Event(enable_timing=timers is not None)
+        for i in range(chunks):
+            lo, hi = bounds[i], bounds[i + 1]
+            if hi == lo:
+                continue
+            t0, t1 = T(), T()
+            if timers is not None:
+                t0.record(main)
+            call("avd_learn_f32", self._layp, hi - lo, 0, ptr(self.theta[lo:hi]), ptr(self.stats[lo:hi]),
+                 ptr(self.theta_t[lo:hi]), ptr(self.stats_t[lo:hi]), ptr(s[lo:hi]), ptr(a[lo:hi]), ptr(r[lo:hi]),
+                 ptr(s2[lo:hi]), c.gamma, self.high, ptr(grads[lo:hi]), ptr(losses[lo:hi]) if losses is not None else None,
+                 _hip.C.c_void_p(main.cuda_stream))
+            t1.record(main)
+            side.wait_event(t1)
+            u0, u1 = T(), T()
+            if timers is not None:
+                u0.record(side)
+            call("avd_adam_polyak_f32", self._layp, hi - lo, ptr(self.theta[lo:hi]), ptr(self.stats[lo:hi]),
+                 ptr(self.theta_t[lo:hi]), ptr(self.stats_t[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                 ptr(grads[lo:hi]), ptr(self.step[lo:hi]), c.actor_lr, c.critic_lr, float(c.tau),
+                 _hip.C.c_void_p(side.cuda_stream))
+            if timers is not None:
+                u1.record(side)
+                timers.setdefault("learn", []).append((t0, t1))
+                timers.setdefault("update", []).append((u0, u1))
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+
     # -- Keras-style weight access (host copies) ---------------------------------------------------
     def get_weights(self, set_idx, which, target=False, trainable_only=False):
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)

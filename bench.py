@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
     ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
+    ap.add_argument("--chunks", type=int, default=8,
+                    help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -95,7 +97,7 @@ def main():
                          fed_method="interfrl" if args.mode == "interfrl" else "normal",
                          weighted_average_enabled=False, random_seed=1 + rank)
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
-                            seed=1 + rank)
+                            seed=1 + rank, pipeline_chunks=args.chunks)
     # synthetic steady state: replay rings full of random-init-platoon-like rows
     ring = vt.replay.ring
     chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
@@ -104,53 +106,14 @@ def main():
     vt.replay.buffer_counter = args.buffer_size
     vt.reset_episode()
 
-    # per-stage HIP events on the launch stream (torch's current stream is the one handed to the C ABI)
+    # per-stage / per-kernel HIP events, each recorded on the stream its kernels are launched on
     names = ("act+env", "replay", "learn", "update")
-    ev = {n: [] for n in names}
-
-    def timed(stage, fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        ev[stage].append((e0, e1))
 
     def one_step(record):
-        if not record:
-            vt.step()
-            return
-        ep, i = vt.episode, vt.ep_step
-        timed("act+env", vt._act)
-        split = {}
+        vt.timers = ev if record else None
+        vt.step()
 
-        def replay_part():
-            env = vt.env
-            vt.replay.add(env.x_prev.view(P * L, 4), vt.actions.view(P * L, 1), env.reward.view(-1),
-                          env.x.view(P * L, 4), 4)
-            vt.ep_reward += env.reward
-            split["batch"] = vt.replay.sample()
-
-        timed("replay", replay_part)
-        timed("learn", lambda: vt.agents.learn(*split["batch"], vt.set_mod, grads=vt.grads, losses=vt.losses))
-
-        def update_part():
-            if vt.shared:
-                from avddpg_amd import vec
-                vt.agents.apply(vec.fed_mean(vt.grads, P, L, group=vt.group))
-            else:
-                vt.agents.apply(vt.grads)
-
-        timed("update", update_part)
-        vt.updates += vt.n_agents
-        vt.env_steps += P
-        vt.ep_step += 1
-        if vt.ep_step >= conf.steps_per_episode:
-            vt.env.reset()
-            vt.ep_step = 0
-            vt.episode += 1
-        else:
-            vt.env.reset(cond=vt.env.any_done)
-
+    ev = {}
     for _ in range(args.warmup):
         one_step(False)
 
@@ -172,7 +135,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stage_ms = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / max(1, len(ev[n])) for n in names}
+    # per step: summed launch durations of each stage (learn/update: all agent slices of the step)
+    stage_ms = {n: sum(a.elapsed_time(b) for a, b in ev.get(n, [])) / args.steps for n in names}
     n_agents = P * L
     env_steps_per_s = world * P * args.steps / elapsed
     updates_per_s = world * n_agents * args.steps / elapsed
@@ -214,6 +178,8 @@ def main():
                        "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
             "stages_ms": stage_ms,
+            "pipeline": (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
+                         "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else "serial",
             "kernels": [r for r in (roof_learn, roof_upd) if r],
         }
         if world == 1 and not args.no_cpu_baseline:

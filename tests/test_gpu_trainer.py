@@ -175,3 +175,21 @@ def test_reference_object_api_roundtrip():
     assert np.array_equal(t_critic.get_weights()[0], tc[0])
     with pytest.raises(ValueError):  # reference refuses platoons longer than its colour table, after construction
         environment.Platoon(7, conf, 0)
+
+
+def test_pipelined_learn_apply_is_bitwise_learn_then_apply():
+    """nofrl: the two-stream agent-slice pipeline (learn || Adam+Polyak) gives exactly the serial result."""
+    conf = config.Config(num_platoons=37, pl_size=3, buffer_size=128)
+    runs = []
+    for chunks in (1, 5):
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, pipeline_chunks=chunks, seed=4)
+        vt.reset_episode()
+        for _ in range(70):
+            vt.step()
+        torch.cuda.synchronize()
+        runs.append(vt)
+    a, b = runs
+    assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
+    assert torch.equal(a.agents.m, b.agents.m) and torch.equal(a.agents.v, b.agents.v)
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.grads, b.grads)
+    assert int(a.agents.step[0]) == int(b.agents.step[-1]) == 6

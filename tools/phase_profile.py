@@ -40,5 +40,6 @@ buf = (ctypes.c_ulonglong * 32)()
 lib.avd_debug_phase_cycles(buf, 0)
 tot = sum(buf)
 print(f"tiles={3 * n}  cycles/tile={tot / (3 * n):.0f}")
-for i in range(20):
+NAMES.update({20: "  dx: issue next-tile loads", 21: "  dx: MFMA loop", 22: "  dx: BN epilogue", 23: "  dx: wait next tile (copy)"})
+for i in range(24):
     print(f"{i:2d} {NAMES[i]:38s} {buf[i] / (3 * n):9.0f} cyc/tile  {100 * buf[i] / tot:5.1f}%")
