@@ -241,13 +241,8 @@ class VecTrainer:
             return None
         if not sync:
             return None
-        done = bool(self.env.any_done.item())
-        if self.group is not None:
-            import torch.distributed as dist
-            flag = self.env.any_done.clone()
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            done = bool(flag.item())
-        return done
+        from .dist import any_terminal
+        return any_terminal(self.env.any_done, self.group)
 
     def update_reward_list(self, ep):
         """trainer.py:510-517 (float32 counters, trailing mean over reward_averaging_window)."""

@@ -382,11 +382,8 @@ def fed_mean(grads, P, M, weights=None, group=None, method="interfrl"):
     call("avd_fed_sum_f32", n_out, n_in, so, si, n, ptr(grads), ptr(weights), ptr(out), ptr(wsum), stream_handle())
     count = float(n_in)
     if group is not None and method == "interfrl":
-        import torch.distributed as dist
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-        if wsum is not None:
-            dist.all_reduce(wsum, op=dist.ReduceOp.SUM, group=group)
-        count = float(n_in * dist.get_world_size(group))
+        from .dist import exchange_fed_sums
+        count = exchange_fed_sums(out, wsum, n_in, group)
     call("avd_fed_finalize_f32", n_out, n, ptr(out), count, ptr(wsum), stream_handle())
     return out
 

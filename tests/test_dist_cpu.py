@@ -1,0 +1,87 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU host logic: platoon sharding, the interfrl gradient
+exchange (all-reduce of per-vehicle-index partial sums) against the oracle's federated mean over ALL platoons,
+and the any-terminal flag. The same code runs over RCCL on GPUs (backend "nccl")."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from avddpg_amd import dist as adist
+from oracle import federated as ofed
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_platoons_partitions_exactly():
+    for total, world in ((32768, 8), (4096, 1), (10, 3), (7, 8)):
+        spans = [adist.shard_platoons(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert adist.shard_platoons(32768, 8, 3) == (12288, 16384)
+    with pytest.raises(ValueError):
+        adist.shard_platoons(8, 2, 2)
+
+
+def _worker(rank, world, port, P_total, M, n, weighted, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(0)  # every rank generates the full problem, uses its shard
+        g = rs.normal(size=(P_total, M, n)).astype(np.float32)
+        w = rs.uniform(0.5, 6.0, size=(P_total, M)).astype(np.float32)
+        lo, hi = adist.shard_platoons(P_total, world, rank)
+        gl, wl = g[lo:hi], w[lo:hi]
+        # local partial sums (what avd_fed_sum_f32 produces on each GPU), fixed platoon order
+        if weighted:
+            out = torch.from_numpy((gl * wl[..., None]).sum(axis=0, dtype=np.float32))
+            ws = torch.from_numpy(wl.sum(axis=0, dtype=np.float32))
+        else:
+            out, ws = torch.from_numpy(gl.sum(axis=0, dtype=np.float32)), None
+        count = adist.exchange_fed_sums(out, ws, hi - lo, dist.group.WORLD)
+        avg = (out * (1.0 / ws)[:, None]) if weighted else out / count  # avd_fed_finalize_f32
+        flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
+        q.put((rank, count, avg.numpy(), adist.any_terminal(flag, dist.group.WORLD),
+               adist.any_terminal(torch.zeros(1, dtype=torch.int32), dist.group.WORLD)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_interfrl_exchange_world2_matches_oracle_mean_over_all_platoons(weighted):
+    world, P_total, M, n = 2, 7, 3, 1000  # 7 platoons -> shards of 4 and 3: unequal on purpose
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P_total, M, n, weighted, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(0)
+    g = rs.normal(size=(P_total, M, n)).astype(np.float32)
+    w = rs.uniform(0.5, 6.0, size=(P_total, M)).astype(np.float32)
+    if weighted:
+        ref = ofed.get_weighted_avg_params([[[w[p, m] * g[p, m]] for p in range(P_total)] for m in range(M)],
+                                           [float(w[:, m].sum()) for m in range(M)])
+    else:
+        ref = ofed.get_avg_params([[[g[p, m]] for p in range(P_total)] for m in range(M)])
+    for rank, count, avg, any1, any0 in res:
+        assert count == P_total and any1 is True and any0 is False
+        for m in range(M):
+            assert np.allclose(avg[m], ref[m][0], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(res[0][2], res[1][2])  # every rank ends with the identical average (bit-equal weights)
