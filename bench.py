@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
     ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
-    ap.add_argument("--chunks", type=int, default=8,
+    ap.add_argument("--chunks", type=int, default=1,
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -149,6 +149,17 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
     else:
         roof_upd = None
+    # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and P == 4096 and L == 5:
+        pmc = json.load(open(pmc_path))["kernels"]
+        for r, key in ((roof_learn, "learn_kernel"), (roof_upd, "adam_polyak_kernel")):
+            hit = [v for k, v in pmc.items() if key in k]
+            if r and hit and hit[0].get("hbm_bytes_per_unit"):
+                launches = max(1, len(ev.get("learn" if r is roof_learn else "update", [])) // args.steps)
+                r["traffic"] = hit[0]["hbm_bytes_per_unit"] * n_agents / launches
+                r["traffic_note"] = "HBM-side bytes per launch, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/pmc_traffic.json"
     for r in (roof_learn, roof_upd):
         if r:
             r["frac"] = r["achieved"] / r["peak"]
