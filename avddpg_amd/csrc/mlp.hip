@@ -90,15 +90,28 @@ __device__ __forceinline__ L1Col l1_load(int K, const float* __restrict__ W, con
     c.mv = on ? mv[k] : 1.f;
     return c;
 }
+// Rows are processed in register blocks of RB: all RB broadcast reads of X are issued before the first
+// FMA/ds_write (a read -> compute -> write loop pays one LDS round trip per row: LDS returns in order).
+constexpr int RB = 16;
 template <int K>
 __device__ __forceinline__ void l1_rows_k(const L1Col& c, const float* X, int xs, float* out, int ld, int col, int r0,
                                           int rstep) {
-#pragma unroll 8
-    for (int r = r0; r < TILE; r += rstep) {
-        float acc = c.b;
+    for (int rb = r0; rb < TILE; rb += RB * rstep) {
+        float xv[RB][K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc = fmaf(X[r * xs + j], c.w[j], acc);
-        out[r * ld + col] = fmaxf(acc, 0.f);
+        for (int i = 0; i < RB; ++i) {
+            const int r = min(rb + i * rstep, TILE - 1);
+#pragma unroll
+            for (int j = 0; j < K; ++j) xv[i][j] = X[r * xs + j];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = rb + i * rstep;
+            float acc = c.b;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = fmaf(xv[i][j], c.w[j], acc);
+            if (r < TILE) out[r * ld + col] = fmaxf(acc, 0.f);
+        }
     }
 }
 __device__ __forceinline__ void l1_rows(const L1Col& c, int K, const float* X, int xs, float* out, int ld, int col,
@@ -351,12 +364,20 @@ __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const f
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[j] = 0.f;
         float sb = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < TILE; ++r) {
-            const float d = DZ[r * ldz + c0 + k];
-            sb += d;
+        for (int rb = 0; rb < TILE; rb += RB) {  // RB rows of operands in registers before the FMAs
+            float dv[RB], xv[RB][K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(X[r * xs + j], d, acc[j]);
+            for (int i = 0; i < RB; ++i) {
+                dv[i] = DZ[(rb + i) * ldz + c0 + k];
+#pragma unroll
+                for (int j = 0; j < K; ++j) xv[i][j] = X[(rb + i) * xs + j];
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                sb += dv[i];
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[j] = fmaf(xv[i][j], dv[i], acc[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) gW[j * H + k] = acc[j];
@@ -394,15 +415,19 @@ __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, cons
     float dw = 0.f, dgm = 0.f, dbt = 0.f;
     if (part < parts) {
         const float wk = w3[k], iv = inv[k], s = sh[k], rs = rsl[k], mean = mml[k];
-#pragma unroll 8
-        for (int r = part * rows; r < (part + 1) * rows; ++r) {
-            const float p = P[r * ldp + k];
-            const float dr = d[r];
-            dw = fmaf(fmaf(p, iv, s), dr, dw);
-            const float dy = dr * wk;
-            dgm = fmaf(dy * (p - mean), rs, dgm);
-            dbt += dy;
-            DZ[r * ldz + k] = (p > 0.f) ? dy * iv : 0.f;
+        for (int rb = part * rows; rb < (part + 1) * rows; rb += 8) {  // rows % 8 == 0; reads before compute/writes
+            float pv[8], dv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = P[(rb + i) * ldp + k], dv[i] = d[rb + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p = pv[i], dr = dv[i];
+                dw = fmaf(fmaf(p, iv, s), dr, dw);
+                const float dy = dr * wk;
+                dgm = fmaf(dy * (p - mean), rs, dgm);
+                dbt += dy;
+                DZ[(rb + i) * ldz + k] = (p > 0.f) ? dy * iv : 0.f;
+            }
         }
     }
     if (gW3) {
@@ -726,7 +751,11 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int s
 // ------------------------------------------------------------------------------------------
 namespace fast {
 
-constexpr int FT = 512;  // 8 waves: two per SIMD, so one wave's LDS/VALU/latency phases run under its partner's MFMAs
+// 4 waves, one per SIMD, two 16-column MFMA tiles each. (An 8-wave / 2-per-SIMD variant measured the same time:
+// the phases are paced by the MFMA pipe and by the cold loads at their heads, not by per-wave stalls; and at two
+// waves per SIMD the 256-register cap leaves no room for the cross-phase prefetch state.)
+constexpr int FT = 256;
+constexpr int NW = FT / 64;
 constexpr int R = 4;     // weight-operand register ring depth (blocks of 16 k)
 
 struct RawA {  // LDS operands of one 16-deep block: post-ReLU activations of 4 row tiles + the block's BN coefficients
@@ -740,47 +769,99 @@ __device__ __forceinline__ void read_a(RawA& q, const float* X, const float* inv
     for (int m = 0; m < 4; ++m) q.x[m] = *(const f32x4*)(X + (m * 16 + lr) * LDX + k4);
 }
 
-// One 16-deep block: sum_k (p*inv + sh)[r][k] * W[k][n] is evaluated as  p @ (inv (.) W)  +  (sh . W[:, n]):
-// the BN scale goes onto the prefetched weight operand (4 v_mul), the shift into a per-column constant (4 v_fma),
-// so the A operand is the raw LDS value and no VALU result sits between an LDS read and an MFMA.
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[4], float& cs, const RawA& q, const float (&w)[4]) {
-    float bs[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        bs[jj] = w[jj] * q.iv[jj];
-        cs = fmaf(w[jj], q.sf[jj], cs);
+template <int NT>
+__device__ __forceinline__ void ldn(float (&d)[NT], const float* p) {  // NT consecutive floats, one access
+    if constexpr (NT == 2) {
+        const f32x2 v = *(const f32x2*)p;
+        d[0] = v[0], d[1] = v[1];
+    } else {
+        d[0] = p[0];
     }
+}
+template <int NT>
+__device__ __forceinline__ void stn(float* p, const float (&d)[NT]) {
+    if constexpr (NT == 2) {
+        f32x2 v;
+        v[0] = d[0], v[1] = d[1];
+        *(f32x2*)p = v;
+    } else {
+        p[0] = d[0];
+    }
+}
+
+// One 16-deep block: sum_k (p*inv + sh)[r][k] * W[k][n] is evaluated as  p @ (inv (.) W)  +  (sh . W[:, n]):
+// the BN scale goes onto the prefetched weight operand (v_mul), the shift into a per-column constant (v_fma),
+// so the A operand is the raw LDS value and no VALU result sits between an LDS read and an MFMA.
+template <int NT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[4][NT], float (&cs)[NT], const RawA& q,
+                                           const float (&w)[4][NT]) {
+    float bs[4][NT];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = MFMA16(q.x[m][jj], bs[jj], acc[m]);
+        for (int t = 0; t < NT; ++t) {
+            bs[jj][t] = w[jj][t] * q.iv[jj];
+            cs[t] = fmaf(w[jj][t], q.sf[jj], cs[t]);
+        }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = MFMA16(q.x[m][jj], bs[jj][t], acc[m][t]);
 }
 
-// out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]), N == 128: wave w owns columns [16w, 16w+16).
-// Per 16-deep block: [issue weight loads R-1 blocks ahead + LDS reads one block ahead] | [16 MFMAs].
+// First R-1 weight blocks + bias of a forward GEMM, requested one phase early (before the first-layer VALU phase
+// that precedes the GEMM) so that the GEMM does not open on a cold HBM miss.
+// Column map: wave w owns columns [16*NT*w, 16*NT*(w+1)); its MFMA tile t holds columns base + NT*lr + t.
+template <int NT>
+struct FwdPre {
+    float ring[R][4][NT];
+    float bc[NT];
+};
+template <int N>
+__device__ __forceinline__ void fwd_prefetch(FwdPre<N / (16 * NW)>& p, const float* __restrict__ W,
+                                             const float* __restrict__ b, int nblk) {
+    constexpr int NT = N / (16 * NW);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int col = wave * 16 * NT + NT * lr;
+    const float* wl = W + (4 * lg) * N + col;
+    ldn<NT>(p.bc, b + col);
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d) {
+        const float* q = wl + min(d, nblk - 1) * (16 * N);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ldn<NT>(p.ring[d][jj], q + jj * N);
+    }
+}
+
+// out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]).
+// Per 16-deep block: [issue weight loads R-1 blocks ahead + LDS reads one block ahead] | [16*NT MFMAs].
 // sched_barrier(0) pins the two stages: hipcc's scheduler otherwise sinks every load down to its first use and
 // neither the register ring nor the LDS double buffer prefetches anything.
 template <int N, int LDX, int LDO>
 __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, int nblk,
-                                         const float* __restrict__ W, const float* __restrict__ b, float* out) {
-    static_assert(N == 16 * (FT / 64), "one 16-column tile per wave");
+                                         const float* __restrict__ W, FwdPre<N / (16 * NW)>& pre, float* out) {
+    constexpr int NT = N / (16 * NW);
+    static_assert(NT == 1 || NT == 2, "one or two 16-column tiles per wave");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    const int col = wave * 16 + lr;
-    const float bc = b[col];
-    f32x4 acc[4];
+    const int col = wave * 16 * NT + NT * lr;
+    f32x4 acc[4][NT];
+    float cs[NT];  // this lane's share (its k's) of sum_k sh[k]*W[k][col..]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float cs = 0.f;                            // this lane's share (its k's) of sum_k sh[k]*W[k][col]
-    const float* wl = W + (4 * lg) * N + col;  // lane's column, row 4*lg of block 0
+    for (int t = 0; t < NT; ++t) {
+        cs[t] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float* wl = W + (4 * lg) * N + col;  // lane's columns, row 4*lg of block 0
     const int last = nblk - 1;
-    float ring[R][4];
-    auto load_blk = [&](float(&dst)[4], int blk) {
+    float(&ring)[R][4][NT] = pre.ring;
+    auto load_blk = [&](float(&dst)[4][NT], int blk) {
         const float* p = wl + blk * (16 * N);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dst[jj] = p[jj * N];
+        for (int jj = 0; jj < 4; ++jj) ldn<NT>(dst[jj], p + jj * N);
     };
-#pragma unroll
-    for (int d = 0; d < R - 1; ++d) load_blk(ring[d], min(d, last));
     RawA raw[2];
     read_a<LDX>(raw[0], X, inv, sh, 4 * lg, lr);
     int blk = 0;
@@ -792,7 +873,7 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
             load_blk(ring[(d + R - 1) % R], min(blk + R - 1, last));
             read_a<LDX>(raw[(d + 1) & 1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block(acc, cs, raw[d & 1], ring[d]);
+            mfma_block<NT>(acc, cs, raw[d & 1], ring[d]);
             __builtin_amdgcn_sched_barrier(0);
             ++blk;
         }
@@ -801,52 +882,68 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
     for (; blk < nblk; ++blk) {  // remainder: blocks already sit in ring[0..R-2]
         read_a<LDX>(raw[1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block(acc, cs, raw[0], ring[0]);
+        mfma_block<NT>(acc, cs, raw[0], ring[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d + 2 < R; ++d)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) ring[d][jj] = ring[d + 1][jj];
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ring[d][jj][t] = ring[d + 1][jj][t];
         raw[0] = raw[1];
     }
-    cs += __shfl_xor(cs, 16);
-    cs += __shfl_xor(cs, 32);
-    cs += bc;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        cs[t] += __shfl_xor(cs[t], 16);
+        cs[t] += __shfl_xor(cs[t], 32);
+        cs[t] += pre.bc[t];
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[(m * 16 + lg * 4 + j) * LDO + col] = fmaxf(acc[m][j] + cs, 0.f);
+        for (int j = 0; j < 4; ++j) {
+            float o[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = fmaxf(acc[m][t][j] + cs[t], 0.f);
+            stn<NT>(out + (m * 16 + lg * 4 + j) * LDO + col, o);
+        }
 }
 
-// dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n], k < K (runtime, % 4 == 0), N == 128.
-// Wave w owns columns [16w, 16w+16); output tile ta of a 64-row block holds rows k0 + 4*i + ta (i = 4*lg + reg).
+// dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n], k < K (runtime, % 4 == 0).
+// Wave w owns columns [16*NT*w, ..); output tile (ta, t) of a 64-row block holds rows k0 + 4*i + ta
+// (i = 4*lg + reg) and columns base + NT*lr + t.
 template <int N, int LDP, int LDZ>
 __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const float* sh, int K, const float* DZ,
                                         const float* db, float* __restrict__ gW) {
-    static_assert(N == 16 * (FT / 64), "one 16-column tile per wave");
+    constexpr int NT = N / (16 * NW);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    const int col = wave * 16 + lr;
-    const float dbc = db[col];
+    const int col = wave * 16 * NT + NT * lr;
+    float dbc[NT];
+    ldn<NT>(dbc, db + col);
     const float* dp = DZ + lg * LDZ + col;
 #pragma nounroll
     for (int k0 = 0; k0 < K; k0 += 64) {
-        f32x4 acc[4];
+        f32x4 acc[4][NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* pp = P + lg * LDP + k0 + 4 * lr;  // may read past K in the last block: those rows are not stored
         f32x4 pa[2];
-        float dz[2];
+        float dz[2][NT];
         pa[0] = *(const f32x4*)(pp);
-        dz[0] = dp[0];
+        ldn<NT>(dz[0], dp);
 #pragma unroll
         for (int it = 0; it < TILE / 4; ++it) {
             if (it + 1 < TILE / 4) {
                 pa[(it + 1) & 1] = *(const f32x4*)(pp + 4 * (it + 1) * LDP);
-                dz[(it + 1) & 1] = dp[4 * (it + 1) * LDZ];
+                ldn<NT>(dz[(it + 1) & 1], dp + 4 * (it + 1) * LDZ);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ta = 0; ta < 4; ++ta) acc[ta] = MFMA16(pa[it & 1][ta], dz[it & 1], acc[ta]);
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[ta][t] = MFMA16(pa[it & 1][ta], dz[it & 1][t], acc[ta][t]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -856,7 +953,12 @@ __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const 
                 const f32x4 iv = *(const f32x4*)(inv + kbase);
                 const f32x4 sf = *(const f32x4*)(sh + kbase);
 #pragma unroll
-                for (int ta = 0; ta < 4; ++ta) gW[(kbase + ta) * N + col] = fmaf(iv[ta], acc[ta][j], sf[ta] * dbc);
+                for (int ta = 0; ta < 4; ++ta) {
+                    float o[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = fmaf(iv[ta], acc[ta][t][j], sf[ta] * dbc[t]);
+                    stn<NT>(gW + (kbase + ta) * N + col, o);
+                }
             }
         }
     }
@@ -870,29 +972,46 @@ struct BnSet {  // BN parameters / gradient outputs of a column range, indexed b
 
 // dy[r][c] = sum_n DZ[r][n]*W[c][n] for c in [c_begin, c_end) (16-column tiles round-robin over the 8 waves), then
 // the BN/ReLU backward of the layer below in place in P. Columns < split use `lo`, the others `hi`.
+template <int N>
+struct DxPre {  // a wave's first tile (W slice + BN parameters), requested before the phase that precedes gemm_dx
+    f32x4 w[N / 16];
+    float bn[3];
+};
+template <int N>
+__device__ __forceinline__ void dx_load_tile(f32x4 (&w)[N / 16], float (&bn)[3], const float* __restrict__ W, int c0,
+                                             const BnSet& lo, const BnSet& hi, int split) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const float* wrow = W + (c0 + lr) * N + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < N / 16; ++q) w[q] = *(const f32x4*)(wrow + 16 * q);
+    const BnSet& s = (c0 < split) ? lo : hi;
+    const int i = c0 + lr - s.base;
+    bn[0] = s.g[i], bn[1] = s.mm[i], bn[2] = s.mv[i];
+}
+template <int N>
+__device__ __forceinline__ void dx_prefetch(DxPre<N>& p, const float* __restrict__ W, int c_begin, int c_end,
+                                            const BnSet& lo, const BnSet& hi, int split) {
+    const int c0 = c_begin + (threadIdx.x >> 6) * 16;
+    p.bn[0] = 0.f, p.bn[1] = 0.f, p.bn[2] = 1.f;
+    if (c0 < c_end) dx_load_tile<N>(p.w, p.bn, W, c0, lo, hi, split);
+}
+
 template <int N, int LDZ, int LDP>
 __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict__ W, int c_begin, int c_end, float* P,
-                                        BnSet lo, BnSet hi, int split, bool write_grads) {
+                                        BnSet lo, BnSet hi, int split, bool write_grads, DxPre<N>& pre) {
     static_assert(N == 128, "N/16 == 8 reduction blocks held in registers");
-    constexpr int NB = N / 16, NW = FT / 64;
+    constexpr int NB = N / 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    f32x4 wc[NB], wn[NB];
-    float bnc[3] = {0.f, 0.f, 1.f}, bnn[3] = {0.f, 0.f, 1.f};
-    auto load_tile = [&](f32x4(&w)[NB], float(&bn)[3], int c0) {
-        const float* wrow = W + (c0 + lr) * N + 4 * lg;
-#pragma unroll
-        for (int q = 0; q < NB; ++q) w[q] = *(const f32x4*)(wrow + 16 * q);
-        const BnSet& s = (c0 < split) ? lo : hi;
-        const int i = c0 + lr - s.base;
-        bn[0] = s.g[i], bn[1] = s.mm[i], bn[2] = s.mv[i];
-    };
+    f32x4(&wc)[NB] = pre.w;
+    f32x4 wn[NB];
+    float(&bnc)[3] = pre.bn;
+    float bnn[3] = {0.f, 0.f, 1.f};
     int c0 = c_begin + wave * 16;
-    if (c0 < c_end) load_tile(wc, bnc, c0);
 #pragma nounroll
     for (; c0 < c_end; c0 += NW * 16) {
         PHX_T0();
         const int cn = c0 + NW * 16;
-        if (cn < c_end) load_tile(wn, bnn, cn);
+        if (cn < c_end) dx_load_tile<N>(wn, bnn, W, cn, lo, hi, split);
         // this tile's P values (the BN backward needs them): read now, consumed after the MFMAs
         float pv[4][4];
 #pragma unroll
@@ -951,6 +1070,82 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
     }
 }
 
+// Per-thread parameter columns of a network's first layers, loaded one phase before they are used.
+template <int K>
+struct L1P {
+    float w[K], b, g, be, mm, mv;
+};
+template <int K>
+__device__ __forceinline__ L1P<K> l1p_load(const float* __restrict__ W, const float* __restrict__ b,
+                                           const float* __restrict__ g, const float* __restrict__ be,
+                                           const float* __restrict__ mm, const float* __restrict__ mv, int H, int k) {
+    L1P<K> c;
+#pragma unroll
+    for (int j = 0; j < K; ++j) c.w[j] = W[j * H + k];
+    c.b = b[k], c.g = g[k], c.be = be[k], c.mm = mm[k], c.mv = mv[k];
+    return c;
+}
+template <int K>
+__device__ __forceinline__ void l1p_coefs(const L1P<K>& c, float* inv, float* sh, int idx) {
+    const float iv = (1.0f / sqrtf(c.mv + BN_EPS)) * c.g;
+    inv[idx] = iv;
+    sh[idx] = c.be - c.mm * iv;
+}
+template <int K>
+__device__ __forceinline__ void l1p_rows(const L1P<K>& c, const float* X, float* out, int ld, int col, int r0,
+                                         int rstep) {
+    for (int rb = r0; rb < TILE; rb += RB * rstep) {  // register blocks of RB rows: see l1_rows_k
+        float xv[RB][K];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = min(rb + i * rstep, TILE - 1);
+#pragma unroll
+            for (int j = 0; j < K; ++j) xv[i][j] = X[r * K + j];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = rb + i * rstep;
+            float acc = c.b;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = fmaf(xv[i][j], c.w[j], acc);
+            if (r < TILE) out[r * ld + col] = fmaxf(acc, 0.f);
+        }
+    }
+}
+template <int S>
+struct ActorPar {
+    L1P<S> c1;
+    L2Col c2;
+    float b3;
+};
+template <int S>
+struct CriticPar {
+    L1P<S> cs;
+    L1P<1> ca;
+    L2Col c2;
+    float b3;
+};
+template <int S, int H1, int H2>
+__device__ __forceinline__ ActorPar<S> load_actor(const avd_mlp_layout& L, Net n, int ks, int tid) {
+    const float* th = n.th;
+    ActorPar<S> p;
+    p.c1 = l1p_load<S>(th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1, H1, ks);
+    p.c2 = l2_load(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, th + L.aW3, H2, tid);
+    p.b3 = th[L.ab3];
+    return p;
+}
+template <int S, int H1, int H2, int HA>
+__device__ __forceinline__ CriticPar<S> load_critic(const avd_mlp_layout& L, Net n, int ks, int ka, int tid) {
+    const float* th = n.th + L.actor_size;
+    const float* st = n.st;
+    CriticPar<S> p;
+    p.cs = l1p_load<S>(th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, H1, ks);
+    p.ca = l1p_load<1>(th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, HA, ka);
+    p.c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, H2, tid);
+    p.b3 = th[L.cb3];
+    return p;
+}
+
 template <int S, int H1, int H2, int HA>
 __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_mod, const float* __restrict__ theta,
                                                       const float* __restrict__ stats,
@@ -973,10 +1168,11 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     float* gc = g + L.actor_size;  // critic block
     const int tid = threadIdx.x;
     constexpr float invn = 1.0f / (float)TILE;  // A == 1
+    constexpr int LPR = FT / 64;                // lanes per batch row in the width-1 output layers
     // thread -> (column, row phase) maps of the first-layer phases
     constexpr int sgroups = FT / H1, agroups = FT / HA;
     const int ks = tid % H1, rs0 = tid / H1;
-    const int ka = tid % HA, ra = tid / HA;
+    const int ka = tid % HA, ra = tid / HA;  // ra >= agroups: spare threads (they still load a valid column)
 
     for (int i = tid; i < TILE * S; i += FT) {
         l.sS[i] = s[(long)agent * TILE * S + i];
@@ -996,56 +1192,67 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
 
     // pass 0: targets (y); pass 1: critic loss + gradient; pass 2: actor -> critic, gradient wrt the action;
     // pass 3: actor forward again (activations kept) + actor gradient          (workers/trainer.py:492-506)
+    // Every phase's global loads are requested one phase early and carried in registers across the phase in
+    // between (weights of the next GEMM, parameter columns of the next forward): with one workgroup per CU there
+    // is nobody else to hide a cold HBM round trip at the head of each phase.
+    ActorPar<S> pa = load_actor<S, H1, H2>(L, tgt, ks, tid);
+    CriticPar<S> pc;
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.sS2 : l.sS;
-        if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
+        if (it != 1) {  // ---- actor forward (agent/model.py:26-36), parameters in `pa`
             const float* th = n.th;
-            const float b3 = th[L.ab3];
-            const L1Col c1 = l1_load(S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1,
-                                     H1, ks);
-            const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, th + L.aW3, H2, tid);
-            if (rs0 == 0) l1_coefs(c1, l.invA, l.shA, ks);
-            l1_rows_k<S>(c1, X, S, l.bufA, LDA, ks, rs0, sgroups);
-            l2_store(c2, l, H2, tid);
+            FwdPre<H2 / (16 * NW)> fp;
+            fwd_prefetch<H2>(fp, th + L.aW2, th + L.ab2, H1 / 16);
+            if (it != 3) pc = load_critic<S, H1, H2, HA>(L, n, ks, ka, tid);  // this pass's critic
+            __builtin_amdgcn_sched_barrier(0);
+            const float b3 = pa.b3;
+            if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
+            l1p_rows<S>(pa.c1, X, l.bufA, LDA, ks, rs0, sgroups);
+            l2_store(pa.c2, l, H2, tid);
             lds_barrier();
             PH(1);
-            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, H1 / 16, th + L.aW2, th + L.ab2, l.bufB);
+            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, H1 / 16, th + L.aW2, fp, l.bufB);
             lds_barrier();
             PH(2);
             const float z = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
-            if ((tid & 7) == 0) {
+            if (tid % LPR == 0) {
                 const float t = tanhf(z);
-                l.sT[tid >> 3] = t;
-                l.sA1[tid >> 3] = t * high;
+                l.sT[tid / LPR] = t;
+                l.sA1[tid / LPR] = t * high;
             }
             lds_barrier();
             PH(3);
         }
-        if (it != 3) {  // ---- critic forward (agent/model.py:63-83)
+        if (it != 3) {  // ---- critic forward (agent/model.py:63-83), parameters in `pc`
             const float* th = n.th + L.actor_size;
-            const float* st = n.st;
             const float* act = (it == 1) ? l.sAct : l.sA1;
-            const float b3 = th[L.cb3];
-            const L1Col cs = l1_load(S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, H1, ks);
-            const L1Col ca = l1_load(1, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, HA,
-                                     ra < agroups ? ka : HA);
-            const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, H2, tid);
-            if (rs0 == 0) l1_coefs(cs, l.invA, l.shA, ks);
-            l1_rows_k<S>(cs, X, S, l.bufA, LDA, ks, rs0, sgroups);
+            FwdPre<H2 / (16 * NW)> fp;
+            fwd_prefetch<H2>(fp, th + L.cW2, th + L.cb2, KC / 16);
+            __builtin_amdgcn_sched_barrier(0);
+            const float b3 = pc.b3;
+            if (rs0 == 0) l1p_coefs(pc.cs, l.invA, l.shA, ks);
+            l1p_rows<S>(pc.cs, X, l.bufA, LDA, ks, rs0, sgroups);
             if (ra < agroups) {
-                if (ra == 0) l1_coefs(ca, l.invA, l.shA, H1 + ka);
-                l1_rows_k<1>(ca, act, 1, l.bufA, LDA, H1 + ka, ra, agroups);
+                if (ra == 0) l1p_coefs(pc.ca, l.invA, l.shA, H1 + ka);
+                l1p_rows<1>(pc.ca, act, l.bufA, LDA, H1 + ka, ra, agroups);
             }
-            l2_store(c2, l, H2, tid);
+            l2_store(pc.c2, l, H2, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            // parameters of the NEXT forward: pass 0 -> critic(net) of pass 1; passes 1, 2 -> actor(net) of the next pass
+            if (it == 0)
+                pc = load_critic<S, H1, H2, HA>(L, net, ks, ka, tid);
+            else
+                pa = load_actor<S, H1, H2>(L, net, ks, tid);
+            __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
             PH(4);
-            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, KC / 16, th + L.cW2, th + L.cb2, l.bufB);
+            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, KC / 16, th + L.cW2, fp, l.bufB);
             lds_barrier();
             PH(5);
             const float q = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
-            if ((tid & 7) == 0) l.sQ[tid >> 3] = q;
+            if (tid % LPR == 0) l.sQ[tid / LPR] = q;
             lds_barrier();
             PH(6);
         }
@@ -1085,6 +1292,18 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         const bool crit = (it != 3), wg = (it != 2);
         const float* wth = crit ? net.th + L.actor_size : net.th;
         float* gout = crit ? gc : ga;
+        BnSet lo, hi;
+        if (crit) {
+            lo = {wth + L.cgs, net.st + L.cmms, net.st + L.cmvs, gc + L.cgs, gc + L.cbes, 0};
+        } else {
+            lo = {wth + L.ag1, net.st + L.amm1, net.st + L.amv1, ga + L.ag1, ga + L.abe1, 0};
+        }
+        hi = {net.th + L.actor_size + L.cga, net.st + L.cmma, net.st + L.cmva, gc + L.cga, gc + L.cbea, H1};
+        const float* wdx = wth + (crit ? L.cW2 : L.aW2);
+        const int dx_begin = (it == 2) ? H1 : 0, dx_end = crit ? KC : H1;
+        DxPre<H2> dxp;
+        dx_prefetch<H2>(dxp, wdx, dx_begin, dx_end, lo, hi, H1);  // consumed by gemm_dx two phases later
+        __builtin_amdgcn_sched_barrier(0);
         out_layer_backward(l.bufB, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, l.bufC, LDB, l.scr,
                            wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
                            gout + (crit ? L.cbe3 : L.abe2));
@@ -1097,20 +1316,9 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             lds_barrier();
             PH(it == 1 ? 9 : 17);
         }
-        {
-            BnSet lo, hi;
-            if (crit) {
-                lo = {wth + L.cgs, net.st + L.cmms, net.st + L.cmvs, gc + L.cgs, gc + L.cbes, 0};
-            } else {
-                lo = {wth + L.ag1, net.st + L.amm1, net.st + L.amv1, ga + L.ag1, ga + L.abe1, 0};
-            }
-            const float* cth = net.th + L.actor_size;
-            hi = {cth + L.cga, net.st + L.cmma, net.st + L.cmva, gc + L.cga, gc + L.cbea, H1};
-            gemm_dx<H2, LDB, LDA>(l.bufC, wth + (crit ? L.cW2 : L.aW2), (it == 2) ? H1 : 0, crit ? KC : H1, l.bufA, lo, hi,
-                                  H1, wg);
-            lds_barrier();
-            PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
-        }
+        gemm_dx<H2, LDB, LDA>(l.bufC, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp);
+        lds_barrier();
+        PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
         if (it == 1) {
             dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, gc + L.cWs, gc + L.cbs);
             dense_in_grads_k<1>(l.sAct, 1, l.bufA, LDA, H1, HA, gc + L.cWa, gc + L.cba);
@@ -1118,12 +1326,12 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             PH(11);
         } else if (it == 2) {  // da1[r] = sum_j dza[r][j] * Wa[0][j]
             const float* cth = net.th + L.actor_size;
-            const int rr = tid >> 3, part = tid & 7;
+            const int rr = tid / LPR, part = tid % LPR;
             float acc = 0.f;
-            for (int j = part; j < HA; j += 8) acc = fmaf(l.bufA[rr * LDA + H1 + j], cth[L.cWa + j], acc);
+            for (int j = part; j < HA; j += LPR) acc = fmaf(l.bufA[rr * LDA + H1 + j], cth[L.cWa + j], acc);
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 4);
+            if (LPR == 8) acc += __shfl_xor(acc, 4);
             if (part == 0) l.sDa[rr] = acc;
             lds_barrier();
             PH(14);

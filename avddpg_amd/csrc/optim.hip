@@ -3,6 +3,8 @@
 // All of these are elementwise, HBM-bound streams over flat float32 slabs (16-byte accesses,
 // grid-stride).  Adam follows TF 2.4.1's ApplyAdam functor exactly and is compiled without FMA
 // contraction so the result is bit-identical to the float32 oracle (oracle/mlp.py:adam_update).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace avd {
@@ -115,6 +117,7 @@ extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float*
     const int n4 = lay->theta_size / 4;
     int gx = (n4 + 255) / 256;
     if (n_sets >= 256 && gx > 8) gx = 8;  // many sets: fewer, longer-lived blocks per set
+    if (const char* e = getenv("AVD_ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh)
     hipLaunchKernelGGL(adam_polyak_kernel, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size,
                        lay->actor_size, (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v,
                        (const float4*)grads, step, actor_lr, critic_lr, tauf, omt);
