@@ -21,6 +21,7 @@ Fixtures:
   G5 replay ring + samples    g5_replay.npz
   G6 trainer inner-loop trace g6_loop.npz
   G7 federated table          g7_federated.json
+  G8 evaluator rollout (stub) g8_evaluator.npz
 """
 import json
 import os
@@ -361,7 +362,42 @@ def g7():
         json.dump(res, f, indent=1)
 
 
+# --------------------------------------------------------------------- G8
+def g8():
+    """Hand-driven replica of the evaluator rollout (workers/evaluator.py:40-95, 145) on the reference's own
+    Platoon object with a stub actor that outputs 0 (TensorFlow is absent): seeding with evaluation_seed,
+    evaluator-mode Platoon, pre-drawn leader input list, reset, noise-free steps, float32 reward counters,
+    pl_rew = round(mean, 3)."""
+    out = {}
+    for L, model, T in ((2, "ModelB", 600), (3, "ModelA", 100)):
+        conf = ref_config.Config()
+        conf.pl_size, conf.model = L, model
+        np.random.seed(conf.evaluation_seed)  # rand.set_global_seed(conf.evaluation_seed) (src/rand.py:10)
+        env = make_platoon(L, conf, 1, evaluator_states_enabled=True)
+        inputs = [ref_util.get_random_val(conf.rand_gen, conf.reset_max_u, std_dev=conf.reset_max_u, config=conf)
+                  for _ in range(T)]
+        counters = np.array([0] * env.num_models, dtype=np.float32)
+        states = env.reset()
+        S, R, J = [], [], []
+        actions = np.zeros((env.num_models, env.num_actions))
+        for i in range(T):
+            states, rewards, terminal = env.step(actions.flatten(), inputs[i])
+            for m in range(env.num_models):
+                counters[m] += rewards[m]
+            S.append(np.array([np.asarray(s) for s in states]))
+            R.append(np.array(rewards))
+            J.append(np.array(env.get_jerk()).ravel())
+        key = f"L{L}_{model}"
+        out[key + "__inputs"] = np.array(inputs)
+        out[key + "__states"] = np.array(S)
+        out[key + "__rewards"] = np.array(R)
+        out[key + "__jerks"] = np.array(J)
+        out[key + "__counters"] = counters
+        out[key + "__pl_rew"] = np.array(round(np.average(counters), 3))
+    np.savez_compressed(os.path.join(OUT, "g8_evaluator.npz"), **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
         fn()
         print("wrote", fn.__name__)

@@ -232,3 +232,15 @@ def test_g7_federated_table():
             assert np.allclose(got[m][i], t["interfrl_weighted"][m][i], rtol=1e-6)
     # hand-computed known answer from SURVEY section 4: model-1 layer-1 = (2*[1,2,3] + 1*[10,11,12]) / 3
     assert np.allclose(got[0][0], (2 * np.array([1, 2, 3.]) + np.array([10, 11, 12.])) / 3)
+
+
+def test_g8_evaluator_rollout():
+    from oracle import evaluator
+
+    g = np.load(os.path.join(G, "g8_evaluator.npz"))
+    for L, model, T in ((2, "ModelB", 600), (3, "ModelA", 100)):
+        key = f"L{L}_{model}"
+        pl_rew, tr = evaluator.run(platoon.EnvParams(model=model), L, None, T)
+        assert pl_rew == float(g[key + "__pl_rew"])
+        assert np.array_equal(tr["states"], g[key + "__states"]) and np.array_equal(tr["leader"], g[key + "__inputs"])
+        assert np.array_equal(tr["jerks"], g[key + "__jerks"]) and np.array_equal(tr["counters"], g[key + "__counters"])
