@@ -152,7 +152,7 @@ def main():
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and P == 4096 and L == 5:
+    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl":
         pmc = json.load(open(pmc_path))["kernels"]
         for r, key in ((roof_learn, "learn_kernel"), (roof_upd, "adam_polyak_kernel")):
             hit = [v for k, v in pmc.items() if key in k]

@@ -225,3 +225,27 @@ def test_evaluator_rollout_matches_reference_golden_and_oracle():
     assert abs(pl_rew - o_rew) <= 2e-3 and np.abs(o_tr["inputs"]).max() > 0.05
     assert np.allclose(tr["inputs"], o_tr["inputs"], atol=5e-5) and np.allclose(tr["states"], o_tr["states"], atol=2e-4, rtol=1e-4)
     assert np.allclose(tr["jerks"], o_tr["jerks"], atol=5e-3)
+
+
+def test_model_a_and_weighted_interfrl_trainer_paths_run():
+    """Model A (3 observed states, 4-wide internal state) through the whole loop, and the weighted interfrl
+    branch (weights |1/mean(last 10 episodic rewards)|, trainer.py:385-398) once episode >= weighted_window."""
+    conf = config.Config(num_platoons=6, pl_size=3, buffer_size=128, model="ModelA")
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=True)
+    assert vt.S == 3 and vt.agents.lay.S == 3
+    vt.reset_episode()
+    for _ in range(70):
+        vt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 6
+    conf = config.Config(num_platoons=4, pl_size=2, buffer_size=128, fed_method="interfrl", weighted_average_enabled=True,
+                         weighted_window=2, episode_sim_time=3.0)  # 30-step episodes
+    np.random.seed(2)
+    vt = trainer.VecTrainer(conf, rng="host")
+    assert vt.shared
+    vt.run(number_of_episodes=4)
+    assert len(vt.all_ep_reward_lists[3][1]) == 4 and vt.fed_weights is not None and vt.fed_weights[0] == 3
+    w = vt.fed_weights[1].cpu().numpy()
+    ref = np.array([[abs(1 / np.mean(vt.all_ep_reward_lists[p][m][-2 - 1:-1])) for m in range(2)] for p in range(4)])
+    assert np.allclose(w, ref, rtol=1e-6)  # weights of episode 3 come from episodes 1-2
+    assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
