@@ -13,6 +13,8 @@
 // the weight-gradient epilogue (dW = inv*(p^T dz) + shift*(1^T dz)).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace avd {
@@ -62,6 +64,63 @@ __device__ unsigned long long g_phase_cycles[32];
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, i.e. waits for every
 // outstanding gradient STORE to be acknowledged by HBM; nothing in learn_kernel re-reads what it stored.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Where a parameter gradient goes. Gradient routines address the agent's slab by pointer; a sink decides what a
+// "store" means: StoreSink writes the gradient itself (grads slab); AdamSink treats the pointer as the position of
+// the parameter in the OUTPUT weight slab and applies Adam + Polyak right there (fused update, no gradient slab).
+struct StoreSink {
+    __device__ __forceinline__ void put(float* p, float g) const { *p = g; }
+};
+struct AdamSink {
+    float* wo;        // agent's slab in theta_out (updated weights are written here)
+    const float* wi;  // same agent in theta (pre-update weights: every forward/backward of the step reads these)
+    float *wt, *m, *v;
+    float alpha_a, alpha_c, tau, omt;
+    int actor_size;
+    __device__ __forceinline__ void put(float* p, float g) const {
+#pragma clang fp contract(off)
+        const long off = p - wo;
+        const float alpha = off < actor_size ? alpha_a : alpha_c;
+        float mm = m[off], vv = v[off];
+        mm = mm + (g - mm) * (1.0f - 0.9f);          // TF ApplyAdam, identical to adam_polyak_kernel (optim.hip)
+        vv = vv + (g * g - vv) * (1.0f - 0.999f);
+        const float w = wi[off] - (mm * alpha) / (sqrtf(vv) + 1e-7f);
+        m[off] = mm, v[off] = vv;
+        *p = w;
+        wt[off] = w * tau + wt[off] * omt;  // update_target on the freshly updated weight
+    }
+    // Two-phase form for bulk gradients (weight-gradient GEMM epilogues): all operand loads of a block are issued
+    // first (load2), the arithmetic and the stores follow (update2) -- one memory round trip per block, not per element.
+    struct Quad {
+        float w[2], t[2], m[2], v[2];
+    };
+    __device__ __forceinline__ void load2(Quad& q, long off) const {
+        const float2 a = *(const float2*)(wi + off), b = *(const float2*)(wt + off);
+        const float2 c = *(const float2*)(m + off), d = *(const float2*)(v + off);
+        q.w[0] = a.x, q.w[1] = a.y, q.t[0] = b.x, q.t[1] = b.y, q.m[0] = c.x, q.m[1] = c.y, q.v[0] = d.x, q.v[1] = d.y;
+    }
+    __device__ __forceinline__ void update2(const Quad& q, long off, const float (&g)[2]) const {
+#pragma clang fp contract(off)
+        const float alpha = off < actor_size ? alpha_a : alpha_c;
+        float2 ow, ot, om, ov;
+        float* pw = &ow.x;
+        float* pt = &ot.x;
+        float* pm = &om.x;
+        float* pv = &ov.x;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float mm = q.m[e] + (g[e] - q.m[e]) * (1.0f - 0.9f);
+            const float vv = q.v[e] + (g[e] * g[e] - q.v[e]) * (1.0f - 0.999f);
+            // exact div/sqrt: approximate rcp/sqrt measured no faster (the epilogue is bound by per-CU memory throughput)
+            const float w = q.w[e] - (mm * alpha) / (sqrtf(vv) + 1e-7f);
+            pm[e] = mm, pv[e] = vv, pw[e] = w, pt[e] = w * tau + q.t[e] * omt;
+        }
+        *(float2*)(wo + off) = ow;
+        *(float2*)(wt + off) = ot;
+        *(float2*)(m + off) = om;
+        *(float2*)(v + off) = ov;
+    }
+};
 
 struct Net {  // pointers into one weight set
     const float* th;
@@ -346,19 +405,21 @@ __device__ __forceinline__ void gemm_dx_bn(const float* DZ, int ldz, int N, cons
 }
 
 // Column sums db[n] = sum_r DZ[r][n] -> LDS db[] and global gdb[]
-__device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float* db, float* __restrict__ gdb) {
+template <class Sink = StoreSink>
+__device__ __forceinline__ void col_sums(const float* DZ, int ldz, int N, float* db, float* __restrict__ gdb,
+                                         Sink sink = Sink()) {
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
         for (int r = 0; r < TILE; ++r) s += DZ[r * ldz + n];
         db[n] = s;
-        if (gdb) gdb[n] = s;
+        if (gdb) sink.put(gdb + n, s);
     }
 }
 
 // First-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*xs+j]*dz[r][k], db[k] = sum_r dz[r][k]
-template <int K>
+template <int K, class Sink = StoreSink>
 __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const float* DZ, int ldz, int c0, int H,
-                                                 float* __restrict__ gW, float* __restrict__ gb) {
+                                                 float* __restrict__ gW, float* __restrict__ gb, Sink sink = Sink()) {
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
         float acc[K];
 #pragma unroll
@@ -380,8 +441,8 @@ __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const f
             }
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) gW[j * H + k] = acc[j];
-        gb[k] = sb;
+        for (int j = 0; j < K; ++j) sink.put(gW + j * H + k, acc[j]);
+        sink.put(gb + k, sb);
     }
 }
 __device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, const float* DZ, int ldz, int c0, int H,
@@ -402,11 +463,12 @@ __device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, co
 //   dW3[k] = sum_r bn(p[r][k])*d[r]; dy = d[r]*w3[k]; dgamma, dbeta; DZ[r][k] = dy*inv*(p>0)
 // The 64 rows are split over blockDim/K thread groups; partial sums meet in LDS scratch scr[3*blockDim].
 // rs/mean come from LDS tables (rsl, mml) filled when the layer's coefficients were built. Ends with a barrier.
+template <class Sink = StoreSink>
 __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, const float* inv, const float* sh,
                                                    const float* d, const float* w3, const float* rsl,
                                                    const float* mml, int K, float* DZ, int ldz, float* scr,
                                                    float* __restrict__ gW3, float* __restrict__ gg,
-                                                   float* __restrict__ gbe) {
+                                                   float* __restrict__ gbe, Sink sink = Sink()) {
     const int nth = blockDim.x;
     int parts = 1;
     while (parts * 2 * K <= nth && parts < 8) parts *= 2;
@@ -437,7 +499,7 @@ __device__ __forceinline__ void out_layer_backward(const float* P, int ldp, cons
             float a = 0.f, b2 = 0.f, c = 0.f;
             for (int q = 0; q < parts; ++q)
                 a += scr[q * K + k], b2 += scr[nth + q * K + k], c += scr[2 * nth + q * K + k];
-            gW3[k] = a, gg[k] = b2, gbe[k] = c;
+            sink.put(gW3 + k, a), sink.put(gg + k, b2), sink.put(gbe + k, c);
         }
     }
     lds_barrier();
@@ -912,10 +974,11 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
 // dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n], k < K (runtime, % 4 == 0).
 // Wave w owns columns [16*NT*w, ..); output tile (ta, t) of a 64-row block holds rows k0 + 4*i + ta
 // (i = 4*lg + reg) and columns base + NT*lr + t.
-template <int N, int LDP, int LDZ>
+template <int N, int LDP, int LDZ, class Sink>
 __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const float* sh, int K, const float* DZ,
-                                        const float* db, float* __restrict__ gW) {
+                                        const float* db, float* __restrict__ gW, Sink sink) {
     constexpr int NT = N / (16 * NW);
+    constexpr bool kFused = !std::is_same<Sink, StoreSink>::value;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     const int col = wave * 16 * NT + NT * lr;
     float dbc[NT];
@@ -923,6 +986,24 @@ __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const 
     const float* dp = DZ + lg * LDZ + col;
 #pragma nounroll
     for (int k0 = 0; k0 < K; k0 += 64) {
+        // Fused update: the Adam operands (w, w_target, m, v) of this block's 16 (row, column-pair) pieces are requested
+        // BEFORE the MFMA loop. vmcnt retires loads and stores in issue order, so operand loads issued after the
+        // previous block's update stores would wait for those stores' acknowledgements; issued here they only
+        // queue behind stores that are a whole MFMA loop old.
+        typename std::conditional<kFused, AdamSink::Quad, int>::type q[16];
+        long base = 0;
+        if constexpr (kFused) {
+            static_assert(NT == 2, "fused epilogue works on column pairs");
+            base = (gW - sink.wo) + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta) {
+                    const int kb = min(k0 + 4 * (lg * 4 + j), K - 4);  // clamp: loads for unused rows stay inside the tensor
+                    sink.load2(q[j * 4 + ta], base + (long)(kb + ta) * N);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x4 acc[4][NT];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -957,7 +1038,10 @@ __device__ __forceinline__ void gemm_dw(const float* P, const float* inv, const 
                     float o[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) o[t] = fmaf(iv[ta], acc[ta][t][j], sf[ta] * dbc[t]);
-                    stn<NT>(gW + (kbase + ta) * N + col, o);
+                    if constexpr (kFused)
+                        sink.update2(q[j * 4 + ta], base + (long)(kbase + ta) * N, o);
+                    else
+                        stn<NT>(gW + (kbase + ta) * N + col, o);
                 }
             }
         }
@@ -996,9 +1080,9 @@ __device__ __forceinline__ void dx_prefetch(DxPre<N>& p, const float* __restrict
     if (c0 < c_end) dx_load_tile<N>(p.w, p.bn, W, c0, lo, hi, split);
 }
 
-template <int N, int LDZ, int LDP>
+template <int N, int LDZ, int LDP, class Sink>
 __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict__ W, int c_begin, int c_end, float* P,
-                                        BnSet lo, BnSet hi, int split, bool write_grads, DxPre<N>& pre) {
+                                        BnSet lo, BnSet hi, int split, bool write_grads, DxPre<N>& pre, Sink sink) {
     static_assert(N == 128, "N/16 == 8 reduction blocks held in registers");
     constexpr int NB = N / 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
@@ -1059,8 +1143,8 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
         sb += __shfl_xor(sb, 32);
         if (write_grads && lg == 0) {
             const BnSet& s = (c0 < split) ? lo : hi;
-            s.dg[c - s.base] = sg;
-            s.dbe[c - s.base] = sb;
+            sink.put(s.dg + (c - s.base), sg);
+            sink.put(s.dbe + (c - s.base), sb);
         }
         PHX(22);
 #pragma unroll
@@ -1146,15 +1230,22 @@ __device__ __forceinline__ CriticPar<S> load_critic(const avd_mlp_layout& L, Net
     return p;
 }
 
-template <int S, int H1, int H2, int HA>
+// Extra arguments of the fused learn+update form (FUSED): Adam + Polyak are applied where each gradient is produced.
+struct UpdArgs {
+    float* theta_out;  // [n_agents][theta_size]: updated weights (theta itself stays pre-update for the whole step)
+    float *m, *v;      // Adam moments, in place
+    const int32_t* step;  // [n_agents] Adam iteration count AFTER this update
+    float actor_lr, critic_lr, tau, omt;
+};
+
+template <int S, int H1, int H2, int HA, bool FUSED>
 __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_mod, const float* __restrict__ theta,
-                                                      const float* __restrict__ stats,
-                                                      const float* __restrict__ theta_t,
-                                                      const float* __restrict__ stats_t,
-                                                      const float* __restrict__ s, const float* __restrict__ a,
+                                                      const float* __restrict__ stats, float* __restrict__ theta_t,
+                                                      float* __restrict__ stats_t, const float* __restrict__ s,
+                                                      const float* __restrict__ a,
                                                       const float* __restrict__ r, const float* __restrict__ s2,
                                                       float gamma, float high, float* __restrict__ grads,
-                                                      float* __restrict__ losses) {
+                                                      float* __restrict__ losses, UpdArgs upd) {
     static_assert(H1 <= FT && HA <= FT && H2 <= FT && FT % H1 == 0 && H1 % 16 == 0 && HA % 16 == 0, "widths");
     constexpr int KC = H1 + HA, LDA = ld_of(KC), LDB = ld_of(H2);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1163,10 +1254,27 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     const int set = set_mod > 0 ? agent % set_mod : agent;
     const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
     const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+    // gradient slab of this agent. Fused form: only the small tensors (biases, BN gamma/beta, first and last layers,
+    // ~6 % of the parameters) are stored here -- a range-restricted Adam launch consumes them; the two W2 matrices
+    // are updated in the weight-gradient GEMM epilogues through `bulk`.
     float* g = grads + (long)agent * L.theta_size;
     float* ga = g;                 // actor block
     float* gc = g + L.actor_size;  // critic block
     const int tid = threadIdx.x;
+    const StoreSink sink;
+    typedef typename std::conditional<FUSED, AdamSink, StoreSink>::type BulkSink;
+    BulkSink bulk;
+    float* gw2 = g;  // where gemm_dw "stores": the gradient slab, or the agent's slab of theta_out
+    if constexpr (FUSED) {
+        const int t = upd.step[agent];
+        const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
+        const float root = sqrtf(1.0f - b2p);
+        const long o = (long)agent * L.theta_size;
+        gw2 = upd.theta_out + o;
+        bulk.wo = gw2, bulk.wi = net.th, bulk.wt = theta_t + o, bulk.m = upd.m + o, bulk.v = upd.v + o;
+        bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+        bulk.tau = upd.tau, bulk.omt = upd.omt, bulk.actor_size = L.actor_size;
+    }
     constexpr float invn = 1.0f / (float)TILE;  // A == 1
     constexpr int LPR = FT / 64;                // lanes per batch row in the width-1 output layers
     // thread -> (column, row phase) maps of the first-layer phases
@@ -1258,6 +1366,11 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         }
         if (it == 0) {  // TD target, no done mask (trainer.py:494)
             if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
+            if constexpr (FUSED) {  // the frozen BN statistics take part in the soft update too (ddpgagent.py:44-53)
+#pragma clang fp contract(off)
+                float* stt = stats_t + (long)set * L.stats_size;
+                for (int i = tid; i < L.stats_size; i += FT) stt[i] = net.st[i] * upd.tau + stt[i] * upd.omt;
+            }
             lds_barrier();
             continue;
         }
@@ -1272,7 +1385,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             const float lc = block_sum64(l.sT, l.red) * invn;
             const float db3 = block_sum64(l.sD, l.red);
             if (tid == 0) {
-                gc[L.cb3] = db3;
+                sink.put(gc + L.cb3, db3);
                 if (losses) losses[(long)agent * 2 + 0] = lc;
             }
         } else if (it == 2) {
@@ -1287,7 +1400,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             }
             lds_barrier();
             const float db3 = block_sum64(l.sD, l.red);
-            if (tid == 0) ga[L.ab3] = db3;
+            if (tid == 0) sink.put(ga + L.ab3, db3);
         }
         const bool crit = (it != 3), wg = (it != 2);
         const float* wth = crit ? net.th + L.actor_size : net.th;
@@ -1306,22 +1419,23 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         __builtin_amdgcn_sched_barrier(0);
         out_layer_backward(l.bufB, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, l.bufC, LDB, l.scr,
                            wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
-                           gout + (crit ? L.cbe3 : L.abe2));
+                           gout + (crit ? L.cbe3 : L.abe2), sink);
         PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
         if (wg) {
-            col_sums(l.bufC, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2));
+            col_sums(l.bufC, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
             lds_barrier();
             PH(it == 1 ? 8 : 16);
-            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, l.bufC, l.db, gout + (crit ? L.cW2 : L.aW2));
+            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, l.bufC, l.db,
+                                  gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk);
             lds_barrier();
             PH(it == 1 ? 9 : 17);
         }
-        gemm_dx<H2, LDB, LDA>(l.bufC, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp);
+        gemm_dx<H2, LDB, LDA>(l.bufC, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp, sink);
         lds_barrier();
         PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
         if (it == 1) {
-            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, gc + L.cWs, gc + L.cbs);
-            dense_in_grads_k<1>(l.sAct, 1, l.bufA, LDA, H1, HA, gc + L.cWa, gc + L.cba);
+            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, gc + L.cWs, gc + L.cbs, sink);
+            dense_in_grads_k<1>(l.sAct, 1, l.bufA, LDA, H1, HA, gc + L.cWa, gc + L.cba, sink);
             lds_barrier();
             PH(11);
         } else if (it == 2) {  // da1[r] = sum_j dza[r][j] * Wa[0][j]
@@ -1336,26 +1450,26 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             lds_barrier();
             PH(14);
         } else {
-            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, ga + L.aW1, ga + L.ab1);
+            dense_in_grads_k<S>(l.sS, S, l.bufA, LDA, 0, H1, ga + L.aW1, ga + L.ab1, sink);
             PH(19);
         }
     }
 }
 
-template <int S, int H1, int H2, int HA>
+template <int S, int H1, int H2, int HA, bool FUSED>
 static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
-                  const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
-                  const float* s2, float gamma, float high, float* grads, float* losses, void* stream) {
+                  float* theta_t, float* stats_t, const float* s, const float* a, const float* r, const float* s2,
+                  float gamma, float high, float* grads, float* losses, UpdArgs upd, void* stream) {
     const size_t lds = sizeof(float) * learn_lds_floats(*lay, FT);
-    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_t<S, H1, H2, HA>,
+    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_t<S, H1, H2, HA, FUSED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         return AVD_E_LAUNCH;
     }
-    hipLaunchKernelGGL((learn_kernel_t<S, H1, H2, HA>), dim3(n_agents), dim3(FT), lds, (hipStream_t)stream, *lay,
-                       set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
-    return check_launch("avd_learn_f32");
+    hipLaunchKernelGGL((learn_kernel_t<S, H1, H2, HA, FUSED>), dim3(n_agents), dim3(FT), lds, (hipStream_t)stream, *lay,
+                       set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, upd);
+    return check_launch(FUSED ? "avd_learn_update_f32" : "avd_learn_f32");
 }
 
 }  // namespace fast
@@ -1571,12 +1685,15 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
     AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads, "avd_learn_f32: null pointer");
     // reference widths (src/config.py:112-117) take the dimension-specialised kernel; anything else the generic one
     if (lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && !getenv("AVD_LEARN_GENERIC")) {
+        const fast::UpdArgs none = {};
         if (lay->S == 4)
-            return fast::launch<4, 256, 128, 48>(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2,
-                                                 gamma, high, grads, losses, stream);
+            return fast::launch<4, 256, 128, 48, false>(lay, n_agents, set_mod, theta, stats, (float*)theta_t,
+                                                        (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
+                                                        stream);
         if (lay->S == 3)
-            return fast::launch<3, 256, 128, 48>(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2,
-                                                 gamma, high, grads, losses, stream);
+            return fast::launch<3, 256, 128, 48, false>(lay, n_agents, set_mod, theta, stats, (float*)theta_t,
+                                                        (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
+                                                        stream);
     }
     const size_t lds = sizeof(float) * learn_lds_floats(*lay);
     if (lds > 160 * 1024) {
@@ -1592,4 +1709,42 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
     hipLaunchKernelGGL(learn_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod, theta,
                        stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
     return check_launch("avd_learn_f32");
+}
+
+// optim.hip: Adam+Polyak over the elements of each slab that lie OUTSIDE [skip_a0, skip_a1) and [skip_c0, skip_c1)
+int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float* theta_in, float* theta_out,
+                              float* theta_t, float* m, float* v, const float* grads, const int32_t* step,
+                              float actor_lr, float critic_lr, double tau, int skip_a0, int skip_a1, int skip_c0,
+                              int skip_c1, void* stream);
+
+extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                                    float* theta_out, float* theta_t, float* stats_t, float* m, float* v,
+                                    const int32_t* step, const float* s, const float* a, const float* r,
+                                    const float* s2, float gamma, float high, float actor_lr, float critic_lr,
+                                    double tau, float* grads_scratch, float* losses, void* stream) {
+    int rc = check_mlp_dims(lay, "avd_learn_update_f32");
+    if (rc) return rc;
+    AVD_REQUIRE(n_agents > 0, "avd_learn_update_f32: n_agents=%d", n_agents);
+    AVD_REQUIRE(theta && stats && theta_out && theta_t && stats_t && m && v && step && s && a && r && s2 && grads_scratch,
+                "avd_learn_update_f32: null pointer");
+    AVD_REQUIRE(theta_out != theta, "avd_learn_update_f32: theta_out must not alias theta (every pass reads pre-update weights)");
+    if (!(lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && lay->B == TILE && (lay->S == 3 || lay->S == 4))) {
+        set_error("avd_learn_update_f32: the fused kernel is built for the reference widths 256/128/48, B=64, S in {3,4} "
+                  "(got %d/%d/%d, B=%d, S=%d); use avd_learn_f32 + avd_adam_polyak_f32",
+                  lay->H1, lay->H2, lay->Ha, lay->B, lay->S);
+        return AVD_E_UNSUPPORTED;
+    }
+    const fast::UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau)};
+    if (lay->S == 4)
+        rc = fast::launch<4, 256, 128, 48, true>(lay, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma,
+                                                 high, grads_scratch, losses, upd, stream);
+    else
+        rc = fast::launch<3, 256, 128, 48, true>(lay, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma,
+                                                 high, grads_scratch, losses, upd, stream);
+    if (rc) return rc;
+    // the small tensors: everything outside the two W2 matrices (which the learn kernel has already updated)
+    const int a0 = lay->aW2, a1 = lay->aW2 + lay->H1 * lay->H2;
+    const int c0 = lay->actor_size + lay->cW2, c1 = c0 + (lay->H1 + lay->Ha) * lay->H2;
+    return launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads_scratch, step, actor_lr,
+                                     critic_lr, tau, a0, a1, c0, c1, stream);
 }

@@ -51,6 +51,53 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(int theta_size, int ac
     }
 }
 
+// Same arithmetic for the float4 groups of each slab OUTSIDE two skip ranges, reading the pre-update weights from
+// theta_in and writing theta_out (second half of avd_learn_update_f32: the learn kernel itself updates the two W2
+// matrices in its weight-gradient epilogues; this pass covers the ~6 % of small tensors).
+__global__ __launch_bounds__(256) void adam_polyak_ranges_kernel(int theta_size, int actor_size,
+                                                                 const float4* __restrict__ theta_in,
+                                                                 float4* __restrict__ theta_out,
+                                                                 float4* __restrict__ theta_t, float4* __restrict__ m,
+                                                                 float4* __restrict__ v,
+                                                                 const float4* __restrict__ grads,
+                                                                 const int32_t* __restrict__ step, float actor_lr,
+                                                                 float critic_lr, float tau, float omt, int a0, int a1,
+                                                                 int c0, int c1) {
+#pragma clang fp contract(off)
+    const int set = blockIdx.y;
+    const int t = step[set];
+    const float b1p = (float)pow((double)ADAM_B1, (double)t);
+    const float b2p = (float)pow((double)ADAM_B2, (double)t);
+    const float root = sqrtf(1.0f - b2p);
+    const float alpha_a = (actor_lr * root) / (1.0f - b1p);
+    const float alpha_c = (critic_lr * root) / (1.0f - b1p);
+    // compact index over the kept float4 groups: [0,a0) [a1,c0) [c1,theta_size)
+    const int n0 = a0 / 4, n1 = (c0 - a1) / 4, n2 = (theta_size - c1) / 4;
+    const long base = (long)set * (theta_size / 4);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n0 + n1 + n2; j += gridDim.x * blockDim.x) {
+        const int i = j < n0 ? j : (j < n0 + n1 ? a1 / 4 + (j - n0) : c1 / 4 + (j - n0 - n1));
+        const float alpha = (i * 4 < actor_size) ? alpha_a : alpha_c;
+        float4 w = theta_in[base + i], wt = theta_t[base + i], mm = m[base + i], vv = v[base + i];
+        const float4 g = grads[base + i];
+        float* wp = &w.x;
+        float* tp = &wt.x;
+        float* mp = &mm.x;
+        float* vp = &vv.x;
+        const float* gp = &g.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mp[k] = mp[k] + (gp[k] - mp[k]) * (1.0f - ADAM_B1);
+            vp[k] = vp[k] + (gp[k] * gp[k] - vp[k]) * (1.0f - ADAM_B2);
+            wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
+            tp[k] = wp[k] * tau + tp[k] * omt;
+        }
+        theta_out[base + i] = w;
+        theta_t[base + i] = wt;
+        m[base + i] = mm;
+        v[base + i] = vv;
+    }
+}
+
 __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __restrict__ t, float tau, float omt) {
 #pragma clang fp contract(off)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -130,6 +177,21 @@ extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float*
     hipLaunchKernelGGL(polyak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ns, stats, stats_t,
                        tauf, omt);
     return check_launch("avd_adam_polyak_f32(stats)");
+}
+
+int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float* theta_in, float* theta_out,
+                              float* theta_t, float* m, float* v, const float* grads, const int32_t* step,
+                              float actor_lr, float critic_lr, double tau, int skip_a0, int skip_a1, int skip_c0,
+                              int skip_c1, void* stream) {
+    AVD_REQUIRE(skip_a0 % 4 == 0 && skip_a1 % 4 == 0 && skip_c0 % 4 == 0 && skip_c1 % 4 == 0 && skip_a1 <= skip_c0,
+                "launch_adam_polyak_ranges: skip ranges must be 4-float aligned and ordered");
+    const int kept4 = (lay->theta_size - (skip_a1 - skip_a0) - (skip_c1 - skip_c0)) / 4;
+    int gx = (kept4 + 255) / 256;
+    hipLaunchKernelGGL(adam_polyak_ranges_kernel, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size,
+                       lay->actor_size, (const float4*)theta_in, (float4*)theta_out, (float4*)theta_t, (float4*)m,
+                       (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau),
+                       skip_a0, skip_a1, skip_c0, skip_c1);
+    return check_launch("avd_learn_update_f32(small tensors)");
 }
 
 extern "C" int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream) {

@@ -64,7 +64,7 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
-                 pipeline_chunks=1):
+                 pipeline_chunks=1, fused_update=False):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'."""
@@ -106,6 +106,7 @@ class VecTrainer:
         self.auto_reset = auto_reset
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
+        self.fused_update = bool(fused_update)  # nofrl + reference widths: avd_learn_update_f32
         self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
         self.timers = None
         self.episode, self.ep_step = 0, 0
@@ -183,6 +184,10 @@ class VecTrainer:
         s, a, r, s2 = batch
         fed = is_fed_enabled(conf)
         self.updates += self.n_agents
+        if not fed and self.fused_update:
+            # nofrl: learn + Adam x2 + Polyak of every agent in one kernel (no gradient slab round trip)
+            self._timed("learn+update", self.agents.learn_update, s, a, r, s2, self.grads, self.losses)
+            return
         if not fed and self.pipeline_chunks > 1:
             # nofrl: every agent learns and updates locally -> software-pipeline the two kernels over agent slices
             self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,

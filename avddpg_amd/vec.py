@@ -298,6 +298,24 @@ class AgentGroup:
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())
 
+    def learn_update(self, s, a, r, s2, grads, losses=None):
+        """Fused Trainer.learn + Adam x2 + update_target for per-agent weight sets (reference nofrl,
+        workers/trainer.py:325-356) in ONE kernel: every gradient is consumed where it is produced, the updated
+        weights go to the alternate slab (theta ping-pong: all forward/backward passes of the step read the
+        pre-update weights, trainer.py:492-506). Same result as learn() followed by apply()."""
+        n = self.n_sets
+        if s.shape[0] != n:
+            raise _hip.AvdError("learn_update needs one weight set per agent (set_mod == 0)")
+        if getattr(self, "theta_alt", None) is None:
+            self.theta_alt = self.theta.clone()  # alignment padding stays zero in both slabs
+        c = self.config
+        self.step += 1
+        call("avd_learn_update_f32", self._layp, n, ptr(self.theta), ptr(self.stats), ptr(self.theta_alt),
+             ptr(self.theta_t), ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(self.step), ptr(s), ptr(a), ptr(r),
+             ptr(s2), c.gamma, self.high, c.actor_lr, c.critic_lr, float(c.tau), ptr(grads), ptr(losses),
+             stream_handle())
+        self.theta, self.theta_alt = self.theta_alt, self.theta
+
     def learn_apply(self, s, a, r, s2, grads, losses=None, chunks=4, timers=None):
         """learn + local update for per-agent weight sets (reference nofrl, workers/trainer.py:325-356).
         Agents are independent, so they are processed in `chunks` slices: the Adam/Polyak kernel of slice c

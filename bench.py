@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
     ap.add_argument("--chunks", type=int, default=1,
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="nofrl: run learn and Adam+Polyak as two kernels instead of the fused avd_learn_update_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -97,7 +99,8 @@ def main():
                          fed_method="interfrl" if args.mode == "interfrl" else "normal",
                          weighted_average_enabled=False, random_seed=1 + rank)
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
-                            seed=1 + rank, pipeline_chunks=args.chunks)
+                            seed=1 + rank, pipeline_chunks=args.chunks,
+                            fused_update=(args.mode == "nofrl" and not args.no_fused))
     # synthetic steady state: replay rings full of random-init-platoon-like rows
     ring = vt.replay.ring
     chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
@@ -107,7 +110,7 @@ def main():
     vt.reset_episode()
 
     # per-stage / per-kernel HIP events, each recorded on the stream its kernels are launched on
-    names = ("act+env", "replay", "learn", "update")
+    names = ("act+env", "replay", "learn", "update", "learn+update")
 
     def one_step(record):
         vt.timers = ev if record else None
@@ -140,30 +143,45 @@ def main():
     n_agents = P * L
     env_steps_per_s = world * P * args.steps / elapsed
     updates_per_s = world * n_agents * args.steps / elapsed
-    learn_s = stage_ms["learn"] / 1e3
-    upd_s = stage_ms["update"] / 1e3
-    roof_learn = {"kernel": "learn_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / learn_s / 1e12,
-                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-    if args.mode == "nofrl":
-        roof_upd = {"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / upd_s / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+    fused = stage_ms["learn+update"] > 0
+    roofs = []
+    if fused:
+        # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
+        # roof it sits closer to
+        t = stage_ms["learn+update"] / 1e3
+        mf = {"kernel": "learn_kernel_t<fused>", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / t / 1e12,
+              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        hb = {"kernel": "learn_kernel_t<fused>", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / t / 1e9,
+              "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        roofs = [mf, hb]
     else:
-        roof_upd = None
+        learn_s = stage_ms["learn"] / 1e3
+        upd_s = stage_ms["update"] / 1e3
+        roofs.append({"kernel": "learn_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / learn_s / 1e12,
+                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "_t": learn_s})
+        if args.mode == "nofrl":
+            roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / upd_s / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl":
+    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1:
         pmc = json.load(open(pmc_path))["kernels"]
-        for r, key in ((roof_learn, "learn_kernel"), (roof_upd, "adam_polyak_kernel")):
-            hit = [v for k, v in pmc.items() if key in k]
-            if r and hit and hit[0].get("hbm_bytes_per_unit"):
-                launches = max(1, len(ev.get("learn" if r is roof_learn else "update", [])) // args.steps)
-                r["traffic"] = hit[0]["hbm_bytes_per_unit"] * n_agents / launches
+        for r in roofs:
+            key = {"learn_kernel_t<fused>": "ELb1", "learn_kernel": "learn_kernel_t", "adam_polyak_kernel": "adam_polyak"}[r["kernel"]]
+            hit = [v for k, v in pmc.items() if (key in k or (key == "ELb1" and "true>" in k))]
+            if hit and hit[0].get("hbm_bytes_per_unit"):
+                r["traffic"] = hit[0]["hbm_bytes_per_unit"] * n_agents
                 r["traffic_note"] = "HBM-side bytes per launch, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/pmc_traffic.json"
-    for r in (roof_learn, roof_upd):
-        if r:
-            r["frac"] = r["achieved"] / r["peak"]
-    dominant = roof_learn if (roof_upd is None or learn_s >= upd_s) else roof_upd
+    for r in roofs:
+        r["frac"] = r["achieved"] / r["peak"]
+    if fused:
+        dominant = max(roofs, key=lambda r: r["frac"])
+    else:
+        dominant = max(roofs, key=lambda r: r.pop("_t"))
+        for r in roofs:
+            r.pop("_t", None)
+    roof_learn, roof_upd = roofs[0], (roofs[1] if len(roofs) > 1 else None)
 
     if rank == 0:
         out = {
@@ -189,8 +207,9 @@ def main():
                        "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
             "stages_ms": stage_ms,
-            "pipeline": (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
-                         "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else "serial",
+            "pipeline": ("fused learn+Adam+Polyak kernel (avd_learn_update_f32)" if fused else
+                         (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
+                          "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else "serial"),
             "kernels": [r for r in (roof_learn, roof_upd) if r],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -173,6 +173,23 @@ int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, flo
                         float* stats_t, float* m, float* v, const float* grads, const int32_t* step, float actor_lr,
                         float critic_lr, double tau, void* stream);
 
+/* Fused form of avd_learn_f32 + avd_adam_polyak_f32 for one weight set per agent (reference nofrl:
+ * workers/trainer.py:325-356 learn, apply_gradients x2, update_target per agent): Adam and the soft update are
+ * applied where each gradient is produced, so no gradient slab is written or read back.
+ *   theta      [n_agents][theta_size] pre-update weights, READ ONLY for the whole call (both gradients are taken
+ *              at the pre-update actor and critic, trainer.py:492-506)
+ *   theta_out  [n_agents][theta_size] receives the updated weights; must not alias theta (callers ping-pong)
+ *   theta_t, stats_t, m, v  updated in place;  step [n_agents] = Adam iteration AFTER this update;
+ *   grads_scratch [n_agents][theta_size] workspace: receives only the gradients of the small tensors (biases, BN
+ *              gamma/beta, first/last layers, ~6 % of the slab), which a second, range-restricted launch consumes;
+ *   losses [n_agents][2] or NULL.  Same result as the two separate calls. Reference widths only
+ *   (256/128/48, B = 64, S in {3,4}); otherwise AVD_E_UNSUPPORTED. */
+int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                         float* theta_out, float* theta_t, float* stats_t, float* m, float* v, const int32_t* step,
+                         const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
+                         float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
+                         void* stream);
+
 /* update_target alone (agent/ddpgagent.py:31-55): t = w*tau + t*(1-tau) over n floats. */
 int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream);
 

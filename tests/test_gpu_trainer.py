@@ -249,3 +249,27 @@ def test_model_a_and_weighted_interfrl_trainer_paths_run():
     ref = np.array([[abs(1 / np.mean(vt.all_ep_reward_lists[p][m][-2 - 1:-1])) for m in range(2)] for p in range(4)])
     assert np.allclose(w, ref, rtol=1e-6)  # weights of episode 3 come from episodes 1-2
     assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
+
+
+@pytest.mark.parametrize("model", ["ModelB", "ModelA"])
+def test_fused_learn_update_is_bitwise_learn_then_apply(model):
+    """avd_learn_update_f32 (Adam + Polyak applied where each gradient is produced, theta ping-pong) gives exactly
+    the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32."""
+    conf = config.Config(num_platoons=21, pl_size=3, buffer_size=128, model=model)
+    runs = []
+    for fused in (False, True):
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, fused_update=fused, seed=4)
+        vt.reset_episode()
+        for _ in range(70):
+            vt.step()
+        torch.cuda.synchronize()
+        runs.append(vt)
+    a, b = runs
+    assert int(a.agents.step[0]) == int(b.agents.step[-1]) == 6
+    assert torch.equal(a.agents.m, b.agents.m) and torch.equal(a.agents.v, b.agents.v)
+    assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
+    assert torch.equal(a.agents.stats_t, b.agents.stats_t) and torch.equal(a.env.x, b.env.x)
+    assert torch.equal(a.losses, b.losses)
+    lay = b.agents.lay
+    assert torch.all(b.agents.theta[:, lay.ab3 + 1:lay.actor_size] == 0)  # padding untouched in both slabs
+    assert torch.all(b.agents.theta_alt[:, lay.ab3 + 1:lay.actor_size] == 0)

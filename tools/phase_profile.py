@@ -24,17 +24,20 @@ NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fw
          18: "actor dX GEMM + BN bwd", 19: "actor L1 grads"}
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+FUSED = len(sys.argv) > 2 and sys.argv[2] == "fused"
 conf = config.Config()
 grp = vec.AgentGroup(n, 4, 1, conf)
 f = lambda *s: torch.randn(*s, device="cuda")
 s, a, r, s2 = f(n, 64, 4), f(n, 64, 1), f(n, 64), f(n, 64, 4)
 lib = _hip.lib()
 lib.avd_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
-grp.learn(s, a, r, s2, 0)
+gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
+run = (lambda: grp.learn_update(s, a, r, s2, gscr)) if FUSED else (lambda: grp.learn(s, a, r, s2, 0))
+run()
 torch.cuda.synchronize()
 lib.avd_debug_phase_cycles(None, 1)
 for _ in range(3):
-    grp.learn(s, a, r, s2, 0)
+    run()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 lib.avd_debug_phase_cycles(buf, 0)
