@@ -215,15 +215,34 @@ class VecTrainer:
             if self.shared:
                 self.agents.apply(avg)
             else:
-                i_begin = 1 if (method == conf.intrafrl and conf.intra_directional_averaging) else 0
-                if i_begin:
-                    # the lead vehicle gets no update at all on a federated step (:417-418): zero grads would
-                    # still move Adam moments, so it is handled by restoring its slabs after the apply
-                    raise NotImplementedError("intra_directional_averaging: next-tier (SURVEY 8f-2)")
+                directional = method == conf.intrafrl and conf.intra_directional_averaging
                 vec.fed_scatter(avg, self.grads, P, M, method)
-                self.agents.apply(self.grads)
+                if directional:
+                    # the lead vehicle of every platoon is skipped entirely on a federated step (:417-418): no Adam
+                    # step, no soft update. Its slabs are saved and put back around the batched apply.
+                    ag = self.agents
+                    lead = lambda x: x.view(P, M, -1)[:, 0]
+                    keep = [lead(x).clone() for x in (ag.theta, ag.theta_t, ag.stats_t, ag.m, ag.v)]
+                    keep_step = ag.step.view(P, M)[:, 0].clone()
+                    ag.apply(self.grads)
+                    for x, k in zip((ag.theta, ag.theta_t, ag.stats_t, ag.m, ag.v), keep):
+                        lead(x).copy_(k)
+                    ag.step.view(P, M)[:, 0].copy_(keep_step)
+                else:
+                    self.agents.apply(self.grads)
         elif is_valid_step_for_federated_training_with_weights(conf, ep, i):
-            raise NotImplementedError("aggregation_method='weights': next-tier (SURVEY 8f-2)")
+            # weights aggregation (:433-456): average `.weights` (trainables AND BN stats) per group, then write the
+            # average of group [0] into EVERY agent's model and target (the reference indexes `[0]` of the server's
+            # result, :442-446 -- for interfrl that is vehicle 0's cross-platoon average, for intrafrl platoon 0's)
+            if self.shared:
+                raise RuntimeError("weights aggregation needs per-agent weight sets")
+            ag = self.agents
+            avg_th = vec.fed_mean(ag.theta, P, M, weights=weights, group=self.group, method=method)[0]
+            avg_st = vec.fed_mean(ag.stats, P, M, weights=weights, group=self.group, method=method)[0]
+            directional = method == conf.intrafrl and conf.intra_directional_averaging
+            for dst, src in ((ag.theta, avg_th), (ag.theta_t, avg_th), (ag.stats, avg_st), (ag.stats_t, avg_st)):
+                view = dst.view(P, M, -1)
+                (view[:, 1:] if directional else view).copy_(src.expand_as(view[:, 1:] if directional else view))
         # else: FRL on, valid step, but not a valid update episode -> no parameter update at all
 
     def step(self, ep=None, i=None, sync=True):

@@ -273,3 +273,44 @@ def test_fused_learn_update_is_bitwise_learn_then_apply(model):
     lay = b.agents.lay
     assert torch.all(b.agents.theta[:, lay.ab3 + 1:lay.actor_size] == 0)  # padding untouched in both slabs
     assert torch.all(b.agents.theta_alt[:, lay.ab3 + 1:lay.actor_size] == 0)
+
+
+def test_intrafrl_directional_and_weights_aggregation_semantics():
+    """intrafrl gradients with intra_directional_averaging (lead vehicle skipped on federated steps,
+    trainer.py:417-418) and aggregation_method='weights' (group [0]'s average written into every model and target,
+    :442-456)."""
+    P, M = 3, 3
+    # --- intrafrl + gradients, directional: followers of a platoon share the platoon-mean gradient, leader frozen
+    conf = config.Config(num_platoons=P, pl_size=M, buffer_size=128, fed_method="intrafrl", weighted_average_enabled=False,
+                         intra_directional_averaging=True)
+    np.random.seed(7)
+    vt = trainer.VecTrainer(conf, rng="host")
+    vt.reset_episode()
+    th0 = vt.agents.theta.clone()
+    for i in range(66):
+        vt.step(0, i)
+    th = vt.agents.theta.view(P, M, -1)
+    assert torch.equal(th[:, 0], th0.view(P, M, -1)[:, 0])  # lead vehicles untouched
+    assert int(vt.agents.step.view(P, M)[0, 0]) == 0 and int(vt.agents.step.view(P, M)[0, 1]) == 2
+    assert torch.equal(th[0, 1], th[0, 2]) and not torch.equal(th[0, 1], th[1, 1])  # same mean grad inside a platoon
+    g = vt.grads.view(P, M, -1)
+    assert torch.equal(g[1, 0], g[1, 2])  # the scattered intra-platoon mean
+    # --- interfrl + weights aggregation with delay 2: odd steps train locally, even steps overwrite everything
+    conf = config.Config(num_platoons=P, pl_size=M, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False,
+                         aggregation_method="weights", fed_update_delay=0.2)
+    assert conf.fed_update_delay_steps == 2
+    np.random.seed(7)
+    vt = trainer.VecTrainer(conf, rng="host")
+    assert not vt.shared
+    vt.reset_episode()
+    for i in range(65):  # steps 0..64; first learn at i=64 (even: federated weights step, no local update before it)
+        vt.step(0, i)
+    assert torch.allclose(vt.agents.theta, th0, rtol=2e-7, atol=0)  # mean of identical weights: (3w)/3 rounds, no training yet
+    vt.step(0, 65)  # odd step: local Adam update -> agents diverge
+    local = vt.agents.theta.clone().view(P, M, -1)
+    assert not torch.equal(local[0, 0], local[1, 0])
+    vt.step(0, 66)  # even step: weights aggregation
+    after = vt.agents.theta.view(P, M, -1)
+    want = local[:, 0].mean(dim=0)  # vehicle 0 averaged over platoons == group [0]
+    assert torch.allclose(after[2, 1], want, rtol=1e-6, atol=1e-8)
+    assert torch.equal(after[0, 0], after[2, 2]) and torch.equal(vt.agents.theta_t, vt.agents.theta)
