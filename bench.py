@@ -149,9 +149,9 @@ def main():
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
         t = stage_ms["learn+update"] / 1e3
-        mf = {"kernel": "learn_kernel_t<fused>", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / t / 1e12,
+        mf = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / t / 1e12,
               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-        hb = {"kernel": "learn_kernel_t<fused>", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / t / 1e9,
+        hb = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / t / 1e9,
               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roofs = [mf, hb]
     else:
@@ -164,15 +164,17 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
     if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1:
         pmc = json.load(open(pmc_path))["kernels"]
+        want = {"learn_kernel_t<fused> + adam_polyak_ranges_kernel": ("learn_kernel_t", "adam_polyak_ranges"),
+                "learn_kernel": ("learn_kernel_t",), "adam_polyak_kernel": ("adam_polyak_kernel",)}
         for r in roofs:
-            key = {"learn_kernel_t<fused>": "ELb1", "learn_kernel": "learn_kernel_t", "adam_polyak_kernel": "adam_polyak"}[r["kernel"]]
-            hit = [v for k, v in pmc.items() if (key in k or (key == "ELb1" and "true>" in k))]
-            if hit and hit[0].get("hbm_bytes_per_unit"):
-                r["traffic"] = hit[0]["hbm_bytes_per_unit"] * n_agents
-                r["traffic_note"] = "HBM-side bytes per launch, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/pmc_traffic.json"
+            per_unit = [next((v["hbm_bytes_per_unit"] for k, v in pmc.items() if s in k), None) for s in want[r["kernel"]]]
+            if all(per_unit):
+                r["traffic"] = sum(per_unit) * n_agents
+                r["traffic_note"] = ("HBM-side bytes per step of these kernels, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/"
+                                     + os.path.basename(pmc_path))
     for r in roofs:
         r["frac"] = r["achieved"] / r["peak"]
     if fused:

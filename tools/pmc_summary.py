@@ -32,22 +32,25 @@ def main():
     theta = int(sys.argv[4]) if len(sys.argv) > 4 else 76488
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     res = {"source": {"fetch": fetch, "write": write}, "kernels": {}}
-    adam = next(k for k in f if "adam_polyak" in k)
-    # adam grid = (8 blocks, n_sets): workgroups / 8 = weight sets
-    adam_sets = f[adam][2] / 8
-    cal16 = (5 * theta * 4 * adam_sets) / f[adam][0]
+    res["fetch_correction"] = {}
+    cals = []
+    adam = next((k for k in f if k.endswith("adam_polyak_kernel")), None)
+    if adam:  # full-slab Adam present (unfused run): grid = (8 blocks, n_sets)
+        adam_sets = f[adam][2] / 8
+        cals.append((5 * theta * 4 * adam_sets) / f[adam][0])
+        res["fetch_correction"]["adam_16B_per_lane"] = cals[-1]
+        res["fetch_correction"]["write_check_adam"] = w[adam][0] / (4 * theta * 4 * adam_sets)
     rows = next((k for k in f if "mlp_rows" in k), None)
-    cal4 = None
     if rows:
         actor_bytes = (4 * 256 + 3 * 256 + 256 * 128 + 3 * 128 + 128 + 1 + 2 * 256 + 2 * 128) * 4
-        cal4 = actor_bytes * f[rows][2] / f[rows][0]
-    res["fetch_correction"] = {"adam_16B_per_lane": cal16, "mlp_rows_4B_per_lane": cal4,
-                               "write_check_adam": w[adam][0] / (4 * theta * 4 * adam_sets)}
-    corr = cal16 if cal4 is None else 0.5 * (cal16 + cal4)
+        cals.append(actor_bytes * f[rows][2] / f[rows][0])
+        res["fetch_correction"]["mlp_rows_4B_per_lane"] = cals[-1]
+    corr = sum(cals) / len(cals)
+    res["fetch_correction"]["applied"] = corr
     for k in f:
         if not k.startswith("avd::"):
             continue
-        units = f[k][2] / (8 if "adam_polyak" in k else 1)
+        units = f[k][2] / (8 if k.endswith("adam_polyak_kernel") else (5 if "adam_polyak_ranges" in k else 1))
         fb, wb = f[k][0] * corr, w.get(k, [0, 0, 0])[0]
         res["kernels"][k] = {"launches": f[k][1], "fetch_raw_bytes_per_launch": f[k][0] / f[k][1],
                              "fetch_bytes_per_launch": fb / f[k][1], "write_bytes_per_launch": wb / max(1, w[k][1]),
