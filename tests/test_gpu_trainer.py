@@ -314,3 +314,33 @@ def test_intrafrl_directional_and_weights_aggregation_semantics():
     want = local[:, 0].mean(dim=0)  # vehicle 0 averaged over platoons == group [0]
     assert torch.allclose(after[2, 1], want, rtol=1e-6, atol=1e-8)
     assert torch.equal(after[0, 0], after[2, 2]) and torch.equal(vt.agents.theta_t, vt.agents.theta)
+
+
+def test_episode_reward_curve_matches_oracle_loop_config1():
+    """BASELINE configs[0] (1 platoon x 3 vehicles, DDPG): several full episodes of training through the
+    reference-shaped facade (Trainer.initialize/run, host RNG) against the oracle's per-object loop: the per-episode
+    cumulative rewards (the `ep_reward` curve of the reference) agree to 1e-4 relative after ~1000 updates/agent."""
+    P, L, EPS, STEPS = 1, 3, 3, 150
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=1000, episode_sim_time=STEPS * 0.1)
+    np.random.seed(conf.random_seed)
+    tr = trainer.Trainer(None, "t0", False, conf, rng="host")
+    tr.initialize()
+    ref = otrainer.RefTrainer(oplatoon.EnvParams(), P, L, seed=conf.random_seed, buffer_size=1000)
+    _copy_weights_to_oracle(tr.engine, ref)
+    curve = []
+    for ep in range(EPS):
+        ref.reset_episode()
+        for i in range(STEPS):
+            if ref.step():
+                break
+        curve.append(np.array(ref.ep_reward).copy())
+    np.random.seed(conf.random_seed)
+    tr = trainer.Trainer(None, "t0", False, conf, rng="host")
+    tr.initialize()
+    ep_lists, avg_lists = tr.run(number_of_episodes=EPS)
+    for ep in range(EPS):
+        for m in range(L):
+            want = float(curve[ep][0][m])
+            assert abs(float(ep_lists[0][m][ep]) - want) <= 1e-4 * abs(want), (ep, m)
+    assert np.isclose(avg_lists[0][1][-1], np.mean([c[0][1] for c in curve]), rtol=1e-4)  # trailing-mean curve
+    assert tr.engine.updates == ref.updates
