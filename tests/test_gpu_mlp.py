@@ -251,3 +251,45 @@ def test_generic_and_specialised_learn_kernels_agree(monkeypatch):
         gcg, gag = grp2.grads_as_lists(g2[v])
         for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
             assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref))
+
+
+def test_full_size_learn_properties_20480_agents():
+    """BASELINE configs[1] size (4096 x 5 = 20480 agents, one weight set each): size-independent properties of
+    Trainer.learn / the federated sum that need no oracle run at this size --
+    lane independence (an agent's gradient depends only on its own batch and weights: duplicated agents give
+    bit-identical rows wherever they sit in the grid), determinism (two launches agree bit for bit), spot checks of
+    three agents against the float64 oracle, and linearity of the federated sum."""
+    need_gpu()
+    n = 4096 * 5
+    conf = config.Config()
+    grp = vec.AgentGroup(n, 4, 1, conf, seed=11)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    grp.theta.add_(torch.randn(grp.theta.shape, device="cuda", generator=g) * 0.01 * (grp.theta != 0))  # agents differ; padding stays 0
+    grp.theta_t.copy_(grp.theta)
+    s = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+    a = torch.rand(n, 64, 1, device="cuda", generator=g) * 5 - 2.5
+    r = -torch.rand(n, 64, device="cuda", generator=g)
+    s2 = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+    # duplicate agent 7 into far-away lanes (different workgroups / XCDs)
+    for dst in (8, 4097, n - 1):
+        for x in (grp.theta, grp.theta_t, grp.stats, grp.stats_t, s, a, r, s2):
+            x[dst].copy_(x[7])
+    g1 = grp.learn(s, a, r, s2, 0)
+    g2 = grp.learn(s, a, r, s2, 0)
+    assert torch.equal(g1, g2) and torch.isfinite(g1).all()
+    for dst in (8, 4097, n - 1):
+        assert torch.equal(g1[dst], g1[7])
+    assert not torch.equal(g1[7], g1[9])
+    for v in (7, 12345, n - 2):
+        nets = _nets(grp, v, np.float64)
+        cg, ag, _ = omlp.learn((s[v].cpu().numpy(), a[v].cpu().numpy(), r[v].cpu().numpy()[:, None], s2[v].cpu().numpy()), *nets)
+        nets32 = _nets(grp, v, np.float32)
+        cg32, ag32, _ = omlp.learn((s[v].cpu().numpy(), a[v].cpu().numpy(), r[v].cpu().numpy()[:, None], s2[v].cpu().numpy()), *nets32)
+        gcg, gag = grp.grads_as_lists(g1[v])
+        for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref))
+    # federated sum is linear: mean(2*g + h) == 2*mean(g) + mean(h)
+    h = torch.randn(n, grp.lay.theta_size, device="cuda", generator=g)
+    lhs = vec.fed_mean(2 * g1 + h, 4096, 5)
+    rhs = 2 * vec.fed_mean(g1, 4096, 5) + vec.fed_mean(h, 4096, 5)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-6)
