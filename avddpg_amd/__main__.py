@@ -1,0 +1,92 @@
+"""`python -m avddpg_amd {tr,esim}` -- the two modes of the reference CLI that touch the hot path, with the
+reference's flag names and override quirks (``src/cmd/api.py:5-50, 59-88``): ``--fed_weight_enabled`` defaults to
+False and always overrides the Config default (True); ``--intra_directional_averaging`` defaults to True; the
+``type=bool`` flags treat any non-empty string as True. Reporting modes (accumr/accums/lsim/lmany/pid) are out of scope."""
+import argparse
+import datetime
+import os
+import sys
+
+from .config import Config
+
+
+def get_cmdl_args(argv, conf):
+    ap = argparse.ArgumentParser(prog="python -m avddpg_amd", description="avddpg hot path on MI355X")
+    sub = ap.add_subparsers(dest="mode")
+    tr = sub.add_parser("tr", help="run in training mode")
+    tr.add_argument("--seed", type=int, default=conf.random_seed)
+    tr.add_argument("--method", choices=[conf.exact, conf.euler])
+    tr.add_argument("--rand_states", type=bool)
+    tr.add_argument("--total_time_steps", type=int)
+    tr.add_argument("--pl_num", type=int)
+    tr.add_argument("--pl_size", type=int)
+    tr.add_argument("--buffer_size", type=int)
+    tr.add_argument("--actor_lr", type=float)
+    tr.add_argument("--critic_lr", type=float)
+    tr.add_argument("--fed_method", choices=[conf.interfrl, conf.intrafrl, conf.nofrl])
+    tr.add_argument("--fed_update_count", type=int)
+    tr.add_argument("--fed_cutoff_ratio", type=float)
+    tr.add_argument("--fed_update_delay", type=float)
+    tr.add_argument("--fed_weight_enabled", type=bool, default=False)
+    tr.add_argument("--fed_weight_window", type=int)
+    tr.add_argument("--fed_agg_method", type=str, choices=["gradients", "weights"])
+    tr.add_argument("--intra_directional_averaging", type=bool, default=True)
+    tr.add_argument("--rng", choices=["host", "device"], default="host",
+                    help="host: reference RNG stream (fixed-seed parity); device: Philox in the kernels (throughput)")
+    tr.add_argument("--out", type=str, default=".outputs")
+    es = sub.add_parser("esim", help="run in evaluation/simulator mode")
+    es.add_argument("exp_path", type=str)
+    es.add_argument("--n_timesteps", type=int, default=100)
+    args = ap.parse_args(argv)
+    return args, set_args_to_config(args, conf)
+
+
+def set_args_to_config(args, conf):
+    """src/cmd/api.py:5-50."""
+    g = lambda n: getattr(args, n, None)
+    if g("seed") is not None:
+        conf.random_seed = args.seed
+    for flag, field in (("method", "method"), ("rand_states", "rand_states"), ("total_time_steps", "total_time_steps"),
+                        ("pl_num", "num_platoons"), ("pl_size", "pl_size"), ("buffer_size", "buffer_size"),
+                        ("actor_lr", "actor_lr"), ("critic_lr", "critic_lr"), ("fed_method", "fed_method"),
+                        ("fed_update_count", "fed_update_count"), ("fed_cutoff_ratio", "fed_cutoff_ratio"),
+                        ("intra_directional_averaging", "intra_directional_averaging"),
+                        ("fed_update_delay", "fed_update_delay"), ("fed_weight_enabled", "weighted_average_enabled"),
+                        ("fed_weight_window", "weighted_window"), ("fed_agg_method", "aggregation_method")):
+        if g(flag) is not None:
+            setattr(conf, field, getattr(args, flag))
+    return conf.refresh()
+
+
+def main(argv=None):
+    conf = Config()
+    args, conf = get_cmdl_args(sys.argv[1:] if argv is None else argv, conf)
+    if args.mode == "tr":
+        import numpy as np
+
+        from . import artifacts, trainer
+        np.random.seed(conf.random_seed)  # rand.set_global_seed (src/rand.py:6-15)
+        base = os.path.join(args.out, datetime.datetime.now().strftime("%y%m%d_%H%M%S"))
+        os.makedirs(base, exist_ok=True)
+        vt = trainer.VecTrainer(conf, rng=args.rng, auto_reset=False)
+        ep, avg = vt.run()
+        artifacts.generate_csvs(base, conf, ep, avg)
+        artifacts.save_agents(base, vt.agents, vt.P, vt.M, shared=vt.shared)
+        artifacts.config_writer(os.path.join(base, "conf.json"), conf)
+        print(base)
+    elif args.mode == "esim":
+        from . import artifacts, evaluator, vec
+        conf = artifacts.config_loader(os.path.join(args.exp_path, "conf.json"), Config)
+        S = 3 if conf.model == conf.modelA else 4
+        for p in range(1, conf.num_platoons + 1):
+            grp = vec.AgentGroup(conf.pl_size, S, 1, conf)
+            for m in range(conf.pl_size):
+                grp.set_weights(m, "actor", artifacts.load_actor_weights(args.exp_path, p, m + 1))
+            rew, _ = evaluator.run(conf=conf, actors=grp, pl_idx=p, manual_timestep_override=args.n_timesteps)
+            print(f"platoon {p}: cumulative platoon reward {rew}")
+    else:
+        raise SystemExit("modes: tr, esim")
+
+
+if __name__ == "__main__":
+    main()

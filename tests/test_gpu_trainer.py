@@ -344,3 +344,27 @@ def test_episode_reward_curve_matches_oracle_loop_config1():
             assert abs(float(ep_lists[0][m][ep]) - want) <= 1e-4 * abs(want), (ep, m)
     assert np.isclose(avg_lists[0][1][-1], np.mean([c[0][1] for c in curve]), rtol=1e-4)  # trailing-mean curve
     assert tr.engine.updates == ref.updates
+
+
+def test_cli_train_then_esim_roundtrip(tmp_path, capsys):
+    """`python -m avddpg_amd tr` writes reward CSVs, conf.json and Keras-ordered checkpoints; `esim` reloads the
+    actors from them and reproduces the evaluator reward of the in-memory agents."""
+    import glob
+    import os
+
+    from avddpg_amd import __main__ as cli
+    from avddpg_amd import artifacts, evaluator
+    from avddpg_amd.config import Config
+
+    cli.main(["tr", "--pl_num", "2", "--pl_size", "2", "--total_time_steps", "1200", "--buffer_size", "500", "--out",
+              str(tmp_path)])
+    base = capsys.readouterr().out.strip().splitlines()[-1]
+    assert os.path.exists(os.path.join(base, "ep_reward__seed1.csv")) and os.path.exists(os.path.join(base, "conf.json"))
+    assert len(glob.glob(os.path.join(base, "*.npz"))) == 2 * 2 * 4
+    w = artifacts.load_actor_weights(base, 2, 1)
+    assert [x.shape for x in w][:3] == [(4, 256), (256,), (256,)] and len(w) == 14
+    cli.main(["esim", base, "--n_timesteps", "60"])
+    out = capsys.readouterr().out
+    assert "platoon 1: cumulative platoon reward" in out and "platoon 2:" in out
+    conf = artifacts.config_loader(os.path.join(base, "conf.json"), Config)
+    assert conf.number_of_episodes == 2 and conf.num_platoons == 2
