@@ -41,6 +41,9 @@ def parse():
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-fused", action="store_true",
                     help="nofrl: run learn and Adam+Polyak as two kernels instead of the fused avd_learn_update_f32")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="plumbing test: every rank uses GPU 0 (a 1-GPU box cannot host one rank per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -84,12 +87,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
         group = dist.group.WORLD
 
     from avddpg_amd import config, trainer
