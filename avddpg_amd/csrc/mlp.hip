@@ -1,7 +1,7 @@
 // Actor/critic MLP kernels for gfx950.
 //
 //  * mlp_rows_kernel  -- batch-1 actor / critic forward per agent (GEMV; weights streamed once).
-//  * learn_kernel     -- Trainer.learn (workers/trainer.py:472-508) for one agent's batch of 64 rows
+//  * learn_kernel_t / learn_kernel_g -- Trainer.learn (workers/trainer.py:472-508) for one agent's batch of 64 rows
 //                        per 256-thread workgroup: 5 forwards + 2 backwards fused, activations
 //                        resident in LDS (~150 KB, one workgroup per CU), the [64xK]x[KxN] products
 //                        on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), weights streamed
@@ -131,62 +131,9 @@ struct Net {  // pointers into one weight set
 // small building blocks (called by all 256 threads of the workgroup)
 // ------------------------------------------------------------------------------------------
 
-// First layer of a branch + the BatchNormalization coefficients of its output, for column k = threadIdx.x < H:
-//   out[r][col0+k] = relu(sum_j X[r*xs + j] * W[j*H + k] + b[k]),  inv/sh[col0+k] = BN coefficients.
-// Every global load of the phase (weight column, bias, gamma, beta, mean, var) is issued before the first use,
-// so the phase pays ONE memory latency instead of one per tensor (one wave per SIMD: nothing else hides it).
-struct L1Col {
-    float w[8], b, g, be, mm, mv;
-};
-__device__ __forceinline__ L1Col l1_load(int K, const float* __restrict__ W, const float* __restrict__ b,
-                                         const float* __restrict__ g, const float* __restrict__ be,
-                                         const float* __restrict__ mm, const float* __restrict__ mv, int H, int k) {
-    L1Col c;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c.w[j] = (j < K && k < H) ? W[j * H + k] : 0.f;
-    const bool on = k < H;
-    c.b = on ? b[k] : 0.f, c.g = on ? g[k] : 0.f, c.be = on ? be[k] : 0.f, c.mm = on ? mm[k] : 0.f,
-    c.mv = on ? mv[k] : 1.f;
-    return c;
-}
-// Rows are processed in register blocks of RB: all RB broadcast reads of X are issued before the first
+// Row loops of the VALU phases work in register blocks of RB rows: all RB reads are issued before the first
 // FMA/ds_write (a read -> compute -> write loop pays one LDS round trip per row: LDS returns in order).
 constexpr int RB = 16;
-template <int K>
-__device__ __forceinline__ void l1_rows_k(const L1Col& c, const float* X, int xs, float* out, int ld, int col, int r0,
-                                          int rstep) {
-    for (int rb = r0; rb < TILE; rb += RB * rstep) {
-        float xv[RB][K];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = min(rb + i * rstep, TILE - 1);
-#pragma unroll
-            for (int j = 0; j < K; ++j) xv[i][j] = X[r * xs + j];
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = rb + i * rstep;
-            float acc = c.b;
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc = fmaf(xv[i][j], c.w[j], acc);
-            if (r < TILE) out[r * ld + col] = fmaxf(acc, 0.f);
-        }
-    }
-}
-__device__ __forceinline__ void l1_rows(const L1Col& c, int K, const float* X, int xs, float* out, int ld, int col,
-                                        int r0, int rstep) {
-    switch (K) {
-        case 1: l1_rows_k<1>(c, X, xs, out, ld, col, r0, rstep); break;
-        case 3: l1_rows_k<3>(c, X, xs, out, ld, col, r0, rstep); break;
-        case 4: l1_rows_k<4>(c, X, xs, out, ld, col, r0, rstep); break;
-        default: l1_rows_k<8>(c, X, xs, out, ld, col, r0, rstep); break;  // w[j >= K] == 0, X padded reads stay in LDS
-    }
-}
-__device__ __forceinline__ void l1_coefs(const L1Col& c, float* inv, float* sh, int idx) {
-    const float iv = (1.0f / sqrtf(c.mv + BN_EPS)) * c.g;
-    inv[idx] = iv;
-    sh[idx] = c.be - c.mm * iv;
-}
 
 // out[r] = sum_k (P[r][k]*inv[k] + sh[k]) * w[k] + b   (output width 1), blockDim/64 lanes per row, 16-byte LDS reads
 __device__ __forceinline__ float out_layer_row(const float* P, int ld, const float* inv, const float* sh,
@@ -323,7 +270,7 @@ __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* in
     }
 }
 
-constexpr int DX_NB = 8;  // reduction blocks of 16 held in registers per tile (N <= 128 per pass)
+constexpr int DX_NB = 16;  // reduction blocks of 16 held in registers per tile (N <= 256)
 
 // Input gradient of a hidden layer + BN/ReLU backward of the layer below, in place:
 //   dy[r][c] = sum_n DZ[r][n] * W[c][n]               (c in [c_begin, c_end), W global [K][N])
@@ -445,20 +392,6 @@ __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const f
         sink.put(gb + k, sb);
     }
 }
-__device__ __forceinline__ void dense_in_grads(const float* X, int xs, int K, const float* DZ, int ldz, int c0, int H,
-                                               float* __restrict__ gW, float* __restrict__ gb) {
-    switch (K) {
-        case 1: dense_in_grads_k<1>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 2: dense_in_grads_k<2>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 3: dense_in_grads_k<3>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 4: dense_in_grads_k<4>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 5: dense_in_grads_k<5>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 6: dense_in_grads_k<6>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        case 7: dense_in_grads_k<7>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-        default: dense_in_grads_k<8>(X, xs, DZ, ldz, c0, H, gW, gb); break;
-    }
-}
-
 // Output layer (width 1) backward through the BN below it, for column k < K (K <= 256):
 //   dW3[k] = sum_r bn(p[r][k])*d[r]; dy = d[r]*w3[k]; dgamma, dbeta; DZ[r][k] = dy*inv*(p>0)
 // The 64 rows are split over blockDim/K thread groups; partial sums meet in LDS scratch scr[3*blockDim].
@@ -575,73 +508,6 @@ __device__ __forceinline__ void l2_store(const L2Col& c, LearnLds& l, int H2, in
     }
 }
 
-// actor forward over the 64 rows in X (LDS [64][S]); leaves p1 in bufA, p2 in bufB, coefs in invA/shA, invB/shB..;
-// writes tanh to sT and action (tanh*high) to out.  (H1, H2 <= NTHREADS)
-__device__ __forceinline__ void actor_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, float high,
-                                               LearnLds& l, float* out PH_ARG) {
-    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
-    const float* th = net.th;
-    const int k = threadIdx.x;
-    const float b3 = th[L.ab3];
-    const L1Col c1 = l1_load(L.S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, net.st + L.amm1, net.st + L.amv1,
-                             L.H1, k);
-    const L2Col c2 = l2_load(th + L.ag2, th + L.abe2, net.st + L.amm2, net.st + L.amv2, th + L.aW3, L.H2, k);
-    if (k < L.H1) {
-        l1_coefs(c1, l.invA, l.shA, k);
-        l1_rows(c1, L.S, X, L.S, l.bufA, ldA, k, 0, 1);
-    }
-    l2_store(c2, l, L.H2, k);
-    lds_barrier();
-    PH(1);
-    gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1, th + L.aW2, th + L.ab2, L.H2, l.bufB, ldB);
-    lds_barrier();
-    PH(2);
-    const float z = out_layer_row(l.bufB, ldB, l.invB, l.shB, l.w3B, b3, L.H2);
-    if ((threadIdx.x & 3) == 0) {
-        const float t = tanhf(z);
-        l.sT[threadIdx.x >> 2] = t;
-        out[threadIdx.x >> 2] = t * high;
-    }
-    lds_barrier();
-    PH(3);
-}
-
-// critic forward over 64 rows: state X (LDS [64][S]), action act (LDS [64]); leaves concat p (state|action) in bufA,
-// p of layer 2 in bufB, coefs in invA/shA (H1+Ha) and invB/shB..; q -> out[64].  (H1, Ha, H2 <= NTHREADS)
-__device__ __forceinline__ void critic_fwd_tile(const avd_mlp_layout& L, Net net, const float* X, const float* act,
-                                                LearnLds& l, float* out PH_ARG) {
-    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
-    const float* th = net.th + L.actor_size;
-    const float* st = net.st;
-    const int k = threadIdx.x;
-    // action branch: Ha columns x row groups so that (almost) every thread works
-    const int agroups = NTHREADS / L.Ha;
-    const int ka = k % L.Ha, ra = k / L.Ha;
-    const float b3 = th[L.cb3];
-    const L1Col cs = l1_load(L.S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, st + L.cmms, st + L.cmvs, L.H1, k);
-    const L1Col ca = l1_load(1, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, st + L.cmma, st + L.cmva, L.Ha,
-                             ra < agroups ? ka : L.Ha);
-    const L2Col c2 = l2_load(th + L.cg3, th + L.cbe3, st + L.cmm3, st + L.cmv3, th + L.cW3, L.H2, k);
-    if (k < L.H1) {
-        l1_coefs(cs, l.invA, l.shA, k);
-        l1_rows(cs, L.S, X, L.S, l.bufA, ldA, k, 0, 1);
-    }
-    if (ra < agroups) {
-        if (ra == 0) l1_coefs(ca, l.invA, l.shA, L.H1 + ka);
-        l1_rows(ca, 1, act, 1, l.bufA, ldA, L.H1 + ka, ra, agroups);
-    }
-    l2_store(c2, l, L.H2, k);
-    lds_barrier();
-    PH(4);
-    gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, th + L.cW2, th + L.cb2, L.H2, l.bufB, ldB);
-    lds_barrier();
-    PH(5);
-    const float q = out_layer_row(l.bufB, ldB, l.invB, l.shB, l.w3B, b3, L.H2);
-    if ((threadIdx.x & 3) == 0) out[threadIdx.x >> 2] = q;
-    lds_barrier();
-    PH(6);
-}
-
 __device__ __forceinline__ float block_sum64(const float* v, float* red) {
     // sum of 64 LDS values by wave 0; result broadcast through red[0]
     if (threadIdx.x < 64) {
@@ -656,148 +522,315 @@ __device__ __forceinline__ float block_sum64(const float* v, float* red) {
     return r;
 }
 
-__global__ __launch_bounds__(NTHREADS) void learn_kernel(avd_mlp_layout L, int set_mod,
-                                                          const float* __restrict__ theta,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ theta_t,
-                                                          const float* __restrict__ stats_t,
-                                                          const float* __restrict__ s, const float* __restrict__ a,
-                                                          const float* __restrict__ r, const float* __restrict__ s2,
-                                                          float gamma, float high, float* __restrict__ grads,
-                                                          float* __restrict__ losses) {
+// ------------------------------------------------------------------------------------------
+// General learn kernel: any widths that fit one workgroup's LDS, multi-action heads (centralized framework:
+// S = 4L states, A = L actions, widths x1.2 zero-padded to MFMA multiples -- reference src/environment.py:35-52,
+// agent/model.py hidd_mult, workers/trainer.py:102-108). Same four-pass plan and the same MFMA GEMM routines as
+// the specialised kernel; the first/last layers (tiny K or N) are plain VALU loops. One LDS buffer fewer: the
+// output-layer backward overwrites p with dz in place. Throughput is secondary here; correctness and generality
+// are the point (the reference widths take learn_kernel_t).
+// Zero padding is exact: a padded unit has zero weights/bias, beta = mean = 0, so it outputs 0, receives zero
+// gradient for every parameter and stays zero under Adam.
+// ------------------------------------------------------------------------------------------
+namespace gen {
+
+constexpr int MAX_A = 16, MAX_S = 64;
+
+struct GLds {
+    float *bufA, *bufB;          // [64][ldA] first-layer outputs (state | action), [64][ldB] second layer / its gradient
+    float *invA, *shA;           // H1+Ha
+    float *invB, *shB, *rsB, *mmB, *db;  // H2
+    float *sX;                   // [64][S]
+    float *sR;                   // [64]
+    float *sAct, *sY, *sQ, *sD, *sA1, *sT, *sDa;  // [64][A]
+    float* red;                  // [8]
+};
+__host__ __device__ inline size_t lds_floats(const avd_mlp_layout& L) {
+    return (size_t)TILE * ld_of(L.H1 + L.Ha) + (size_t)TILE * ld_of(L.H2) + 2 * (L.H1 + L.Ha) + 5 * L.H2 +
+           TILE * L.S + TILE + 7 * TILE * L.A + 8;
+}
+__device__ __forceinline__ GLds carve(float* p, const avd_mlp_layout& L) {
+    GLds l;
+    l.bufA = p, p += TILE * ld_of(L.H1 + L.Ha);
+    l.bufB = p, p += TILE * ld_of(L.H2);
+    l.invA = p, p += L.H1 + L.Ha;
+    l.shA = p, p += L.H1 + L.Ha;
+    l.invB = p, p += L.H2;
+    l.shB = p, p += L.H2;
+    l.rsB = p, p += L.H2;
+    l.mmB = p, p += L.H2;
+    l.db = p, p += L.H2;
+    l.sX = p, p += TILE * L.S;
+    l.sR = p, p += TILE;
+    l.sAct = p, p += TILE * L.A;
+    l.sY = p, p += TILE * L.A;
+    l.sQ = p, p += TILE * L.A;
+    l.sD = p, p += TILE * L.A;
+    l.sA1 = p, p += TILE * L.A;
+    l.sT = p, p += TILE * L.A;
+    l.sDa = p, p += TILE * L.A;
+    l.red = p;
+    return l;
+}
+
+// first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k
+__device__ __forceinline__ void l1_fwd(const float* X, int K, const float* __restrict__ W, const float* __restrict__ b,
+                                       const float* __restrict__ g, const float* __restrict__ be,
+                                       const float* __restrict__ mm, const float* __restrict__ mv, int H, float* out,
+                                       int ld, int col0, float* inv, float* sh) {
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+        inv[col0 + k] = iv;
+        sh[col0 + k] = be[k] - mm[k] * iv;
+        const float bk = b[k];
+        for (int rb = 0; rb < TILE; rb += RB) {
+            float acc[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) acc[i] = bk;
+            for (int j = 0; j < K; ++j) {
+                const float w = W[j * H + k];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) acc[i] = fmaf(X[(rb + i) * K + j], w, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) out[(rb + i) * ld + col0 + k] = fmaxf(acc[i], 0.f);
+        }
+    }
+}
+
+// BN coefficient tables of the layer in front of the output layer
+__device__ __forceinline__ void coefs_b(const float* __restrict__ g, const float* __restrict__ be,
+                                        const float* __restrict__ mm, const float* __restrict__ mv, int H2, GLds& l) {
+    for (int k = threadIdx.x; k < H2; k += NTHREADS) {
+        const float rs = 1.0f / sqrtf(mv[k] + BN_EPS);
+        const float iv = rs * g[k];
+        l.invB[k] = iv, l.shB[k] = be[k] - mm[k] * iv, l.rsB[k] = rs, l.mmB[k] = mm[k];
+    }
+}
+
+// output layer, width A: out[r][a] = sum_k bn(P[r][k]) * W3[k*A+a] + b3[a]
+__device__ __forceinline__ void out_fwd(const GLds& l, int ldB, const float* __restrict__ W3,
+                                        const float* __restrict__ b3, int H2, int A, float* out) {
+    for (int idx = threadIdx.x; idx < TILE * A; idx += NTHREADS) {
+        const int r = idx / A, a = idx - r * A;
+        float acc = b3[a];
+        for (int k = 0; k < H2; ++k) acc = fmaf(fmaf(l.bufB[r * ldB + k], l.invB[k], l.shB[k]), W3[k * A + a], acc);
+        out[idx] = acc;
+    }
+}
+
+// output layer backward through the BN below it, in place: bufB[r][k] (p) -> dz[r][k]
+//   dW3[k][a] = sum_r y[r][k]*D[r][a]; db3[a] = sum_r D[r][a]; dy[r][k] = sum_a D[r][a]*W3[k][a]
+__device__ __forceinline__ void out_bwd(GLds& l, int ldB, const float* D, const float* __restrict__ W3, int H2, int A,
+                                        float* __restrict__ gW3, float* __restrict__ gb3, float* __restrict__ gg,
+                                        float* __restrict__ gbe) {
+    for (int k = threadIdx.x; k < H2; k += NTHREADS) {
+        float w[MAX_A], dw[MAX_A];
+#pragma unroll
+        for (int a = 0; a < MAX_A; ++a) w[a] = (a < A) ? W3[k * A + a] : 0.f, dw[a] = 0.f;
+        const float iv = l.invB[k], s = l.shB[k], rs = l.rsB[k], mean = l.mmB[k];
+        float dgm = 0.f, dbt = 0.f;
+        for (int r = 0; r < TILE; ++r) {
+            const float p = l.bufB[r * ldB + k];
+            const float y = fmaf(p, iv, s);
+            float dy = 0.f;
+#pragma unroll
+            for (int a = 0; a < MAX_A; ++a)
+                if (a < A) {
+                    const float d = D[r * A + a];
+                    dy = fmaf(d, w[a], dy);
+                    dw[a] = fmaf(y, d, dw[a]);
+                }
+            dgm = fmaf(dy * (p - mean), rs, dgm);
+            dbt += dy;
+            l.bufB[r * ldB + k] = (p > 0.f) ? dy * iv : 0.f;
+        }
+        if (gW3) {
+#pragma unroll
+            for (int a = 0; a < MAX_A; ++a)
+                if (a < A) gW3[k * A + a] = dw[a];
+            gg[k] = dgm, gbe[k] = dbt;
+        }
+    }
+    if (gb3 && threadIdx.x < A) {
+        float sum = 0.f;
+        for (int r = 0; r < TILE; ++r) sum += D[r * A + threadIdx.x];
+        gb3[threadIdx.x] = sum;
+    }
+}
+
+// first-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*K+j]*dz[r][k], db[k] = sum_r dz[r][k]
+__device__ __forceinline__ void l1_grads(const float* X, int K, const float* DZ, int ldz, int c0, int H,
+                                         float* __restrict__ gW, float* __restrict__ gb) {
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+        for (int j0 = 0; j0 < K; j0 += 8) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float sb = 0.f;
+            for (int r = 0; r < TILE; ++r) {
+                const float d = DZ[r * ldz + c0 + k];
+                sb += d;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (j0 + jj < K) acc[jj] = fmaf(X[r * K + j0 + jj], d, acc[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (j0 + jj < K) gW[(j0 + jj) * H + k] = acc[jj];
+            if (j0 == 0) gb[k] = sb;
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum(const float* v, int n, float* red) {  // sum of n LDS values, all threads get it
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += NTHREADS) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    lds_barrier();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    lds_barrier();
+    return t;
+}
+
+__global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int set_mod,
+                                                            const float* __restrict__ theta,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ theta_t,
+                                                            const float* __restrict__ stats_t,
+                                                            const float* __restrict__ s, const float* __restrict__ a,
+                                                            const float* __restrict__ r, const float* __restrict__ s2,
+                                                            float gamma, float high, float* __restrict__ grads,
+                                                            float* __restrict__ losses) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    LearnLds l = carve(smem, L);
-    const int agent = blockIdx.x;
+    GLds l = carve(smem, L);
+    const int S = L.S, A = L.A, H1 = L.H1, H2 = L.H2, Ha = L.Ha, KC = H1 + Ha;
+    const int ldA = ld_of(KC), ldB = ld_of(H2);
+    const int agent = blockIdx.x, tid = threadIdx.x;
     const int set = set_mod > 0 ? agent % set_mod : agent;
     const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
     const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
-    float* g = grads + (long)agent * L.theta_size;
-    float* ga = g;                 // actor block
-    float* gc = g + L.actor_size;  // critic block
-    const int ldA = ld_of(L.H1 + L.Ha), ldB = ld_of(L.H2);
-    const int tid = threadIdx.x;
-    const float invn = 1.0f / (float)(TILE * L.A);
+    float* ga = grads + (long)agent * L.theta_size;
+    float* gc = ga + L.actor_size;
+    const float invn = 1.0f / (float)(TILE * A);
 
-    // ---- stage the batch ----
-    for (int i = tid; i < TILE * L.S; i += NTHREADS) {
-        l.sS[i] = s[(long)agent * TILE * L.S + i];
-        l.sS2[i] = s2[(long)agent * TILE * L.S + i];
+    if (tid < TILE) l.sR[tid] = r[(long)agent * TILE + tid];
+    for (int i = tid; i < TILE * A; i += NTHREADS) l.sAct[i] = a[(long)agent * TILE * A + i];
+    if (tid == 0) {  // alignment padding of the gradient slab (only the A-wide biases can end off a 4-float boundary)
+        for (int i = L.ab3 + A; i < L.actor_size; ++i) ga[i] = 0.f;
+        for (int i = L.cb3 + A; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
     }
-    if (tid < TILE) {
-        l.sAct[tid] = a[(long)agent * TILE + tid];
-        l.sR[tid] = r[(long)agent * TILE + tid];
-    }
-    // zero the alignment padding of this agent's gradient slab (never written below)
-    if (tid == 0) {
-        for (int i = L.ab3 + L.A; i < L.actor_size; ++i) ga[i] = 0.f;
-        for (int i = L.cb3 + L.A; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
-    }
-    lds_barrier();
-    PH_INIT();
-    PH(0);
 
-    // ---- TD target: y = r + gamma * Q'(s2, mu'(s2))   (trainer.py:493-494) ----
-    actor_fwd_tile(L, tgt, l.sS2, high, l, l.sA1 PH_PASS);
-    critic_fwd_tile(L, tgt, l.sS2, l.sA1, l, l.sQ PH_PASS);
-    if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
-    lds_barrier();
-
-    // ---- critic loss + gradient (trainer.py:495-498) ----
-    critic_fwd_tile(L, net, l.sS, l.sAct, l, l.sQ PH_PASS);
-    if (tid < TILE) {
-        const float e = l.sY[tid] - l.sQ[tid];
-        l.sD[tid] = -2.0f * e * invn;  // d mean((y-q)^2) / dq
-        l.sT[tid] = e * e;
-    }
-    lds_barrier();
-    {
-        const float lc = block_sum64(l.sT, l.red) * invn;
-        const float db3 = block_sum64(l.sD, l.red);
-        if (tid == 0) {
-            gc[L.cb3] = db3;
-            if (losses) losses[(long)agent * 2 + 0] = lc;
+    // pass 0: targets (y); 1: critic loss + gradient; 2: actor -> critic, gradient wrt the actions; 3: actor gradient
+#pragma nounroll
+    for (int it = 0; it < 4; ++it) {
+        const Net n = (it == 0) ? tgt : net;
+        if (it < 2) {  // state batch of this pass: s2 for the targets, s afterwards
+            lds_barrier();
+            const float* src = (it == 0 ? s2 : s) + (long)agent * TILE * S;
+            for (int i = tid; i < TILE * S; i += NTHREADS) l.sX[i] = src[i];
+            lds_barrier();
         }
-    }
-    {
-        const float* cth = net.th + L.actor_size;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr,
-                           gc + L.cW3, gc + L.cg3, gc + L.cbe3);
-        PH(7);
-        col_sums(l.bufC, ldB, L.H2, l.db, gc + L.cb2);
-        lds_barrier();
-        PH(8);
-        gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1 + L.Ha, l.bufC, ldB, l.db, L.H2, gc + L.cW2);
-        lds_barrier();
-        PH(9);
-        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, 0, L.H1, l.bufA, ldA, cth + L.cgs, net.st + L.cmms,
-                   net.st + L.cmvs, gc + L.cgs, gc + L.cbes);
-        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
-                   net.st + L.cmva, gc + L.cga, gc + L.cbea);
-        lds_barrier();
-        PH(10);
-        dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, gc + L.cWs, gc + L.cbs);
-        dense_in_grads(l.sAct, 1, 1, l.bufA, ldA, L.H1, L.Ha, gc + L.cWa, gc + L.cba);
-        lds_barrier();
-        PH(11);
-    }
-
-    // ---- actor loss: La = -mean(Q(s, mu(s)))   (trainer.py:501-506) ----
-    // pass 1: a1 = mu(s) (activations discarded), critic forward on (s, a1), gradient wrt the action input
-    actor_fwd_tile(L, net, l.sS, high, l, l.sA1 PH_PASS);
-    critic_fwd_tile(L, net, l.sS, l.sA1, l, l.sQ PH_PASS);
-    {
-        const float la = -block_sum64(l.sQ, l.red) * invn;
-        if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
-        if (tid < TILE) l.sD[tid] = -invn;  // dLa/dq1
-        lds_barrier();
-        const float* cth = net.th + L.actor_size;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr, nullptr,
-                           nullptr, nullptr);
-        PH(12);
-        gemm_dx_bn(l.bufC, ldB, L.H2, cth + L.cW2, L.H1, L.H1 + L.Ha, l.bufA, ldA, cth + L.cga, net.st + L.cmma,
-                   net.st + L.cmva, nullptr, nullptr);
-        lds_barrier();
-        PH(13);
-        // da1[r] = sum_j dza[r][j] * Wa[0][j]
-        {
-            const int rr = tid >> 2, part = tid & 3;
-            float acc = 0.f;
-            for (int j = part; j < L.Ha; j += 4) acc = fmaf(l.bufA[rr * ldA + L.H1 + j], cth[L.cWa + j], acc);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            if (part == 0) l.sDa[rr] = acc;
+        if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
+            const float* th = n.th;
+            l1_fwd(l.sX, S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1, H1, l.bufA, ldA,
+                   0, l.invA, l.shA);
+            coefs_b(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, H2, l);
+            lds_barrier();
+            gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, H1, th + L.aW2, th + L.ab2, H2, l.bufB, ldB);
+            lds_barrier();
+            out_fwd(l, ldB, th + L.aW3, th + L.ab3, H2, A, l.sQ);
+            lds_barrier();
+            for (int i = tid; i < TILE * A; i += NTHREADS) {
+                const float t = tanhf(l.sQ[i]);
+                l.sT[i] = t, l.sA1[i] = t * high;
+            }
+            lds_barrier();
+        }
+        if (it != 3) {  // ---- critic forward (agent/model.py:63-83)
+            const float* th = n.th + L.actor_size;
+            const float* act = (it == 1) ? l.sAct : l.sA1;
+            l1_fwd(l.sX, S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, n.st + L.cmms, n.st + L.cmvs, H1, l.bufA, ldA,
+                   0, l.invA, l.shA);
+            l1_fwd(act, A, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, n.st + L.cmma, n.st + L.cmva, Ha, l.bufA, ldA,
+                   H1, l.invA, l.shA);
+            coefs_b(th + L.cg3, th + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, H2, l);
+            lds_barrier();
+            gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, KC, th + L.cW2, th + L.cb2, H2, l.bufB, ldB);
+            lds_barrier();
+            out_fwd(l, ldB, th + L.cW3, th + L.cb3, H2, A, l.sQ);
+            lds_barrier();
+        }
+        if (it == 0) {  // y = r + gamma * Q'(s2, mu'(s2)), r broadcast over the A outputs, no done mask (trainer.py:494)
+            for (int i = tid; i < TILE * A; i += NTHREADS) l.sY[i] = fmaf(gamma, l.sQ[i], l.sR[i / A]);
+            continue;
+        }
+        if (it == 1) {  // Lc = mean((y - q)^2) over B*A (trainer.py:496)
+            for (int i = tid; i < TILE * A; i += NTHREADS) {
+                const float e = l.sY[i] - l.sQ[i];
+                l.sD[i] = -2.0f * e * invn;
+                l.sT[i] = e * e;
+            }
+            lds_barrier();
+            const float lc = block_sum(l.sT, TILE * A, l.red) * invn;
+            if (tid == 0 && losses) losses[(long)agent * 2 + 0] = lc;
+        } else if (it == 2) {  // La = -mean(q1) (trainer.py:504)
+            const float la = -block_sum(l.sQ, TILE * A, l.red) * invn;
+            if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
+            for (int i = tid; i < TILE * A; i += NTHREADS) l.sD[i] = -invn;
+        } else {  // through tanh(.)*high
+            for (int i = tid; i < TILE * A; i += NTHREADS) {
+                const float t = l.sT[i];
+                l.sD[i] = l.sDa[i] * high * (1.0f - t * t);
+            }
         }
         lds_barrier();
-        PH(14);
-    }
-    // pass 2: actor forward again keeping p1 (bufA), p2 (bufB), tanh (sT); then backward
-    actor_fwd_tile(L, net, l.sS, high, l, l.sA1 PH_PASS);
-    if (tid < TILE) {
-        const float t = l.sT[tid];
-        l.sD[tid] = l.sDa[tid] * high * (1.0f - t * t);  // d/d(pre-tanh)
-    }
-    lds_barrier();
-    {
-        const float db3 = block_sum64(l.sD, l.red);
-        if (tid == 0) ga[L.ab3] = db3;
-        const float* ath = net.th;
-        out_layer_backward(l.bufB, ldB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, L.H2, l.bufC, ldB, l.scr,
-                           ga + L.aW3, ga + L.ag2, ga + L.abe2);
-        PH(15);
-        col_sums(l.bufC, ldB, L.H2, l.db, ga + L.ab2);
+        const bool crit = (it != 3), wg = (it != 2);
+        const float* wth = crit ? net.th + L.actor_size : net.th;
+        float* gout = crit ? gc : ga;
+        out_bwd(l, ldB, l.sD, wth + (crit ? L.cW3 : L.aW3), H2, A, wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr,
+                wg ? gout + (crit ? L.cb3 : L.ab3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
+                gout + (crit ? L.cbe3 : L.abe2));
         lds_barrier();
-        PH(16);
-        gemm_dw(l.bufA, ldA, l.invA, l.shA, L.H1, l.bufC, ldB, l.db, L.H2, ga + L.aW2);
+        if (wg) {
+            col_sums(l.bufB, ldB, H2, l.db, gout + (crit ? L.cb2 : L.ab2));
+            lds_barrier();
+            gemm_dw(l.bufA, ldA, l.invA, l.shA, crit ? KC : H1, l.bufB, ldB, l.db, H2, gout + (crit ? L.cW2 : L.aW2));
+            lds_barrier();
+        }
+        const float* w2 = wth + (crit ? L.cW2 : L.aW2);
+        if (it != 2) {
+            if (crit)
+                gemm_dx_bn(l.bufB, ldB, H2, w2, 0, H1, l.bufA, ldA, wth + L.cgs, net.st + L.cmms, net.st + L.cmvs,
+                           gc + L.cgs, gc + L.cbes);
+            else
+                gemm_dx_bn(l.bufB, ldB, H2, w2, 0, H1, l.bufA, ldA, wth + L.ag1, net.st + L.amm1, net.st + L.amv1,
+                           ga + L.ag1, ga + L.abe1);
+        }
+        if (crit) {
+            const float* cth = net.th + L.actor_size;
+            gemm_dx_bn(l.bufB, ldB, H2, w2, H1, KC, l.bufA, ldA, cth + L.cga, net.st + L.cmma, net.st + L.cmva,
+                       wg ? gc + L.cga : nullptr, wg ? gc + L.cbea : nullptr);
+        }
         lds_barrier();
-        PH(17);
-        gemm_dx_bn(l.bufC, ldB, L.H2, ath + L.aW2, 0, L.H1, l.bufA, ldA, ath + L.ag1, net.st + L.amm1,
-                   net.st + L.amv1, ga + L.ag1, ga + L.abe1);
-        lds_barrier();
-        PH(18);
-        dense_in_grads(l.sS, L.S, L.S, l.bufA, ldA, 0, L.H1, ga + L.aW1, ga + L.ab1);
-        PH(19);
+        if (it == 1) {
+            l1_grads(l.sX, S, l.bufA, ldA, 0, H1, gc + L.cWs, gc + L.cbs);
+            l1_grads(l.sAct, A, l.bufA, ldA, H1, Ha, gc + L.cWa, gc + L.cba);
+        } else if (it == 2) {  // da[r][a] = sum_j dza[r][j] * Wa[a][j]
+            const float* cth = net.th + L.actor_size;
+            for (int i = tid; i < TILE * A; i += NTHREADS) {
+                const int rr = i / A, aa = i - rr * A;
+                float acc = 0.f;
+                for (int j = 0; j < Ha; ++j) acc = fmaf(l.bufA[rr * ldA + H1 + j], cth[L.cWa + aa * Ha + j], acc);
+                l.sDa[i] = acc;
+            }
+        } else {
+            l1_grads(l.sX, S, l.bufA, ldA, 0, H1, ga + L.aW1, ga + L.ab1);
+        }
     }
 }
+
+}  // namespace gen
 
 // ------------------------------------------------------------------------------------------
 // Dimension-specialised learn kernel (reference widths known at compile time).
@@ -1178,7 +1211,7 @@ __device__ __forceinline__ void l1p_coefs(const L1P<K>& c, float* inv, float* sh
 template <int K>
 __device__ __forceinline__ void l1p_rows(const L1P<K>& c, const float* X, float* out, int ld, int col, int r0,
                                          int rstep) {
-    for (int rb = r0; rb < TILE; rb += RB * rstep) {  // register blocks of RB rows: see l1_rows_k
+    for (int rb = r0; rb < TILE; rb += RB * rstep) {  // register blocks of RB rows
         float xv[RB][K];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -1510,9 +1543,10 @@ __device__ __forceinline__ void bn_apply(float* y, int n, const float* __restric
     }
 }
 
-__device__ __forceinline__ float block_dot(const float* x, const float* __restrict__ w, int n, float* part) {
+__device__ __forceinline__ float block_dot(const float* x, const float* __restrict__ w, int wstride, int n,
+                                           float* part) {
     float acc = 0.f;
-    for (int k = threadIdx.x; k < n; k += NTHREADS) acc = fmaf(x[k], w[k], acc);
+    for (int k = threadIdx.x; k < n; k += NTHREADS) acc = fmaf(x[k], w[(long)k * wstride], acc);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -1522,7 +1556,7 @@ __device__ __forceinline__ float block_dot(const float* x, const float* __restri
     return r;
 }
 
-// mode 0: actor, out = tanh(.)*high ; mode 1: critic, out = q
+// mode 0: actor, out[agent][a] = tanh(.)*high ; mode 1: critic, out[agent][a] = q      (A = num_actions outputs)
 __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, int mode, int set_mod,
                                                              const float* __restrict__ theta,
                                                              const float* __restrict__ stats,
@@ -1533,13 +1567,14 @@ __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, in
     float* h1 = smem;                    // H1 + Ha
     float* h2 = h1 + L.H1 + L.Ha;        // H2
     float* part = h2 + L.H2;             // 256
-    float* xin = part + NTHREADS;        // 8 + 8
+    float* xin = part + NTHREADS;        // S (<= 64) then A (<= 16)
+    float* ain = xin + gen::MAX_S;
     const int agent = blockIdx.x;
     const int set = set_mod > 0 ? agent % set_mod : agent;
     const float* th = theta + (long)set * L.theta_size;
     const float* st = stats + (long)set * L.stats_size;
     if (threadIdx.x < L.S) xin[threadIdx.x] = state[(long)agent * x_stride + threadIdx.x];
-    if (mode == 1 && threadIdx.x == 0) xin[8] = action[agent];
+    if (mode == 1 && threadIdx.x < L.A) ain[threadIdx.x] = action[(long)agent * L.A + threadIdx.x];
     __syncthreads();
     if (mode == 0) {
         gemv_relu(xin, L.S, th + L.aW1, th + L.ab1, L.H1, part, h1);
@@ -1548,20 +1583,24 @@ __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, in
         gemv_relu(h1, L.H1, th + L.aW2, th + L.ab2, L.H2, part, h2);
         bn_apply(h2, L.H2, th + L.ag2, th + L.abe2, st + L.amm2, st + L.amv2);
         __syncthreads();
-        const float z = block_dot(h2, th + L.aW3, L.H2, part) + th[L.ab3];
-        if (threadIdx.x == 0) out[agent] = tanhf(z) * high;
+        for (int a = 0; a < L.A; ++a) {
+            const float z = block_dot(h2, th + L.aW3 + a, L.A, L.H2, part) + th[L.ab3 + a];
+            if (threadIdx.x == 0) out[(long)agent * L.A + a] = tanhf(z) * high;
+        }
     } else {
         const float* c = th + L.actor_size;
         gemv_relu(xin, L.S, c + L.cWs, c + L.cbs, L.H1, part, h1);
-        gemv_relu(xin + 8, 1, c + L.cWa, c + L.cba, L.Ha, part, h1 + L.H1);
+        gemv_relu(ain, L.A, c + L.cWa, c + L.cba, L.Ha, part, h1 + L.H1);
         bn_apply(h1, L.H1, c + L.cgs, c + L.cbes, st + L.cmms, st + L.cmvs);
         bn_apply(h1 + L.H1, L.Ha, c + L.cga, c + L.cbea, st + L.cmma, st + L.cmva);
         __syncthreads();
         gemv_relu(h1, L.H1 + L.Ha, c + L.cW2, c + L.cb2, L.H2, part, h2);
         bn_apply(h2, L.H2, c + L.cg3, c + L.cbe3, st + L.cmm3, st + L.cmv3);
         __syncthreads();
-        const float q = block_dot(h2, c + L.cW3, L.H2, part) + c[L.cb3];
-        if (threadIdx.x == 0) out[agent] = q;
+        for (int a = 0; a < L.A; ++a) {
+            const float q = block_dot(h2, c + L.cW3 + a, L.A, L.H2, part) + c[L.cb3 + a];
+            if (threadIdx.x == 0) out[(long)agent * L.A + a] = q;
+        }
     }
 }
 
@@ -1615,13 +1654,10 @@ extern "C" int avd_mlp_layout_init(avd_mlp_layout* o, int S, int A, int H1, int 
 
 static int check_mlp_dims(const avd_mlp_layout* L, const char* who) {
     AVD_REQUIRE(L, "%s: null layout", who);
-    if (L->A != 1) {
-        set_error("%s: num_actions=%d; only A == 1 (decentralized framework) is implemented", who, L->A);
-        return AVD_E_UNSUPPORTED;
-    }
-    if (L->S > 8 || (L->H1 % 16) || (L->H2 % 16) || (L->Ha % 16)) {
-        set_error("%s: need S <= 8 and H1,H2,Ha multiples of 16 (got S=%d H1=%d H2=%d Ha=%d)", who, L->S, L->H1, L->H2,
-                  L->Ha);
+    if (L->A > gen::MAX_A || L->S > gen::MAX_S || (L->H1 % 16) || (L->Ha % 16) || (L->H2 % 32) || L->H2 > 16 * DX_NB) {
+        set_error("%s: need S <= %d, A <= %d, H1 and Ha multiples of 16, H2 a multiple of 32 and <= %d (got S=%d A=%d "
+                  "H1=%d H2=%d Ha=%d); pad the widths with zero units",
+                  who, gen::MAX_S, gen::MAX_A, 16 * DX_NB, L->S, L->A, L->H1, L->H2, L->Ha);
         return AVD_E_UNSUPPORTED;
     }
     return AVD_OK;
@@ -1635,7 +1671,7 @@ static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int se
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0 && x_stride >= lay->S, "%s: n_agents=%d set_mod=%d x_stride=%d", who,
                 n_agents, set_mod, x_stride);
     AVD_REQUIRE(theta && stats && state && out && (mode == 0 || action), "%s: null pointer", who);
-    const size_t lds = sizeof(float) * (size_t)(lay->H1 + lay->Ha + lay->H2 + NTHREADS + 16);
+    const size_t lds = sizeof(float) * (size_t)(lay->H1 + lay->Ha + lay->H2 + NTHREADS + gen::MAX_S + gen::MAX_A);
     if (lds > 160 * 1024) {
         set_error("%s: hidden sizes need %zu B of LDS (> 160 KiB)", who, lds);
         return AVD_E_UNSUPPORTED;
@@ -1667,46 +1703,37 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
                              float* losses, void* stream) {
     int rc = check_mlp_dims(lay, "avd_learn_f32");
     if (rc) return rc;
-    if (lay->H1 > NTHREADS || lay->Ha > NTHREADS) {
-        set_error("avd_learn_f32: layer1/action-layer size %d/%d; the tile kernel implements widths <= %d", lay->H1,
-                  lay->Ha, NTHREADS);
-        return AVD_E_UNSUPPORTED;
-    }
-    if (lay->H2 % 32 || lay->H2 > 16 * DX_NB) {
-        set_error("avd_learn_f32: layer2 size %d; the tile kernel implements H2 %% 32 == 0 and H2 <= %d", lay->H2,
-                  16 * DX_NB);
-        return AVD_E_UNSUPPORTED;
-    }
     if (lay->B != TILE) {
         set_error("avd_learn_f32: batch_size=%d; the tile kernel implements B == %d", lay->B, TILE);
         return AVD_E_UNSUPPORTED;
     }
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0, "avd_learn_f32: n_agents=%d set_mod=%d", n_agents, set_mod);
     AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads, "avd_learn_f32: null pointer");
-    // reference widths (src/config.py:112-117) take the dimension-specialised kernel; anything else the generic one
-    if (lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && !getenv("AVD_LEARN_GENERIC")) {
+    // reference widths (src/config.py:112-117) take the dimension-specialised kernel; anything else the general one
+    if (lay->A == 1 && lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && (lay->S == 3 || lay->S == 4) &&
+        !getenv("AVD_LEARN_GENERAL")) {
         const fast::UpdArgs none = {};
         if (lay->S == 4)
             return fast::launch<4, 256, 128, 48, false>(lay, n_agents, set_mod, theta, stats, (float*)theta_t,
                                                         (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
                                                         stream);
-        if (lay->S == 3)
-            return fast::launch<3, 256, 128, 48, false>(lay, n_agents, set_mod, theta, stats, (float*)theta_t,
-                                                        (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
-                                                        stream);
+        return fast::launch<3, 256, 128, 48, false>(lay, n_agents, set_mod, theta, stats, (float*)theta_t,
+                                                    (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
+                                                    stream);
     }
-    const size_t lds = sizeof(float) * learn_lds_floats(*lay);
+    const size_t lds = sizeof(float) * gen::lds_floats(*lay);
     if (lds > 160 * 1024) {
-        set_error("avd_learn_f32: widths H1=%d H2=%d Ha=%d need %zu B of LDS per tile (> 160 KiB)", lay->H1, lay->H2,
-                  lay->Ha, lds);
+        set_error("avd_learn_f32: S=%d A=%d H1=%d H2=%d Ha=%d need %zu B of LDS per 64-row tile (> 160 KiB)", lay->S,
+                  lay->A, lay->H1, lay->H2, lay->Ha, lds);
         return AVD_E_UNSUPPORTED;
     }
-    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gen::learn_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) {
         set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         return AVD_E_LAUNCH;
     }
-    hipLaunchKernelGGL(learn_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod, theta,
+    hipLaunchKernelGGL(gen::learn_kernel_g, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod, theta,
                        stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
     return check_launch("avd_learn_f32");
 }

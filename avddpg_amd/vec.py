@@ -235,11 +235,13 @@ class AgentGroup:
     def __init__(self, n_sets, num_states, num_actions, config, device=None, hidd_mult=1, seed=None, high_bound=None):
         c = config
         self.config, self.device, self.n_sets = c, _dev(device), int(n_sets)
-        self.lay = _hip.make_layout(num_states, num_actions, int(c.actor_layer1_size * hidd_mult),
-                                    int(c.actor_layer2_size * hidd_mult), int(c.critic_act_layer_size * hidd_mult),
-                                    c.batch_size)
         if (c.critic_layer1_size, c.critic_layer2_size) != (c.actor_layer1_size, c.actor_layer2_size):
             raise _hip.AvdError("actor and critic layer1/layer2 sizes must match (reference defaults do)")
+        # logical widths (agent/model.py:27,30,65,70: int(size * hidd_mult)); the slabs use zero-padded widths
+        self.dims = params.Dims(num_states, num_actions, int(c.actor_layer1_size * hidd_mult),
+                                int(c.actor_layer2_size * hidd_mult), int(c.critic_act_layer_size * hidd_mult))
+        H1p, H2p, Hap = params.padded_widths(self.dims.H1, self.dims.H2, self.dims.Ha)
+        self.lay = _hip.make_layout(num_states, num_actions, H1p, H2p, Hap, c.batch_size)
         self.high = float(c.action_high if high_bound is None else high_bound)
         f32 = dict(dtype=torch.float32, device=self.device)
         n, T, S = self.n_sets, self.lay.theta_size, self.lay.stats_size
@@ -252,7 +254,7 @@ class AgentGroup:
         self.step = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._layp = C.byref(self.lay)
         rs = np.random.RandomState(c.random_seed if seed is None else seed)
-        th, st = params.init_weights(self.lay, rs, nominal=(c.actor_layer1_size, c.actor_layer2_size))
+        th, st = params.init_weights(self.lay, rs, nominal=(c.actor_layer1_size, c.actor_layer2_size), dims=self.dims)
         # every agent starts from agent (0,0)'s weights; targets copy their online nets (trainer.py:121-131)
         self.theta.copy_(torch.from_numpy(th).to(self.device).expand(n, T))
         self.stats.copy_(torch.from_numpy(st).to(self.device).expand(n, S))
@@ -261,10 +263,11 @@ class AgentGroup:
 
     # -- forward ----------------------------------------------------------------------------------
     def actor(self, states, set_mod, x_stride=None, out=None, target=False):
-        """states [n_agents, x_stride] -> tanh(.)*high [n_agents] (agent/model.py:26-36)."""
+        """states [n_agents, x_stride] -> tanh(.)*high [n_agents] ([n_agents, A] when A > 1) (agent/model.py:26-36)."""
         n_agents = states.shape[0]
         x_stride = states.shape[-1] if x_stride is None else x_stride
-        out = torch.empty(n_agents, dtype=torch.float32, device=self.device) if out is None else out
+        shape = (n_agents,) if self.lay.A == 1 else (n_agents, self.lay.A)
+        out = torch.empty(*shape, dtype=torch.float32, device=self.device) if out is None else out
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
         call("avd_actor_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
              self.high, ptr(out), stream_handle())
@@ -273,7 +276,8 @@ class AgentGroup:
     def critic(self, states, actions, set_mod, x_stride=None, out=None, target=False):
         n_agents = states.shape[0]
         x_stride = states.shape[-1] if x_stride is None else x_stride
-        out = torch.empty(n_agents, dtype=torch.float32, device=self.device) if out is None else out
+        shape = (n_agents,) if self.lay.A == 1 else (n_agents, self.lay.A)
+        out = torch.empty(*shape, dtype=torch.float32, device=self.device) if out is None else out
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
         call("avd_critic_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
              ptr(actions), ptr(out), stream_handle())
@@ -365,12 +369,13 @@ class AgentGroup:
     # -- Keras-style weight access (host copies) ---------------------------------------------------
     def get_weights(self, set_idx, which, target=False, trainable_only=False):
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
-        return params.unpack(self.lay, th[set_idx].cpu().numpy(), st[set_idx].cpu().numpy(), which, trainable_only)
+        return params.unpack(self.lay, th[set_idx].cpu().numpy(), st[set_idx].cpu().numpy(), which, trainable_only,
+                             dims=self.dims)
 
     def set_weights(self, set_idx, which, weights, target=False):
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
         h_th, h_st = th[set_idx].cpu().numpy(), st[set_idx].cpu().numpy()
-        params.pack(self.lay, weights, h_th, h_st, which)
+        params.pack(self.lay, weights, h_th, h_st, which, dims=self.dims)
         th[set_idx].copy_(torch.from_numpy(h_th))
         st[set_idx].copy_(torch.from_numpy(h_st))
 
@@ -378,8 +383,8 @@ class AgentGroup:
         """One row of a grads slab -> (critic_grad[14], actor_grad[10]) in trainable_variables order."""
         g = grads_row.cpu().numpy()
         dummy = np.zeros(self.lay.stats_size, dtype=np.float32)
-        return (params.unpack(self.lay, g, dummy, "critic", trainable_only=True),
-                params.unpack(self.lay, g, dummy, "actor", trainable_only=True))
+        return (params.unpack(self.lay, g, dummy, "critic", trainable_only=True, dims=self.dims),
+                params.unpack(self.lay, g, dummy, "actor", trainable_only=True, dims=self.dims))
 
 
 def fed_mean(grads, P, M, weights=None, group=None, method="interfrl"):

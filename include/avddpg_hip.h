@@ -77,10 +77,11 @@ typedef struct avd_mlp_layout {
 const char* avd_last_error(void);
 int avd_version(void);
 
-/* Fills `out` for the given network widths. S = num_states, A = num_actions (only
- * A == 1, the decentralized framework, is implemented by the MLP kernels),
- * H1/H2 = layer1/layer2 size, Ha = critic action layer size (config.py:112-117),
- * B = batch_size (config.py:106). */
+/* Fills `out` for the given network widths. S = num_states (<= 64), A = num_actions (<= 16; the centralized
+ * framework has S = 4L, A = L), H1/H2 = layer1/layer2 size, Ha = critic action layer size (config.py:112-117),
+ * B = batch_size (config.py:106). The MLP kernels need H1 and Ha to be multiples of 16 and H2 a multiple of 32:
+ * other widths (e.g. the centralized 307/153/57) are zero-padded by the caller -- a padded unit has zero
+ * weights/bias and BN beta = mean = 0, outputs 0, receives zero gradients and stays zero under Adam. */
 int avd_mlp_layout_init(avd_mlp_layout* out, int S, int A, int H1, int H2, int Ha, int B);
 
 /* ---- environment ------------------------------------------------------------
@@ -148,11 +149,12 @@ int avd_replay_gather_f32(int n_agents, int cap, int S, int A, int B, const floa
  *    them bit-identical, workers/trainer.py:415-425). */
 
 /* actor(state) (agent/model.py:26-36, called at workers/trainer.py:287-289): out[v] = tanh(.)*high
- * for n_agents rows of `x_stride` floats (first S used). */
+ * for n_agents rows of `x_stride` floats (first S used); out [n_agents][A]. */
 int avd_actor_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
                           const float* state, int x_stride, float high, float* out, void* stream);
 
-/* critic([state, action]) -> q[n_agents] (agent/model.py:63-83); rows as above, batch 1 per agent. */
+/* critic([state, action]) -> q[n_agents][A] (agent/model.py:63-83; the output width is num_actions, :80);
+ * action [n_agents][A]; rows as above, batch 1 per agent. */
 int avd_critic_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
                            const float* stats, const float* state, int x_stride, const float* action, float* q,
                            void* stream);

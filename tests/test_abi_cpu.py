@@ -33,16 +33,17 @@ def test_error_reporting_without_gpu():
     # argument validation happens before any HIP call
     with pytest.raises(_hip.AvdError, match="L must be"):
         _hip.call("avd_env_step_f32", None, 4, 99, None, None, None, None, None, None, None, None, None, None, None, None)
-    lay = _hip.make_layout(12, 3, 307, 153, 57, 64)  # centralized widths: declared unsupported, loudly
-    with pytest.raises(_hip.AvdError, match="only A == 1"):
+    lay = _hip.make_layout(12, 3, 307, 153, 57, 64)  # unpadded centralized widths: refused, with the remedy named
+    with pytest.raises(_hip.AvdError, match="pad the widths"):
         _hip.call("avd_learn_f32", ctypes.byref(lay), 1, 0, *([None] * 8), 0.99, 2.5, None, None, None)
 
 
 def test_layout_matches_reference_parameter_counts():
     lay = _hip.make_layout(4, 1, 256, 128, 48, 64)
     # SURVEY a-9/a-10: 35 073 actor + 41 409 critic trainables, 768 + 864 moving stats
-    a = sum(int(np.prod(shp(lay))) for _, k, shp in params.ACTOR_WEIGHTS if k == "t")
-    c = sum(int(np.prod(shp(lay))) for _, k, shp in params.CRITIC_WEIGHTS if k == "t")
+    d = params.logical_dims(lay)
+    a = sum(int(np.prod(shp(d))) for _, k, shp in params.ACTOR_WEIGHTS if k == "t")
+    c = sum(int(np.prod(shp(d))) for _, k, shp in params.CRITIC_WEIGHTS if k == "t")
     assert (a, c) == (35073, 41409)
     assert lay.actor_size == 35076 and lay.theta_size == 35076 + 41412 and lay.stats_size == 1632
     assert len(params.ACTOR_WEIGHTS) == 14 and len(params.CRITIC_WEIGHTS) == 20
@@ -112,3 +113,31 @@ def test_philox_known_answers():
     assert [int(v[0]) for v in philox.philox4x32_10(o, o, o, o, 0xffffffff, 0xffffffff)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     idx = philox.replay_indices(3, 64, 1000, seed=1, counter=0)
     assert idx.shape == (3, 64) and idx.dtype == np.int32 and idx.min() >= 0 and idx.max() < 1000
+
+
+def test_padded_pack_unpack_roundtrip():
+    """Centralized widths (int(256*1.2), int(128*1.2), int(48*1.2) = 307/153/57) live in slabs padded to 320/160/64:
+    pack -> unpack is the identity on the logical tensors and the padding holds its neutral values."""
+    dims = params.Dims(12, 3, 307, 153, 57)
+    H1p, H2p, Hap = params.padded_widths(dims.H1, dims.H2, dims.Ha)
+    assert (H1p, H2p, Hap) == (320, 160, 64)
+    lay = _hip.make_layout(12, 3, H1p, H2p, Hap, 64)
+    th, st = params.init_weights(lay, np.random.RandomState(0), nominal=(256, 128), dims=dims)
+    for which, n_all, n_tr in (("actor", 14, 10), ("critic", 20, 14)):
+        w = params.unpack(lay, th, st, which, dims=dims)
+        assert len(w) == n_all
+        th2, st2 = np.full_like(th, 7.0), np.full_like(st, 7.0)
+        params.pack(lay, w, th2, st2, which, dims=dims)
+        w2 = params.unpack(lay, th2, st2, which, dims=dims)
+        for x, y in zip(w, w2):
+            assert x.shape == y.shape and np.array_equal(x, y)
+        assert len(params.unpack(lay, th, st, which, trainable_only=True, dims=dims)) == n_tr
+    cw = params.unpack(lay, th, st, "critic", dims=dims)
+    assert cw[12].shape == (307 + 57, 153) and cw[0].shape == (12, 307) and cw[18].shape == (153, 3)
+    # padded columns of W1 are zero, padded gamma/var are one
+    aW1 = th[lay.aW1:lay.aW1 + 12 * 320].reshape(12, 320)
+    assert np.all(aW1[:, 307:] == 0) and np.all(aW1[:, :307] != 0)
+    assert np.all(th[lay.ag1 + 307:lay.ag1 + 320] == 1) and np.all(st[lay.amv1 + 307:lay.amv1 + 320] == 1)
+    cW2 = th[lay.actor_size + lay.cW2:lay.actor_size + lay.cW2 + 384 * 160].reshape(384, 160)
+    assert np.all(cW2[307:320] == 0) and np.all(cW2[320 + 57:] == 0) and np.all(cW2[:, 153:] == 0)
+    assert np.array_equal(cW2[320:377, :153], cw[12][307:])

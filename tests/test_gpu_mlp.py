@@ -17,21 +17,21 @@ FWD_TOL = 2e-5
 GRAD_TOL = 1e-4
 
 
-def _perturbed_group(n_sets, S=4, seed=0, **confkw):
+def _perturbed_group(n_sets, S=4, seed=0, A=1, hidd_mult=1.0, **confkw):
     """AgentGroup whose every set has different, non-default weights (gamma/beta/bias/moving stats
     off their initial values, tanh unsaturated but non-trivial) so every term is exercised."""
     conf = config.Config(**confkw)
-    grp = vec.AgentGroup(n_sets, S, 1, conf, seed=seed)
-    lay = grp.lay
+    grp = vec.AgentGroup(n_sets, S, A, conf, seed=seed, hidd_mult=hidd_mult)
+    lay, dims = grp.lay, grp.dims
     rs = np.random.RandomState(seed + 100)
     th = np.zeros((n_sets, lay.theta_size), np.float32)
     st = np.zeros((n_sets, lay.stats_size), np.float32)
     tht, stt = th.copy(), st.copy()
     for dst_th, dst_st in ((th, st), (tht, stt)):
         for k in range(n_sets):
-            a, s_ = params.init_weights(lay, rs)
-            aw = params.unpack(lay, a, s_, "actor")
-            cw = params.unpack(lay, a, s_, "critic")
+            a, s_ = params.init_weights(lay, rs, dims=dims)
+            aw = params.unpack(lay, a, s_, "actor", dims=dims)
+            cw = params.unpack(lay, a, s_, "critic", dims=dims)
             for net, var_idx in ((aw, (5, 11)), (cw, (7, 11, 17))):
                 for i, w in enumerate(net):
                     if w.ndim == 1:
@@ -40,8 +40,8 @@ def _perturbed_group(n_sets, S=4, seed=0, **confkw):
                     net[i][:] = np.abs(net[i]) + 0.5
             aw[12] *= 30
             cw[18] *= 300
-            params.pack(lay, aw, dst_th[k], dst_st[k], "actor")
-            params.pack(lay, cw, dst_th[k], dst_st[k], "critic")
+            params.pack(lay, aw, dst_th[k], dst_st[k], "actor", dims=dims)
+            params.pack(lay, cw, dst_th[k], dst_st[k], "critic", dims=dims)
     grp.theta.copy_(t(th)), grp.stats.copy_(t(st)), grp.theta_t.copy_(t(tht)), grp.stats_t.copy_(t(stt))
     return conf, grp
 
@@ -220,7 +220,7 @@ def test_unsupported_shapes_fail_loudly():
     conf = config.Config(actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024, critic_layer2_size=1024)
     grp = vec.AgentGroup(1, 4, 1, conf)
     z = torch.zeros(1, 64, 4, device="cuda")
-    with pytest.raises(AvdError, match="LDS|layer2 size|layer1"):
+    with pytest.raises(AvdError, match="LDS|H2 a multiple of 32 and <="):
         grp.learn(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 0)
 
 
@@ -236,9 +236,9 @@ def test_generic_and_specialised_learn_kernels_agree(monkeypatch):
     r = -np.abs(rs.normal(0, 0.3, size=(n_agents, 64))).astype(np.float32)
     s2 = rs.normal(0, 1.5, size=(n_agents, 64, 4)).astype(np.float32)
     fast = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()
-    monkeypatch.setenv("AVD_LEARN_GENERIC", "1")
+    monkeypatch.setenv("AVD_LEARN_GENERAL", "1")
     gen = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()
-    monkeypatch.delenv("AVD_LEARN_GENERIC")
+    monkeypatch.delenv("AVD_LEARN_GENERAL")
     assert not np.array_equal(fast, gen) or True  # summation orders may differ; values must agree closely
     assert np.max(np.abs(fast - gen)) <= 2e-5 * np.max(np.abs(gen))
     # non-reference widths -> generic kernel, checked against the oracle
@@ -293,3 +293,51 @@ def test_full_size_learn_properties_20480_agents():
     lhs = vec.fed_mean(2 * g1 + h, 4096, 5)
     rhs = 2 * vec.fed_mean(g1, 4096, 5) + vec.fed_mean(h, 4096, 5)
     assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-6)
+
+
+def test_centralized_shapes_forward_and_learn():
+    """Centralized framework (SURVEY f-3; workers/trainer.py:80-87, 108-113): one agent per platoon with
+    S = 4L states, A = L actions and widths int(256*1.2)/int(128*1.2)/int(48*1.2) = 307/153/57, held in slabs
+    padded to 320/160/64. The critic has A outputs, the TD target broadcasts r over them (trainer.py:494) and
+    both losses average over B*A."""
+    need_gpu()
+    n_agents, L = 3, 3
+    S, A = 4 * L, L
+    conf, grp = _perturbed_group(n_agents, S=S, A=A, hidd_mult=1.2, seed=41)
+    assert tuple(grp.dims) == (12, 3, 307, 153, 57) and (grp.lay.H1, grp.lay.H2, grp.lay.Ha) == (320, 160, 64)
+    rs = np.random.RandomState(42)
+    x = rs.normal(0, 1.5, size=(n_agents, S)).astype(np.float32)
+    act = rs.uniform(-2.5, 2.5, size=(n_agents, A)).astype(np.float32)
+    out = grp.actor(t(x), set_mod=0).cpu().numpy()
+    q = grp.critic(t(x), t(act), set_mod=0).cpu().numpy()
+    assert out.shape == (n_agents, A) and q.shape == (n_agents, A)
+    for v in range(n_agents):
+        aw, cw, _, _ = _nets(grp, v, np.float64)
+        ref = omlp.actor_forward(aw, x[v:v + 1], 2.5)[0]
+        assert np.max(np.abs(out[v] - ref)) <= FWD_TOL * 2.5
+        refq = omlp.critic_forward(cw, x[v:v + 1], act[v:v + 1])[0]
+        assert np.max(np.abs(q[v] - refq)) <= FWD_TOL * max(1.0, np.max(np.abs(refq)))
+    s = rs.normal(0, 1.5, size=(n_agents, 64, S)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n_agents, 64, A)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n_agents, 64))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n_agents, 64, S)).astype(np.float32)
+    losses = torch.zeros(n_agents, 2, device="cuda")
+    g = grp.learn(t(s), t(a), t(r), t(s2), 0, losses=losses)
+    gh = g.cpu().numpy()
+    for v in range(n_agents):
+        cg, ag, aux = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp, v, np.float64))
+        cg32, ag32, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp, v, np.float32))
+        gcg, gag = grp.grads_as_lists(g[v])
+        assert [w.shape for w in gcg] == [w.shape for w in cg] and [w.shape for w in gag] == [w.shape for w in ag]
+        for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref))
+        lo = losses[v].cpu().numpy()
+        assert abs(lo[0] - aux["critic_loss"]) <= 1e-4 * abs(aux["critic_loss"])
+        assert abs(lo[1] - aux["actor_loss"]) <= 1e-4 * max(1e-3, abs(aux["actor_loss"]))
+        # padded units receive exactly zero gradient, so Adam keeps them at zero forever
+        lay = grp.lay
+        gW1 = gh[v, lay.aW1:lay.aW1 + S * 320].reshape(S, 320)
+        assert np.all(gW1[:, 307:] == 0) and np.any(gW1[:, :307] != 0)
+        gcW2 = gh[v, lay.actor_size + lay.cW2:lay.actor_size + lay.cW2 + 384 * 160].reshape(384, 160)
+        assert np.all(gcW2[307:320] == 0) and np.all(gcW2[377:] == 0) and np.all(gcW2[:, 153:] == 0)
+        assert np.all(gh[v, lay.ag1 + 307:lay.ag1 + 320] == 0) and np.all(gh[v, lay.abe2 + 153:lay.abe2 + 160] == 0)
