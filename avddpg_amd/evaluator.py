@@ -25,20 +25,22 @@ def run(conf=None, actors=None, pl_idx=None, seed=True, manual_timestep_override
         (lambda: np.random.normal(0, conf.reset_max_u))
     inputs = np.array([rand() for _ in range(steps)], dtype=np.float32)  # :55-56
     d_inputs = torch.from_numpy(inputs).to(env.device)
-    counters = torch.zeros(L, dtype=torch.float32, device=env.device)  # float32 counters (:67)
+    M, A = env.num_models, env.num_actions  # centralized: one model with L actions and a 4L-wide observation (:48, :58)
+    xs = 4 * L // M
+    counters = torch.zeros(M, dtype=torch.float32, device=env.device)  # float32 counters (:67)
     env.reset()
     act = torch.zeros(1, L, dtype=torch.float32, device=env.device)
-    raw = torch.zeros(L, dtype=torch.float32, device=env.device)
-    sm = L if set_mod is None else set_mod
+    raw = torch.zeros(M * A, dtype=torch.float32, device=env.device)
+    sm = M if set_mod is None else set_mod
     states = torch.zeros(steps, L, env.obs_width, device=env.device)
     ctrl = torch.zeros(steps, L, device=env.device)
     jerks = torch.zeros(steps, L, device=env.device)
     for i in range(steps):
-        actors.actor(env.x.view(L, 4), sm, x_stride=4, out=raw)
+        actors.actor(env.x.view(M, xs), sm, x_stride=xs, out=raw)
         call("avd_policy_f32", L, ptr(raw), None, conf.action_low, conf.action_high, ptr(act), stream_handle())  # no noise
         pa_before = env.prev_a.clone()
         env.step(act, d_inputs[i:i + 1])
-        counters += env.reward[0]
+        counters += env.reward[0] if M == L else env.reward_mean
         states[i] = env.observations()[0]
         ctrl[i] = act[0]
         jerks[i] = env.get_jerk_from(env.x_prev, pa_before)[0]

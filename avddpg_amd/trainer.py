@@ -71,12 +71,21 @@ class VecTrainer:
         conf.refresh()
         self.conf, self.rng, self.group = conf, rng, group
         self.device = torch.device(device if device is not None else "cuda")
-        self.P, self.M = conf.num_platoons, conf.pl_size
-        if conf.framework != conf.dcntrl:
-            raise NotImplementedError("centralized framework: next-tier row of SURVEY section 8(f)")
+        self.P, self.L = conf.num_platoons, conf.pl_size
         seed = conf.random_seed if seed is None else seed
-        self.env = vec.VecPlatoon(self.P, self.M, conf, self.device, rand_states=conf.rand_states, rng=rng, seed=seed)
+        self.env = vec.VecPlatoon(self.P, self.L, conf, self.device, rand_states=conf.rand_states, rng=rng, seed=seed)
+        # models per platoon: L decentralized, 1 centralized (environment.py:35-42). The reference trainer iterates
+        # conf.pl_size models (trainer.py:45) and therefore only completes a centralized step when pl_size == 1; for
+        # pl_size > 1 this follows the loop shape of its evaluator (workers/evaluator.py:48-91: env.num_models).
+        self.centralized = conf.framework == conf.cntrl
+        self.M = self.env.num_models
         self.S, self.A = self.env.num_states, self.env.num_actions
+        if self.centralized and conf.model == conf.modelA and self.L > 1:
+            # every Vehicle is handed the platoon's num_states = 3L >= 4 and returns x[0:3L] = all 4 entries
+            # (environment.py:55-63, 518): the 4L-wide observation does not fit the 3L-wide network input.
+            raise ValueError("centralized + Model A with pl_size > 1: the reference's observation is 4L wide but its "
+                             "network input 3L (src/environment.py:45-63, 518); not a runnable configuration")
+        self.x_stride = 4 * self.L // self.M  # floats between consecutive agents' observations in env.x
         n_agents = self.P * self.M
         self.n_agents = n_agents
         self.ou = vec.VecOUNoise(n_agents, conf, self.device, rng=rng, seed=seed)
@@ -88,12 +97,13 @@ class VecTrainer:
         if self.shared and not can_share:
             raise ValueError("shared weight sets are only exact for interfrl+gradients with every step federated")
         self.set_mod = self.M if self.shared else 0
-        self.agents = vec.AgentGroup(self.M if self.shared else n_agents, self.S, self.A, conf, self.device, seed=seed)
+        self.agents = vec.AgentGroup(self.M if self.shared else n_agents, self.S, self.A, conf, self.device, seed=seed,
+                                     hidd_mult=self.env.hidden_multiplier)
         self.replay = vec.VecReplay(n_agents, conf.buffer_size, conf.batch_size, self.S, self.A, self.device, rng=rng,
                                     seed=seed)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.actor_out = torch.zeros(n_agents, **f32)
-        self.actions = torch.zeros(self.P, self.M, **f32)  # self.actions[p][m] (trainer.py:179)
+        self.actor_out = torch.zeros(n_agents, self.A, **f32)
+        self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)
         self.grads = torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
         self.losses = torch.zeros(n_agents, 2, **f32)
@@ -107,6 +117,8 @@ class VecTrainer:
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
         self.fused_update = bool(fused_update)  # nofrl + reference widths: avd_learn_update_f32
+        if self.fused_update and self.centralized:
+            raise ValueError("fused_update is specialised for the decentralized reference widths")
         self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
         self.timers = None
         self.episode, self.ep_step = 0, 0
@@ -134,8 +146,8 @@ class VecTrainer:
     def _act(self):
         """advance_environment (trainer.py:282-302): actor -> OU noise -> clip, leader exog, env step."""
         conf, P, M = self.conf, self.P, self.M
-        states = self.env.x.view(P * M, 4)
-        self.agents.actor(states, self.set_mod, x_stride=4, out=self.actor_out)
+        states = self.env.x.view(P * M, self.x_stride)
+        self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out)
         if self.rng == "host":
             # reference draw order per platoon: M OU normals, then the leader exog (trainer.py:286-295)
             normals = np.empty((P, M))
@@ -152,10 +164,12 @@ class VecTrainer:
             call("avd_normal_f32", P, ptr(self.leader_exog), conf.reset_max_u, self.seed, self.exog_calls,
                  stream_handle())
             self.exog_calls += 1
-        call("avd_policy_f32", self.n_agents, ptr(self.actor_out), ptr(noise), conf.action_low, conf.action_high,
-             ptr(self.actions), stream_handle())
+        if self.A > 1:  # one scalar OU process per model, broadcast over its A actions (ddpgagent.py:22)
+            noise = noise.view(-1, 1).expand(-1, self.A).contiguous()
+        call("avd_policy_f32", self.n_agents * self.A, ptr(self.actor_out), ptr(noise), conf.action_low,
+             conf.action_high, ptr(self.actions), stream_handle())
         self.env.any_done.zero_()
-        self.env.step(self.actions, self.leader_exog)
+        self.env.step(self.actions.view(P, self.L), self.leader_exog)
 
     def _weights_for_fed(self, ep):
         """trainer.py:385-398: w = |1 / mean(last `weighted_window` episodic rewards)| per agent."""
@@ -171,9 +185,12 @@ class VecTrainer:
         env = self.env
 
         def replay_part():
-            self.replay.add(env.x_prev.view(P * M, 4), self.actions.view(P * M, 1), env.reward.view(-1),
-                            env.x.view(P * M, 4), 4)
-            self.ep_reward += env.reward
+            # centralized: the platoon reward (1/L) * sum of the vehicles' (environment.py:236, 281)
+            reward = env.reward_mean.view(P, 1) if self.centralized else env.reward
+            xs = self.x_stride
+            self.replay.add(env.x_prev.view(P * M, xs), self.actions.view(P * M, self.A), reward.view(-1),
+                            env.x.view(P * M, xs), xs)
+            self.ep_reward += reward
             if not self.replay.buffer_counter > conf.batch_size:  # strict gate: first update after the 65th add (:322)
                 return None
             return self.replay.sample()
@@ -338,8 +355,9 @@ def learn(rbuffer, actor_model, critic_model, target_actor, target_critic, gamma
          actor_model.high, ptr(grads), None, stream_handle())
     g = grads[0].cpu().numpy()
     dummy = np.zeros(lay.stats_size, dtype=np.float32)
-    return (params.unpack(lay, g, dummy, "critic", trainable_only=True),
-            params.unpack(lay, g, dummy, "actor", trainable_only=True))
+    dims = getattr(actor_model, "dims", None)
+    return (params.unpack(lay, g, dummy, "critic", trainable_only=True, dims=dims),
+            params.unpack(lay, g, dummy, "actor", trainable_only=True, dims=dims))
 
 
 Trainer.learn = staticmethod(learn)

@@ -16,7 +16,7 @@ def run(ep: platoon.EnvParams, pl_size, actors, steps, evaluation_seed=6, high=2
     inputs = [platoon.get_random_val(ep.rand_gen, ep.reset_max_u, std_dev=ep.reset_max_u) for _ in range(steps)]  # :55-56
     counters = np.array([0] * env.num_models, dtype=np.float32)
     states = env.reset()
-    actions = np.zeros((env.num_models, 1))
+    actions = np.zeros((env.num_models, env.num_actions))  # :58
     S, U, J = [], [], []
     for i in range(steps):
         for m in range(env.num_models):

@@ -2,7 +2,12 @@
 
 Restates ``workers/trainer.py``: initialize :71-179, run inner loop :246-271,
 advance_environment :282-302, train_all_models :304-356 (nofrl local updates) and
-the interfrl+gradients branch :400-431.  Structured like the reference -- one
+the interfrl+gradients branch :400-431.  The centralized framework follows the
+loop shape of workers/evaluator.py:48-91 (``env.num_models`` = 1 model per platoon
+with S = 4L, A = L, widths x centrl_hidd_mult; one scalar OU process broadcast
+over the L actions, agent/ddpgagent.py:22): the trainer itself iterates
+``conf.pl_size`` models (trainer.py:45) and so only runs centralized for pl_size = 1,
+where both readings coincide.  Structured like the reference -- one
 Platoon / OU / replay / actor / critic / Adam object per (platoon, vehicle), global
 legacy numpy RNG, float64 env, float32 networks -- so that timing it on one core
 is the CPU baseline ``bench.py`` reports beside the GPU number (kind "port":
@@ -15,16 +20,22 @@ from . import federated, mlp, noise, platoon, replay
 
 class RefTrainer:
     def __init__(self, ep: platoon.EnvParams, num_platoons=1, pl_size=3, seed=1, buffer_size=100000, batch_size=64,
-                 gamma=0.99, tau=0.001, critic_lr=5e-4, actor_lr=5e-5, fed_method="normal", H1=256, H2=128, Ha=48):
+                 gamma=0.99, tau=0.001, critic_lr=5e-4, actor_lr=5e-5, fed_method="normal", H1=256, H2=128, Ha=48,
+                 hidd_mult=1.2):
         np.random.seed(seed)  # src/rand.py:10
-        self.ep, self.P, self.M = ep, num_platoons, pl_size
+        self.ep, self.P = ep, num_platoons
         self.batch_size, self.gamma, self.tau, self.fed_method = batch_size, gamma, tau, fed_method
-        S, A = ep.num_obs, 1
+        centralized = ep.framework == "centralized"
+        self.M = 1 if centralized else pl_size  # environment.py:35-42
+        S, A = ep.num_obs * (pl_size if centralized else 1), (pl_size if centralized else 1)
+        if centralized and fed_method != "normal":
+            raise ValueError("FRL is decentralized-only (trainer.py:632)")
+        hm = hidd_mult if centralized else 1  # environment.py:37, 41
         wrs = np.random.RandomState(seed + 7919)  # TF initialiser stream is not reproducible; own stream
         self.envs, self.ous, self.actors, self.critics, self.t_actors, self.t_critics = [], [], [], [], [], []
         self.a_opts, self.c_opts, self.rbufs = [], [], []
-        init_a = mlp.init_actor(wrs, S, A, H1, H2)
-        init_c = mlp.init_critic(wrs, S, A, H1, H2, Ha)
+        init_a = mlp.init_actor(wrs, S, A, H1, H2, hidd_mult=hm)
+        init_c = mlp.init_critic(wrs, S, A, H1, H2, Ha, hidd_mult=hm)
         for p in range(self.P):  # trainer.py:71-171
             self.envs.append(platoon.RefPlatoon(pl_size, ep))
             self.ous.append([noise.RefOUNoise(np.zeros(1)) for _ in range(self.M)])

@@ -22,6 +22,7 @@ Fixtures:
   G6 trainer inner-loop trace g6_loop.npz
   G7 federated table          g7_federated.json
   G8 evaluator rollout (stub) g8_evaluator.npz
+  G9 same, centralized        g9_evaluator_centralized.npz
 """
 import json
 import os
@@ -363,15 +364,15 @@ def g7():
 
 
 # --------------------------------------------------------------------- G8
-def g8():
+def g8(cases=((2, "ModelB", 600, "decentralized"), (3, "ModelA", 100, "decentralized")), fname="g8_evaluator.npz"):
     """Hand-driven replica of the evaluator rollout (workers/evaluator.py:40-95, 145) on the reference's own
     Platoon object with a stub actor that outputs 0 (TensorFlow is absent): seeding with evaluation_seed,
     evaluator-mode Platoon, pre-drawn leader input list, reset, noise-free steps, float32 reward counters,
     pl_rew = round(mean, 3)."""
     out = {}
-    for L, model, T in ((2, "ModelB", 600), (3, "ModelA", 100)):
+    for L, model, T, framework in cases:
         conf = ref_config.Config()
-        conf.pl_size, conf.model = L, model
+        conf.pl_size, conf.model, conf.framework = L, model, framework
         np.random.seed(conf.evaluation_seed)  # rand.set_global_seed(conf.evaluation_seed) (src/rand.py:10)
         env = make_platoon(L, conf, 1, evaluator_states_enabled=True)
         inputs = [ref_util.get_random_val(conf.rand_gen, conf.reset_max_u, std_dev=conf.reset_max_u, config=conf)
@@ -387,17 +388,24 @@ def g8():
             S.append(np.array([np.asarray(s) for s in states]))
             R.append(np.array(rewards))
             J.append(np.array(env.get_jerk()).ravel())
-        key = f"L{L}_{model}"
+        key = f"L{L}_{model}" + ("" if framework == "decentralized" else "_" + framework)
         out[key + "__inputs"] = np.array(inputs)
         out[key + "__states"] = np.array(S)
         out[key + "__rewards"] = np.array(R)
         out[key + "__jerks"] = np.array(J)
         out[key + "__counters"] = counters
         out[key + "__pl_rew"] = np.array(round(np.average(counters), 3))
-    np.savez_compressed(os.path.join(OUT, "g8_evaluator.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def g9():
+    """G8 for the centralized framework: one model, the 4L-wide observation, the platoon-mean reward
+    (src/environment.py:234-236, 281)."""
+    g8(cases=((3, "ModelB", 200, "centralized"), (1, "ModelB", 100, "centralized")),
+       fname="g9_evaluator_centralized.npz")
 
 
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         fn()
         print("wrote", fn.__name__)

@@ -51,7 +51,7 @@ def test_vectorised_loop_matches_reference_shaped_oracle_loop(fed_method):
         act = vt.actions.cpu().numpy()
         x = vt.env.x.cpu().numpy()
         tol = 1e-5 if i < 65 else 2e-3  # after the first Adam steps f32 rounding is amplified by m/sqrt(v)
-        assert np.allclose(act, traj[i][0][..., 0], rtol=0, atol=tol * 2.5), (i, np.abs(act - traj[i][0][..., 0]).max())
+        assert np.allclose(act, traj[i][0], rtol=0, atol=tol * 2.5), (i, np.abs(act - traj[i][0]).max())
         assert np.allclose(x, traj[i][1], rtol=0, atol=tol * np.maximum(1.0, np.abs(traj[i][1]))), i
         assert done == traj[i][2]
     assert np.random.normal(0, 1) == next_draw_ref  # identical consumption of the global RNG stream
@@ -368,3 +368,87 @@ def test_cli_train_then_esim_roundtrip(tmp_path, capsys):
     assert "platoon 1: cumulative platoon reward" in out and "platoon 2:" in out
     conf = artifacts.config_loader(os.path.join(base, "conf.json"), Config)
     assert conf.number_of_episodes == 2 and conf.num_platoons == 2
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_centralized_loop_matches_oracle_loop(L):
+    """Centralized framework: one model per platoon, S = 4L, A = L, widths x1.2 (307/153/57, padded
+    to 320/160/64 in HBM), platoon-mean reward, one scalar OU process broadcast over the L actions. L = 1 is the
+    case the reference trainer itself completes (trainer.py:45 iterates pl_size models); L = 3 follows its
+    evaluator's env.num_models loop (evaluator.py:48-91)."""
+    P, steps = 2, 70
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, framework="centralized")
+    np.random.seed(5)
+    vt0 = trainer.VecTrainer(conf, rng="host")
+    assert (vt0.M, vt0.S, vt0.A) == (1, 4 * L, L) and tuple(vt0.agents.dims)[2:] == (307, 153, 57)
+    ref = otrainer.RefTrainer(oplatoon.EnvParams(framework="centralized"), P, L, seed=5, buffer_size=128)
+    _copy_weights_to_oracle(vt0, ref)
+    assert ref.actors[0][0][0].shape == (4 * L, 307) and ref.critics[0][0][18].shape == (153, L)
+    ref.reset_episode()
+    traj = []
+    for i in range(steps):
+        done = ref.step()
+        traj.append((ref.actions.copy(), np.array([np.asarray(ref.prev_states[p][0]) for p in range(P)]), done,
+                     np.array([ref.ep_reward[p][0] for p in range(P)])))
+        assert not done
+    next_draw_ref = np.random.normal(0, 1)
+    np.random.seed(5)
+    vt = trainer.VecTrainer(conf, rng="host")
+    assert torch.equal(vt.agents.theta, vt0.agents.theta)
+    vt.reset_episode()
+    for i in range(steps):
+        done = vt.step(0, i)
+        act = vt.actions.cpu().numpy()
+        x = vt.env.x.cpu().numpy().reshape(P, 4 * L)
+        tol = 1e-5 if i < 65 else 2e-3
+        assert np.allclose(act, traj[i][0], rtol=0, atol=tol * 2.5), (i, np.abs(act - traj[i][0]).max())
+        assert np.allclose(x, traj[i][1], rtol=0, atol=tol * np.maximum(1.0, np.abs(traj[i][1]))), i
+        assert done == traj[i][2]
+        assert np.allclose(vt.ep_reward.cpu().numpy()[:, 0], traj[i][3], rtol=1e-4, atol=1e-6)
+    assert np.random.normal(0, 1) == next_draw_ref
+    assert vt.updates == (steps - 64) * P == ref.updates
+    for p in range(P):
+        for which, refw, lr in (("actor", ref.actors[p][0], conf.actor_lr), ("critic", ref.critics[p][0], conf.critic_lr)):
+            for got, want in zip(vt.agents.get_weights(p, which), refw):
+                assert got.shape == want.shape
+                d = np.abs(got - want)
+                assert d.max() <= 2 * lr * (steps - 64) and d.mean() <= 0.05 * lr * (steps - 64), (which, d.max(), d.mean())
+    # the zero padding of the slabs survives Adam and Polyak
+    lay = vt.agents.lay
+    for slab in (vt.agents.theta, vt.agents.theta_t):
+        w1 = slab[:, lay.aW1:lay.aW1 + 4 * L * 320].reshape(P, 4 * L, 320)
+        assert torch.all(w1[:, :, 307:] == 0) and torch.any(w1[:, :, :307] != 0)
+    with pytest.raises(ValueError, match="Model A"):
+        trainer.VecTrainer(config.Config(num_platoons=1, pl_size=2, framework="centralized", model="ModelA"), rng="device")
+
+
+def test_centralized_evaluator_rollout_matches_reference_golden_and_oracle():
+    """workers/evaluator.py with env.num_models = 1: zero policy vs the golden captured from the reference env (G9),
+    a non-trivial centralized actor vs the oracle rollout."""
+    import os
+
+    from avddpg_amd import evaluator, vec
+    from oracle import evaluator as oeval
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_evaluator_centralized.npz"))
+    for L, T in ((3, 200), (1, 100)):
+        conf = config.Config(pl_size=L, framework="centralized")
+        grp = vec.AgentGroup(1, 4 * L, L, conf, hidd_mult=conf.centrl_hidd_mult)
+        lay = grp.lay
+        grp.theta[:, lay.aW3:lay.aW3 + lay.H2 * L].zero_()
+        pl_rew, tr = evaluator.run(conf=conf, actors=grp, pl_idx=1, manual_timestep_override=T)
+        key = f"L{L}_ModelB_centralized"
+        assert abs(pl_rew - float(g[key + "__pl_rew"])) <= 2e-3 and np.all(tr["inputs"] == 0)
+        ref = g[key + "__states"].reshape(T, L, 4)
+        assert np.all(np.abs(tr["states"] - ref) <= 1e-5 * T * np.maximum(1.0, np.abs(ref)))
+        assert np.allclose(tr["counters"], g[key + "__counters"], rtol=2e-5)
+    L = 3
+    conf = config.Config(pl_size=L, framework="centralized")
+    grp = vec.AgentGroup(1, 4 * L, L, conf, seed=3, hidd_mult=conf.centrl_hidd_mult)
+    grp.theta[:, grp.lay.aW3:grp.lay.aW3 + grp.lay.H2 * L] *= 40
+    actors = [[w.astype(np.float64) for w in grp.get_weights(0, "actor")]]
+    pl_rew, tr = evaluator.run(conf=conf, actors=grp, pl_idx=1, manual_timestep_override=100)
+    o_rew, o_tr = oeval.run(oplatoon.EnvParams(framework="centralized"), L, actors, 100)
+    assert abs(pl_rew - o_rew) <= 2e-3 and np.abs(o_tr["inputs"]).max() > 0.05
+    assert np.allclose(tr["inputs"], o_tr["inputs"], atol=5e-5)
+    assert np.allclose(tr["states"], o_tr["states"].reshape(100, L, 4), atol=2e-4, rtol=1e-4)

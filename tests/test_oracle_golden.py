@@ -244,3 +244,16 @@ def test_g8_evaluator_rollout():
         assert pl_rew == float(g[key + "__pl_rew"])
         assert np.array_equal(tr["states"], g[key + "__states"]) and np.array_equal(tr["leader"], g[key + "__inputs"])
         assert np.array_equal(tr["jerks"], g[key + "__jerks"]) and np.array_equal(tr["counters"], g[key + "__counters"])
+
+
+def test_g9_evaluator_rollout_centralized():
+    """Centralized framework: one model, 4L-wide observation, platoon-mean reward (environment.py:234-236, 281)."""
+    from oracle import evaluator
+
+    g = np.load(os.path.join(G, "g9_evaluator_centralized.npz"))
+    for L, T in ((3, 200), (1, 100)):
+        key = f"L{L}_ModelB_centralized"
+        pl_rew, tr = evaluator.run(platoon.EnvParams(framework="centralized"), L, None, T)
+        assert pl_rew == float(g[key + "__pl_rew"]) and tr["states"].shape == (T, 1, 4 * L)
+        assert np.array_equal(tr["states"], g[key + "__states"]) and np.array_equal(tr["leader"], g[key + "__inputs"])
+        assert np.array_equal(tr["jerks"], g[key + "__jerks"]) and np.array_equal(tr["counters"], g[key + "__counters"])
