@@ -127,6 +127,15 @@ struct Net {  // pointers into one weight set
     const float* st;
 };
 
+// Optimisation fences. LLVM's loop-invariant code motion otherwise hoists every `base + lane offset` address of the
+// pass loop's body (a hundred 64-bit values) above the loop and spills them to scratch; a value that passes through
+// one of these inside the loop body is opaque, so its uses are recomputed (one add) where they are needed.
+__device__ __forceinline__ int opaque_zero() {  // a wave-uniform 0 the optimiser cannot see through
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+
 // ------------------------------------------------------------------------------------------
 // small building blocks (called by all 256 threads of the workgroup)
 // ------------------------------------------------------------------------------------------
@@ -372,6 +381,7 @@ __device__ __forceinline__ void dense_in_grads_k(const float* X, int xs, const f
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[j] = 0.f;
         float sb = 0.f;
+#pragma nounroll  // unrolled, the scheduler hoists all 64 rows' LDS reads to the top and spills them to scratch
         for (int rb = 0; rb < TILE; rb += RB) {  // RB rows of operands in registers before the FMAs
             float dv[RB], xv[RB][K];
 #pragma unroll
@@ -934,8 +944,8 @@ __device__ __forceinline__ void fwd_prefetch(FwdPre<N / (16 * NW)>& p, const flo
 // Per 16-deep block: [issue weight loads R-1 blocks ahead + LDS reads one block ahead] | [16*NT MFMAs].
 // sched_barrier(0) pins the two stages: hipcc's scheduler otherwise sinks every load down to its first use and
 // neither the register ring nor the LDS double buffer prefetches anything.
-template <int N, int LDX, int LDO>
-__device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, int nblk,
+template <int N, int LDX, int LDO, int NBLK>
+__device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh,
                                          const float* __restrict__ W, FwdPre<N / (16 * NW)>& pre, float* out) {
     constexpr int NT = N / (16 * NW);
     static_assert(NT == 1 || NT == 2, "one or two 16-column tiles per wave");
@@ -950,7 +960,6 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
         for (int m = 0; m < 4; ++m) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float* wl = W + (4 * lg) * N + col;  // lane's columns, row 4*lg of block 0
-    const int last = nblk - 1;
     float(&ring)[R][4][NT] = pre.ring;
     auto load_blk = [&](float(&dst)[4][NT], int blk) {
         const float* p = wl + blk * (16 * N);
@@ -959,33 +968,16 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
     };
     RawA raw[2];
     read_a<LDX>(raw[0], X, inv, sh, 4 * lg, lr);
-    int blk = 0;
-    const int ngrp = nblk / R;
-#pragma nounroll
-    for (int g = 0; g < ngrp; ++g) {
+    // Fully unrolled over the NBLK reduction blocks. As a loop over groups of R blocks the compiler placed register
+    // copies of the ring on the back-edge, i.e. an s_waitcnt vmcnt(0) per group: the 3-block lookahead was drained
+    // every 4 blocks (measured ~30 % of the GEMM time).
 #pragma unroll
-        for (int d = 0; d < R; ++d) {
-            load_blk(ring[(d + R - 1) % R], min(blk + R - 1, last));
-            read_a<LDX>(raw[(d + 1) & 1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_block<NT>(acc, cs, raw[d & 1], ring[d]);
-            __builtin_amdgcn_sched_barrier(0);
-            ++blk;
-        }
-    }
-#pragma nounroll
-    for (; blk < nblk; ++blk) {  // remainder: blocks already sit in ring[0..R-2]
-        read_a<LDX>(raw[1], X, inv, sh, 16 * min(blk + 1, last) + 4 * lg, lr);
+    for (int blk = 0; blk < NBLK; ++blk) {
+        if (blk + R - 1 < NBLK) load_blk(ring[(blk + R - 1) % R], blk + R - 1);
+        if (blk + 1 < NBLK) read_a<LDX>(raw[(blk + 1) & 1], X, inv, sh, 16 * (blk + 1) + 4 * lg, lr);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block<NT>(acc, cs, raw[0], ring[0]);
+        mfma_block<NT>(acc, cs, raw[blk & 1], ring[blk % R]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d + 2 < R; ++d)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) ring[d][jj][t] = ring[d + 1][jj][t];
-        raw[0] = raw[1];
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1285,8 +1277,8 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     LearnLds l = carve(smem, L, FT);
     const int agent = blockIdx.x;
     const int set = set_mod > 0 ? agent % set_mod : agent;
-    const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
-    const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+    Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
+    Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
     // gradient slab of this agent. Fused form: only the small tensors (biases, BN gamma/beta, first and last layers,
     // ~6 % of the parameters) are stored here -- a range-restricted Adam launch consumes them; the two W2 matrices
     // are updated in the weight-gradient GEMM epilogues through `bulk`.
@@ -1336,17 +1328,28 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     // Every phase's global loads are requested one phase early and carried in registers across the phase in
     // between (weights of the next GEMM, parameter columns of the next forward): with one workgroup per CU there
     // is nobody else to hide a cold HBM round trip at the head of each phase.
+    // The number of loads issued on every path between a load and its first use is kept identical (both parameter
+    // sets are always fetched together): s_waitcnt vmcnt(N) for an older load counts the younger loads in flight, and
+    // where paths differ the compiler must take the smallest count -- i.e. wait for the extra loads of the longer path.
     ActorPar<S> pa = load_actor<S, H1, H2>(L, tgt, ks, tid);
-    CriticPar<S> pc;
+    CriticPar<S> pc = load_critic<S, H1, H2, HA>(L, tgt, ks, ka, tid);
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
+        // fences (see opaque_zero): every global / LDS address below is rebuilt inside the pass
+        const int z = opaque_zero();
+        net.th += z, net.st += z, tgt.th += z, tgt.st += z, g += z, gw2 += z;
+        ga = g, gc = g + L.actor_size;
+        if constexpr (FUSED) {
+            bulk.wo = gw2, bulk.wi = net.th;
+            bulk.wt += z, bulk.m += z, bulk.v += z;
+        }
+        l = carve(smem + z, L, FT);
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.sS2 : l.sS;
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36), parameters in `pa`
             const float* th = n.th;
             FwdPre<H2 / (16 * NW)> fp;
             fwd_prefetch<H2>(fp, th + L.aW2, th + L.ab2, H1 / 16);
-            if (it != 3) pc = load_critic<S, H1, H2, HA>(L, n, ks, ka, tid);  // this pass's critic
             __builtin_amdgcn_sched_barrier(0);
             const float b3 = pa.b3;
             if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             l2_store(pa.c2, l, H2, tid);
             lds_barrier();
             PH(1);
-            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, H1 / 16, th + L.aW2, fp, l.bufB);
+            gemm_fwd<H2, LDA, LDB, H1 / 16>(l.bufA, l.invA, l.shA, th + L.aW2, fp, l.bufB);
             lds_barrier();
             PH(2);
             const float z = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
@@ -1381,15 +1384,13 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             }
             l2_store(pc.c2, l, H2, tid);
             __builtin_amdgcn_sched_barrier(0);
-            // parameters of the NEXT forward: pass 0 -> critic(net) of pass 1; passes 1, 2 -> actor(net) of the next pass
-            if (it == 0)
-                pc = load_critic<S, H1, H2, HA>(L, net, ks, ka, tid);
-            else
-                pa = load_actor<S, H1, H2>(L, net, ks, tid);
+            // parameters of the next forwards (critic(net) of passes 1, 2; actor(net) of passes 2, 3)
+            pc = load_critic<S, H1, H2, HA>(L, net, ks, ka, tid);
+            pa = load_actor<S, H1, H2>(L, net, ks, tid);
             __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
             PH(4);
-            gemm_fwd<H2, LDA, LDB>(l.bufA, l.invA, l.shA, KC / 16, th + L.cW2, fp, l.bufB);
+            gemm_fwd<H2, LDA, LDB, KC / 16>(l.bufA, l.invA, l.shA, th + L.cW2, fp, l.bufB);
             lds_barrier();
             PH(5);
             const float q = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
