@@ -1,0 +1,862 @@
+// Shared-weight-set ("wide") learner: Trainer.learn for agents that share their networks, as layer-wise bf16 MFMA
+// GEMMs over ALL rows of a set at once.
+//
+// When interfrl averages gradients every step, the P platoons' vehicle-m agents keep identical weights (SURVEY 3.4;
+// workers/trainer.py:121-128, 400-431) and the federated mean of their 64-row batch gradients IS the gradient of one
+// (P x 64)-row batch: the per-agent LDS-resident kernel (mlp.hip) is then the wrong shape -- and at hidden sizes
+// like BASELINE config 5 (1024) it does not fit LDS at all. Here each layer is one GEMM over N = P*64 rows per set:
+//     forward   P2  = relu(C  @ (inv (.) W2) + (b2 + sh @ W2))          D[N ][H2] = A[N ][K ] . B[H2][K ]^T
+//     backward  dC  = dZ2 @ W2^T, BN/ReLU backward in the epilogue      D[N ][K ] = A[N ][H2] . B[K ][H2]^T
+//     weights   dW2 = inv (.) (C^T @ dZ2) + sh (x) db2                  D[K ][H2] = A[K ][N ] . B[H2][N ]^T
+// -- all three in the one `A . B^T, both operands reduction-contiguous` form, because the producers of C and dZ2 also
+// write their transposes. Activations and GEMM operands are bf16, accumulation / parameters / gradients f32
+// (v_mfma_f32_16x16x32_bf16). First layers (K = S or A), the width-A output layer and the BN parameter gradients
+// are bandwidth-bound row/column reductions.
+//
+// Output: the MEAN gradient per weight set in the standard slab layout (so avd_adam_polyak_f32 applies it), i.e.
+// exactly what fed_sum/fed_finalize produce from per-agent gradients, up to bf16 rounding of the GEMM operands.
+#include <type_traits>
+
+#include "common.h"
+
+namespace avd {
+namespace wide {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float BN_EPS = 1e-3f;  // tf.keras BatchNormalization default epsilon (agent/model.py:28)
+
+__host__ __device__ constexpr long rup(long x, long m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+// D = A . B^T   A[M][K], B[Nc][K] bf16 with K contiguous (leading dimensions lda, ldb), f32 accumulate.
+// 128x128 macro tile, K step 64, 4 waves as 2x2, 64x64 per wave (4x4 MFMA tiles), LDS double buffer filled through
+// registers, one barrier per K step. Rows of 128 B in LDS are XOR-swizzled in 16-byte chunks so that the 16 lanes
+// of a fragment read (same k chunk, 16 consecutive rows) hit 8 different bank groups.
+// Operands are over-allocated to tile multiples by the caller (no bounds checks on loads); the epilogue guards.
+// ------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64, GT = 256;
+
+struct GemmP {
+    const bf16* A;
+    const bf16* B;
+    long lda, ldb;
+    long setA, setB;  // element strides between weight sets (blockIdx.z / ksplit)
+    int M, Nc, K;     // K: reduction length of ONE split (multiple of BK)
+    int ksplit;       // number of K splits (dW); split s covers reduction [s*K, (s+1)*K)
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+template <class Epi>
+__global__ __launch_bounds__(GT) void gemm_bt_kernel(GemmP p, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* sA = (bf16*)smem_raw;       // [2][BM*BK]
+    bf16* sB = sA + 2 * BM * BK;      // [2][BN*BK]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int set = blockIdx.z / p.ksplit, ks = blockIdx.z - set * p.ksplit;
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    const bf16* A = p.A + (long)set * p.setA + (long)row0 * p.lda + (long)ks * p.K;
+    const bf16* B = p.B + (long)set * p.setB + (long)col0 * p.ldb + (long)ks * p.K;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + GT * i, r = c >> 3, ch = c & 7;
+            ra[i] = *(const uint4*)(A + (long)r * p.lda + k0 + ch * 8);
+            rb[i] = *(const uint4*)(B + (long)r * p.ldb + k0 + ch * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + GT * i, r = c >> 3, ch = c & 7;
+            *(uint4*)(sA + buf * BM * BK + swz(r, ch)) = ra[i];
+            *(uint4*)(sB + buf * BN * BK + swz(r, ch)) = rb[i];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const bf16* a_s = sA + buf * BM * BK;
+        const bf16* b_s = sB + buf * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = lg + 4 * kk;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(a_s + swz(wm * 64 + 16 * i + lr, ch));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_s + swz(wn * 64 + 16 * j + lr, ch));
+            // operands swapped: the tile comes out transposed, i.e. a lane's 4 accumulator registers are 4
+            // CONSECUTIVE OUTPUT COLUMNS of one row (8-byte bf16 / 16-byte f32 stores in the epilogues)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[i][j][r]: row = row0 + wm*64 + 16i + lr, col = col0 + wn*64 + 16j + 4lg + r
+    epi(acc, row0 + wm * 64 + lr, col0 + wn * 64 + 4 * lg, set, ks, p);
+}
+
+// ---- epilogues: operator()(acc, row_base, col_base, set, ks, p); element (i, j, r) -> (row_base + 16i, col_base + 16j + r)
+struct EpiStoreF32 {  // plain D (tests)
+    float* D;
+    long ldd, setD;
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = rb + 16 * i, col = cb + 16 * j;
+                if (row < p.M && col < p.Nc) *(f32x4*)(D + (long)set * setD + (long)row * ldd + col) = acc[i][j];
+            }
+    }
+};
+
+struct EpiFwd {  // out = relu(acc + bias[col]) as bf16
+    bf16* out;
+    long ldo, setO;
+    const float* bias;  // [sets][setBias]
+    long setBias;
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+        const float* b = bias + (long)set * setBias;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cb + 16 * j;
+            if (col >= p.Nc) continue;
+            const f32x4 bv = *(const f32x4*)(b + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rb + 16 * i;
+                if (row >= p.M) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[i][j][r] + bv[r], 0.f);
+                *(bf16x4*)(out + (long)set * setO + (long)row * ldo + col) = o;
+            }
+        }
+    }
+};
+
+// BatchNorm(inference form) + ReLU backward of the layer below: dy = acc; dz = dy * inv * (p > 0);
+// dgamma[c] += sum_rows dy (p - mean) rs; dbeta[c] += sum_rows dy.   Columns are offset by c_off in all tables.
+struct EpiDx {
+    const bf16* P;  // activations of the layer below [rows][ldp], same rows/cols as the output
+    bf16* dZ;
+    long ldp, setP;
+    const float *inv, *rs, *mean;  // [sets][setTab] tables over the concatenated features
+    float *dgamma, *dbeta;         // [sets][setTab] accumulators (or NULL)
+    long setTab;
+    int c_off;
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+        const long tb = (long)set * setTab + c_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cb + 16 * j;
+            const bool cok = col < p.Nc;
+            f32x4 iv = {0, 0, 0, 0}, rsv = iv, mv = iv;
+            if (cok) iv = *(const f32x4*)(inv + tb + col), rsv = *(const f32x4*)(rs + tb + col), mv = *(const f32x4*)(mean + tb + col);
+            float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rb + 16 * i;
+                if (!cok || row >= p.M) continue;
+                const long o = (long)set * setP + (long)row * ldp + c_off + col;
+                const bf16x4 pv = *(const bf16x4*)(P + o);
+                bf16x4 dz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dy = acc[i][j][r], pp = (float)pv[r];
+                    sg[r] = fmaf(dy * (pp - mv[r]), rsv[r], sg[r]);
+                    sb[r] += dy;
+                    dz[r] = (bf16)(pp > 0.f ? dy * iv[r] : 0.f);
+                }
+                *(bf16x4*)(dZ + o) = dz;
+            }
+            if (dgamma) {  // reduce over the 16 lanes (rows) of each lane group, one atomic per column per wave
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) sg[r] += __shfl_xor(sg[r], o), sb[r] += __shfl_xor(sb[r], o);
+                }
+                if ((threadIdx.x & 15) == 0 && cok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        atomicAdd(dgamma + tb + col + r, sg[r]);
+                        atomicAdd(dbeta + tb + col + r, sb[r]);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// dW[k][j] += inv[k] * acc (+ sh[k] * db[j] from split 0): rows = features k, cols = outputs j, f32 atomics
+struct EpiDw {
+    float* dW;  // [sets][setW] + offset of this matrix
+    long ldw, setW;
+    const float *inv, *sh;  // [sets][setTab]
+    const float* db;        // [sets][setDb]
+    long setTab, setDb;
+    float scale;
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int ks, const GemmP& p) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rb + 16 * i;
+            if (row >= p.M) continue;
+            const float iv = inv[(long)set * setTab + row] * scale, sf = (ks == 0) ? sh[(long)set * setTab + row] * scale : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cb + 16 * j;
+                if (col >= p.Nc) continue;
+                const f32x4 dbv = *(const f32x4*)(db + (long)set * setDb + col);
+                float* o = dW + (long)set * setW + (long)row * ldw + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(o + r, fmaf(iv, acc[i][j][r], sf * dbv[r]));
+            }
+        }
+    }
+};
+
+template <class Epi>
+static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st, const char* who) {
+    const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16);  // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)rup(p.Nc, BN) / BN, (unsigned)rup(p.M, BM) / BM, (unsigned)(n_sets * p.ksplit));
+    hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), lds, st, p, e);
+    return check_launch(who);
+}
+
+// ------------------------------------------------------------------------------------------
+// bandwidth-bound pieces. Rows of a set: n in [0, Ns); buffers hold Np = rup(Ns, 128) rows, rows >= Ns are ZERO
+// wherever a buffer feeds a reduction over rows (the transposed copies).
+// ------------------------------------------------------------------------------------------
+struct Dims {
+    int S, H1, H2, Ha, KC, KCp;  // KCp = rup(H1 + Ha, 64): row length of the first-layer activation buffers
+    int Ns, Np, n_sets;
+    long theta_size, stats_size;
+};
+
+// BN tables of `len` features: inv = g / sqrt(var + eps), sh = be - mean * inv, rs = 1/sqrt(var + eps), mean
+__global__ void bn_tables_kernel(const float* th, const float* st, long set_th, long set_st, int g_off, int be_off,
+                                 int mm_off, int mv_off, int len, float* inv, float* sh, float* rs, float* mean, long set_tab,
+                                 int t_off, int pad_to) {
+    const int set = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= pad_to) return;
+    float iv = 0.f, s = 0.f, r = 0.f, m = 0.f;
+    if (k < len) {
+        const float* t = th + (long)set * set_th;
+        const float* q = st + (long)set * set_st;
+        r = 1.0f / sqrtf(q[mv_off + k] + BN_EPS);
+        iv = r * t[g_off + k];
+        m = q[mm_off + k];
+        s = t[be_off + k] - m * iv;
+    }
+    const long o = (long)set * set_tab + t_off + k;
+    inv[o] = iv, sh[o] = s, rs[o] = r, mean[o] = m;
+}
+
+// Layer-2 weights W[K][N] (f32, Keras layout) -> WT[N][Kp] = bf16(inv[k] * W[k][n]) (forward B operand) and
+// Wn[K][N] = bf16(W[k][n]) (dX B operand: rows = features, reduction over n). 32x32 LDS transpose tiles.
+__global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, int N, int Kp, const float* inv, long set_tab,
+                               bf16* WT, long set_wt, bf16* Wn, long set_wn) {
+    __shared__ float tile[32][33];
+    const int set = blockIdx.z, k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const float* W = th + (long)set * set_th + w_off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        float w = 0.f;
+        if (k < K && n < N) w = W[(long)k * N + n];
+        tile[r][tx] = w;
+        if (Wn && k < K && n < N) Wn[(long)set * set_wn + (long)k * N + n] = (bf16)w;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < Kp) {
+            const float iv = (k < K) ? inv[(long)set * set_tab + k] : 0.f;
+            WT[(long)set * set_wt + (long)n * Kp + k] = (bf16)(tile[tx][r] * iv);
+        }
+    }
+}
+
+// bias2[n] = b2[n] + sum_k sh[k] * W[k][n]
+__global__ void bias2_kernel(const float* th, long set_th, int w_off, int b_off, int K, int N, const float* sh, long set_tab,
+                             float* bias, long set_bias) {
+    const int set = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* t = th + (long)set * set_th;
+    float acc = t[b_off + n];
+    for (int k = 0; k < K; ++k) acc = fmaf(sh[(long)set * set_tab + k], t[w_off + (long)k * N + n], acc);
+    bias[(long)set * set_bias + n] = acc;
+}
+
+// First layer of a branch: C[n][c0 + k] = bf16(relu(sum_j X[n][j] W[j][k] + b[k])) for k < H (pad columns up to Hpad get 0),
+// and CT[c0 + k][n] (or NULL). X: f32 [sets][Ns][KIN]. One block = 64 rows x 64 columns.
+template <int KIN>
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* X, long set_x, const float* th, long set_th, int w_off,
+                                                      int b_off, int H, int Hpad, int c0, int Ns, int Np, bf16* C,
+                                                      long ldc, long set_c, bf16* CT, long ldct, long set_ct) {
+    __shared__ float sx[64][KIN];
+    __shared__ bf16 so[64][66];
+    const int set = blockIdx.z, n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float* t = th + (long)set * set_th;
+    for (int i = tid; i < 64 * KIN; i += 256) {
+        const int n = n0 + i / KIN;
+        sx[i / KIN][i % KIN] = (n < Ns) ? X[(long)set * set_x + (long)n * KIN + (i % KIN)] : 0.f;
+    }
+    __syncthreads();
+    const int kc = tid & 63, k = k0 + kc;
+    float w[KIN], b = 0.f;
+#pragma unroll
+    for (int j = 0; j < KIN; ++j) w[j] = (k < H) ? t[w_off + (long)j * H + k] : 0.f;
+    if (k < H) b = t[b_off + k];
+    for (int r = tid >> 6; r < 64; r += 4) {
+        float acc = b;
+#pragma unroll
+        for (int j = 0; j < KIN; ++j) acc = fmaf(sx[r][j], w[j], acc);
+        const int n = n0 + r;
+        const bf16 o = (bf16)((k < H && n < Ns) ? fmaxf(acc, 0.f) : 0.f);
+        if (k < Hpad && n < Np) C[(long)set * set_c + (long)n * ldc + c0 + k] = o;
+        so[r][kc] = o;
+    }
+    if (CT) {
+        __syncthreads();
+        const int nr = tid & 63;
+        for (int c = tid >> 6; c < 64; c += 4) {
+            const int kk = k0 + c, n = n0 + nr;
+            if (kk < Hpad && n < Np) CT[(long)set * set_ct + (long)(c0 + kk) * ldct + n] = so[nr][c];
+        }
+    }
+}
+
+// Output layer, width 1: z[n] = sum_k P[n][k] * c[k] + c0  with c = inv (.) w3 and c0 = b3 + sh . w3 (BN folded).
+// mode 0: out[n] = z. mode 1 (actor): out[n] = tanh(z) * high, tout[n] = tanh(z).
+// One wave per row, 4 rows per block.
+__global__ __launch_bounds__(256) void row_dot_kernel(const bf16* P, long ldp, long set_p, int c_off, int K, const float* cvec,
+                                                       long set_c, const float* c0v, int Ns, int mode, float high, float* out,
+                                                       float* tout, long set_o) {
+    const int set = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= Ns) return;
+    const bf16* row = P + (long)set * set_p + (long)n * ldp + c_off;
+    const float* c = cvec + (long)set * set_c;
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const bf16x4 v = *(const bf16x4*)(row + k);
+        const f32x4 cv = *(const f32x4*)(c + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf((float)v[e], cv[e], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float z = acc + (c0v ? c0v[set] : 0.f);
+        if (mode == 0) {
+            out[(long)set * set_o + n] = z;
+        } else {
+            const float t = tanhf(z);
+            out[(long)set * set_o + n] = t * high;
+            tout[(long)set * set_o + n] = t;
+        }
+    }
+}
+
+// Output layer backward + the ReLU/BN below it: dZ2[n][k] = (P2[n][k] > 0) ? d[n] * c[k] : 0 with c = w3 (.) inv3
+// (also transposed), u[k] += sum_n P2[n][k] d[n], cs[k] += sum_n dZ2[n][k].  Block = 64 rows x 64 columns.
+__global__ __launch_bounds__(256) void out_bwd_kernel(const bf16* P2, long ldp, long set_p, const float* d, long set_d,
+                                                       const float* cvec, long set_c, int H2, int Ns, int Np, bf16* dZ,
+                                                       bf16* dZT, long ldt, long set_t, float* u, float* cs, long set_u) {
+    __shared__ bf16 so[64][66];
+    __shared__ float sd[64];
+    __shared__ float red[2][4][64];
+    const int set = blockIdx.z, n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, tid = threadIdx.x;
+    if (tid < 64) sd[tid] = (n0 + tid < Ns) ? d[(long)set * set_d + n0 + tid] : 0.f;
+    __syncthreads();
+    const int kc = tid & 63, k = k0 + kc, rg = tid >> 6;
+    const float c = (k < H2) ? cvec[(long)set * set_c + k] : 0.f;
+    float su = 0.f, sc = 0.f;
+    for (int r = rg; r < 64; r += 4) {
+        const int n = n0 + r;
+        float p = 0.f;
+        if (k < H2 && n < Ns) p = (float)P2[(long)set * set_p + (long)n * ldp + k];
+        const float dz = (p > 0.f) ? sd[r] * c : 0.f;
+        su = fmaf(p, sd[r], su);
+        sc += dz;
+        const bf16 o = (bf16)dz;
+        if (k < H2 && n < Np) dZ[(long)set * set_p + (long)n * ldp + k] = o;
+        so[r][kc] = o;
+    }
+    red[0][rg][kc] = su, red[1][rg][kc] = sc;
+    __syncthreads();
+    if (tid < 64 && k < H2) {
+        if (u) atomicAdd(u + (long)set * set_u + k, red[0][0][kc] + red[0][1][kc] + red[0][2][kc] + red[0][3][kc]);
+        if (cs) atomicAdd(cs + (long)set * set_u + k, red[1][0][kc] + red[1][1][kc] + red[1][2][kc] + red[1][3][kc]);
+    }
+    if (dZT) {
+        const int nr = tid & 63;
+        for (int cc = tid >> 6; cc < 64; cc += 4) {
+            const int kk = k0 + cc, n = n0 + nr;
+            if (kk < H2 && n < Np) dZT[(long)set * set_t + (long)kk * ldt + n] = so[nr][cc];
+        }
+    }
+}
+
+// First-layer gradients: dW[j][k] += sum_n X[n][j] dZ[n][c0 + k], db[k] += sum_n dZ[n][c0 + k] (scaled).
+// Block = 64 columns x `rows_per_block` rows.
+template <int KIN>
+__global__ __launch_bounds__(256) void l1_grads_kernel(const float* X, long set_x, const bf16* dZ, long ldz, long set_z, int c0,
+                                                        int H, int Ns, int rows_per_block, float scale, float* g, long set_g,
+                                                        int w_off, int b_off) {
+    __shared__ float red[4][64][KIN + 1];
+    const int set = blockIdx.z, k = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int nb = blockIdx.y * rows_per_block, ne = min(nb + rows_per_block, Ns);
+    float acc[KIN + 1];
+#pragma unroll
+    for (int j = 0; j <= KIN; ++j) acc[j] = 0.f;
+    if (k < H) {
+        for (int n = nb + rg; n < ne; n += 4) {
+            const float dz = (float)dZ[(long)set * set_z + (long)n * ldz + c0 + k];
+            const float* x = X + (long)set * set_x + (long)n * KIN;
+#pragma unroll
+            for (int j = 0; j < KIN; ++j) acc[j] = fmaf(x[j], dz, acc[j]);
+            acc[KIN] += dz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= KIN; ++j) red[rg][threadIdx.x & 63][j] = acc[j];
+    __syncthreads();
+    if (rg == 0 && k < H) {
+        float* gs = g + (long)set * set_g;
+#pragma unroll
+        for (int j = 0; j <= KIN; ++j) {
+            const int c = threadIdx.x & 63;
+            const float s = (red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j]) * scale;
+            atomicAdd(j < KIN ? gs + w_off + (long)j * H + k : gs + b_off + k, s);
+        }
+    }
+}
+
+// elementwise glue over rows -----------------------------------------------------------------
+// mode 0: y = r + gamma * q            (TD target, no done mask: workers/trainer.py:494)
+// mode 1: d = 2 (q - y) / N, acc[set][0] += (y - q)^2, acc[set][1] += d      (critic loss seed)
+// mode 2: d = -1 / N,        acc[set][2] += q                                   (actor loss seed)
+// mode 3: d = da * high * (1 - t^2), acc[set][3] += d                           (through tanh * high)
+__global__ __launch_bounds__(256) void rows_kernel(int mode, int Ns, long set_o, const float* q, const float* y_or_t,
+                                                    const float* r_or_da, float gamma_or_high, float* out, float* acc) {
+    const int set = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const long o = (long)set * set_o + n;
+    float a0 = 0.f, a1 = 0.f;
+    if (n < Ns) {
+        if (mode == 0) {
+            out[o] = fmaf(gamma_or_high, q[o], r_or_da[o]);
+        } else if (mode == 1) {
+            const float e = y_or_t[o] - q[o], d = -2.0f * e / (float)Ns;
+            out[o] = d, a0 = e * e, a1 = d;
+        } else if (mode == 2) {
+            out[o] = -1.0f / (float)Ns, a0 = q[o];
+        } else {
+            const float t = y_or_t[o], d = r_or_da[o] * gamma_or_high * (1.0f - t * t);
+            out[o] = d, a0 = d;
+        }
+    }
+    if (mode == 0) return;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) a0 += __shfl_xor(a0, s), a1 += __shfl_xor(a1, s);
+    if ((threadIdx.x & 63) == 0) {
+        if (mode == 1) atomicAdd(acc + set * 4 + 0, a0), atomicAdd(acc + set * 4 + 1, a1);
+        if (mode == 2) atomicAdd(acc + set * 4 + 2, a0);
+        if (mode == 3) atomicAdd(acc + set * 4 + 3, a0);
+    }
+}
+
+// output-layer coefficient vectors of one net: cf[k] = inv[k] * w3[k] (forward), cb[k] = w3[k] * inv[k] (same),
+// c0 = b3 + sum_k sh[k] w3[k]
+__global__ void out_coefs_kernel(const float* th, long set_th, int w3_off, int b3_off, int H2, const float* inv, const float* sh,
+                                 long set_tab, float* cf, float* c0, long set_c) {
+    __shared__ float part[256];
+    const int set = blockIdx.x;
+    const float* t = th + (long)set * set_th;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < H2; k += 256) {
+        const float w = t[w3_off + k];
+        cf[(long)set * set_c + k] = inv[(long)set * set_tab + k] * w;
+        s = fmaf(sh[(long)set * set_tab + k], w, s);
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) c0[set] = part[0] + t[b3_off];
+}
+
+// small gradients of the layers around the output: with sdq = sum_n d[n], u[k] = sum_n P2[n][k] d[n]:
+//   dW3[k] = inv[k] u[k] + sh[k] sdq; db3 = sdq; dgamma[k] = w3[k] rs[k] (u[k] - mean[k] sdq); dbeta[k] = w3[k] sdq;
+//   db2[k] = cs[k]
+__global__ void out_grads_kernel(const float* th, long set_th, int w3_off, int H2, const float* inv, const float* sh,
+                                 const float* rs, const float* mean, long set_tab, const float* u, const float* cs, long set_u,
+                                 const float* acc, int acc_idx, float* g, long set_g, int gw3, int gb3, int gg, int gbe, int gb2,
+                                 int write_w3) {
+    const int set = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H2) return;
+    const float sdq = acc[set * 4 + acc_idx];
+    const long tb = (long)set * set_tab + k;
+    const float w3 = th[(long)set * set_th + w3_off + k], uk = u[(long)set * set_u + k];
+    float* gs = g + (long)set * set_g;
+    if (write_w3) {
+        gs[gw3 + k] = fmaf(inv[tb], uk, sh[tb] * sdq);
+        if (k == 0) gs[gb3] = sdq;
+    }
+    gs[gg + k] = w3 * rs[tb] * (uk - mean[tb] * sdq);
+    gs[gbe + k] = w3 * sdq;
+    gs[gb2 + k] = cs[(long)set * set_u + k];
+}
+
+__global__ void losses_kernel(const float* acc, int Ns, int n_sets, float* losses) {
+    const int set = threadIdx.x;
+    if (set < n_sets && losses) {
+        losses[set * 2 + 0] = acc[set * 4 + 0] / (float)Ns;   // mean((y - q)^2)   (trainer.py:496)
+        losses[set * 2 + 1] = -acc[set * 4 + 2] / (float)Ns;  // -mean(q1)         (trainer.py:504)
+    }
+}
+
+}  // namespace wide
+}  // namespace avd
+
+using namespace avd;
+using namespace avd::wide;
+
+extern "C" int avd_gemm_bt_bf16(int M, int Nc, int K, const void* A, long lda, const void* B, long ldb, float* D, long ldd,
+                                void* stream) {
+    AVD_REQUIRE(M > 0 && Nc > 0 && K > 0 && K % BK == 0 && lda >= K && ldb >= K && ldd >= Nc && ldd % 4 == 0,
+                "avd_gemm_bt_bf16: M=%d Nc=%d K=%d (K %% 64 == 0) lda=%ld ldb=%ld ldd=%ld", M, Nc, K, lda, ldb, ldd);
+    AVD_REQUIRE(A && B && D, "avd_gemm_bt_bf16: null pointer");
+    GemmP p = {(const bf16*)A, (const bf16*)B, lda, ldb, 0, 0, M, Nc, K, 1};
+    EpiStoreF32 e = {D, ldd, 0};
+    return launch_gemm(p, e, 1, (hipStream_t)stream, "avd_gemm_bt_bf16");
+}
+
+// ---- workspace plan -------------------------------------------------------------------------
+namespace {
+struct Plan {
+    Dims d;
+    // byte offsets into the workspace
+    size_t C, CT, P2, dZ2, dZ2T, dZ1;                // activations (all sets)
+    size_t WT[4], Wn[2], bias[4];                    // weights: 0 actor, 1 critic, 2 target actor, 3 target critic
+    size_t tabs[4];                                  // per net: inv/sh/rs/mean tables of [KCp + H2] floats x 4
+    size_t cf[4], c0[4];                             // output-layer coefficient vectors
+    size_t q, y, dq, a1, tt, da;                     // row vectors [sets][Np]
+    size_t u, cs, acc;                               // [sets][H2] x 2, [sets][4]
+    size_t total;
+    long ldT;  // table stride per set: KCp + H2
+};
+
+static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets) {
+    Plan p;
+    Dims& d = p.d;
+    d.S = L.S, d.H1 = L.H1, d.H2 = L.H2, d.Ha = L.Ha, d.KC = L.H1 + L.Ha, d.KCp = (int)rup(d.KC, 64);
+    d.n_sets = n_sets, d.Ns = (n_agents / n_sets) * L.B, d.Np = (int)rup(d.Ns, 128);
+    d.theta_size = L.theta_size, d.stats_size = L.stats_size;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += rup((long)bytes, 256);
+        return at;
+    };
+    const size_t sets = n_sets, Np = d.Np;
+    const size_t KCn = rup(d.KC, 128) + 128, H2n = rup(d.H2, 128), KCp = d.KCp;  // +128: dX tiles start at column H1
+    p.C = take(sets * Np * KCp * 2), p.CT = take(sets * KCn * Np * 2);
+    p.P2 = take(sets * Np * d.H2 * 2), p.dZ2 = take(sets * Np * d.H2 * 2), p.dZ2T = take(sets * H2n * Np * 2);
+    p.dZ1 = take(sets * Np * KCp * 2);
+    for (int i = 0; i < 4; ++i) p.WT[i] = take(sets * H2n * KCp * 2), p.bias[i] = take(sets * d.H2 * 4);
+    for (int i = 0; i < 2; ++i) p.Wn[i] = take(sets * KCn * d.H2 * 2);
+    p.ldT = KCp + d.H2;
+    for (int i = 0; i < 4; ++i) p.tabs[i] = take(sets * p.ldT * 4 * 4), p.cf[i] = take(sets * d.H2 * 4), p.c0[i] = take(sets * 4);
+    p.q = take(sets * Np * 4), p.y = take(sets * Np * 4), p.dq = take(sets * Np * 4), p.a1 = take(sets * Np * 4);
+    p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4);
+    p.u = take(sets * d.H2 * 4), p.cs = take(sets * d.H2 * 4), p.acc = take(sets * 4 * 4);
+    p.total = o;
+    return p;
+}
+
+static int check_wide(const avd_mlp_layout* L, int n_agents, int n_sets, const char* who) {
+    AVD_REQUIRE(L, "%s: null layout", who);
+    AVD_REQUIRE(n_sets > 0 && n_agents > 0 && n_agents % n_sets == 0, "%s: n_agents=%d must be a multiple of n_sets=%d", who,
+                n_agents, n_sets);
+    if (L->A != 1 || (L->S != 3 && L->S != 4) || L->H1 % 64 || L->H2 % 64 || L->Ha % 16 || L->B % 64) {
+        set_error("%s: the shared-set learner implements A == 1, S in {3, 4}, layer1/layer2 sizes that are multiples of 64, an "
+                  "action layer size multiple of 16 and batch sizes multiple of 64 (got S=%d A=%d H1=%d H2=%d Ha=%d B=%d)",
+                  who, L->S, L->A, L->H1, L->H2, L->Ha, L->B);
+        return AVD_E_UNSUPPORTED;
+    }
+    return AVD_OK;
+}
+}  // namespace
+
+extern "C" int avd_learn_shared_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes) {
+    int rc = check_wide(lay, n_agents, n_sets, "avd_learn_shared_workspace");
+    if (rc) return rc;
+    AVD_REQUIRE(bytes, "avd_learn_shared_workspace: null pointer");
+    *bytes = make_plan(*lay, n_agents, n_sets).total;
+    return AVD_OK;
+}
+
+namespace {
+// one network's prepared operands
+struct NetOps {
+    const float *th, *st;  // [sets][theta_size] (actor block at 0, critic at actor_size), [sets][stats_size]
+    float *inv, *sh, *rs, *mean;  // tables [sets][ldT]: first-layer features at [0, KCp), second layer at [KCp, KCp + H2)
+    bf16 *WT, *Wn;
+    float *bias, *cf, *c0;
+};
+}  // namespace
+
+#define WIDE_CHECK(call)         \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_) return rc_;     \
+    } while (0)
+
+extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta,
+                                     const float* stats, const float* theta_t, const float* stats_t, const float* s,
+                                     const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
+                                     float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_wide(lay, n_agents, n_sets, "avd_learn_shared_bf16");
+    if (rc) return rc;
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads && workspace,
+                "avd_learn_shared_bf16: null pointer");
+    const avd_mlp_layout& L = *lay;
+    const Plan pl = make_plan(L, n_agents, n_sets);
+    AVD_REQUIRE(workspace_bytes >= pl.total, "avd_learn_shared_bf16: workspace %zu B < %zu B", workspace_bytes, pl.total);
+    const Dims& d = pl.d;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    auto B16 = [&](size_t off) { return (bf16*)(ws + off); };
+    auto F32 = [&](size_t off) { return (float*)(ws + off); };
+    const int sets = n_sets, Ns = d.Ns, Np = d.Np, H1 = d.H1, H2 = d.H2, Ha = d.Ha, KC = d.KC, KCp = d.KCp;
+    const long KCn = rup(KC, 128) + 128, H2n = rup(H2, 128), ldT = pl.ldT;
+    const long setC = (long)Np * KCp, setCT = KCn * Np, setP2 = (long)Np * H2, setZT = H2n * Np;
+    const long setWT = H2n * KCp, setWn = KCn * H2;
+    const int asz = L.actor_size;
+
+    // zero what is accumulated into or read as padding
+    (void)hipMemsetAsync(grads, 0, sizeof(float) * (size_t)sets * L.theta_size, st);
+    (void)hipMemsetAsync(ws + pl.acc, 0, sizeof(float) * sets * 4, st);
+    // (activation buffers need no clearing: their producers write every row < Np and every column < KCp, zeros in the
+    //  padding; rows/columns beyond that only ever feed output elements the GEMM epilogues do not store)
+
+    // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
+    NetOps net[4];  // 0 actor, 1 critic, 2 target actor, 3 target critic
+    for (int i = 0; i < 4; ++i) {
+        NetOps& n = net[i];
+        const bool critic = (i & 1), target = (i >= 2);
+        n.th = (target ? theta_t : theta) + (critic ? asz : 0);
+        n.st = target ? stats_t : stats;
+        float* tab = F32(pl.tabs[i]);
+        n.inv = tab, n.sh = tab + (long)sets * ldT, n.rs = tab + 2L * sets * ldT, n.mean = tab + 3L * sets * ldT;
+        n.WT = B16(pl.WT[i]), n.Wn = target ? nullptr : B16(pl.Wn[i]);
+        n.bias = F32(pl.bias[i]), n.cf = F32(pl.cf[i]), n.c0 = F32(pl.c0[i]);
+        const int K = critic ? KC : H1;
+        auto tables = [&](int g, int be, int mm, int mv, int len, int t_off, int pad_to) {
+            hipLaunchKernelGGL(bn_tables_kernel, dim3((unsigned)rup(pad_to, 256) / 256, sets), dim3(256), 0, st, n.th, n.st,
+                               (long)L.theta_size, (long)L.stats_size, g, be, mm, mv, len, n.inv, n.sh, n.rs, n.mean, ldT, t_off,
+                               pad_to);
+        };
+        if (critic) {
+            tables(L.cgs, L.cbes, L.cmms, L.cmvs, H1, 0, H1);
+            tables(L.cga, L.cbea, L.cmma, L.cmva, Ha, H1, KCp - H1);
+            tables(L.cg3, L.cbe3, L.cmm3, L.cmv3, H2, KCp, H2);
+        } else {
+            tables(L.ag1, L.abe1, L.amm1, L.amv1, H1, 0, KCp);
+            tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
+        }
+        const int w2 = critic ? L.cW2 : L.aW2, b2 = critic ? L.cb2 : L.ab2, w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3;
+        hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, n.th,
+                           (long)L.theta_size, w2, K, H2, KCp, n.inv, ldT, n.WT, setWT, n.Wn, setWn);
+        hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w2, b2, K,
+                           H2, n.sh, ldT, n.bias, (long)H2);
+        hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3, b3, H2, n.inv + KCp,
+                           n.sh + KCp, ldT, n.cf, n.c0, (long)H2);
+    }
+    WIDE_CHECK(check_launch("avd_learn_shared_bf16: operand preparation"));
+
+    bf16 *C = B16(pl.C), *CT = B16(pl.CT), *P2 = B16(pl.P2), *dZ2 = B16(pl.dZ2), *dZ2T = B16(pl.dZ2T), *dZ1 = B16(pl.dZ1);
+    float *q = F32(pl.q), *y = F32(pl.y), *dq = F32(pl.dq), *a1 = F32(pl.a1), *tt = F32(pl.tt), *da = F32(pl.da);
+    float *u = F32(pl.u), *cs = F32(pl.cs), *acc = F32(pl.acc);
+    const long setX = (long)Ns * L.S, setR = Ns;
+    const dim3 g64((unsigned)1, (unsigned)rup(Np, 64) / 64, sets);
+
+    // first layer: states (S = 3 or 4) or actions (1) -> columns [c0, c0 + H)
+    auto l1 = [&](const NetOps& n, bool critic, bool action, const float* X, long set_x, bool transpose) {
+        const int H = action ? Ha : H1, c0 = action ? H1 : 0;
+        const int Hpad = action ? (KCp - H1) : H1;
+        const int w = critic ? (action ? L.cWa : L.cWs) : L.aW1, b = critic ? (action ? L.cba : L.cbs) : L.ab1;
+        dim3 grid((unsigned)rup(Hpad, 64) / 64, g64.y, sets);
+        bf16* ct = transpose ? CT : nullptr;
+        if (action)
+            hipLaunchKernelGGL((l1_fwd_kernel<1>), grid, dim3(256), 0, st, X, set_x, n.th, (long)L.theta_size, w, b, H, Hpad, c0, Ns,
+                               Np, C, (long)KCp, setC, ct, (long)Np, setCT);
+        else if (L.S == 4)
+            hipLaunchKernelGGL((l1_fwd_kernel<4>), grid, dim3(256), 0, st, X, set_x, n.th, (long)L.theta_size, w, b, H, Hpad, c0, Ns,
+                               Np, C, (long)KCp, setC, ct, (long)Np, setCT);
+        else
+            hipLaunchKernelGGL((l1_fwd_kernel<3>), grid, dim3(256), 0, st, X, set_x, n.th, (long)L.theta_size, w, b, H, Hpad, c0, Ns,
+                               Np, C, (long)KCp, setC, ct, (long)Np, setCT);
+    };
+    // second layer forward: P2 = relu(C @ WT^T + bias)
+    auto l2 = [&](const NetOps& n, bool critic) {
+        GemmP p = {C, n.WT, KCp, KCp, setC, setWT, Ns, H2, critic ? KCp : (int)rup(H1, 64), 1};
+        EpiFwd e = {P2, H2, setP2, n.bias, H2};
+        return launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: forward GEMM");
+    };
+    auto out_layer = [&](const NetOps& n, int mode, float* out) {
+        hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, P2, (long)H2, setP2, 0, H2, n.cf,
+                           (long)H2, n.c0, Ns, mode, high, out, tt, (long)Np);
+    };
+    auto rows = [&](int mode, const float* qv, const float* yt, const float* rd, float gh, float* out) {
+        hipLaunchKernelGGL(rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, sets), dim3(256), 0, st, mode, Ns, (long)Np, qv, yt, rd, gh,
+                           out, acc);
+    };
+    // Note on row-vector strides: r arrives as [sets][Ns] (stride Ns), internal vectors use stride Np. The TD kernel
+    // reads r with the internal stride, so r is first copied into `da` (free at that point) with the padded stride.
+    auto actor_forward = [&](const NetOps& n, const float* X, bool transpose) {
+        l1(n, false, false, X, setX, transpose);
+        WIDE_CHECK(l2(n, false));
+        out_layer(n, 1, a1);
+        return AVD_OK;
+    };
+    auto critic_forward = [&](const NetOps& n, const float* X, const float* act, long set_act, bool transpose) {
+        l1(n, true, false, X, setX, transpose);
+        l1(n, true, true, act, set_act, transpose);
+        WIDE_CHECK(l2(n, true));
+        out_layer(n, 0, q);
+        return AVD_OK;
+    };
+    // backward of layers 3 and 2 of `n` given the seed d[n]; weight gradients when `wg`
+    auto backward = [&](const NetOps& n, bool critic, const float* dvec, bool wg, int acc_idx, float* gnet) {
+        (void)hipMemsetAsync(u, 0, sizeof(float) * sets * H2, st);
+        (void)hipMemsetAsync(cs, 0, sizeof(float) * sets * H2, st);
+        hipLaunchKernelGGL(out_bwd_kernel, dim3((unsigned)rup(H2, 64) / 64, g64.y, sets), dim3(256), 0, st, P2, (long)H2, setP2, dvec,
+                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, wg ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2);
+        const int K = critic ? KC : H1;
+        if (wg) {
+            const int w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3, gg = critic ? L.cg3 : L.ag2,
+                      gbe = critic ? L.cbe3 : L.abe2, gb2 = critic ? L.cb2 : L.ab2;
+            hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,
+                               H2, n.inv + KCp, n.sh + KCp, n.rs + KCp, n.mean + KCp, ldT, u, cs, (long)H2, acc, acc_idx, gnet,
+                               (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
+            // dW2 = inv (.) (C^T dZ2) + sh (x) db2: reduction over the rows, split into chunks with f32 atomics
+            int ksplit = 1;
+            while (Np / ksplit > 4096 && Np % (ksplit * 2 * BK) == 0) ksplit *= 2;
+            GemmP p = {CT, dZ2T, Np, Np, setCT, setZT, K, H2, Np / ksplit, ksplit};
+            EpiDw e = {gnet + (critic ? L.cW2 : L.aW2), H2, (long)L.theta_size, n.inv, n.sh, cs, ldT, H2, 1.0f};
+            WIDE_CHECK(launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: weight-gradient GEMM"));
+        }
+        return AVD_OK;
+    };
+    // dX GEMM with the BN/ReLU backward of the first layer(s) over columns [c_begin, c_end)
+    auto dx = [&](const NetOps& n, int c_begin, int c_end, bool wg, bool critic) {
+        GemmP p = {dZ2, n.Wn + (long)c_begin * H2, H2, H2, setP2, setWn, Ns, c_end - c_begin, H2, 1};
+        EpiDx e = {C, dZ1, KCp, setC, n.inv, n.rs, n.mean, nullptr, nullptr, ldT, c_begin};
+        if (wg) {  // dgamma / dbeta of the first layers accumulate in table-shaped scratch, copied into the slab by flush_bn1
+            e.dgamma = F32(pl.tabs[2 + (critic ? 1 : 0)]);               // target-net tables are dead after pass 0
+            e.dbeta = e.dgamma + (long)sets * ldT;
+        }
+        return launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: input-gradient GEMM");
+    };
+    auto l1_grads = [&](const float* X, long set_x, int kin, int c0, int H, float* gnet, int w_off, int b_off) {
+        const int rpb = 2048;
+        dim3 grid((unsigned)rup(H, 64) / 64, (unsigned)rup(Ns, rpb) / rpb, sets);
+        if (kin == 1)
+            hipLaunchKernelGGL((l1_grads_kernel<1>), grid, dim3(256), 0, st, X, set_x, dZ1, (long)KCp, setC, c0, H, Ns, rpb, 1.0f, gnet,
+                               (long)L.theta_size, w_off, b_off);
+        else if (kin == 4)
+            hipLaunchKernelGGL((l1_grads_kernel<4>), grid, dim3(256), 0, st, X, set_x, dZ1, (long)KCp, setC, c0, H, Ns, rpb, 1.0f, gnet,
+                               (long)L.theta_size, w_off, b_off);
+        else
+            hipLaunchKernelGGL((l1_grads_kernel<3>), grid, dim3(256), 0, st, X, set_x, dZ1, (long)KCp, setC, c0, H, Ns, rpb, 1.0f, gnet,
+                               (long)L.theta_size, w_off, b_off);
+    };
+    // copy of the table-shaped dgamma/dbeta accumulators into the slab
+    auto flush_bn1 = [&](bool critic, float* gnet) {
+        float* dg = F32(pl.tabs[2 + (critic ? 1 : 0)]);
+        float* dbe = dg + (long)sets * ldT;
+        for (int sidx = 0; sidx < sets; ++sidx) {
+            float* gs = gnet + (long)sidx * L.theta_size;
+            if (critic) {
+                (void)hipMemcpyAsync(gs + L.cgs, dg + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(gs + L.cbes, dbe + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(gs + L.cga, dg + sidx * ldT + H1, sizeof(float) * Ha, hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(gs + L.cbea, dbe + sidx * ldT + H1, sizeof(float) * Ha, hipMemcpyDeviceToDevice, st);
+            } else {
+                (void)hipMemcpyAsync(gs + L.ag1, dg + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(gs + L.abe1, dbe + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
+            }
+        }
+    };
+
+    // ---- pass 0: targets  y = r + gamma * Q'(s2, mu'(s2))                                   (trainer.py:493-494)
+    WIDE_CHECK(actor_forward(net[2], s2, false));
+    WIDE_CHECK(critic_forward(net[3], s2, a1, (long)Np, false));
+    (void)hipMemcpy2DAsync(da, sizeof(float) * Np, r, sizeof(float) * Ns, sizeof(float) * Ns, sets, hipMemcpyDeviceToDevice, st);
+    rows(0, q, nullptr, da, gamma, y);
+    // the target nets' tables are dead now: they become the dgamma/dbeta accumulators of the first layers
+    (void)hipMemsetAsync(ws + pl.tabs[2], 0, sizeof(float) * 2 * sets * ldT, st);
+    (void)hipMemsetAsync(ws + pl.tabs[3], 0, sizeof(float) * 2 * sets * ldT, st);
+
+    // ---- pass 1: critic loss and gradient                                                   (trainer.py:495-498)
+    float* gcrit = grads + asz;
+    WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
+    rows(1, q, y, nullptr, 0.f, dq);
+    WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit));
+    WIDE_CHECK(dx(net[1], 0, KC, true, true));
+    l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
+    l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+    flush_bn1(true, gcrit);
+
+    // ---- pass 2: actor through the critic, gradient w.r.t. the action                       (trainer.py:502-506)
+    WIDE_CHECK(actor_forward(net[0], s, false));
+    WIDE_CHECK(critic_forward(net[1], s, a1, (long)Np, false));
+    rows(2, q, nullptr, nullptr, 0.f, dq);
+    WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
+    WIDE_CHECK(dx(net[1], H1, KC, false, true));
+    // da[n] = sum_k dZ1[n][H1 + k] * Wa[0][k]
+    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,
+                       net[1].th + L.cWa, (long)L.theta_size, (const float*)nullptr, Ns, 0, 0.f, da, (float*)nullptr, (long)Np);
+
+    // ---- pass 3: actor forward again (activations + transposes kept this time) and its gradient
+    WIDE_CHECK(actor_forward(net[0], s, true));
+    rows(3, nullptr, tt, da, high, dq);
+    WIDE_CHECK(backward(net[0], false, dq, true, 3, grads));
+    WIDE_CHECK(dx(net[0], 0, H1, true, false));
+    l1_grads(s, setX, L.S, 0, H1, grads, L.aW1, L.ab1);
+    flush_bn1(false, grads);
+    hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(64), 0, st, acc, Ns, sets, losses);
+    return check_launch("avd_learn_shared_bf16");
+}

@@ -294,6 +294,24 @@ class AgentGroup:
              ptr(losses), stream_handle())
         return grads
 
+    def learn_shared(self, s, a, r, s2, n_agents, grads=None, losses=None):
+        """Trainer.learn + federated mean for agents that SHARE this group's ``n_sets`` weight sets (interfrl with every
+        step federated), as layer-wise bf16 GEMMs over all rows of a set (csrc/wide.hip). Batches are SET-MAJOR:
+        s, s2 [n_sets, rows, S], a [n_sets, rows, 1], r [n_sets, rows] with rows = n_agents / n_sets * batch_size.
+        Returns the mean gradient per set [n_sets, theta_size]."""
+        import ctypes
+        if grads is None:
+            grads = torch.empty(self.n_sets, self.lay.theta_size, dtype=torch.float32, device=self.device)
+        need = ctypes.c_size_t(0)
+        call("avd_learn_shared_workspace", self._layp, n_agents, self.n_sets, ctypes.byref(need))
+        ws = getattr(self, "_wide_ws", None)
+        if ws is None or ws.numel() < need.value:
+            ws = self._wide_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        call("avd_learn_shared_bf16", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
+             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), self.config.gamma, self.high,
+             ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
+        return grads
+
     def apply(self, grads):
         """critic Adam, actor Adam, then Polyak (workers/trainer.py:348-356) for every weight set."""
         c = self.config

@@ -20,6 +20,7 @@
 #ifndef AVDDPG_HIP_H
 #define AVDDPG_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -211,6 +212,29 @@ int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float*
  * vehicle under intra_directional_averaging, :417-418). */
 int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n, const float* src,
                         float* dst, void* stream);
+
+/* ---- shared-weight-set learner (interfrl with every step federated; BASELINE config 5) -----------------
+ * When the P platoons' vehicle-m agents share one weight set (workers/trainer.py:121-128, 400-431: identical initial
+ * weights + identical averaged gradients every step), Trainer.learn (:472-508) followed by the federated mean
+ * (src/server/federated.py:69-92) equals ONE learn over the set's P x B rows. This entry point computes that as
+ * layer-wise bf16 MFMA GEMMs (f32 accumulation, f32 parameters and gradients):
+ *   theta/stats/theta_t/stats_t [n_sets][...]   weight sets (same slabs as avd_learn_f32 with set_mod = n_sets)
+ *   s, s2 [n_sets][rows][S], a [n_sets][rows][1], r [n_sets][rows]   SET-MAJOR batches, rows = (n_agents / n_sets) * B
+ *   grads [n_sets][theta_size]   mean gradient per set (what avd_fed_sum + avd_fed_finalize give for per-agent gradients)
+ *   losses [n_sets][2] or NULL   mean critic / actor loss per set
+ *   workspace: device scratch of at least avd_learn_shared_workspace() bytes.
+ * Widths: layer1/layer2 sizes multiples of 64, action layer multiple of 16, A == 1, S in {3, 4}, B multiple of 64. */
+int avd_learn_shared_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
+int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                          const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                          const float* s2, float gamma, float high, float* grads, float* losses, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* D[M][Nc] (f32, ldd) = A[M][K] . B[Nc][K]^T with bf16 operands (K contiguous, K % 64 == 0) and f32 accumulation: the
+ * GEMM under avd_learn_shared_bf16, exposed for parity tests. A and B must be readable up to the next multiple of 128
+ * rows. */
+int avd_gemm_bt_bf16(int M, int Nc, int K, const void* A, long lda, const void* B, long ldb, float* D, long ldd,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+"""GPU parity of the shared-weight-set learner (csrc/wide.hip): the bf16 MFMA GEMM on its own, and Trainer.learn +
+federated mean over P agents that share one weight set, against (a) the oracle on the concatenated batch and (b) the
+per-agent f32 kernel followed by the federated mean kernels. Tolerances are bf16 ones (8 significant bits on the GEMM
+operands, f32 accumulation) and are written next to each assertion."""
+import numpy as np
+import pytest
+import torch
+
+from avddpg_amd import _hip, config, vec
+from avddpg_amd._hip import call, ptr, stream_handle
+from oracle import mlp as omlp
+from tests.gpu_util import need_gpu, t
+from tests.test_gpu_mlp import _nets, _perturbed_group, _relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,Nc,K", [(128, 128, 64), (200, 72, 192), (1024, 304, 1088), (64, 1024, 4096)])
+def test_bf16_gemm_matches_float64_on_the_same_bf16_operands(M, Nc, K):
+    need_gpu()
+    rs = np.random.RandomState(M + Nc + K)
+    Mp, Np_ = (M + 127) // 128 * 128, (Nc + 127) // 128 * 128  # operands readable to the next tile multiple
+    A = torch.zeros(Mp, K, dtype=torch.bfloat16, device="cuda")
+    B = torch.zeros(Np_, K, dtype=torch.bfloat16, device="cuda")
+    A[:M] = t(rs.normal(0, 1, (M, K)).astype(np.float32)).to(torch.bfloat16)
+    B[:Nc] = t(rs.normal(0, 1, (Nc, K)).astype(np.float32)).to(torch.bfloat16)
+    ldd = (Nc + 3) // 4 * 4
+    D = torch.full((M, ldd), float("nan"), device="cuda")
+    call("avd_gemm_bt_bf16", M, Nc, K, ptr(A), K, ptr(B), K, ptr(D), ldd, stream_handle())
+    ref = A[:M].double().cpu().numpy() @ B[:Nc].double().cpu().numpy().T
+    got = D[:, :Nc].cpu().numpy()
+    # identical bf16 operands, f32 accumulation in a different order: 1e-5 of the result scale sqrt(K)
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.sqrt(K) * 4, np.max(np.abs(got - ref))
+    if ldd > Nc:
+        assert torch.isnan(D[:, Nc:]).all()  # nothing stored outside the matrix
+
+
+@pytest.mark.parametrize("S,P,widths,tol", [(4, 6, (256, 128, 48), 2e-2), (3, 4, (128, 64, 32), 2e-2),
+                                            (4, 8, (1024, 1024, 48), 8e-2)])
+def test_shared_learner_matches_oracle_on_concatenated_batch(S, P, widths, tol):
+    """n_sets = 2 weight sets, P agents each: the mean of the agents' gradients == the gradient of the P*64-row batch."""
+    need_gpu()
+    n_sets, B = 2, 64
+    H1, H2, Ha = widths
+    conf, grp = _perturbed_group(n_sets, S=S, seed=61, actor_layer1_size=H1, actor_layer2_size=H2, critic_layer1_size=H1,
+                                 critic_layer2_size=H2, critic_act_layer_size=Ha)
+    rs = np.random.RandomState(62)
+    rows = P * B
+    s = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n_sets, rows, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n_sets, rows))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
+    losses = torch.zeros(n_sets, 2, device="cuda")
+    g = grp.learn_shared(t(s), t(a), t(r), t(s2), n_sets * P, losses=losses)
+    torch.cuda.synchronize()
+    for k in range(n_sets):
+        cg, ag, aux = omlp.learn((s[k], a[k], r[k][:, None], s2[k]), *_nets(grp, k, np.float64))
+        gcg, gag = grp.grads_as_lists(g[k])
+        names = ["cWs", "cbs", "cWa", "cba", "cgs", "cbes", "cga", "cbea", "cW2", "cb2", "cg3", "cbe3", "cW3", "cb3",
+                 "aW1", "ab1", "ag1", "abe1", "aW2", "ab2", "ag2", "abe2", "aW3", "ab3"]
+        for name, got, ref in zip(names, gcg + gag, cg + ag):
+            # bf16 GEMM operands (2^-9 relative rounding per element) against the float64 oracle: 2 % of the tensor's max
+            # at the reference widths; at BASELINE config 5's hidden = 1024 the first-layer actor gradients sit behind
+            # five bf16 GEMMs with 1024-long reductions and only 512 rows to average over here: 8 %
+            assert _relerr(got, ref) <= tol, (k, name, _relerr(got, ref))
+        lo = losses[k].cpu().numpy()
+        assert abs(lo[0] - aux["critic_loss"]) <= 1e-2 * abs(aux["critic_loss"])
+        assert abs(lo[1] - aux["actor_loss"]) <= 1e-2 * max(1e-2, abs(aux["actor_loss"]))
+
+
+def test_shared_learner_equals_per_agent_kernel_plus_federated_mean():
+    """Same quantity two ways on the GPU: avd_learn_f32 per agent (f32 MFMA) + fed_mean over the platoons, and the
+    shared-set learner on the set-major batch."""
+    need_gpu()
+    P, M, B, S = 8, 3, 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=71)
+    rs = np.random.RandomState(72)
+    n = P * M  # agent v = p*M + m uses set m
+    s = rs.normal(0, 1.5, size=(n, B, S)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n, B, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n, B))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n, B, S)).astype(np.float32)
+    per_agent = grp.learn(t(s), t(a), t(r), t(s2), M)
+    avg = vec.fed_mean(per_agent, P, M, method=conf.interfrl)  # [M, theta]
+    sm = lambda x: t(np.ascontiguousarray(x.reshape(P, M, *x.shape[1:]).swapaxes(0, 1)).reshape(M, P * B, *x.shape[2:]))
+    g = grp.learn_shared(sm(s), sm(a), sm(r), sm(s2), n)
+    a_, b_ = avg.cpu().numpy(), g.cpu().numpy()
+    lay = grp.lay
+    for name, lo, hi in (("actor", 0, lay.actor_size), ("critic", lay.actor_size, lay.theta_size)):
+        d = np.abs(a_[:, lo:hi] - b_[:, lo:hi]).max()
+        assert d <= 2e-2 * np.abs(a_[:, lo:hi]).max(), (name, d, np.abs(a_[:, lo:hi]).max())
+
+
+def test_shared_learner_rejects_unsupported_shapes():
+    need_gpu()
+    conf = config.Config(actor_layer1_size=320, actor_layer2_size=160, critic_layer1_size=320, critic_layer2_size=160)
+    grp = vec.AgentGroup(1, 4, 1, conf)
+    z = torch.zeros(1, 64, 4, device="cuda")
+    with pytest.raises(_hip.AvdError, match="multiples of 64"):
+        grp.learn_shared(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 1)
