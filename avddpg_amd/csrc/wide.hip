@@ -26,6 +26,7 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float BN_EPS = 1e-3f;  // tf.keras BatchNormalization default epsilon (agent/model.py:28)
 
 __host__ __device__ constexpr long rup(long x, long m) { return (x + m - 1) / m * m; }
@@ -43,42 +44,58 @@ struct GemmP {
     const bf16* A;
     const bf16* B;
     long lda, ldb;
-    long setA, setB;  // element strides between weight sets (blockIdx.z / ksplit)
+    long setA, setB;  // element strides between weight sets (blockIdx.z)
     int M, Nc, K;     // K: reduction length of ONE split (multiple of BK)
     int ksplit;       // number of K splits (dW); split s covers reduction [s*K, (s+1)*K)
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+// 16 consecutive rows at one k chunk (a quarter-wave of a ds_read_b128) must cover all 64 banks: row bit 0 selects the
+// 128-byte half, bits 1..3 permute the eight 16-byte chunks
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
+// 64 KiB of LDS per workgroup = 2 workgroups (2 waves per SIMD) per CU: tell the register allocator so (it otherwise
+// aims at 4 waves per SIMD and spills the staging registers to scratch)
 template <class Epi>
-__global__ __launch_bounds__(GT) void gemm_bt_kernel(GemmP p, Epi epi) {
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bt_kernel(GemmP p, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* sA = (bf16*)smem_raw;       // [2][BM*BK]
     bf16* sB = sA + 2 * BM * BK;      // [2][BN*BK]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int set = blockIdx.z / p.ksplit, ks = blockIdx.z - set * p.ksplit;
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    // XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles that
+    // share an operand -- the column tiles of one row tile (forward, dX), all tiles of one reduction chunk (dW) -- are
+    // given ids that are congruent mod 8 and consecutive in time: 8 such groups are in flight, one per XCD.
+    const int ncol = (p.Nc + BN - 1) / BN, nrow = (p.M + BM - 1) / BM;
+    const int gsz = (p.ksplit > 1) ? nrow * ncol : ncol;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int grp = (jj / gsz) * 8 + xcd, tin = jj - (jj / gsz) * gsz;
+    const int set = blockIdx.z;
+    int ks = 0, rt = grp, ct = tin;
+    if (p.ksplit > 1) ks = grp, rt = tin / ncol, ct = tin - rt * ncol;
+    if (ks >= p.ksplit || rt >= nrow) return;
+    const int row0 = rt * BM, col0 = ct * BN;
     const bf16* A = p.A + (long)set * p.setA + (long)row0 * p.lda + (long)ks * p.K;
     const bf16* B = p.B + (long)set * p.setB + (long)col0 * p.ldb + (long)ks * p.K;
 
-    uint4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + GT * i, r = c >> 3, ch = c & 7;
-            ra[i] = *(const uint4*)(A + (long)r * p.lda + k0 + ch * 8);
-            rb[i] = *(const uint4*)(B + (long)r * p.ldb + k0 + ch * 8);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + GT * i, r = c >> 3, ch = c & 7;
-            *(uint4*)(sA + buf * BM * BK + swz(r, ch)) = ra[i];
-            *(uint4*)(sB + buf * BN * BK + swz(r, ch)) = rb[i];
-        }
-    };
+    // Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no LDS store
+    // instructions). One wave instruction fills 1024 consecutive LDS bytes = 8 tile rows in order, lane l -> row l / 8,
+    // 16-byte slot l % 8; the swizzle is therefore applied on the GLOBAL side: the lane fetches the k chunk that
+    // belongs in its slot. Wave w issues instructions i = 0..3 for rows 32w + 8i .. + 8 of each operand.
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int l8 = lane >> 3, slot = lane & 7;
+    const int ch0 = slot ^ (lane >> 4), ch1 = slot ^ (4 + (lane >> 4));  // ((row >> 1) & 7) for even / odd i
+    const bf16* ga = A + (long)(32 * wave + l8) * p.lda;
+    const bf16* gb = B + (long)(32 * wave + l8) * p.ldb;
+    const long sa8 = 8 * p.lda, sb8 = 8 * p.ldb;
+    bf16* la = sA + (32 * wave) * BK;
+    bf16* lb = sB + (32 * wave) * BK;
+#define WIDE_GLDS(buf, k0)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                  \
+        const int ch_ = ((i_ & 1) ? ch1 : ch0) * 8 + (k0);                                                             \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga + i_ * sa8 + ch_), (lptr_t)(la + (buf) * BM * BK + i_ * 8 * BK), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb + i_ * sb8 + ch_), (lptr_t)(lb + (buf) * BN * BK + i_ * 8 * BK), 16, 0, 0); \
+    }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -86,12 +103,13 @@ __global__ __launch_bounds__(GT) void gemm_bt_kernel(GemmP p, Epi epi) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    WIDE_GLDS(0, 0)
+    __syncthreads();  // (drains vmcnt: the tile has landed)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const int kn = min(kt + 1, nk - 1) * BK;  // the last step re-loads its own tile instead of branching
+        // buf ^ 1 was last read in step kt - 1, which every wave has left (barrier below)
+        WIDE_GLDS(buf ^ 1, kn)
         const bf16* a_s = sA + buf * BM * BK;
         const bf16* b_s = sB + buf * BN * BK;
 #pragma unroll
@@ -110,24 +128,24 @@ __global__ __launch_bounds__(GT) void gemm_bt_kernel(GemmP p, Epi epi) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // vmcnt(0) + barrier: the next tile is in LDS, this one is free
     }
+#undef WIDE_GLDS
     // acc[i][j][r]: row = row0 + wm*64 + 16i + lr, col = col0 + wn*64 + 16j + 4lg + r
-    epi(acc, row0 + wm * 64 + lr, col0 + wn * 64 + 4 * lg, set, ks, p);
+    epi(acc, row0 + wm * 64 + lr, col0 + wn * 64 + 4 * lg, set, ks, p.M, p.Nc);
 }
 
-// ---- epilogues: operator()(acc, row_base, col_base, set, ks, p); element (i, j, r) -> (row_base + 16i, col_base + 16j + r)
+// ---- epilogues: operator()(acc, row_base, col_base, set, ks, M, Nc); element (i, j, r) -> (row_base + 16i, col_base + 16j + r)
 struct EpiStoreF32 {  // plain D (tests)
     float* D;
     long ldd, setD;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = rb + 16 * i, col = cb + 16 * j;
-                if (row < p.M && col < p.Nc) *(f32x4*)(D + (long)set * setD + (long)row * ldd + col) = acc[i][j];
+                if (row < M && col < Nc) *(f32x4*)(D + (long)set * setD + (long)row * ldd + col) = acc[i][j];
             }
     }
 };
@@ -137,17 +155,17 @@ struct EpiFwd {  // out = relu(acc + bias[col]) as bf16
     long ldo, setO;
     const float* bias;  // [sets][setBias]
     long setBias;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
         const float* b = bias + (long)set * setBias;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = cb + 16 * j;
-            if (col >= p.Nc) continue;
+            if (col >= Nc) continue;
             const f32x4 bv = *(const f32x4*)(b + col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rb + 16 * i;
-                if (row >= p.M) continue;
+                if (row >= M) continue;
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[i][j][r] + bv[r], 0.f);
@@ -157,6 +175,7 @@ struct EpiFwd {  // out = relu(acc + bias[col]) as bf16
     }
 };
 
+constexpr int NSLICE = 32;
 // BatchNorm(inference form) + ReLU backward of the layer below: dy = acc; dz = dy * inv * (p > 0);
 // dgamma[c] += sum_rows dy (p - mean) rs; dbeta[c] += sum_rows dy.   Columns are offset by c_off in all tables.
 struct EpiDx {
@@ -164,22 +183,22 @@ struct EpiDx {
     bf16* dZ;
     long ldp, setP;
     const float *inv, *rs, *mean;  // [sets][setTab] tables over the concatenated features
-    float *dgamma, *dbeta;         // [sets][setTab] accumulators (or NULL)
-    long setTab;
+    float *dgamma, *dbeta;         // [NSLICE][sets][setTab] accumulators (or NULL): row tile t adds into slice t % NSLICE
+    long setTab, sliceStride;      // (thousands of row tiles adding into one address would serialise)
     int c_off;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, const GemmP& p) const {
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
         const long tb = (long)set * setTab + c_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = cb + 16 * j;
-            const bool cok = col < p.Nc;
+            const bool cok = col < Nc;
             f32x4 iv = {0, 0, 0, 0}, rsv = iv, mv = iv;
             if (cok) iv = *(const f32x4*)(inv + tb + col), rsv = *(const f32x4*)(rs + tb + col), mv = *(const f32x4*)(mean + tb + col);
             float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rb + 16 * i;
-                if (!cok || row >= p.M) continue;
+                if (!cok || row >= M) continue;
                 const long o = (long)set * setP + (long)row * ldp + c_off + col;
                 const bf16x4 pv = *(const bf16x4*)(P + o);
                 bf16x4 dz;
@@ -199,10 +218,11 @@ struct EpiDx {
                     for (int o = 1; o < 16; o <<= 1) sg[r] += __shfl_xor(sg[r], o), sb[r] += __shfl_xor(sb[r], o);
                 }
                 if ((threadIdx.x & 15) == 0 && cok) {
+                    const long so = (long)((rb >> 7) & (NSLICE - 1)) * sliceStride + tb + col;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        atomicAdd(dgamma + tb + col + r, sg[r]);
-                        atomicAdd(dbeta + tb + col + r, sb[r]);
+                        atomicAdd(dgamma + so + r, sg[r]);
+                        atomicAdd(dbeta + so + r, sb[r]);
                     }
                 }
             }
@@ -218,16 +238,16 @@ struct EpiDw {
     const float* db;        // [sets][setDb]
     long setTab, setDb;
     float scale;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int ks, const GemmP& p) const {
+    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int ks, int M, int Nc) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = rb + 16 * i;
-            if (row >= p.M) continue;
+            if (row >= M) continue;
             const float iv = inv[(long)set * setTab + row] * scale, sf = (ks == 0) ? sh[(long)set * setTab + row] * scale : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = cb + 16 * j;
-                if (col >= p.Nc) continue;
+                if (col >= Nc) continue;
                 const f32x4 dbv = *(const f32x4*)(db + (long)set * setDb + col);
                 float* o = dW + (long)set * setW + (long)row * ldw + col;
 #pragma unroll
@@ -245,7 +265,9 @@ static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st,
         (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((unsigned)rup(p.Nc, BN) / BN, (unsigned)rup(p.M, BM) / BM, (unsigned)(n_sets * p.ksplit));
+    const long ncol = rup(p.Nc, BN) / BN, nrow = rup(p.M, BM) / BM;
+    const long gsz = p.ksplit > 1 ? nrow * ncol : ncol, groups = p.ksplit > 1 ? p.ksplit : nrow;
+    dim3 grid((unsigned)(gsz * rup(groups, 8)), 1, (unsigned)n_sets);
     hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), lds, st, p, e);
     return check_launch(who);
 }
@@ -538,6 +560,19 @@ __global__ void out_grads_kernel(const float* th, long set_th, int w3_off, int H
     gs[gb2 + k] = cs[(long)set * set_u + k];
 }
 
+// first-layer dgamma / dbeta: sum the NSLICE partial tables into the gradient slab
+__global__ void bn1_flush_kernel(const float* dg, const float* dbe, long set_tab, long slice_stride, int t_off, int len, float* g,
+                                 long set_g, int gg, int gbe) {
+    const int set = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= len) return;
+    float a = 0.f, b = 0.f;
+    for (int sl = 0; sl < NSLICE; ++sl) {
+        const long o = (long)sl * slice_stride + (long)set * set_tab + t_off + k;
+        a += dg[o], b += dbe[o];
+    }
+    g[(long)set * set_g + gg + k] = a, g[(long)set * set_g + gbe + k] = b;
+}
+
 __global__ void losses_kernel(const float* acc, int Ns, int n_sets, float* losses) {
     const int set = threadIdx.x;
     if (set < n_sets && losses) {
@@ -573,6 +608,7 @@ struct Plan {
     size_t cf[4], c0[4];                             // output-layer coefficient vectors
     size_t q, y, dq, a1, tt, da;                     // row vectors [sets][Np]
     size_t u, cs, acc;                               // [sets][H2] x 2, [sets][4]
+    size_t bnacc;                                    // first-layer dgamma | dbeta partial tables [2][NSLICE][sets][ldT]
     size_t total;
     long ldT;  // table stride per set: KCp + H2
 };
@@ -601,6 +637,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets) {
     p.q = take(sets * Np * 4), p.y = take(sets * Np * 4), p.dq = take(sets * Np * 4), p.a1 = take(sets * Np * 4);
     p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4);
     p.u = take(sets * d.H2 * 4), p.cs = take(sets * d.H2 * 4), p.acc = take(sets * 4 * 4);
+    p.bnacc = take(2 * (size_t)NSLICE * sets * p.ldT * 4);
     p.total = o;
     return p;
 }
@@ -709,7 +746,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     bf16 *C = B16(pl.C), *CT = B16(pl.CT), *P2 = B16(pl.P2), *dZ2 = B16(pl.dZ2), *dZ2T = B16(pl.dZ2T), *dZ1 = B16(pl.dZ1);
     float *q = F32(pl.q), *y = F32(pl.y), *dq = F32(pl.dq), *a1 = F32(pl.a1), *tt = F32(pl.tt), *da = F32(pl.da);
     float *u = F32(pl.u), *cs = F32(pl.cs), *acc = F32(pl.acc);
-    const long setX = (long)Ns * L.S, setR = Ns;
+    const long setX = (long)Ns * L.S;
     const dim3 g64((unsigned)1, (unsigned)rup(Np, 64) / 64, sets);
 
     // first layer: states (S = 3 or 4) or actions (1) -> columns [c0, c0 + H)
@@ -773,7 +810,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                                (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
             // dW2 = inv (.) (C^T dZ2) + sh (x) db2: reduction over the rows, split into chunks with f32 atomics
             int ksplit = 1;
-            while (Np / ksplit > 4096 && Np % (ksplit * 2 * BK) == 0) ksplit *= 2;
+            while (Np / ksplit > 16384 && Np % (ksplit * 2 * BK) == 0) ksplit *= 2;  // f32 atomics cost ~ one MFMA K-chunk of 4096
             GemmP p = {CT, dZ2T, Np, Np, setCT, setZT, K, H2, Np / ksplit, ksplit};
             EpiDw e = {gnet + (critic ? L.cW2 : L.aW2), H2, (long)L.theta_size, n.inv, n.sh, cs, ldT, H2, 1.0f};
             WIDE_CHECK(launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: weight-gradient GEMM"));
@@ -783,10 +820,12 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // dX GEMM with the BN/ReLU backward of the first layer(s) over columns [c_begin, c_end)
     auto dx = [&](const NetOps& n, int c_begin, int c_end, bool wg, bool critic) {
         GemmP p = {dZ2, n.Wn + (long)c_begin * H2, H2, H2, setP2, setWn, Ns, c_end - c_begin, H2, 1};
-        EpiDx e = {C, dZ1, KCp, setC, n.inv, n.rs, n.mean, nullptr, nullptr, ldT, c_begin};
-        if (wg) {  // dgamma / dbeta of the first layers accumulate in table-shaped scratch, copied into the slab by flush_bn1
-            e.dgamma = F32(pl.tabs[2 + (critic ? 1 : 0)]);               // target-net tables are dead after pass 0
-            e.dbeta = e.dgamma + (long)sets * ldT;
+        EpiDx e = {C, dZ1, KCp, setC, n.inv, n.rs, n.mean, nullptr, nullptr, ldT, (long)sets * ldT, c_begin};
+        (void)critic;
+        if (wg) {  // dgamma / dbeta of the first layers accumulate in sliced table-shaped scratch, summed by flush_bn1
+            (void)hipMemsetAsync(ws + pl.bnacc, 0, sizeof(float) * 2 * NSLICE * sets * ldT, st);
+            e.dgamma = F32(pl.bnacc);
+            e.dbeta = e.dgamma + (long)NSLICE * sets * ldT;
         }
         return launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: input-gradient GEMM");
     };
@@ -803,21 +842,18 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             hipLaunchKernelGGL((l1_grads_kernel<3>), grid, dim3(256), 0, st, X, set_x, dZ1, (long)KCp, setC, c0, H, Ns, rpb, 1.0f, gnet,
                                (long)L.theta_size, w_off, b_off);
     };
-    // copy of the table-shaped dgamma/dbeta accumulators into the slab
     auto flush_bn1 = [&](bool critic, float* gnet) {
-        float* dg = F32(pl.tabs[2 + (critic ? 1 : 0)]);
-        float* dbe = dg + (long)sets * ldT;
-        for (int sidx = 0; sidx < sets; ++sidx) {
-            float* gs = gnet + (long)sidx * L.theta_size;
-            if (critic) {
-                (void)hipMemcpyAsync(gs + L.cgs, dg + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(gs + L.cbes, dbe + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(gs + L.cga, dg + sidx * ldT + H1, sizeof(float) * Ha, hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(gs + L.cbea, dbe + sidx * ldT + H1, sizeof(float) * Ha, hipMemcpyDeviceToDevice, st);
-            } else {
-                (void)hipMemcpyAsync(gs + L.ag1, dg + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(gs + L.abe1, dbe + sidx * ldT, sizeof(float) * H1, hipMemcpyDeviceToDevice, st);
-            }
+        const float* dg = F32(pl.bnacc);
+        const float* dbe = dg + (long)NSLICE * sets * ldT;
+        auto go = [&](int t_off, int len, int gg, int gbe) {
+            hipLaunchKernelGGL(bn1_flush_kernel, dim3((unsigned)rup(len, 256) / 256, sets), dim3(256), 0, st, dg, dbe, ldT,
+                               (long)sets * ldT, t_off, len, gnet, (long)L.theta_size, gg, gbe);
+        };
+        if (critic) {
+            go(0, H1, L.cgs, L.cbes);
+            go(H1, Ha, L.cga, L.cbea);
+        } else {
+            go(0, H1, L.ag1, L.abe1);
         }
     };
 
@@ -826,9 +862,6 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(critic_forward(net[3], s2, a1, (long)Np, false));
     (void)hipMemcpy2DAsync(da, sizeof(float) * Np, r, sizeof(float) * Ns, sizeof(float) * Ns, sets, hipMemcpyDeviceToDevice, st);
     rows(0, q, nullptr, da, gamma, y);
-    // the target nets' tables are dead now: they become the dgamma/dbeta accumulators of the first layers
-    (void)hipMemsetAsync(ws + pl.tabs[2], 0, sizeof(float) * 2 * sets * ldT, st);
-    (void)hipMemsetAsync(ws + pl.tabs[3], 0, sizeof(float) * 2 * sets * ldT, st);
 
     // ---- pass 1: critic loss and gradient                                                   (trainer.py:495-498)
     float* gcrit = grads + asz;
