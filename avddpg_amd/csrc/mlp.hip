@@ -1653,8 +1653,15 @@ extern "C" int avd_mlp_layout_init(avd_mlp_layout* o, int S, int A, int H1, int 
     return AVD_OK;
 }
 
-static int check_mlp_dims(const avd_mlp_layout* L, const char* who) {
+static int check_mlp_dims(const avd_mlp_layout* L, const char* who, bool rows_only = false) {
     AVD_REQUIRE(L, "%s: null layout", who);
+    if (rows_only) {  // batch-1 forward: plain GEMVs, any widths
+        if (L->A > gen::MAX_A || L->S > gen::MAX_S) {
+            set_error("%s: need S <= %d and A <= %d (got S=%d A=%d)", who, gen::MAX_S, gen::MAX_A, L->S, L->A);
+            return AVD_E_UNSUPPORTED;
+        }
+        return AVD_OK;
+    }
     if (L->A > gen::MAX_A || L->S > gen::MAX_S || (L->H1 % 16) || (L->Ha % 16) || (L->H2 % 32) || L->H2 > 16 * DX_NB) {
         set_error("%s: need S <= %d, A <= %d, H1 and Ha multiples of 16, H2 a multiple of 32 and <= %d (got S=%d A=%d "
                   "H1=%d H2=%d Ha=%d); pad the widths with zero units",
@@ -1667,7 +1674,7 @@ static int check_mlp_dims(const avd_mlp_layout* L, const char* who) {
 static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int set_mod, const float* theta,
                        const float* stats, const float* state, int x_stride, const float* action, float high,
                        float* out, void* stream, const char* who) {
-    int rc = check_mlp_dims(lay, who);
+    int rc = check_mlp_dims(lay, who, true);
     if (rc) return rc;
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0 && x_stride >= lay->S, "%s: n_agents=%d set_mod=%d x_stride=%d", who,
                 n_agents, set_mod, x_stride);

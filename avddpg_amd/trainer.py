@@ -64,7 +64,7 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
-                 pipeline_chunks=1, fused_update=False):
+                 pipeline_chunks=1, fused_update=False, shared_engine=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'."""
@@ -102,10 +102,23 @@ class VecTrainer:
         self.replay = vec.VecReplay(n_agents, conf.buffer_size, conf.batch_size, self.S, self.A, self.device, rng=rng,
                                     seed=seed)
         f32 = dict(dtype=torch.float32, device=self.device)
+        # Shared weight sets: "per_agent" = the f32 LDS-resident kernel per agent + fed_sum (exact f32, widths up to
+        # 256); "batched" = one learn over each set's P x 64 rows as bf16 MFMA GEMMs (csrc/wide.hip; any width multiple
+        # of 64, e.g. BASELINE config 5's 1024). Default: per_agent where it exists.
+        lay = self.agents.lay
+        fits = lay.H2 <= 256
+        self.shared_engine = shared_engine or ("batched" if (self.shared and not fits) else "per_agent")
+        if self.shared_engine not in ("per_agent", "batched"):
+            raise ValueError(f"shared_engine={shared_engine!r}")
+        if self.shared_engine == "batched" and not self.shared:
+            raise ValueError("the batched learner needs shared weight sets (interfrl + gradients, every step federated)")
+        if self.shared_engine == "batched" and conf.weighted_average_enabled:
+            raise ValueError("the batched learner computes the unweighted federated mean: set weighted_average_enabled=False")
         self.actor_out = torch.zeros(n_agents, self.A, **f32)
         self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)
-        self.grads = torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
+        batched = self.shared and self.shared_engine == "batched"  # no per-agent gradient slab (188 GB at hidden 1024)
+        self.grads = None if batched else torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
         self.losses = torch.zeros(n_agents, 2, **f32)
         self.ep_reward = torch.zeros(self.P, self.M, **f32)  # float32 accumulators (trainer.py:249, 321)
         self.all_ep_reward_lists = [[[] for _ in range(self.M)] for _ in range(self.P)]
@@ -210,8 +223,28 @@ class VecTrainer:
             self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,
                                     timers=self.timers)
             return
+        if self.shared and self.shared_engine == "batched":
+            self._timed("learn", self._learn_batched, s, a, r, s2)
+            self._timed("update", self.agents.apply, self.set_grads)
+            return
         self._timed("learn", self.agents.learn, s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
         self._timed("update", self._update, ep, i, fed)
+
+    def _learn_batched(self, s, a, r, s2):
+        """interfrl with every step federated, shared sets: Trainer.learn + federated mean (trainer.py:400-431) as ONE
+        learn over each set's P x B rows. The sampled batch is agent-major (agent v = p*M + m); the learner wants it
+        set-major. Across ranks the per-set means are combined like the per-agent path's sums (dist.exchange_fed_sums)."""
+        P, M, B = self.P, self.M, self.conf.batch_size
+        sm = lambda x: x.view(P, M, *x.shape[1:]).transpose(0, 1).reshape(M, P * B, *x.shape[2:]).contiguous()
+        if getattr(self, "set_grads", None) is None:
+            self.set_grads = torch.empty(M, self.agents.lay.theta_size, dtype=torch.float32, device=self.device)
+            self.set_losses = torch.zeros(M, 2, dtype=torch.float32, device=self.device)
+        self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses)
+        if self.group is not None:
+            from .dist import exchange_fed_sums
+            self.set_grads.mul_(float(P))  # local mean -> local sum over platoons
+            total = exchange_fed_sums(self.set_grads, None, P, self.group)
+            self.set_grads.div_(total)
 
     def _update(self, ep, i, fed):
         conf, P, M = self.conf, self.P, self.M

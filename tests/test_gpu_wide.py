@@ -98,3 +98,56 @@ def test_shared_learner_rejects_unsupported_shapes():
     z = torch.zeros(1, 64, 4, device="cuda")
     with pytest.raises(_hip.AvdError, match="multiples of 64"):
         grp.learn_shared(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 1)
+
+
+def test_trainer_batched_engine_tracks_per_agent_engine_under_interfrl():
+    """VecTrainer with shared weight sets: the batched bf16 learner against the exact f32 per-agent kernel + fed_sum,
+    same host RNG stream. Before the first update the trajectories are identical; afterwards they differ by bf16
+    rounding of the gradients, amplified by Adam's normalisation (|dw| <= lr per step either way)."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    P, L, steps = 6, 3, 72
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+    runs = []
+    for engine in ("per_agent", "batched"):
+        np.random.seed(11)
+        vt = trainer.VecTrainer(conf, rng="host", shared_sets=True, shared_engine=engine)
+        vt.reset_episode()
+        traj = []
+        for i in range(steps):
+            vt.step(0, i)
+            traj.append((vt.actions.cpu().numpy().copy(), vt.env.x.cpu().numpy().copy()))
+        runs.append((vt, traj))
+    (a, ta), (b, tb) = runs
+    assert b.grads is None and b.shared_engine == "batched" and a.updates == b.updates == (steps - 64) * P * L
+    for i in range(steps):
+        tol = 0.0 if i < 65 else 5e-3
+        assert np.abs(ta[i][0] - tb[i][0]).max() <= tol * 2.5, i
+        assert np.abs(ta[i][1] - tb[i][1]).max() <= tol * max(1.0, np.abs(ta[i][1]).max()), i
+    n_upd = steps - 64
+    for lr, lo, hi in ((conf.actor_lr, 0, a.agents.lay.actor_size), (conf.critic_lr, a.agents.lay.actor_size, a.agents.lay.theta_size)):
+        d = (a.agents.theta[:, lo:hi] - b.agents.theta[:, lo:hi]).abs()
+        assert d.max().item() <= 2 * lr * n_upd and d.mean().item() <= 0.1 * lr * n_upd
+    assert torch.isfinite(b.agents.theta).all() and int(b.agents.step[0]) == n_upd
+
+
+def test_trainer_runs_hidden_1024_with_shared_sets():
+    """BASELINE config 5's shape (actor/critic hidden = 1024) at a small platoon count: only the batched engine exists
+    for it (the LDS-resident kernel refuses H2 > 256 loudly)."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    conf = config.Config(num_platoons=8, pl_size=5, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False,
+                         actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024, critic_layer2_size=1024)
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=True)
+    assert vt.shared and vt.shared_engine == "batched" and vt.agents.n_sets == 5
+    th0 = vt.agents.theta.clone()
+    vt.reset_episode()
+    for _ in range(68):
+        vt.step()
+    torch.cuda.synchronize()
+    assert vt.updates == 4 * 40 and torch.isfinite(vt.agents.theta).all() and torch.isfinite(vt.env.x).all()
+    assert not torch.equal(vt.agents.theta, th0) and (vt.set_losses[:, 0] >= 0).all()
+    with pytest.raises(ValueError, match="shared weight sets"):
+        trainer.VecTrainer(config.Config(num_platoons=2, pl_size=2), rng="device", shared_engine="batched")
