@@ -603,6 +603,7 @@ struct Plan {
     Dims d;
     // byte offsets into the workspace
     size_t C, CT, P2, dZ2, dZ2T, dZ1;                // activations (all sets)
+    size_t aC, aCT, aP2;                             // the online actor's activations, kept from pass 2 to pass 3
     size_t WT[4], Wn[2], bias[4];                    // weights: 0 actor, 1 critic, 2 target actor, 3 target critic
     size_t tabs[4];                                  // per net: inv/sh/rs/mean tables of [KCp + H2] floats x 4
     size_t cf[4], c0[4];                             // output-layer coefficient vectors
@@ -613,11 +614,11 @@ struct Plan {
     long ldT;  // table stride per set: KCp + H2
 };
 
-static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets) {
+static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int rows_per_agent = 0) {
     Plan p;
     Dims& d = p.d;
     d.S = L.S, d.H1 = L.H1, d.H2 = L.H2, d.Ha = L.Ha, d.KC = L.H1 + L.Ha, d.KCp = (int)rup(d.KC, 64);
-    d.n_sets = n_sets, d.Ns = (n_agents / n_sets) * L.B, d.Np = (int)rup(d.Ns, 128);
+    d.n_sets = n_sets, d.Ns = (n_agents / n_sets) * (rows_per_agent ? rows_per_agent : L.B), d.Np = (int)rup(d.Ns, 128);
     d.theta_size = L.theta_size, d.stats_size = L.stats_size;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -630,6 +631,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets) {
     p.C = take(sets * Np * KCp * 2), p.CT = take(sets * KCn * Np * 2);
     p.P2 = take(sets * Np * d.H2 * 2), p.dZ2 = take(sets * Np * d.H2 * 2), p.dZ2T = take(sets * H2n * Np * 2);
     p.dZ1 = take(sets * Np * KCp * 2);
+    p.aC = take(sets * Np * KCp * 2), p.aCT = take(sets * KCn * Np * 2), p.aP2 = take(sets * Np * d.H2 * 2);
     for (int i = 0; i < 4; ++i) p.WT[i] = take(sets * H2n * KCp * 2), p.bias[i] = take(sets * d.H2 * 4);
     for (int i = 0; i < 2; ++i) p.Wn[i] = take(sets * KCn * d.H2 * 2);
     p.ldT = KCp + d.H2;
@@ -744,6 +746,10 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(check_launch("avd_learn_shared_bf16: operand preparation"));
 
     bf16 *C = B16(pl.C), *CT = B16(pl.CT), *P2 = B16(pl.P2), *dZ2 = B16(pl.dZ2), *dZ2T = B16(pl.dZ2T), *dZ1 = B16(pl.dZ1);
+    // the lambdas below work on whichever activation buffers C / CT / P2 currently point to
+    auto use_actor_buffers = [&](bool yes) {
+        C = B16(yes ? pl.aC : pl.C), CT = B16(yes ? pl.aCT : pl.CT), P2 = B16(yes ? pl.aP2 : pl.P2);
+    };
     float *q = F32(pl.q), *y = F32(pl.y), *dq = F32(pl.dq), *a1 = F32(pl.a1), *tt = F32(pl.tt), *da = F32(pl.da);
     float *u = F32(pl.u), *cs = F32(pl.cs), *acc = F32(pl.acc);
     const long setX = (long)Ns * L.S;
@@ -874,8 +880,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     flush_bn1(true, gcrit);
 
     // ---- pass 2: actor through the critic, gradient w.r.t. the action                       (trainer.py:502-506)
-    WIDE_CHECK(actor_forward(net[0], s, false));
-    WIDE_CHECK(critic_forward(net[1], s, a1, (long)Np, false));
+    use_actor_buffers(true);
+    WIDE_CHECK(actor_forward(net[0], s, true));  // activations and transposes stay for pass 3
+    use_actor_buffers(false);
+    // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
+    l1(net[1], true, true, a1, (long)Np, false);
+    WIDE_CHECK(l2(net[1], true));
+    out_layer(net[1], 0, q);
     rows(2, q, nullptr, nullptr, 0.f, dq);
     WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
     WIDE_CHECK(dx(net[1], H1, KC, false, true));
@@ -883,8 +894,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,
                        net[1].th + L.cWa, (long)L.theta_size, (const float*)nullptr, Ns, 0, 0.f, da, (float*)nullptr, (long)Np);
 
-    // ---- pass 3: actor forward again (activations + transposes kept this time) and its gradient
-    WIDE_CHECK(actor_forward(net[0], s, true));
+    // ---- pass 3: actor gradient from the activations kept in pass 2
+    use_actor_buffers(true);
     rows(3, nullptr, tt, da, high, dq);
     WIDE_CHECK(backward(net[0], false, dq, true, 3, grads));
     WIDE_CHECK(dx(net[0], 0, H1, true, false));
@@ -892,4 +903,58 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     flush_bn1(false, grads);
     hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(64), 0, st, acc, Ns, sets, losses);
     return check_launch("avd_learn_shared_bf16");
+}
+
+// ---- acting with shared weight sets: actor(state) for every agent of a set as one GEMM chain ---------------
+extern "C" int avd_actor_forward_shared_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes) {
+    int rc = check_wide(lay, n_agents, n_sets, "avd_actor_forward_shared_workspace");
+    if (rc) return rc;
+    AVD_REQUIRE(bytes, "avd_actor_forward_shared_workspace: null pointer");
+    *bytes = make_plan(*lay, n_agents, n_sets, 1).total;
+    return AVD_OK;
+}
+
+extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta,
+                                             const float* stats, const float* state, float high, float* out, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    int rc = check_wide(lay, n_agents, n_sets, "avd_actor_forward_shared_bf16");
+    if (rc) return rc;
+    AVD_REQUIRE(theta && stats && state && out && workspace, "avd_actor_forward_shared_bf16: null pointer");
+    const avd_mlp_layout& L = *lay;
+    const Plan pl = make_plan(L, n_agents, n_sets, 1);
+    AVD_REQUIRE(workspace_bytes >= pl.total, "avd_actor_forward_shared_bf16: workspace %zu B < %zu B", workspace_bytes, pl.total);
+    const Dims& d = pl.d;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    const int sets = n_sets, Ns = d.Ns, Np = d.Np, H1 = d.H1, H2 = d.H2, KCp = d.KCp;
+    const long H2n = rup(H2, 128), ldT = pl.ldT, setC = (long)Np * KCp, setP2 = (long)Np * H2, setWT = H2n * KCp;
+    float* tab = (float*)(ws + pl.tabs[0]);
+    float *inv = tab, *sh = tab + (long)sets * ldT, *rs = tab + 2L * sets * ldT, *mean = tab + 3L * sets * ldT;
+    bf16 *C = (bf16*)(ws + pl.C), *P2 = (bf16*)(ws + pl.P2), *WT = (bf16*)(ws + pl.WT[0]);
+    float *bias = (float*)(ws + pl.bias[0]), *cf = (float*)(ws + pl.cf[0]), *c0 = (float*)(ws + pl.c0[0]), *tt = (float*)(ws + pl.tt);
+    auto tables = [&](int g, int be, int mm, int mv, int len, int t_off, int pad_to) {
+        hipLaunchKernelGGL(bn_tables_kernel, dim3((unsigned)rup(pad_to, 256) / 256, sets), dim3(256), 0, st, theta, stats,
+                           (long)L.theta_size, (long)L.stats_size, g, be, mm, mv, len, inv, sh, rs, mean, ldT, t_off, pad_to);
+    };
+    tables(L.ag1, L.abe1, L.amm1, L.amv1, H1, 0, KCp);
+    tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
+    hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, theta,
+                       (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L);
+    hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW2, L.ab2,
+                       H1, H2, sh, ldT, bias, (long)H2);
+    hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW3, L.ab3, H2, inv + KCp, sh + KCp,
+                       ldT, cf, c0, (long)H2);
+    dim3 grid((unsigned)rup(H1, 64) / 64, (unsigned)rup(Np, 64) / 64, sets);
+    if (L.S == 4)
+        hipLaunchKernelGGL((l1_fwd_kernel<4>), grid, dim3(256), 0, st, state, (long)Ns * 4, theta, (long)L.theta_size, L.aW1, L.ab1, H1, H1,
+                           0, Ns, Np, C, (long)KCp, setC, (bf16*)nullptr, 0L, 0L);
+    else
+        hipLaunchKernelGGL((l1_fwd_kernel<3>), grid, dim3(256), 0, st, state, (long)Ns * 3, theta, (long)L.theta_size, L.aW1, L.ab1, H1, H1,
+                           0, Ns, Np, C, (long)KCp, setC, (bf16*)nullptr, 0L, 0L);
+    GemmP p = {C, WT, KCp, KCp, setC, setWT, Ns, H2, (int)rup(H1, 64), 1};
+    EpiFwd e = {P2, H2, setP2, bias, H2};
+    WIDE_CHECK(launch_gemm(p, e, sets, st, "avd_actor_forward_shared_bf16: forward GEMM"));
+    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, P2, (long)H2, setP2, 0, H2, cf, (long)H2, c0,
+                       Ns, 1, high, out, tt, (long)Ns);
+    return check_launch("avd_actor_forward_shared_bf16");
 }

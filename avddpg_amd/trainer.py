@@ -160,7 +160,14 @@ class VecTrainer:
         """advance_environment (trainer.py:282-302): actor -> OU noise -> clip, leader exog, env step."""
         conf, P, M = self.conf, self.P, self.M
         states = self.env.x.view(P * M, self.x_stride)
-        self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out)
+        if self.shared and self.shared_engine == "batched" and self.agents.lay.H2 > 256:
+            # wide shared sets: every agent re-reading its set's megabytes of weights is the wrong shape; one GEMM
+            # chain per set instead (bf16 operands, like this engine's learner)
+            sm = self.env.x.view(P, M, 4)[..., :self.S].transpose(0, 1).contiguous()  # set-major [M, P, S]
+            o = self.agents.actor_shared(sm, P * M)
+            self.actor_out.copy_(o.transpose(0, 1).reshape(P * M, 1))
+        else:
+            self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out)
         if self.rng == "host":
             # reference draw order per platoon: M OU normals, then the leader exog (trainer.py:286-295)
             normals = np.empty((P, M))

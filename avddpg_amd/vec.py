@@ -312,6 +312,22 @@ class AgentGroup:
              ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
+    def actor_shared(self, states_set_major, n_agents, out=None):
+        """actor(state) for agents sharing this group's weight sets as one bf16 GEMM chain per set (csrc/wide.hip):
+        states [n_sets, rows, S] set-major, tightly packed -> [n_sets, rows]."""
+        import ctypes
+        rows = n_agents // self.n_sets
+        if out is None:
+            out = torch.empty(self.n_sets, rows, dtype=torch.float32, device=self.device)
+        need = ctypes.c_size_t(0)
+        call("avd_actor_forward_shared_workspace", self._layp, n_agents, self.n_sets, ctypes.byref(need))
+        ws = getattr(self, "_wide_act_ws", None)
+        if ws is None or ws.numel() < need.value:
+            ws = self._wide_act_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        call("avd_actor_forward_shared_bf16", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
+             ptr(states_set_major), self.high, ptr(out), ptr(ws), ws.numel(), stream_handle())
+        return out
+
     def apply(self, grads):
         """critic Adam, actor Adam, then Polyak (workers/trainer.py:348-356) for every weight set."""
         c = self.config

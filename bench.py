@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure is 2:1 sparse)
 LEARN_FLOP_PER_SAMPLE = 0.751e6  # 5 forwards + 2 backwards per replay sample
 ADAM_BYTES_PER_AGENT = 2.47e6  # r/w of W, W_target, m, v per agent-update
 
@@ -37,6 +38,11 @@ def parse():
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
     ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
+    ap.add_argument("--engine", choices=["per_agent", "batched"], default=None,
+                    help="interfrl: per_agent = f32 LDS-resident learn kernel per agent + federated sum; batched = one "
+                         "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist)")
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="actor/critic layer1 = layer2 size (BASELINE config 5: 1024; needs --mode interfrl)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-fused", action="store_true",
@@ -105,9 +111,13 @@ def main():
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
                          fed_method="interfrl" if args.mode == "interfrl" else "normal",
                          weighted_average_enabled=False, random_seed=1 + rank)
+    if args.hidden:
+        conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
                             seed=1 + rank, pipeline_chunks=args.chunks,
-                            fused_update=(args.mode == "nofrl" and not args.no_fused))
+                            fused_update=(args.mode == "nofrl" and not args.no_fused),
+                            shared_engine=args.engine if args.mode == "interfrl" else None)
+    batched = vt.shared and vt.shared_engine == "batched"
     # synthetic steady state: replay rings full of random-init-platoon-like rows
     ring = vt.replay.ring
     chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
@@ -161,6 +171,16 @@ def main():
         hb = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / t / 1e9,
               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roofs = [mf, hb]
+    elif batched:
+        # shared-set learner: the GEMM FLOPs of the chain (forward x6, weight-gradient x2, input-gradient x3) over the
+        # whole learn stage (GEMMs + the bandwidth-bound row/column kernels between them), against the dense bf16 peak
+        lay = vt.agents.lay
+        H1, H2, KC, rows = lay.H1, lay.H2, lay.H1 + lay.Ha, 64 * n_agents
+        flops = 2.0 * rows * H2 * ((3 * H1 + 3 * KC) + (KC + H1) + (KC + lay.Ha + H1))
+        learn_s = stage_ms["learn"] / 1e3
+        roofs.append({"kernel": "avd_learn_shared_bf16 (gemm_bt_kernel x11 + row/column kernels)", "bound": "mfma",
+                      "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                      "_t": learn_s})
     else:
         learn_s = stage_ms["learn"] / 1e3
         upd_s = stage_ms["update"] / 1e3
@@ -205,12 +225,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32",
             "data": "synthetic",
             "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
                                    + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
                                       if args.mode == "nofrl" else
-                                      "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads")
+                                      "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
+                                      + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else "")))
                                    + f", B=64, replay capacity {args.buffer_size} (full), 1 update per env step",
                        "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": args.mode,
                        "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
@@ -218,7 +239,8 @@ def main():
             "stages_ms": stage_ms,
             "pipeline": ("fused learn+Adam+Polyak kernel (avd_learn_update_f32)" if fused else
                          (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
-                          "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else "serial"),
+                          "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else
+                         ("batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
             "kernels": [r for r in (roof_learn, roof_upd) if r],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -230,6 +230,14 @@ int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, c
                           const float* s2, float gamma, float high, float* grads, float* losses, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* actor(state) (agent/model.py:26-36, workers/trainer.py:286-289) for agents that share n_sets weight sets, as the same
+ * bf16 GEMM chain: state [n_sets][rows][S] SET-MAJOR (rows = n_agents / n_sets, tightly packed S floats per row),
+ * out [n_sets][rows] = tanh(.) * high. */
+int avd_actor_forward_shared_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
+int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta,
+                                  const float* stats, const float* state, float high, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* D[M][Nc] (f32, ldd) = A[M][K] . B[Nc][K]^T with bf16 operands (K contiguous, K % 64 == 0) and f32 accumulation: the
  * GEMM under avd_learn_shared_bf16, exposed for parity tests. A and B must be readable up to the next multiple of 128
  * rows. */

@@ -151,3 +151,17 @@ def test_trainer_runs_hidden_1024_with_shared_sets():
     assert not torch.equal(vt.agents.theta, th0) and (vt.set_losses[:, 0] >= 0).all()
     with pytest.raises(ValueError, match="shared weight sets"):
         trainer.VecTrainer(config.Config(num_platoons=2, pl_size=2), rng="device", shared_engine="batched")
+
+
+def test_shared_actor_forward_matches_per_agent_rows_kernel():
+    """Acting with shared sets as a GEMM chain (bf16 operands) vs the f32 batch-1 kernel: tanh(.)*high within 2e-2 * high."""
+    need_gpu()
+    P, M, S = 37, 3, 4
+    conf, grp = _perturbed_group(M, S=S, seed=81, actor_layer1_size=512, actor_layer2_size=320, critic_layer1_size=512,
+                                 critic_layer2_size=320)
+    rs = np.random.RandomState(82)
+    x = rs.normal(0, 1.5, size=(P * M, S)).astype(np.float32)  # agent v = p*M + m
+    ref = grp.actor(t(x), set_mod=M).cpu().numpy()
+    sm = t(np.ascontiguousarray(x.reshape(P, M, S).swapaxes(0, 1)))
+    got = grp.actor_shared(sm, P * M).cpu().numpy().T.reshape(-1)
+    assert np.abs(ref).max() > 0.05 and np.abs(got - ref).max() <= 2e-2 * 2.5
