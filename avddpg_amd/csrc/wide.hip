@@ -132,16 +132,102 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 #undef WIDE_GLDS
     // acc[i][j][r]: row = row0 + wm*64 + 16i + lr, col = col0 + wn*64 + 16j + 4lg + r
-    epi(acc, row0 + wm * 64 + lr, col0 + wn * 64 + 4 * lg, set, ks, p.M, p.Nc);
+    epi.template operator()<4>(acc, row0 + wm * 64 + lr, col0 + wn * 64 + 4 * lg, set, ks, p.M, p.Nc);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The same GEMM for large problems: 256x256 macro tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave. The 128^2 kernel
+// above moves 1 operand byte per 64 FLOP from L2 into LDS and saturates the L2 -> LDS path at ~0.7 PFLOP/s; this tile
+// halves the bytes per FLOP. One workgroup per CU (96 KiB of LDS), so nothing else hides a drained pipeline: K steps
+// of 32 through THREE LDS stages, the loads of two steps stay in flight across the barrier (counted vmcnt, raw
+// s_barrier -- __syncthreads() would wait for vmcnt(0)).
+// LDS rows are 64 B (4 chunks of 16 B); chunk' = chunk ^ 2*bit2(row) is conflict-free for the (non-contiguous) 16-lane
+// groups ds_read_b128 is serviced in (MI355X_MICROARCH.md, LDS table; checked by enumeration). One global_load_lds wave
+// instruction fills 16 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int TM = 256, TN = 256, TK = 32, TT = 512, NSTG = 3;
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * TK + ((chunk ^ (((row >> 2) & 1) << 1)) << 3); }
+
+template <class Epi>
+__global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bt256_kernel(GemmP p, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* sA = (bf16*)smem_raw;         // [NSTG][TM*TK]
+    bf16* sB = sA + NSTG * TM * TK;     // [NSTG][TN*TK]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ncol = (p.Nc + TN - 1) / TN, nrow = (p.M + TM - 1) / TM;
+    const int gsz = (p.ksplit > 1) ? nrow * ncol : ncol;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int grp = (jj / gsz) * 8 + xcd, tin = jj - (jj / gsz) * gsz;
+    const int set = blockIdx.z;
+    int ks = 0, rt = grp, ct = tin;
+    if (p.ksplit > 1) ks = grp, rt = tin / ncol, ct = tin - rt * ncol;
+    if (ks >= p.ksplit || rt >= nrow) return;
+    const int row0 = rt * TM, col0 = ct * TN;
+    const bf16* A = p.A + (long)set * p.setA + (long)row0 * p.lda + (long)ks * p.K;
+    const bf16* B = p.B + (long)set * p.setB + (long)col0 * p.ldb + (long)ks * p.K;
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // wave w fills rows 32w .. 32w+31 of each operand: 2 instructions of 16 rows; lane -> row l / 4, slot l % 4
+    const int l4 = lane >> 2, slot = lane & 3;
+    const int chs = (slot ^ (((l4 >> 2) & 1) << 1)) * 8;  // bit 2 of row = 32w + 16i + l4 is bit 2 of l4
+    const bf16* ga = A + (long)(32 * wave + l4) * p.lda + chs;
+    const bf16* gb = B + (long)(32 * wave + l4) * p.ldb + chs;
+    const long sa16 = 16 * p.lda, sb16 = 16 * p.ldb;
+    bf16* la = sA + (32 * wave) * TK;
+    bf16* lb = sB + (32 * wave) * TK;
+#define WIDE_GLDS3(stg, k0)                                                                                                    \
+    {                                                                                                                          \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga + (k0)), (lptr_t)(la + (stg) * TM * TK), 16, 0, 0);                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga + sa16 + (k0)), (lptr_t)(la + (stg) * TM * TK + 16 * TK), 16, 0, 0);      \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb + (k0)), (lptr_t)(lb + (stg) * TN * TK), 16, 0, 0);                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb + sb16 + (k0)), (lptr_t)(lb + (stg) * TN * TK + 16 * TK), 16, 0, 0);      \
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / TK;
+    WIDE_GLDS3(0, 0)
+    WIDE_GLDS3(1, min(1, nk - 1) * TK)
+    int stg = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // step kt's 4 loads are the oldest in flight; the 4 of step kt+1 may stay in flight
+        __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4), expcnt/lgkmcnt untouched
+        __builtin_amdgcn_s_barrier();        // every wave's share of step kt has landed; everyone has left step kt-1
+        const int nstg = (stg + 2 >= NSTG) ? stg + 2 - NSTG : stg + 2;
+        WIDE_GLDS3(nstg, min(kt + 2, nk - 1) * TK)  // into the stage read in step kt-1; (tail: harmless re-loads)
+        const bf16* a_s = sA + stg * TM * TK;
+        const bf16* b_s = sB + stg * TN * TK;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_s + swz32(wm * 128 + 16 * i + lr, lg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_s + swz32(wn * 64 + 16 * j + lr, lg));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        stg = (stg + 1 == NSTG) ? 0 : stg + 1;
+    }
+#undef WIDE_GLDS3
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the tail re-loads before the workgroup's LDS is released
+    epi.template operator()<8>(acc, row0 + wm * 128 + lr, col0 + wn * 64 + 4 * lg, set, ks, p.M, p.Nc);
 }
 
 // ---- epilogues: operator()(acc, row_base, col_base, set, ks, M, Nc); element (i, j, r) -> (row_base + 16i, col_base + 16j + r)
 struct EpiStoreF32 {  // plain D (tests)
     float* D;
     long ldd, setD;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
+    template <int MI>
+    __device__ void operator()(f32x4 (&acc)[MI][4], int rb, int cb, int set, int, int M, int Nc) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = rb + 16 * i, col = cb + 16 * j;
@@ -150,26 +236,48 @@ struct EpiStoreF32 {  // plain D (tests)
     }
 };
 
-struct EpiFwd {  // out = relu(acc + bias[col]) as bf16
+struct EpiFwd {  // out = relu(acc + bias[col]) as bf16; optionally the width-1 output layer on top: z[row] += out[row][:] . cf[:]
     bf16* out;
     long ldo, setO;
     const float* bias;  // [sets][setBias]
     long setBias;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
+    const float* cf;    // [sets][setBias] output-layer coefficients (BN folded) or NULL
+    float* z;           // [sets][setZ], pre-filled with the constant term; f32 atomics (16 partial sums per row at H2 = 1024)
+    long setZ;
+    template <int MI>
+    __device__ void operator()(f32x4 (&acc)[MI][4], int rb, int cb, int set, int, int M, int Nc) const {
         const float* b = bias + (long)set * setBias;
+        float dot[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dot[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = cb + 16 * j;
             if (col >= Nc) continue;
             const f32x4 bv = *(const f32x4*)(b + col);
+            f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+            if (cf) cv = *(const f32x4*)(cf + (long)set * setBias + col);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int row = rb + 16 * i;
                 if (row >= M) continue;
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaxf(acc[i][j][r] + bv[r], 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (bf16)fmaxf(acc[i][j][r] + bv[r], 0.f);
+                    dot[i] = fmaf((float)o[r], cv[r], dot[i]);  // the stored (rounded) activation, as the backward pass sees it
+                }
                 *(bf16x4*)(out + (long)set * setO + (long)row * ldo + col) = o;
+            }
+        }
+        if (cf) {  // lanes lr, lr+16, lr+32, lr+48 hold the same rows: one atomic per row per wave
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float d = dot[i];
+                d += __shfl_xor(d, 16);
+                d += __shfl_xor(d, 32);
+                const int row = rb + 16 * i;
+                if ((threadIdx.x & 63) < 16 && row < M) atomicAdd(z + (long)set * setZ + row, d);
             }
         }
     }
@@ -186,7 +294,8 @@ struct EpiDx {
     float *dgamma, *dbeta;         // [NSLICE][sets][setTab] accumulators (or NULL): row tile t adds into slice t % NSLICE
     long setTab, sliceStride;      // (thousands of row tiles adding into one address would serialise)
     int c_off;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int, int M, int Nc) const {
+    template <int MI>
+    __device__ void operator()(f32x4 (&acc)[MI][4], int rb, int cb, int set, int, int M, int Nc) const {
         const long tb = (long)set * setTab + c_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -196,7 +305,7 @@ struct EpiDx {
             if (cok) iv = *(const f32x4*)(inv + tb + col), rsv = *(const f32x4*)(rs + tb + col), mv = *(const f32x4*)(mean + tb + col);
             float sg[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int row = rb + 16 * i;
                 if (!cok || row >= M) continue;
                 const long o = (long)set * setP + (long)row * ldp + c_off + col;
@@ -238,9 +347,10 @@ struct EpiDw {
     const float* db;        // [sets][setDb]
     long setTab, setDb;
     float scale;
-    __device__ void operator()(f32x4 (&acc)[4][4], int rb, int cb, int set, int ks, int M, int Nc) const {
+    template <int MI>
+    __device__ void operator()(f32x4 (&acc)[MI][4], int rb, int cb, int set, int ks, int M, int Nc) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int row = rb + 16 * i;
             if (row >= M) continue;
             const float iv = inv[(long)set * setTab + row] * scale, sf = (ks == 0) ? sh[(long)set * setTab + row] * scale : 0.f;
@@ -259,16 +369,23 @@ struct EpiDw {
 
 template <class Epi>
 static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st, const char* who) {
-    const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16);  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * (BM + BN) * BK * sizeof(bf16)));
+        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(NSTG * (TM + TN) * TK * sizeof(bf16)));
         attr_set = true;
     }
-    const long ncol = rup(p.Nc, BN) / BN, nrow = rup(p.M, BM) / BM;
+    const bool big = p.M >= 2 * TM && p.Nc >= 2 * TN && !getenv("AVD_GEMM_128");  // large problems: 256^2 tiles
+    const int tm = big ? TM : BM, tn = big ? TN : BN;
+    const long ncol = rup(p.Nc, tn) / tn, nrow = rup(p.M, tm) / tm;
     const long gsz = p.ksplit > 1 ? nrow * ncol : ncol, groups = p.ksplit > 1 ? p.ksplit : nrow;
     dim3 grid((unsigned)(gsz * rup(groups, 8)), 1, (unsigned)n_sets);
-    hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), lds, st, p, e);
+    if (big)
+        hipLaunchKernelGGL((gemm_bt256_kernel<Epi>), grid, dim3(TT), NSTG * (TM + TN) * TK * sizeof(bf16), st, p, e);
+    else
+        hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), 2 * (BM + BN) * BK * sizeof(bf16), st, p, e);
     return check_launch(who);
 }
 
@@ -488,6 +605,20 @@ __global__ __launch_bounds__(256) void l1_grads_kernel(const float* X, long set_
 // mode 1: d = 2 (q - y) / N, acc[set][0] += (y - q)^2, acc[set][1] += d      (critic loss seed)
 // mode 2: d = -1 / N,        acc[set][2] += q                                   (actor loss seed)
 // mode 3: d = da * high * (1 - t^2), acc[set][3] += d                           (through tanh * high)
+// z[set][n] = c0[set] (the output layer's constant term; the forward GEMM's epilogue adds the dot products)
+__global__ void fill_rows_kernel(float* z, long set_z, const float* c0, int Np) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < Np) z[(long)blockIdx.y * set_z + n] = c0[blockIdx.y];
+}
+// actor head: a = tanh(z) * high, t = tanh(z)
+__global__ void tanh_rows_kernel(const float* z, long set_z, int Ns, float high, float* a, float* t) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= Ns) return;
+    const long o = (long)blockIdx.y * set_z + n;
+    const float th = tanhf(z[o]);
+    a[o] = th * high, t[o] = th;
+}
+
 __global__ __launch_bounds__(256) void rows_kernel(int mode, int Ns, long set_o, const float* q, const float* y_or_t,
                                                     const float* r_or_da, float gamma_or_high, float* out, float* acc) {
     const int set = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -607,7 +738,7 @@ struct Plan {
     size_t WT[4], Wn[2], bias[4];                    // weights: 0 actor, 1 critic, 2 target actor, 3 target critic
     size_t tabs[4];                                  // per net: inv/sh/rs/mean tables of [KCp + H2] floats x 4
     size_t cf[4], c0[4];                             // output-layer coefficient vectors
-    size_t q, y, dq, a1, tt, da;                     // row vectors [sets][Np]
+    size_t q, y, dq, a1, tt, da, zbuf;               // row vectors [sets][Np]
     size_t u, cs, acc;                               // [sets][H2] x 2, [sets][4]
     size_t bnacc;                                    // first-layer dgamma | dbeta partial tables [2][NSLICE][sets][ldT]
     size_t total;
@@ -618,7 +749,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int row
     Plan p;
     Dims& d = p.d;
     d.S = L.S, d.H1 = L.H1, d.H2 = L.H2, d.Ha = L.Ha, d.KC = L.H1 + L.Ha, d.KCp = (int)rup(d.KC, 64);
-    d.n_sets = n_sets, d.Ns = (n_agents / n_sets) * (rows_per_agent ? rows_per_agent : L.B), d.Np = (int)rup(d.Ns, 128);
+    d.n_sets = n_sets, d.Ns = (n_agents / n_sets) * (rows_per_agent ? rows_per_agent : L.B), d.Np = (int)rup(d.Ns, 256);
     d.theta_size = L.theta_size, d.stats_size = L.stats_size;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -627,7 +758,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int row
         return at;
     };
     const size_t sets = n_sets, Np = d.Np;
-    const size_t KCn = rup(d.KC, 128) + 128, H2n = rup(d.H2, 128), KCp = d.KCp;  // +128: dX tiles start at column H1
+    const size_t KCn = rup(d.KC, 256) + 256, H2n = rup(d.H2, 256), KCp = d.KCp;  // + a tile: dX tiles may start at column H1
     p.C = take(sets * Np * KCp * 2), p.CT = take(sets * KCn * Np * 2);
     p.P2 = take(sets * Np * d.H2 * 2), p.dZ2 = take(sets * Np * d.H2 * 2), p.dZ2T = take(sets * H2n * Np * 2);
     p.dZ1 = take(sets * Np * KCp * 2);
@@ -637,7 +768,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int row
     p.ldT = KCp + d.H2;
     for (int i = 0; i < 4; ++i) p.tabs[i] = take(sets * p.ldT * 4 * 4), p.cf[i] = take(sets * d.H2 * 4), p.c0[i] = take(sets * 4);
     p.q = take(sets * Np * 4), p.y = take(sets * Np * 4), p.dq = take(sets * Np * 4), p.a1 = take(sets * Np * 4);
-    p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4);
+    p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4), p.zbuf = take(sets * Np * 4);
     p.u = take(sets * d.H2 * 4), p.cs = take(sets * d.H2 * 4), p.acc = take(sets * 4 * 4);
     p.bnacc = take(2 * (size_t)NSLICE * sets * p.ldT * 4);
     p.total = o;
@@ -699,7 +830,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     auto B16 = [&](size_t off) { return (bf16*)(ws + off); };
     auto F32 = [&](size_t off) { return (float*)(ws + off); };
     const int sets = n_sets, Ns = d.Ns, Np = d.Np, H1 = d.H1, H2 = d.H2, Ha = d.Ha, KC = d.KC, KCp = d.KCp;
-    const long KCn = rup(KC, 128) + 128, H2n = rup(H2, 128), ldT = pl.ldT;
+    const long KCn = rup(KC, 256) + 256, H2n = rup(H2, 256), ldT = pl.ldT;
     const long setC = (long)Np * KCp, setCT = KCn * Np, setP2 = (long)Np * H2, setZT = H2n * Np;
     const long setWT = H2n * KCp, setWn = KCn * H2;
     const int asz = L.actor_size;
@@ -751,7 +882,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         C = B16(yes ? pl.aC : pl.C), CT = B16(yes ? pl.aCT : pl.CT), P2 = B16(yes ? pl.aP2 : pl.P2);
     };
     float *q = F32(pl.q), *y = F32(pl.y), *dq = F32(pl.dq), *a1 = F32(pl.a1), *tt = F32(pl.tt), *da = F32(pl.da);
-    float *u = F32(pl.u), *cs = F32(pl.cs), *acc = F32(pl.acc);
+    float *u = F32(pl.u), *cs = F32(pl.cs), *acc = F32(pl.acc), *zbuf = F32(pl.zbuf);
     const long setX = (long)Ns * L.S;
     const dim3 g64((unsigned)1, (unsigned)rup(Np, 64) / 64, sets);
 
@@ -775,12 +906,16 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // second layer forward: P2 = relu(C @ WT^T + bias)
     auto l2 = [&](const NetOps& n, bool critic) {
         GemmP p = {C, n.WT, KCp, KCp, setC, setWT, Ns, H2, critic ? KCp : (int)rup(H1, 64), 1};
-        EpiFwd e = {P2, H2, setP2, n.bias, H2};
+        // the output layer rides on the GEMM epilogue: q (critic) or z (actor, in `da`-free scratch `zbuf`) = c0 + P2 . cf
+        float* zdst = critic ? q : zbuf;
+        hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, zdst, (long)Np, n.c0, Np);
+        EpiFwd e = {P2, H2, setP2, n.bias, H2, n.cf, zdst, (long)Np};
         return launch_gemm(p, e, sets, st, "avd_learn_shared_bf16: forward GEMM");
     };
-    auto out_layer = [&](const NetOps& n, int mode, float* out) {
-        hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, P2, (long)H2, setP2, 0, H2, n.cf,
-                           (long)H2, n.c0, Ns, mode, high, out, tt, (long)Np);
+    auto out_layer = [&](const NetOps&, int mode, float* out) {
+        if (mode == 1)  // actor head; the critic's q is complete once the GEMM has run
+            hipLaunchKernelGGL(tanh_rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, sets), dim3(256), 0, st, zbuf, (long)Np, Ns, high,
+                               out, tt);
     };
     auto rows = [&](int mode, const float* qv, const float* yt, const float* rd, float gh, float* out) {
         hipLaunchKernelGGL(rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, sets), dim3(256), 0, st, mode, Ns, (long)Np, qv, yt, rd, gh,
@@ -927,7 +1062,7 @@ extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_ag
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     const int sets = n_sets, Ns = d.Ns, Np = d.Np, H1 = d.H1, H2 = d.H2, KCp = d.KCp;
-    const long H2n = rup(H2, 128), ldT = pl.ldT, setC = (long)Np * KCp, setP2 = (long)Np * H2, setWT = H2n * KCp;
+    const long H2n = rup(H2, 256), ldT = pl.ldT, setC = (long)Np * KCp, setP2 = (long)Np * H2, setWT = H2n * KCp;
     float* tab = (float*)(ws + pl.tabs[0]);
     float *inv = tab, *sh = tab + (long)sets * ldT, *rs = tab + 2L * sets * ldT, *mean = tab + 3L * sets * ldT;
     bf16 *C = (bf16*)(ws + pl.C), *P2 = (bf16*)(ws + pl.P2), *WT = (bf16*)(ws + pl.WT[0]);
@@ -952,9 +1087,13 @@ extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_ag
         hipLaunchKernelGGL((l1_fwd_kernel<3>), grid, dim3(256), 0, st, state, (long)Ns * 3, theta, (long)L.theta_size, L.aW1, L.ab1, H1, H1,
                            0, Ns, Np, C, (long)KCp, setC, (bf16*)nullptr, 0L, 0L);
     GemmP p = {C, WT, KCp, KCp, setC, setWT, Ns, H2, (int)rup(H1, 64), 1};
-    EpiFwd e = {P2, H2, setP2, bias, H2};
+    float* zbuf = (float*)(ws + pl.zbuf);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, zbuf, (long)Np, c0, Np);
+    EpiFwd e = {P2, H2, setP2, bias, H2, cf, zbuf, (long)Np};
     WIDE_CHECK(launch_gemm(p, e, sets, st, "avd_actor_forward_shared_bf16: forward GEMM"));
-    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, P2, (long)H2, setP2, 0, H2, cf, (long)H2, c0,
-                       Ns, 1, high, out, tt, (long)Ns);
+    // out is tightly packed [sets][Ns]: strided copy through tanh
+    for (int k = 0; k < sets; ++k)
+        hipLaunchKernelGGL(tanh_rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, 1), dim3(256), 0, st, zbuf + (long)k * Np, 0L, Ns, high,
+                           out + (long)k * Ns, tt + (long)k * Np);
     return check_launch("avd_actor_forward_shared_bf16");
 }

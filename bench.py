@@ -172,13 +172,13 @@ def main():
               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roofs = [mf, hb]
     elif batched:
-        # shared-set learner: the GEMM FLOPs of the chain (forward x6, weight-gradient x2, input-gradient x3) over the
+        # shared-set learner: the GEMM FLOPs of the chain (forward x5, weight-gradient x2, input-gradient x3) over the
         # whole learn stage (GEMMs + the bandwidth-bound row/column kernels between them), against the dense bf16 peak
         lay = vt.agents.lay
         H1, H2, KC, rows = lay.H1, lay.H2, lay.H1 + lay.Ha, 64 * n_agents
-        flops = 2.0 * rows * H2 * ((3 * H1 + 3 * KC) + (KC + H1) + (KC + lay.Ha + H1))
+        flops = 2.0 * rows * H2 * ((2 * H1 + 3 * KC) + (KC + H1) + (KC + lay.Ha + H1))  # actor fwd x2, critic fwd x3
         learn_s = stage_ms["learn"] / 1e3
-        roofs.append({"kernel": "avd_learn_shared_bf16 (gemm_bt_kernel x11 + row/column kernels)", "bound": "mfma",
+        roofs.append({"kernel": "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)", "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})
     else:

@@ -239,7 +239,7 @@ int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n
                                   size_t workspace_bytes, void* stream);
 
 /* D[M][Nc] (f32, ldd) = A[M][K] . B[Nc][K]^T with bf16 operands (K contiguous, K % 64 == 0) and f32 accumulation: the
- * GEMM under avd_learn_shared_bf16, exposed for parity tests. A and B must be readable up to the next multiple of 128
+ * GEMM under avd_learn_shared_bf16, exposed for parity tests. A and B must be readable up to the next multiple of 256
  * rows. */
 int avd_gemm_bt_bf16(int M, int Nc, int K, const void* A, long lda, const void* B, long ldb, float* D, long ldd,
                      void* stream);

@@ -15,11 +15,12 @@ from tests.test_gpu_mlp import _nets, _perturbed_group, _relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,Nc,K", [(128, 128, 64), (200, 72, 192), (1024, 304, 1088), (64, 1024, 4096)])
+@pytest.mark.parametrize("M,Nc,K", [(128, 128, 64), (200, 72, 192), (1024, 304, 1088), (64, 1024, 4096), (1000, 1072, 1024),
+                                    (2048, 512, 64)])
 def test_bf16_gemm_matches_float64_on_the_same_bf16_operands(M, Nc, K):
     need_gpu()
     rs = np.random.RandomState(M + Nc + K)
-    Mp, Np_ = (M + 127) // 128 * 128, (Nc + 127) // 128 * 128  # operands readable to the next tile multiple
+    Mp, Np_ = (M + 255) // 256 * 256, (Nc + 255) // 256 * 256  # operands readable to the next tile multiple
     A = torch.zeros(Mp, K, dtype=torch.bfloat16, device="cuda")
     B = torch.zeros(Np_, K, dtype=torch.bfloat16, device="cuda")
     A[:M] = t(rs.normal(0, 1, (M, K)).astype(np.float32)).to(torch.bfloat16)

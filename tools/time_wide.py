@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 N = M * rows
 KC = H1 + Ha
-flops = 2.0 * N * H2 * (3 * H1 + 3 * KC)      # forward GEMMs: actor x3, critic x3
+flops = 2.0 * N * H2 * (2 * H1 + 3 * KC)      # forward GEMMs: actor x2 (target, online), critic x3
 flops += 2.0 * N * H2 * (KC + H1)              # weight-gradient GEMMs
 flops += 2.0 * N * H2 * (KC + Ha + H1)         # input-gradient GEMMs
 print(f"P={P} M={M} widths={H1}/{H2}/{Ha}: {ms:.3f} ms per learn  ({flops / ms * 1e-9:.1f} TFLOP/s of GEMM work, "
