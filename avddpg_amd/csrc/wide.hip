@@ -526,76 +526,103 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const bf16* P, long ldp, l
 }
 
 // Output layer backward + the ReLU/BN below it: dZ2[n][k] = (P2[n][k] > 0) ? d[n] * c[k] : 0 with c = w3 (.) inv3
-// (also transposed), u[k] += sum_n P2[n][k] d[n], cs[k] += sum_n dZ2[n][k].  Block = 64 rows x 64 columns.
+// (also transposed), u[k] += sum_n P2[n][k] d[n], cs[k] += sum_n dZ2[n][k].  Block = 64 rows x 64 columns, 8-byte accesses.
 __global__ __launch_bounds__(256) void out_bwd_kernel(const bf16* P2, long ldp, long set_p, const float* d, long set_d,
                                                        const float* cvec, long set_c, int H2, int Ns, int Np, bf16* dZ,
                                                        bf16* dZT, long ldt, long set_t, float* u, float* cs, long set_u) {
-    __shared__ bf16 so[64][66];
+    __shared__ bf16 so[64][68];
     __shared__ float sd[64];
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][16][64];
     const int set = blockIdx.z, n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, tid = threadIdx.x;
     if (tid < 64) sd[tid] = (n0 + tid < Ns) ? d[(long)set * set_d + n0 + tid] : 0.f;
     __syncthreads();
-    const int kc = tid & 63, k = k0 + kc, rg = tid >> 6;
-    const float c = (k < H2) ? cvec[(long)set * set_c + k] : 0.f;
-    float su = 0.f, sc = 0.f;
-    for (int r = rg; r < 64; r += 4) {
-        const int n = n0 + r;
-        float p = 0.f;
-        if (k < H2 && n < Ns) p = (float)P2[(long)set * set_p + (long)n * ldp + k];
-        const float dz = (p > 0.f) ? sd[r] * c : 0.f;
-        su = fmaf(p, sd[r], su);
-        sc += dz;
-        const bf16 o = (bf16)dz;
-        if (k < H2 && n < Np) dZ[(long)set * set_p + (long)n * ldp + k] = o;
-        so[r][kc] = o;
+    const int cg = tid & 15, rg = tid >> 4, k = k0 + 4 * cg;  // H2 % 64 == 0: k + 3 < H2
+    const f32x4 c = *(const f32x4*)(cvec + (long)set * set_c + k);
+    float su[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rg + 16 * rr, n = n0 + r;
+        bf16x4 pv = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, o;
+        if (n < Ns) pv = *(const bf16x4*)(P2 + (long)set * set_p + (long)n * ldp + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = (float)pv[e];
+            const float dz = (p > 0.f) ? sd[r] * c[e] : 0.f;
+            su[e] = fmaf(p, sd[r], su[e]);
+            sc[e] += dz;
+            o[e] = (bf16)dz;
+        }
+        if (n < Np) *(bf16x4*)(dZ + (long)set * set_p + (long)n * ldp + k) = o;
+        *(bf16x4*)(&so[r][4 * cg]) = o;
     }
-    red[0][rg][kc] = su, red[1][rg][kc] = sc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[0][rg][4 * cg + e] = su[e], red[1][rg][4 * cg + e] = sc[e];
     __syncthreads();
-    if (tid < 64 && k < H2) {
-        if (u) atomicAdd(u + (long)set * set_u + k, red[0][0][kc] + red[0][1][kc] + red[0][2][kc] + red[0][3][kc]);
-        if (cs) atomicAdd(cs + (long)set * set_u + k, red[1][0][kc] + red[1][1][kc] + red[1][2][kc] + red[1][3][kc]);
+    if (tid < 128) {
+        const int which = tid >> 6, kc = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[which][g][kc];
+        float* dst = which ? cs : u;
+        if (dst) atomicAdd(dst + (long)set * set_u + k0 + kc, s);
     }
     if (dZT) {
-        const int nr = tid & 63;
-        for (int cc = tid >> 6; cc < 64; cc += 4) {
-            const int kk = k0 + cc, n = n0 + nr;
-            if (kk < H2 && n < Np) dZT[(long)set * set_t + (long)kk * ldt + n] = so[nr][cc];
+        const int ng = tid & 15;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int cidx = (tid >> 4) + 16 * cc, n = n0 + 4 * ng;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = so[4 * ng + e][cidx];
+            if (n < Np) *(bf16x4*)(dZT + (long)set * set_t + (long)(k0 + cidx) * ldt + n) = o;
         }
     }
 }
 
 // First-layer gradients: dW[j][k] += sum_n X[n][j] dZ[n][c0 + k], db[k] += sum_n dZ[n][c0 + k] (scaled).
-// Block = 64 columns x `rows_per_block` rows.
+// Block = 64 columns x `rows_per_block` rows; a thread owns 4 consecutive columns (8-byte loads) of every 16th row.
 template <int KIN>
 __global__ __launch_bounds__(256) void l1_grads_kernel(const float* X, long set_x, const bf16* dZ, long ldz, long set_z, int c0,
                                                         int H, int Ns, int rows_per_block, float scale, float* g, long set_g,
                                                         int w_off, int b_off) {
-    __shared__ float red[4][64][KIN + 1];
-    const int set = blockIdx.z, k = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ float red[16][64][KIN + 1];
+    const int set = blockIdx.z, cg = threadIdx.x & 15, rg = threadIdx.x >> 4, k = blockIdx.x * 64 + 4 * cg;
     const int nb = blockIdx.y * rows_per_block, ne = min(nb + rows_per_block, Ns);
-    float acc[KIN + 1];
+    float acc[4][KIN + 1];
 #pragma unroll
-    for (int j = 0; j <= KIN; ++j) acc[j] = 0.f;
-    if (k < H) {
-        for (int n = nb + rg; n < ne; n += 4) {
-            const float dz = (float)dZ[(long)set * set_z + (long)n * ldz + c0 + k];
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j <= KIN; ++j) acc[e][j] = 0.f;
+    if (k < H) {  // H % 16 == 0: all 4 columns are valid
+        for (int n = nb + rg; n < ne; n += 16) {
+            const bf16x4 dv = *(const bf16x4*)(dZ + (long)set * set_z + (long)n * ldz + c0 + k);
             const float* x = X + (long)set * set_x + (long)n * KIN;
+            float xv[KIN];
 #pragma unroll
-            for (int j = 0; j < KIN; ++j) acc[j] = fmaf(x[j], dz, acc[j]);
-            acc[KIN] += dz;
+            for (int j = 0; j < KIN; ++j) xv[j] = x[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dz = (float)dv[e];
+#pragma unroll
+                for (int j = 0; j < KIN; ++j) acc[e][j] = fmaf(xv[j], dz, acc[e][j]);
+                acc[e][KIN] += dz;
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j <= KIN; ++j) red[rg][threadIdx.x & 63][j] = acc[j];
-    __syncthreads();
-    if (rg == 0 && k < H) {
-        float* gs = g + (long)set * set_g;
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j <= KIN; ++j) {
-            const int c = threadIdx.x & 63;
-            const float s = (red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j]) * scale;
-            atomicAdd(j < KIN ? gs + w_off + (long)j * H + k : gs + b_off + k, s);
+        for (int j = 0; j <= KIN; ++j) red[rg][4 * cg + e][j] = acc[e][j];
+    __syncthreads();
+    const int c = threadIdx.x & 63, jq = threadIdx.x >> 6;  // 4 threads per column share the KIN + 1 outputs
+    const int kk = blockIdx.x * 64 + c;
+    if (kk < H) {
+        float* gs = g + (long)set * set_g;
+        for (int j = jq; j <= KIN; j += 4) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += red[q][c][j];
+            atomicAdd(j < KIN ? gs + w_off + (long)j * H + kk : gs + b_off + kk, sum * scale);
         }
     }
 }
@@ -638,9 +665,13 @@ __global__ __launch_bounds__(256) void rows_kernel(int mode, int Ns, long set_o,
         }
     }
     if (mode == 0) return;
+    __shared__ float part[2][4];
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) a0 += __shfl_xor(a0, s), a1 += __shfl_xor(a1, s);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = a0, part[1][threadIdx.x >> 6] = a1;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block and quantity: thousands of waves on one address serialise
+        a0 = part[0][0] + part[0][1] + part[0][2] + part[0][3], a1 = part[1][0] + part[1][1] + part[1][2] + part[1][3];
         if (mode == 1) atomicAdd(acc + set * 4 + 0, a0), atomicAdd(acc + set * 4 + 1, a1);
         if (mode == 2) atomicAdd(acc + set * 4 + 2, a0);
         if (mode == 3) atomicAdd(acc + set * 4 + 3, a0);
