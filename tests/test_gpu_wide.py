@@ -166,3 +166,30 @@ def test_shared_actor_forward_matches_per_agent_rows_kernel():
     sm = t(np.ascontiguousarray(x.reshape(P, M, S).swapaxes(0, 1)))
     got = grp.actor_shared(sm, P * M).cpu().numpy().T.reshape(-1)
     assert np.abs(ref).max() > 0.05 and np.abs(got - ref).max() <= 2e-2 * 2.5
+
+
+def test_full_size_shared_learner_is_the_mean_of_its_halves():
+    """BASELINE config 4 / configs[1] size (4096 platoons x 5 vehicle indices, 64-row batches): a size-independent
+    property instead of the oracle -- the mean gradient over all 4096 platoons' rows equals the average of the mean
+    gradients over platoons [0, 2048) and [2048, 4096) (every row's contribution is independent of the other rows:
+    inference-mode BN, no batch statistics). Identical bf16 operand rounding on both sides; only the f32 summation
+    order (split-K atomics) differs: 1e-3 of each slab's max."""
+    need_gpu()
+    P, M, B, S = 4096, 5, 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=91)
+    g = torch.Generator(device="cuda").manual_seed(92)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    s, a, r, s2 = 1.5 * rn(M, P * B, S), 2.5 * (2 * torch.rand(M, P * B, 1, device="cuda", generator=g) - 1), -rn(M, P * B).abs() * 0.3, 1.5 * rn(M, P * B, S)
+    full = grp.learn_shared(s, a, r, s2, P * M).clone()
+    h = P * B // 2
+    halves = []
+    for lo in (0, h):
+        sl = lambda x: x[:, lo:lo + h].contiguous()
+        halves.append(grp.learn_shared(sl(s), sl(a), sl(r), sl(s2), P * M // 2).clone())
+    avg = 0.5 * (halves[0] + halves[1])
+    assert torch.isfinite(full).all() and full.abs().max() > 0
+    lay = grp.lay
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        d = (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item()
+        assert d <= 1e-3 * full[:, lo:hi].abs().max().item(), (lo, d)
+    assert not torch.allclose(halves[0], halves[1])  # the halves are different batches
