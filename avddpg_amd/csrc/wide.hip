@@ -647,18 +647,21 @@ __global__ void tanh_rows_kernel(const float* z, long set_z, int Ns, float high,
 }
 
 __global__ __launch_bounds__(256) void rows_kernel(int mode, int Ns, long set_o, const float* q, const float* y_or_t,
-                                                    const float* r_or_da, float gamma_or_high, float* out, float* acc) {
+                                                    const float* r_or_da, float gamma_or_high, float* out, float* acc,
+                                                    const float* row_weight) {
     const int set = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     const long o = (long)set * set_o + n;
     float a0 = 0.f, a1 = 0.f;
+    // weighted federated mean (src/server/federated.py:99-118): each row's loss seed carries its platoon's weight
+    const float rw = (row_weight && n < Ns) ? row_weight[(long)set * Ns + n] : 1.0f;
     if (n < Ns) {
         if (mode == 0) {
             out[o] = fmaf(gamma_or_high, q[o], r_or_da[o]);
         } else if (mode == 1) {
-            const float e = y_or_t[o] - q[o], d = -2.0f * e / (float)Ns;
+            const float e = y_or_t[o] - q[o], d = -2.0f * e * rw / (float)Ns;
             out[o] = d, a0 = e * e, a1 = d;
         } else if (mode == 2) {
-            out[o] = -1.0f / (float)Ns, a0 = q[o];
+            out[o] = -rw / (float)Ns, a0 = q[o];
         } else {
             const float t = y_or_t[o], d = r_or_da[o] * gamma_or_high * (1.0f - t * t);
             out[o] = d, a0 = d;
@@ -846,8 +849,9 @@ struct NetOps {
 
 extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta,
                                      const float* stats, const float* theta_t, const float* stats_t, const float* s,
-                                     const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
-                                     float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* a, const float* r, const float* s2, const float* row_weight, float gamma,
+                                     float high, float* grads, float* losses, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     int rc = check_wide(lay, n_agents, n_sets, "avd_learn_shared_bf16");
     if (rc) return rc;
     AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads && workspace,
@@ -950,7 +954,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     auto rows = [&](int mode, const float* qv, const float* yt, const float* rd, float gh, float* out) {
         hipLaunchKernelGGL(rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, sets), dim3(256), 0, st, mode, Ns, (long)Np, qv, yt, rd, gh,
-                           out, acc);
+                           out, acc, row_weight);
     };
     // Note on row-vector strides: r arrives as [sets][Ns] (stride Ns), internal vectors use stride Np. The TD kernel
     // reads r with the internal stride, so r is first copied into `da` (free at that point) with the padded stride.

@@ -112,8 +112,6 @@ class VecTrainer:
             raise ValueError(f"shared_engine={shared_engine!r}")
         if self.shared_engine == "batched" and not self.shared:
             raise ValueError("the batched learner needs shared weight sets (interfrl + gradients, every step federated)")
-        if self.shared_engine == "batched" and conf.weighted_average_enabled:
-            raise ValueError("the batched learner computes the unweighted federated mean: set weighted_average_enabled=False")
         self.actor_out = torch.zeros(n_agents, self.A, **f32)
         self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)
@@ -231,13 +229,18 @@ class VecTrainer:
                                     timers=self.timers)
             return
         if self.shared and self.shared_engine == "batched":
-            self._timed("learn", self._learn_batched, s, a, r, s2)
+            weights = None
+            if is_weighted_fed_enabled(conf, ep):
+                if self.fed_weights is None or self.fed_weights[0] != ep:
+                    self.fed_weights = (ep, self._weights_for_fed(ep))
+                weights = self.fed_weights[1]
+            self._timed("learn", self._learn_batched, s, a, r, s2, weights)
             self._timed("update", self.agents.apply, self.set_grads)
             return
         self._timed("learn", self.agents.learn, s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
         self._timed("update", self._update, ep, i, fed)
 
-    def _learn_batched(self, s, a, r, s2):
+    def _learn_batched(self, s, a, r, s2, weights=None):
         """interfrl with every step federated, shared sets: Trainer.learn + federated mean (trainer.py:400-431) as ONE
         learn over each set's P x B rows. The sampled batch is agent-major (agent v = p*M + m); the learner wants it
         set-major. Across ranks the per-set means are combined like the per-agent path's sums (dist.exchange_fed_sums)."""
@@ -246,12 +249,18 @@ class VecTrainer:
         if getattr(self, "set_grads", None) is None:
             self.set_grads = torch.empty(M, self.agents.lay.theta_size, dtype=torch.float32, device=self.device)
             self.set_losses = torch.zeros(M, 2, dtype=torch.float32, device=self.device)
-        self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses)
+        rw = wsum = None
+        if weights is not None:  # [P, M] -> per-row factors w_p * P / sum_p w_p, set-major (federated.py:99-118)
+            wsum = weights.sum(dim=0)  # [M]
+            rw = (weights * (float(P) / wsum)).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()
+        self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses,
+                                 row_weight=rw)
         if self.group is not None:
             from .dist import exchange_fed_sums
-            self.set_grads.mul_(float(P))  # local mean -> local sum over platoons
-            total = exchange_fed_sums(self.set_grads, None, P, self.group)
-            self.set_grads.div_(total)
+            # local (weighted) mean -> local (weighted) sum over platoons, all-reduce, divide by the global count / weight
+            self.set_grads.mul_(float(P) if wsum is None else wsum.view(M, 1))
+            total = exchange_fed_sums(self.set_grads, wsum, P, self.group)
+            self.set_grads.div_(total if wsum is None else wsum.view(M, 1))
 
     def _update(self, ep, i, fed):
         conf, P, M = self.conf, self.P, self.M

@@ -294,10 +294,11 @@ class AgentGroup:
              ptr(losses), stream_handle())
         return grads
 
-    def learn_shared(self, s, a, r, s2, n_agents, grads=None, losses=None):
+    def learn_shared(self, s, a, r, s2, n_agents, grads=None, losses=None, row_weight=None):
         """Trainer.learn + federated mean for agents that SHARE this group's ``n_sets`` weight sets (interfrl with every
         step federated), as layer-wise bf16 GEMMs over all rows of a set (csrc/wide.hip). Batches are SET-MAJOR:
         s, s2 [n_sets, rows, S], a [n_sets, rows, 1], r [n_sets, rows] with rows = n_agents / n_sets * batch_size.
+        row_weight [n_sets, rows] (optional): w_p * P / sum(w) on platoon p's rows = the weighted federated mean.
         Returns the mean gradient per set [n_sets, theta_size]."""
         import ctypes
         if grads is None:
@@ -308,8 +309,8 @@ class AgentGroup:
         if ws is None or ws.numel() < need.value:
             ws = self._wide_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         call("avd_learn_shared_bf16", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
-             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), self.config.gamma, self.high,
-             ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
+             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), ptr(row_weight), self.config.gamma,
+             self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
     def actor_shared(self, states_set_major, n_agents, out=None):

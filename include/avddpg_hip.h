@@ -220,6 +220,8 @@ int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int 
  * layer-wise bf16 MFMA GEMMs (f32 accumulation, f32 parameters and gradients):
  *   theta/stats/theta_t/stats_t [n_sets][...]   weight sets (same slabs as avd_learn_f32 with set_mod = n_sets)
  *   s, s2 [n_sets][rows][S], a [n_sets][rows][1], r [n_sets][rows]   SET-MAJOR batches, rows = (n_agents / n_sets) * B
+ *   row_weight [n_sets][rows] or NULL   per-row factor on both loss seeds: w_p * P / sum_p w_p on platoon p's rows gives
+ *                                Server.get_weighted_avg_params (src/server/federated.py:99-118); losses stay unweighted
  *   grads [n_sets][theta_size]   mean gradient per set (what avd_fed_sum + avd_fed_finalize give for per-agent gradients)
  *   losses [n_sets][2] or NULL   mean critic / actor loss per set
  *   workspace: device scratch of at least avd_learn_shared_workspace() bytes.
@@ -227,8 +229,8 @@ int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int 
 int avd_learn_shared_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
 int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                           const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
-                          const float* s2, float gamma, float high, float* grads, float* losses, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          const float* s2, const float* row_weight, float gamma, float high, float* grads, float* losses,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* actor(state) (agent/model.py:26-36, workers/trainer.py:286-289) for agents that share n_sets weight sets, as the same
  * bf16 GEMM chain: state [n_sets][rows][S] SET-MAJOR (rows = n_agents / n_sets, tightly packed S floats per row),

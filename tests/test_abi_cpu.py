@@ -141,3 +141,18 @@ def test_padded_pack_unpack_roundtrip():
     cW2 = th[lay.actor_size + lay.cW2:lay.actor_size + lay.cW2 + 384 * 160].reshape(384, 160)
     assert np.all(cW2[307:320] == 0) and np.all(cW2[320 + 57:] == 0) and np.all(cW2[:, 153:] == 0)
     assert np.array_equal(cW2[320:377, :153], cw[12][307:])
+
+
+def test_shared_learner_argument_validation_without_gpu():
+    """check_wide runs before any HIP call: unsupported widths and bad agent counts are refused with the rule named."""
+    need = ctypes.c_size_t(0)
+    lay = _hip.make_layout(4, 1, 320, 160, 48, 64)
+    with pytest.raises(_hip.AvdError, match="multiples of 64"):
+        _hip.call("avd_learn_shared_workspace", ctypes.byref(lay), 10, 5, ctypes.byref(need))
+    lay = _hip.make_layout(4, 1, 1024, 1024, 48, 64)
+    with pytest.raises(_hip.AvdError, match="multiple of n_sets"):
+        _hip.call("avd_learn_shared_workspace", ctypes.byref(lay), 11, 5, ctypes.byref(need))
+    _hip.call("avd_learn_shared_workspace", ctypes.byref(lay), 20480, 5, ctypes.byref(need))
+    assert 20 * 2**30 < need.value < 40 * 2**30  # BASELINE config 5: ~26 GiB of scratch, fits 288 GB beside the replay ring
+    with pytest.raises(_hip.AvdError, match="K %"):
+        _hip.call("avd_gemm_bt_bf16", 128, 128, 100, None, 100, None, 100, None, 128, None)

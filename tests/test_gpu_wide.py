@@ -193,3 +193,32 @@ def test_full_size_shared_learner_is_the_mean_of_its_halves():
         d = (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item()
         assert d <= 1e-3 * full[:, lo:hi].abs().max().item(), (lo, d)
     assert not torch.allclose(halves[0], halves[1])  # the halves are different batches
+
+
+def test_shared_learner_weighted_mean_matches_weighted_fed_mean():
+    """Server.get_weighted_avg_params (src/server/federated.py:99-118) through per-row weights w_p * P / sum(w)."""
+    need_gpu()
+    P, M, B, S = 6, 2, 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=101)
+    rs = np.random.RandomState(102)
+    n = P * M
+    s = rs.normal(0, 1.5, size=(n, B, S)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n, B, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n, B))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n, B, S)).astype(np.float32)
+    # make the platoons' gradients differ (else any weighting gives the same mean): platoon-dependent reward scale / state offset
+    for p in range(P):
+        r[p * M:(p + 1) * M] *= 1.0 + 4.0 * p
+        s[p * M:(p + 1) * M] += 0.5 * p
+    w = np.linspace(0.2, 3.0, P)[:, None].repeat(M, axis=1).astype(np.float32) * rs.uniform(0.8, 1.2, size=(P, M)).astype(np.float32)
+    per_agent = grp.learn(t(s), t(a), t(r), t(s2), M)
+    avg = vec.fed_mean(per_agent, P, M, weights=t(w), method=conf.interfrl).cpu().numpy()
+    sm = lambda x: t(np.ascontiguousarray(x.reshape(P, M, *x.shape[1:]).swapaxes(0, 1)).reshape(M, P * B, *x.shape[2:]))
+    rw = np.repeat((w * (P / w.sum(axis=0))).T[:, :, None], B, axis=2).reshape(M, P * B).astype(np.float32)
+    g = grp.learn_shared(sm(s), sm(a), sm(r), sm(s2), n, row_weight=t(rw)).cpu().numpy()
+    unweighted = grp.learn_shared(sm(s), sm(a), sm(r), sm(s2), n).cpu().numpy()
+    lay = grp.lay
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        scale = np.abs(avg[:, lo:hi]).max()
+        assert np.abs(avg[:, lo:hi] - g[:, lo:hi]).max() <= 2e-2 * scale
+        assert np.abs(avg[:, lo:hi] - unweighted[:, lo:hi]).max() > 5e-2 * scale  # the weights matter in this case
