@@ -1346,10 +1346,18 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         l = carve(smem + z, L, FT);
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.sS2 : l.sS;
+        // Layer-2 buffers by pass. Pass 3 needs the online actor's layer-2 activations of pass 2 again: pass 2 therefore
+        // parks them in bufC -- its own critic backward runs IN PLACE in bufB (each element is read, then overwritten, by
+        // the same thread; no weight gradients are taken there) -- and pass 3 skips the actor's second-layer GEMM (one
+        // W2 read less) and output layer (tanh values are still in sT). The first layer is cheap VALU work and is
+        // recomputed: its 64 KB do not fit beside the critic's buffers.
+        float* const aP2 = (it >= 2) ? l.bufC : l.bufB;              // actor layer-2 activations
+        float* const bP2 = (it == 3) ? l.bufC : l.bufB;              // activations the backward pass reads
+        float* const bDZ = (it == 1) ? l.bufC : l.bufB;              // ... and the gradient it writes
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36), parameters in `pa`
             const float* th = n.th;
             FwdPre<H2 / (16 * NW)> fp;
-            fwd_prefetch<H2>(fp, th + L.aW2, th + L.ab2, H1 / 16);
+            fwd_prefetch<H2>(fp, th + L.aW2, th + L.ab2, H1 / 16);  // (pass 3: 13 unused loads keep the load counts path-independent)
             __builtin_amdgcn_sched_barrier(0);
             const float b3 = pa.b3;
             if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
@@ -1357,17 +1365,19 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             l2_store(pa.c2, l, H2, tid);
             lds_barrier();
             PH(1);
-            gemm_fwd<H2, LDA, LDB, H1 / 16>(l.bufA, l.invA, l.shA, th + L.aW2, fp, l.bufB);
-            lds_barrier();
-            PH(2);
-            const float z = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
-            if (tid % LPR == 0) {
-                const float t = tanhf(z);
-                l.sT[tid / LPR] = t;
-                l.sA1[tid / LPR] = t * high;
+            if (it != 3) {
+                gemm_fwd<H2, LDA, LDB, H1 / 16>(l.bufA, l.invA, l.shA, th + L.aW2, fp, aP2);
+                lds_barrier();
+                PH(2);
+                const float z = out_layer_row(aP2, LDB, l.invB, l.shB, l.w3B, b3, H2);
+                if (tid % LPR == 0) {
+                    const float t = tanhf(z);
+                    l.sT[tid / LPR] = t;
+                    l.sA1[tid / LPR] = t * high;
+                }
+                lds_barrier();
+                PH(3);
             }
-            lds_barrier();
-            PH(3);
         }
         if (it != 3) {  // ---- critic forward (agent/model.py:63-83), parameters in `pc`
             const float* th = n.th + L.actor_size;
@@ -1451,20 +1461,20 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         DxPre<H2> dxp;
         dx_prefetch<H2>(dxp, wdx, dx_begin, dx_end, lo, hi, H1);  // consumed by gemm_dx two phases later
         __builtin_amdgcn_sched_barrier(0);
-        out_layer_backward(l.bufB, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, l.bufC, LDB, l.scr,
+        out_layer_backward(bP2, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, bDZ, LDB, l.scr,
                            wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
                            gout + (crit ? L.cbe3 : L.abe2), sink);
         PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
         if (wg) {
-            col_sums(l.bufC, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
+            col_sums(bDZ, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
             lds_barrier();
             PH(it == 1 ? 8 : 16);
-            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, l.bufC, l.db,
+            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, bDZ, l.db,
                                   gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk);
             lds_barrier();
             PH(it == 1 ? 9 : 17);
         }
-        gemm_dx<H2, LDB, LDA>(l.bufC, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp, sink);
+        gemm_dx<H2, LDB, LDA>(bDZ, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp, sink);
         lds_barrier();
         PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
         if (it == 1) {
