@@ -926,7 +926,7 @@ struct FwdPre {
 };
 template <int N>
 __device__ __forceinline__ void fwd_prefetch(FwdPre<N / (16 * NW)>& p, const float* __restrict__ W,
-                                             const float* __restrict__ b, int nblk) {
+                                             const float* __restrict__ b, int nblk, int first = 0) {
     constexpr int NT = N / (16 * NW);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     const int col = wave * 16 * NT + NT * lr;
@@ -934,7 +934,7 @@ __device__ __forceinline__ void fwd_prefetch(FwdPre<N / (16 * NW)>& p, const flo
     ldn<NT>(p.bc, b + col);
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) {
-        const float* q = wl + min(d, nblk - 1) * (16 * N);
+        const float* q = wl + min(first + d, nblk - 1) * (16 * N);  // first % R == 0: block first + d sits in ring[d]
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) ldn<NT>(p.ring[d][jj], q + jj * N);
     }
@@ -944,20 +944,37 @@ __device__ __forceinline__ void fwd_prefetch(FwdPre<N / (16 * NW)>& p, const flo
 // Per 16-deep block: [issue weight loads R-1 blocks ahead + LDS reads one block ahead] | [16*NT MFMAs].
 // sched_barrier(0) pins the two stages: hipcc's scheduler otherwise sinks every load down to its first use and
 // neither the register ring nor the LDS double buffer prefetches anything.
-template <int N, int LDX, int LDO, int NBLK>
+// FIRST / SNAP split the reduction for inputs whose leading SNAP blocks do not change between two calls (the critic's
+// state features in passes 1 and 2): a call with `snap` set stores the accumulators as they stand before block SNAP
+// (layout of the outputs; the lane's shift sums go to cs_snap), a call with FIRST == SNAP resumes from them and runs only
+// blocks FIRST.. -- the same additions in the same order as a full run, bit for bit.
+template <int N, int LDX, int LDO, int NBLK, int FIRST = 0, int SNAP = 0>
 __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh,
-                                         const float* __restrict__ W, FwdPre<N / (16 * NW)>& pre, float* out) {
+                                         const float* __restrict__ W, FwdPre<N / (16 * NW)>& pre, float* out,
+                                         float* snap = nullptr, float* cs_snap = nullptr) {
     constexpr int NT = N / (16 * NW);
     static_assert(NT == 1 || NT == 2, "one or two 16-column tiles per wave");
+    static_assert(FIRST % R == 0 && FIRST < NBLK && SNAP < NBLK, "resume point must be ring-aligned");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     const int col = wave * 16 * NT + NT * lr;
     f32x4 acc[4][NT];
     float cs[NT];  // this lane's share (its k's) of sum_k sh[k]*W[k][col..]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        cs[t] = 0.f;
+        cs[t] = (FIRST > 0) ? cs_snap[t] : 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (FIRST > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[NT];
+                ldn<NT>(v, snap + (m * 16 + lg * 4 + j) * LDO + col);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t][j] = v[t];
+            }
     }
     const float* wl = W + (4 * lg) * N + col;  // lane's columns, row 4*lg of block 0
     float(&ring)[R][4][NT] = pre.ring;
@@ -967,12 +984,25 @@ __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const
         for (int jj = 0; jj < 4; ++jj) ldn<NT>(dst[jj], p + jj * N);
     };
     RawA raw[2];
-    read_a<LDX>(raw[0], X, inv, sh, 4 * lg, lr);
+    read_a<LDX>(raw[FIRST & 1], X, inv, sh, 16 * FIRST + 4 * lg, lr);
     // Fully unrolled over the NBLK reduction blocks. As a loop over groups of R blocks the compiler placed register
     // copies of the ring on the back-edge, i.e. an s_waitcnt vmcnt(0) per group: the 3-block lookahead was drained
     // every 4 blocks (measured ~30 % of the GEMM time).
 #pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) {
+    for (int blk = FIRST; blk < NBLK; ++blk) {
+        if (SNAP > 0 && blk == SNAP && snap) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = acc[m][t][j];
+                    stn<NT>(snap + (m * 16 + lg * 4 + j) * LDO + col, v);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cs_snap[t] = cs[t];
+        }
         if (blk + R - 1 < NBLK) load_blk(ring[(blk + R - 1) % R], blk + R - 1);
         if (blk + 1 < NBLK) read_a<LDX>(raw[(blk + 1) & 1], X, inv, sh, 16 * (blk + 1) + 4 * lg, lr);
         __builtin_amdgcn_sched_barrier(0);
@@ -1333,6 +1363,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     // where paths differ the compiler must take the smallest count -- i.e. wait for the extra loads of the longer path.
     ActorPar<S> pa = load_actor<S, H1, H2>(L, tgt, ks, tid);
     CriticPar<S> pc = load_critic<S, H1, H2, HA>(L, tgt, ks, ka, tid);
+    float cs_snap[H2 / (16 * NW)] = {};  // lane-local shift sums of the critic's state blocks, pass 1 -> pass 2
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
         // fences (see opaque_zero): every global / LDS address below is rebuilt inside the pass
@@ -1346,14 +1377,19 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         l = carve(smem + z, L, FT);
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.sS2 : l.sS;
-        // Layer-2 buffers by pass. Pass 3 needs the online actor's layer-2 activations of pass 2 again: pass 2 therefore
-        // parks them in bufC -- its own critic backward runs IN PLACE in bufB (each element is read, then overwritten, by
-        // the same thread; no weight gradients are taken there) -- and pass 3 skips the actor's second-layer GEMM (one
+        // Layer-2 buffers by pass. Pass 3 needs the online actor's layer-2 activations of pass 2 again: they stay in bufB --
+        // pass 2's critic works in bufC, its backward IN PLACE (each element is read, then overwritten, by the same
+        // thread) -- and pass 3 skips the actor's second-layer GEMM (one
         // W2 read less) and output layer (tanh values are still in sT). The first layer is cheap VALU work and is
         // recomputed: its 64 KB do not fit beside the critic's buffers.
-        float* const aP2 = (it >= 2) ? l.bufC : l.bufB;              // actor layer-2 activations
-        float* const bP2 = (it == 3) ? l.bufC : l.bufB;              // activations the backward pass reads
-        float* const bDZ = (it == 1) ? l.bufC : l.bufB;              // ... and the gradient it writes
+        // Further, passes 1 and 2 run the critic on the same states with the same weights: pass 1 snapshots the second
+        // layer's accumulators after the 16 state blocks into bufC (its own backward runs in place in bufB) and pass 2
+        // resumes from them with the 3 action blocks only, in place in bufC -- no state first layer, 1/6 of the GEMM
+        // and of the W2 read.
+        float* const aP2 = l.bufB;                                   // actor layer-2 activations (passes 0, 2; kept for 3)
+        float* const cP2 = (it == 2) ? l.bufC : l.bufB;              // critic layer-2 activations
+        float* const bP2 = (it == 2) ? l.bufC : l.bufB;              // activations the backward pass reads
+        float* const bDZ = (it == 1) ? l.bufB : l.bufC;              // ... and the gradient it writes (in place in 1, 2)
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36), parameters in `pa`
             const float* th = n.th;
             FwdPre<H2 / (16 * NW)> fp;
@@ -1383,11 +1419,13 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             const float* th = n.th + L.actor_size;
             const float* act = (it == 1) ? l.sAct : l.sA1;
             FwdPre<H2 / (16 * NW)> fp;
-            fwd_prefetch<H2>(fp, th + L.cW2, th + L.cb2, KC / 16);
+            fwd_prefetch<H2>(fp, th + L.cW2, th + L.cb2, KC / 16, (it == 2) ? H1 / 16 : 0);
             __builtin_amdgcn_sched_barrier(0);
             const float b3 = pc.b3;
-            if (rs0 == 0) l1p_coefs(pc.cs, l.invA, l.shA, ks);
-            l1p_rows<S>(pc.cs, X, l.bufA, LDA, ks, rs0, sgroups);
+            if (it != 2) {  // pass 2 resumes from pass 1's state-feature sums: no state first layer
+                if (rs0 == 0) l1p_coefs(pc.cs, l.invA, l.shA, ks);
+                l1p_rows<S>(pc.cs, X, l.bufA, LDA, ks, rs0, sgroups);
+            }
             if (ra < agroups) {
                 if (ra == 0) l1p_coefs(pc.ca, l.invA, l.shA, H1 + ka);
                 l1p_rows<1>(pc.ca, act, l.bufA, LDA, H1 + ka, ra, agroups);
@@ -1400,10 +1438,14 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
             PH(4);
-            gemm_fwd<H2, LDA, LDB, KC / 16>(l.bufA, l.invA, l.shA, th + L.cW2, fp, l.bufB);
+            if (it == 2)
+                gemm_fwd<H2, LDA, LDB, KC / 16, H1 / 16, 0>(l.bufA, l.invA, l.shA, th + L.cW2, fp, cP2, l.bufC, cs_snap);
+            else
+                gemm_fwd<H2, LDA, LDB, KC / 16, 0, H1 / 16>(l.bufA, l.invA, l.shA, th + L.cW2, fp, cP2,
+                                                            it == 1 ? l.bufC : nullptr, cs_snap);
             lds_barrier();
             PH(5);
-            const float q = out_layer_row(l.bufB, LDB, l.invB, l.shB, l.w3B, b3, H2);
+            const float q = out_layer_row(cP2, LDB, l.invB, l.shB, l.w3B, b3, H2);
             if (tid % LPR == 0) l.sQ[tid / LPR] = q;
             lds_barrier();
             PH(6);
