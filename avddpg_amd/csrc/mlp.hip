@@ -1380,8 +1380,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         // Layer-2 buffers by pass. Pass 3 needs the online actor's layer-2 activations of pass 2 again: they stay in bufB --
         // pass 2's critic works in bufC, its backward IN PLACE (each element is read, then overwritten, by the same
         // thread) -- and pass 3 skips the actor's second-layer GEMM (one
-        // W2 read less) and output layer (tanh values are still in sT). The first layer is cheap VALU work and is
-        // recomputed: its 64 KB do not fit beside the critic's buffers.
+        // W2 read less) and output layer (tanh values are still in sT).
         // Further, passes 1 and 2 run the critic on the same states with the same weights: pass 1 snapshots the second
         // layer's accumulators after the 16 state blocks into bufC (its own backward runs in place in bufB) and pass 2
         // resumes from them with the 3 action blocks only, in place in bufC -- no state first layer, 1/6 of the GEMM
@@ -1396,8 +1395,11 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             fwd_prefetch<H2>(fp, th + L.aW2, th + L.ab2, H1 / 16);  // (pass 3: 13 unused loads keep the load counts path-independent)
             __builtin_amdgcn_sched_barrier(0);
             const float b3 = pa.b3;
-            if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
-            l1p_rows<S>(pa.c1, X, l.bufA, LDA, ks, rs0, sgroups);
+            if (it != 3) {  // pass 3: the first-layer activations and coefficients of pass 2 are still in bufA / invA / shA --
+                            // pass 2's critic only touched the action columns (resumed GEMM, action-only dX)
+                if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
+                l1p_rows<S>(pa.c1, X, l.bufA, LDA, ks, rs0, sgroups);
+            }
             l2_store(pa.c2, l, H2, tid);
             lds_barrier();
             PH(1);
