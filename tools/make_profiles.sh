@@ -10,6 +10,7 @@ python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 python bench.py --mode interfrl --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
 python bench.py --mode interfrl --engine batched --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_batched.json 2>/dev/null
 python bench.py --mode interfrl --hidden 1024 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
+python bench.py --pl-size 10 --buffer-size 50000 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_config3_4096x10.json 2>/dev/null
 python tools/phase_profile.py 4096 > $OUT/${TAG}_phase_profile.txt 2>/dev/null
 python tools/phase_profile.py 4096 fused > $OUT/${TAG}_phase_profile_fused.txt 2>/dev/null
 python tools/time_gemm.py > $OUT/${TAG}_gemm_bf16_tflops.txt 2>/dev/null
