@@ -1,17 +1,29 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Diagnostic: step time of the centralized framework (one model per platoon, S = 4L, A = L, widths x1.2; general learn
+kernel) at 4096 platoons x 5 vehicles."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
 from avddpg_amd import config, trainer
+
 conf = config.Config(num_platoons=4096, pl_size=5, framework="centralized", buffer_size=20000)
 vt = trainer.VecTrainer(conf, rng="device", auto_reset=True)
-ring = vt.replay.ring
-ring.normal_(0, 1)
+vt.replay.ring.normal_(0, 1)
 vt.replay.buffer_counter = 20000
 vt.reset_episode()
-for _ in range(3): vt.step()
+for _ in range(3):
+    vt.step()
 torch.cuda.synchronize()
 vt.timers = {}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10): vt.step()
-e1.record(); torch.cuda.synchronize()
-print("centralized 4096x5: ms/step", e0.elapsed_time(e1) / 10, {k: sum(a.elapsed_time(b) for a, b in v) / 10 for k, v in vt.timers.items()})
+for _ in range(10):
+    vt.step()
+e1.record()
+torch.cuda.synchronize()
+print("centralized 4096x5: ms/step", e0.elapsed_time(e1) / 10,
+      {k: sum(a.elapsed_time(b) for a, b in v) / 10 for k, v in vt.timers.items()})
