@@ -146,17 +146,20 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // groups ds_read_b128 is serviced in (MI355X_MICROARCH.md, LDS table; checked by enumeration). One global_load_lds wave
 // instruction fills 16 rows.
 // ------------------------------------------------------------------------------------------
-constexpr int TM = 256, TN = 256, TK = 32, TT = 512, NSTG = 3;
+constexpr int TM = 256, TK = 32, NSTG = 3;
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * TK + ((chunk ^ (((row >> 2) & 1) << 1)) << 3); }
 
-template <class Epi>
-__global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bt256_kernel(GemmP p, Epi epi) {
+// TNV = 256: 8 waves, one workgroup per CU (96 KiB). TNV = 128: 4 waves, 72 KiB, two independent workgroups per CU.
+template <class Epi, int TNV>
+__global__ __launch_bounds__(TNV * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bt256_kernel(GemmP p, Epi epi) {
+    constexpr int NWV = TNV / 32;                             // waves: 2 (M) x TNV/64 (N)
+    constexpr int IA = TM / (16 * NWV), IB = TNV / (16 * NWV);  // global_load_lds instructions per wave, stage and operand
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* sA = (bf16*)smem_raw;         // [NSTG][TM*TK]
-    bf16* sB = sA + NSTG * TM * TK;     // [NSTG][TN*TK]
+    bf16* sB = sA + NSTG * TM * TK;     // [NSTG][TNV*TK]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ncol = (p.Nc + TN - 1) / TN, nrow = (p.M + TM - 1) / TM;
+    const int wm = wave / (TNV / 64), wn = wave % (TNV / 64);
+    const int ncol = (p.Nc + TNV - 1) / TNV, nrow = (p.M + TM - 1) / TM;
     const int gsz = (p.ksplit > 1) ? nrow * ncol : ncol;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int grp = (jj / gsz) * 8 + xcd, tin = jj - (jj / gsz) * gsz;
@@ -164,26 +167,26 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int ks = 0, rt = grp, ct = tin;
     if (p.ksplit > 1) ks = grp, rt = tin / ncol, ct = tin - rt * ncol;
     if (ks >= p.ksplit || rt >= nrow) return;
-    const int row0 = rt * TM, col0 = ct * TN;
+    const int row0 = rt * TM, col0 = ct * TNV;
     const bf16* A = p.A + (long)set * p.setA + (long)row0 * p.lda + (long)ks * p.K;
     const bf16* B = p.B + (long)set * p.setB + (long)col0 * p.ldb + (long)ks * p.K;
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // wave w fills rows 32w .. 32w+31 of each operand: 2 instructions of 16 rows; lane -> row l / 4, slot l % 4
+    // wave w fills rows [16 IA w, 16 IA (w+1)) of A and [16 IB w, ..) of B, 16 rows per instruction; lane -> row l / 4, slot l % 4
     const int l4 = lane >> 2, slot = lane & 3;
-    const int chs = (slot ^ (((l4 >> 2) & 1) << 1)) * 8;  // bit 2 of row = 32w + 16i + l4 is bit 2 of l4
-    const bf16* ga = A + (long)(32 * wave + l4) * p.lda + chs;
-    const bf16* gb = B + (long)(32 * wave + l4) * p.ldb + chs;
+    const int chs = (slot ^ (((l4 >> 2) & 1) << 1)) * 8;  // bit 2 of the row is bit 2 of l4 (row offsets are multiples of 16)
+    const bf16* ga = A + (long)(16 * IA * wave + l4) * p.lda + chs;
+    const bf16* gb = B + (long)(16 * IB * wave + l4) * p.ldb + chs;
     const long sa16 = 16 * p.lda, sb16 = 16 * p.ldb;
-    bf16* la = sA + (32 * wave) * TK;
-    bf16* lb = sB + (32 * wave) * TK;
-#define WIDE_GLDS3(stg, k0)                                                                                                    \
-    {                                                                                                                          \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ga + (k0)), (lptr_t)(la + (stg) * TM * TK), 16, 0, 0);                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ga + sa16 + (k0)), (lptr_t)(la + (stg) * TM * TK + 16 * TK), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb + (k0)), (lptr_t)(lb + (stg) * TN * TK), 16, 0, 0);                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb + sb16 + (k0)), (lptr_t)(lb + (stg) * TN * TK + 16 * TK), 16, 0, 0);      \
+    bf16* la = sA + (16 * IA * wave) * TK;
+    bf16* lb = sB + (16 * IB * wave) * TK;
+#define WIDE_GLDS3(stg, k0)                                                                                                       \
+    {                                                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < IA; ++i_)                                                                         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga + i_ * sa16 + (k0)), (lptr_t)(la + (stg) * TM * TK + i_ * 16 * TK), 16, 0, 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_)                                                                         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb + i_ * sb16 + (k0)), (lptr_t)(lb + (stg) * TNV * TK + i_ * 16 * TK), 16, 0, 0); \
     }
     f32x4 acc[8][4];
 #pragma unroll
@@ -196,13 +199,13 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     WIDE_GLDS3(1, min(1, nk - 1) * TK)
     int stg = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // step kt's 4 loads are the oldest in flight; the 4 of step kt+1 may stay in flight
-        __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4), expcnt/lgkmcnt untouched
-        __builtin_amdgcn_s_barrier();        // every wave's share of step kt has landed; everyone has left step kt-1
+        // step kt's IA + IB loads are the oldest in flight; those of step kt+1 may stay in flight
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (IA + IB));  // vmcnt(IA + IB), expcnt/lgkmcnt untouched
+        __builtin_amdgcn_s_barrier();                     // every wave's share of step kt has landed; everyone has left step kt-1
         const int nstg = (stg + 2 >= NSTG) ? stg + 2 - NSTG : stg + 2;
         WIDE_GLDS3(nstg, min(kt + 2, nk - 1) * TK)  // into the stage read in step kt-1; (tail: harmless re-loads)
         const bf16* a_s = sA + stg * TM * TK;
-        const bf16* b_s = sB + stg * TN * TK;
+        const bf16* b_s = sB + stg * TNV * TK;
         bf16x8 af[8], bfr[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_s + swz32(wm * 128 + 16 * i + lr, lg));
@@ -369,23 +372,29 @@ struct EpiDw {
 
 template <class Epi>
 static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st, const char* who) {
+    constexpr size_t lds128 = 2 * (BM + BN) * BK * sizeof(bf16), lds256 = NSTG * (TM + 256) * TK * sizeof(bf16),
+                     lds256x128 = NSTG * (TM + 128) * TK * sizeof(bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(2 * (BM + BN) * BK * sizeof(bf16)));
-        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(NSTG * (TM + TN) * TK * sizeof(bf16)));
+        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256x128);
         attr_set = true;
     }
-    const bool big = p.M >= 2 * TM && p.Nc >= 2 * TN && !getenv("AVD_GEMM_128");  // large problems: 256^2 tiles
-    const int tm = big ? TM : BM, tn = big ? TN : BN;
+    static const char* force = getenv("AVD_GEMM_TILE");  // diagnostics: "128", "256x128", "256"
+    int tile = (p.M >= 2 * TM && p.Nc >= 2 * 256) ? 256 : 128;  // large problems: 256^2 tiles
+    if (force) tile = !strcmp(force, "128") ? 128 : (!strcmp(force, "256x128") ? 192 : 256);
+    if (tile != 128 && (p.M < TM || p.K % TK)) tile = 128;
+    const int tm = tile == 128 ? BM : TM, tn = tile == 256 ? 256 : 128;
     const long ncol = rup(p.Nc, tn) / tn, nrow = rup(p.M, tm) / tm;
     const long gsz = p.ksplit > 1 ? nrow * ncol : ncol, groups = p.ksplit > 1 ? p.ksplit : nrow;
     dim3 grid((unsigned)(gsz * rup(groups, 8)), 1, (unsigned)n_sets);
-    if (big)
-        hipLaunchKernelGGL((gemm_bt256_kernel<Epi>), grid, dim3(TT), NSTG * (TM + TN) * TK * sizeof(bf16), st, p, e);
+    if (tile == 256)
+        hipLaunchKernelGGL((gemm_bt256_kernel<Epi, 256>), grid, dim3(512), lds256, st, p, e);
+    else if (tile == 192)
+        hipLaunchKernelGGL((gemm_bt256_kernel<Epi, 128>), grid, dim3(256), lds256x128, st, p, e);
     else
-        hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), 2 * (BM + BN) * BK * sizeof(bf16), st, p, e);
+        hipLaunchKernelGGL((gemm_bt_kernel<Epi>), grid, dim3(GT), lds128, st, p, e);
     return check_launch(who);
 }
 

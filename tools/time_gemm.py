@@ -10,8 +10,9 @@ import torch
 from avddpg_amd._hip import call, ptr, stream_handle
 
 for M, N, K in [(4096, 4096, 4096), (8192, 8192, 8192), (262144, 1024, 1088), (262144, 1072, 1024), (1072, 1024, 16384)]:
-    A = torch.randn(M + 256, K, device="cuda").to(torch.bfloat16)
-    B = torch.randn(N + 256, K, device="cuda").to(torch.bfloat16)
+    zeros = os.environ.get("GEMM_ZEROS")  # zero operands draw less power: the chip holds a higher clock (upper bound only)
+    A = (torch.zeros if zeros else torch.randn)(M + 256, K, device="cuda").to(torch.bfloat16)
+    B = (torch.zeros if zeros else torch.randn)(N + 256, K, device="cuda").to(torch.bfloat16)
     D = torch.empty(M, N, device="cuda")
     f = lambda: call("avd_gemm_bt_bf16", M, N, K, ptr(A), K, ptr(B), K, ptr(D), N, stream_handle())
     f()
