@@ -1209,6 +1209,142 @@ __device__ __forceinline__ void gemm_dx(const float* DZ, const float* __restrict
     }
 }
 
+// Weight-gradient and input-gradient GEMMs of one layer, interleaved per block of 64 features:
+//     for k0:  dW rows [k0, k0+64) (+ the fused Adam/Polyak epilogue)  |  barrier  |  dX columns [k0, k0+64), one 16-column
+//              tile per wave, BN/ReLU backward in place in P
+// Legal because block k0 of dW is the only reader of P's columns [k0, k0+64). Why: the input-gradient GEMM needs W2's
+// rows [k0, k0+64) -- exactly the rows the update epilogue of this block has just pulled through L2 -- so its operand
+// loads are L2 hits instead of a second trip to HBM after the whole update stream has gone by. They are issued between
+// the MFMA loop and the epilogue, i.e. ahead of the epilogue's stores in vmcnt order.
+template <int N, int LDP, int LDZ, class Sink, class SmallSink>
+__device__ __forceinline__ void gemm_dw_dx(float* P, const float* inv, const float* sh, int K, const float* DZ,
+                                           const float* db, float* __restrict__ gW, Sink sink,
+                                           const float* __restrict__ W, BnSet lo, BnSet hi, int split, SmallSink small) {
+    static_assert(N == 128, "N/16 == 8 reduction blocks held in registers");
+    constexpr int NT = N / (16 * NW), NB = N / 16;
+    constexpr bool kFused = !std::is_same<Sink, StoreSink>::value;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int col = wave * 16 * NT + NT * lr;
+    float dbc[NT];
+    ldn<NT>(dbc, db + col);
+    const float* dp = DZ + lg * LDZ + col;
+#pragma nounroll
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        typename std::conditional<kFused, AdamSink::Quad, int>::type q[16];
+        long base = 0;
+        if constexpr (kFused) {
+            static_assert(NT == 2, "fused epilogue works on column pairs");
+            base = (gW - sink.wo) + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta) {
+                    const int kb = min(k0 + 4 * (lg * 4 + j), K - 4);
+                    sink.load2(q[j * 4 + ta], base + (long)(kb + ta) * N);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* pp = P + lg * LDP + k0 + 4 * lr;
+        f32x4 pa[2];
+        float dz[2][NT];
+        pa[0] = *(const f32x4*)(pp);
+        ldn<NT>(dz[0], dp);
+#pragma unroll
+        for (int it = 0; it < TILE / 4; ++it) {
+            if (it + 1 < TILE / 4) {
+                pa[(it + 1) & 1] = *(const f32x4*)(pp + 4 * (it + 1) * LDP);
+                ldn<NT>(dz[(it + 1) & 1], dp + 4 * (it + 1) * LDZ);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[ta][t] = MFMA16(pa[it & 1][ta], dz[it & 1][t], acc[ta][t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this wave's input-gradient tile of the block: W2 rows c0 .. c0+15 (L2 hits) and the tile's BN parameters
+        const int c0 = k0 + wave * 16;
+        const bool have = c0 < K;
+        f32x4 wc[NB];
+        float bn[3] = {0.f, 0.f, 1.f};
+        if (have) dx_load_tile<N>(wc, bn, W, c0, lo, hi, split);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();  // every wave is done reading P[:, k0 .. k0+63]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kbase = k0 + 4 * (lg * 4 + j);
+            if (kbase < K) {
+                const f32x4 iv = *(const f32x4*)(inv + kbase);
+                const f32x4 sf = *(const f32x4*)(sh + kbase);
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta) {
+                    float o[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = fmaf(iv[ta], acc[ta][t][j], sf[ta] * dbc[t]);
+                    if constexpr (kFused)
+                        sink.update2(q[j * 4 + ta], base + (long)(kbase + ta) * N, o);
+                    else
+                        stn<NT>(gW + (kbase + ta) * N + col, o);
+                }
+            }
+        }
+        if (have) {
+            float pv[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[m][j] = P[(m * 16 + lg * 4 + j) * LDP + c0 + lr];
+            f32x4 dacc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) dacc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 a[2][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[0][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 4 * lg);
+#pragma unroll
+            for (int qq = 0; qq < NB; ++qq) {
+                if (qq + 1 < NB)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        a[(qq + 1) & 1][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 16 * (qq + 1) + 4 * lg);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) dacc[m] = MFMA16(a[qq & 1][m][jj], wc[qq][jj], dacc[m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int c = c0 + lr;
+            const float rs = 1.0f / sqrtf(bn[2] + BN_EPS);
+            const float gam = bn[0], mean = bn[1];
+            float sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dy = dacc[m][j];
+                    const float p = pv[m][j];
+                    sg = fmaf(dy * (p - mean), rs, sg);
+                    sb += dy;
+                    P[(m * 16 + lg * 4 + j) * LDP + c] = (p > 0.f) ? dy * (rs * gam) : 0.f;
+                }
+            sg += __shfl_xor(sg, 16);
+            sg += __shfl_xor(sg, 32);
+            sb += __shfl_xor(sb, 16);
+            sb += __shfl_xor(sb, 32);
+            if (lg == 0) {
+                const BnSet& s = (c0 < split) ? lo : hi;
+                small.put(s.dg + (c - s.base), sg);
+                small.put(s.dbe + (c - s.base), sb);
+            }
+        }
+    }
+}
+
 // Per-thread parameter columns of a network's first layers, loaded one phase before they are used.
 template <int K>
 struct L1P {
@@ -1502,8 +1638,12 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
         hi = {net.th + L.actor_size + L.cga, net.st + L.cmma, net.st + L.cmva, gc + L.cga, gc + L.cbea, H1};
         const float* wdx = wth + (crit ? L.cW2 : L.aW2);
         const int dx_begin = (it == 2) ? H1 : 0, dx_end = crit ? KC : H1;
+        // Fused form: weight gradient (+ update) and input gradient interleaved per 64-feature block, so that the
+        // input-gradient GEMM finds its W2 rows in L2 (gemm_dw_dx; PMC FETCH_SIZE -16 %). Gradients-out form: the two
+        // GEMMs back to back, the input-gradient one with its own tile prefetch (faster when nothing streams in between).
+        constexpr bool kInterleave = FUSED;
         DxPre<H2> dxp;
-        dx_prefetch<H2>(dxp, wdx, dx_begin, dx_end, lo, hi, H1);  // consumed by gemm_dx two phases later
+        if (it == 2 || !kInterleave) dx_prefetch<H2>(dxp, wdx, dx_begin, dx_end, lo, hi, H1);  // consumed by gemm_dx
         __builtin_amdgcn_sched_barrier(0);
         out_layer_backward(bP2, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, H2, bDZ, LDB, l.scr,
                            wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
@@ -1513,12 +1653,20 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             col_sums(bDZ, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
             lds_barrier();
             PH(it == 1 ? 8 : 16);
-            gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, bDZ, l.db,
-                                  gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk);
-            lds_barrier();
-            PH(it == 1 ? 9 : 17);
+            if constexpr (kInterleave) {
+                gemm_dw_dx<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, bDZ, l.db,
+                                         gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk, wdx, lo, hi, H1, sink);
+                PH(it == 1 ? 9 : 17);
+            } else {
+                gemm_dw<H2, LDA, LDB>(l.bufA, l.invA, l.shA, crit ? KC : H1, bDZ, l.db,
+                                      gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk);
+                lds_barrier();
+                PH(it == 1 ? 9 : 17);
+                gemm_dx<H2, LDB, LDA>(bDZ, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, true, dxp, sink);
+            }
+        } else {
+            gemm_dx<H2, LDB, LDA>(bDZ, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, false, dxp, sink);
         }
-        gemm_dx<H2, LDB, LDA>(bDZ, wdx, dx_begin, dx_end, l.bufA, lo, hi, H1, wg, dxp, sink);
         lds_barrier();
         PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
         if (it == 1) {
