@@ -43,6 +43,8 @@ def parse():
                          "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist)")
     ap.add_argument("--hidden", type=int, default=None,
                     help="actor/critic layer1 = layer2 size (BASELINE config 5: 1024; needs --mode interfrl)")
+    ap.add_argument("--framework", choices=["decentralized", "centralized"], default="decentralized",
+                    help="centralized: one model per platoon with S = 4L, A = L, widths x1.2 (SURVEY 8 f-3; general learn kernel)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-fused", action="store_true",
@@ -110,12 +112,12 @@ def main():
     P, L = args.platoons, args.pl_size
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
                          fed_method="interfrl" if args.mode == "interfrl" else "normal",
-                         weighted_average_enabled=False, random_seed=1 + rank)
+                         weighted_average_enabled=False, random_seed=1 + rank, framework=args.framework)
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
                             seed=1 + rank, pipeline_chunks=args.chunks,
-                            fused_update=(args.mode == "nofrl" and not args.no_fused),
+                            fused_update=(args.mode == "nofrl" and not args.no_fused and args.framework == "decentralized"),
                             shared_engine=args.engine if args.mode == "interfrl" else None)
     batched = vt.shared and vt.shared_engine == "batched"
     # synthetic steady state: replay rings full of random-init-platoon-like rows
@@ -157,18 +159,31 @@ def main():
 
     # per step: summed launch durations of each stage (learn/update: all agent slices of the step)
     stage_ms = {n: sum(a.elapsed_time(b) for a, b in ev.get(n, [])) / args.steps for n in names}
-    n_agents = P * L
+    n_agents = P * vt.M  # models: L per platoon (decentralized), 1 (centralized)
     env_steps_per_s = world * P * args.steps / elapsed
     updates_per_s = world * n_agents * args.steps / elapsed
     fused = stage_ms["learn+update"] > 0
+    # algorithmic work per agent-update from the LOGICAL network dims (at the reference widths these are the
+    # module constants: 0.751 MFLOP per sample, 2.47 MB per update)
+    d = vt.agents.dims
+    a_fwd = 2 * (d.S * d.H1 + d.H1 * d.H2 + d.H2 * d.A)
+    c_fwd = 2 * (d.S * d.H1 + d.A * d.Ha + (d.H1 + d.Ha) * d.H2 + d.H2 * d.A)
+    n_train = (d.S * d.H1 + 3 * d.H1 + d.H1 * d.H2 + 3 * d.H2 + d.H2 * d.A + d.A) + \
+              (d.S * d.H1 + 3 * d.H1 + d.A * d.Ha + 3 * d.Ha + (d.H1 + d.Ha) * d.H2 + 3 * d.H2 + d.H2 * d.A + d.A)
+    n_stats = 2 * (d.H1 + d.H2) + 2 * (d.H1 + d.Ha + d.H2)
+    flop_per_sample = 4 * a_fwd + 6 * c_fwd  # 5 forwards + the backward passes of critic, actor and actor-through-critic
+    adam_bytes = 32 * n_train + 12 * n_stats  # r/w of W, W_target, m, v + the soft update of the BN statistics
+    if (d.S, d.A, d.H1, d.H2, d.Ha) == (4, 1, 256, 128, 48):
+        assert abs(flop_per_sample - LEARN_FLOP_PER_SAMPLE) < 0.01 * LEARN_FLOP_PER_SAMPLE
+        assert abs(adam_bytes - ADAM_BYTES_PER_AGENT) < 0.01 * ADAM_BYTES_PER_AGENT
     roofs = []
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
         t = stage_ms["learn+update"] / 1e3
-        mf = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / t / 1e12,
+        mf = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / t / 1e12,
               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-        hb = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / t / 1e9,
+        hb = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / t / 1e9,
               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roofs = [mf, hb]
     elif batched:
@@ -184,15 +199,15 @@ def main():
     else:
         learn_s = stage_ms["learn"] / 1e3
         upd_s = stage_ms["update"] / 1e3
-        roofs.append({"kernel": "learn_kernel", "bound": "mfma", "achieved": LEARN_FLOP_PER_SAMPLE * 64 * n_agents / learn_s / 1e12,
+        roofs.append({"kernel": "learn_kernel" if args.framework == "decentralized" else "gen::learn_kernel_g", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "_t": learn_s})
         if args.mode == "nofrl":
-            roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": ADAM_BYTES_PER_AGENT * n_agents / upd_s / 1e9,
+            roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
-    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1:
+    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
         pmc = json.load(open(pmc_path))["kernels"]
         want = {"learn_kernel_t<fused> + adam_polyak_ranges_kernel": ("learn_kernel_t", "adam_polyak_ranges"),
                 "learn_kernel": ("learn_kernel_t",), "adam_polyak_kernel": ("adam_polyak_kernel",)}
@@ -228,6 +243,7 @@ def main():
             "dtype": "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32",
             "data": "synthetic",
             "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
+                                   + ("centralized " if args.framework == "centralized" else "")
                                    + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
                                       if args.mode == "nofrl" else
                                       "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
