@@ -546,6 +546,15 @@ namespace gen {
 
 constexpr int MAX_A = 16, MAX_S = 64;
 
+// Out-of-line helpers (one copy of each in the kernel: it runs them from up to five call sites and would not fit the
+// instruction cache inlined) take their pointers with explicit address spaces -- a plain pointer argument is generic,
+// and a generic access to LDS is a slow flat_load instead of ds_read.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(1))) float glb_f;
+#define LDSP(p) ((lds_f*)(p))
+#define GLBP(p) ((glb_f*)(p))
+#define CGLBP(p) ((const glb_f*)(p))
+
 struct GLds {
     float *bufA, *bufB;          // [64][ldA] first-layer outputs (state | action), [64][ldB] second layer / its gradient
     float *invA, *shA;           // H1+Ha
@@ -583,28 +592,49 @@ __device__ __forceinline__ GLds carve(float* p, const avd_mlp_layout& L) {
     return l;
 }
 
-// first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k
-__device__ __forceinline__ void l1_fwd(const float* X, int K, const float* __restrict__ W, const float* __restrict__ b,
-                                       const float* __restrict__ g, const float* __restrict__ be,
-                                       const float* __restrict__ mm, const float* __restrict__ mv, int H, float* out,
-                                       int ld, int col0, float* inv, float* sh) {
+// first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k.
+// One column per thread, its 64 rows in registers; the K inputs go by in chunks of 4 whose weights are loaded together
+// (one L2 round trip per chunk, the next chunk's requested before the current one is used) -- a weight load inside the
+// row loop costs its full latency per use.
+__device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
+                                       const glb_f* __restrict__ g, const glb_f* __restrict__ be,
+                                       const glb_f* __restrict__ mm, const glb_f* __restrict__ mv, int H, lds_f* out,
+                                       int ld, int col0, lds_f* inv, lds_f* sh) {
     for (int k = threadIdx.x; k < H; k += NTHREADS) {
         const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
         inv[col0 + k] = iv;
         sh[col0 + k] = be[k] - mm[k] * iv;
         const float bk = b[k];
-        for (int rb = 0; rb < TILE; rb += RB) {
-            float acc[RB];
+        float acc[TILE];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) acc[i] = bk;
-            for (int j = 0; j < K; ++j) {
-                const float w = W[j * H + k];
+        for (int r = 0; r < TILE; ++r) acc[r] = bk;
+        float wn[4];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) acc[i] = fmaf(X[(rb + i) * K + j], w, acc[i]);
+        for (int jj = 0; jj < 4; ++jj) wn[jj] = (jj < K) ? W[jj * H + k] : 0.f;
+#pragma nounroll
+        for (int j0 = 0; j0 < K; j0 += 4) {  // one chunk of weights serves all 64 rows: its successor's L2 round trip hides
+            float w[4];                      // under ~250 LDS reads + FMAs
+            int jx[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w[jj] = wn[jj], jx[jj] = min(j0 + jj, K - 1);  // tail: weight 0, index clamped
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) wn[jj] = (j0 + 4 + jj < K) ? W[(j0 + 4 + jj) * H + k] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < TILE; rb += 8) {  // operands of 8 rows first, then the FMAs: a read -> use -> read
+                float xv[8][4];                      // chain pays one LDS round trip per value
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[rb + i] = fmaf(xv[i][jj], w[jj], acc[rb + i]);
+                __builtin_amdgcn_sched_barrier(0);  // or the scheduler hoists all 256 reads of the chunk and spills them
             }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) out[(rb + i) * ld + col0 + k] = fmaxf(acc[i], 0.f);
         }
+#pragma unroll
+        for (int r = 0; r < TILE; ++r) out[r * ld + col0 + k] = fmaxf(acc[r], 0.f);
     }
 }
 
@@ -618,49 +648,95 @@ __device__ __forceinline__ void coefs_b(const float* __restrict__ g, const float
     }
 }
 
-// output layer, width A: out[r][a] = sum_k bn(P[r][k]) * W3[k*A+a] + b3[a]
-__device__ __forceinline__ void out_fwd(const GLds& l, int ldB, const float* __restrict__ W3,
-                                        const float* __restrict__ b3, int H2, int A, float* out) {
-    for (int idx = threadIdx.x; idx < TILE * A; idx += NTHREADS) {
-        const int r = idx / A, a = idx - r * A;
-        float acc = b3[a];
-        for (int k = 0; k < H2; ++k) acc = fmaf(fmaf(l.bufB[r * ldB + k], l.invB[k], l.shB[k]), W3[k * A + a], acc);
-        out[idx] = acc;
+// output layer, width A: out[r][a] = sum_k bn(P[r][k]) * W3[k*A+a] + b3[a].  4 lanes per batch row split k, partial sums
+// meet by shuffles. Outputs go by in chunks of 4 (uniform branch per chunk; inside a chunk every load is unconditional with
+// a clamped index -- a load under its own `if (a < A)` is waited for before the next one is issued).
+__device__ __attribute__((noinline)) void out_fwd(const lds_f* bufB, const lds_f* invB, const lds_f* shB, int ldB, const glb_f* __restrict__ W3,
+                                        const glb_f* __restrict__ b3, int H2, int A, lds_f* out) {
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+#pragma nounroll
+    for (int a0 = 0; a0 < A; a0 += 4) {
+        int ax[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ax[i] = min(a0 + i, A - 1);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+        for (int k0 = part; k0 < H2; k0 += 32) {  // 8 k's per step: all operands first, then the FMAs
+            float y[8], wv[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + 4 * u, H2 - 1);
+                const float ok = (k0 + 4 * u < H2) ? 1.f : 0.f;
+                y[u] = fmaf(bufB[r * ldB + k], invB[k], shB[k]) * ok;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wv[u][i] = W3[k * A + ax[i]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(y[u], wv[u][i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (part == 0 && a0 + i < A) out[r * A + a0 + i] = v + b3[a0 + i];
+        }
     }
 }
 
 // output layer backward through the BN below it, in place: bufB[r][k] (p) -> dz[r][k]
 //   dW3[k][a] = sum_r y[r][k]*D[r][a]; db3[a] = sum_r D[r][a]; dy[r][k] = sum_a D[r][a]*W3[k][a]
-__device__ __forceinline__ void out_bwd(GLds& l, int ldB, const float* D, const float* __restrict__ W3, int H2, int A,
-                                        float* __restrict__ gW3, float* __restrict__ gb3, float* __restrict__ gg,
-                                        float* __restrict__ gbe) {
+// One column k per thread; its 64 activations stay in registers while the outputs go by in chunks of 4 (see out_fwd).
+__device__ __attribute__((noinline)) void out_bwd(lds_f* bufB, const lds_f* invB, const lds_f* shB, const lds_f* rsB, const lds_f* mmB, int ldB,
+                                        const lds_f* D, const glb_f* __restrict__ W3, int H2, int A, glb_f* __restrict__ gW3,
+                                        glb_f* __restrict__ gb3, glb_f* __restrict__ gg, glb_f* __restrict__ gbe) {
     for (int k = threadIdx.x; k < H2; k += NTHREADS) {
-        float w[MAX_A], dw[MAX_A];
-#pragma unroll
-        for (int a = 0; a < MAX_A; ++a) w[a] = (a < A) ? W3[k * A + a] : 0.f, dw[a] = 0.f;
-        const float iv = l.invB[k], s = l.shB[k], rs = l.rsB[k], mean = l.mmB[k];
+        const float iv = invB[k], s = shB[k], rs = rsB[k], mean = mmB[k];
         float dgm = 0.f, dbt = 0.f;
-        for (int r = 0; r < TILE; ++r) {
-            const float p = l.bufB[r * ldB + k];
-            const float y = fmaf(p, iv, s);
-            float dy = 0.f;
+        constexpr int HR = TILE / 2;  // rows per half: 2 x 32 registers instead of 2 x 64
+#pragma nounroll
+        for (int h = 0; h < 2; ++h) {
+            const int rb = h * HR;
+            float p[HR], dy[HR];
 #pragma unroll
-            for (int a = 0; a < MAX_A; ++a)
-                if (a < A) {
-                    const float d = D[r * A + a];
-                    dy = fmaf(d, w[a], dy);
-                    dw[a] = fmaf(y, d, dw[a]);
+            for (int r = 0; r < HR; ++r) p[r] = bufB[(rb + r) * ldB + k], dy[r] = 0.f;
+#pragma nounroll
+            for (int a0 = 0; a0 < A; a0 += 4) {
+                int ax[4];
+                float w[4], dw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ax[i] = min(a0 + i, A - 1);
+                    w[i] = (a0 + i < A) ? 1.f : 0.f;  // tail: clamped index, zero weight
                 }
-            dgm = fmaf(dy * (p - mean), rs, dgm);
-            dbt += dy;
-            l.bufB[r * ldB + k] = (p > 0.f) ? dy * iv : 0.f;
-        }
-        if (gW3) {
 #pragma unroll
-            for (int a = 0; a < MAX_A; ++a)
-                if (a < A) gW3[k * A + a] = dw[a];
-            gg[k] = dgm, gbe[k] = dbt;
+                for (int i = 0; i < 4; ++i) w[i] *= W3[k * A + ax[i]];
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    const float y = fmaf(p[r], iv, s);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float d = D[(rb + r) * A + ax[i]];
+                        dy[r] = fmaf(d, w[i], dy[r]);
+                        dw[i] = fmaf(y, d, dw[i]);
+                    }
+                }
+                if (gW3) {  // the second half adds to what the first one stored
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (a0 + i < A) gW3[k * A + a0 + i] = (h ? gW3[k * A + a0 + i] : 0.f) + dw[i];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                dgm = fmaf(dy[r] * (p[r] - mean), rs, dgm);
+                dbt += dy[r];
+                bufB[(rb + r) * ldB + k] = (p[r] > 0.f) ? dy[r] * iv : 0.f;
+            }
         }
+        if (gW3) gg[k] = dgm, gbe[k] = dbt;
     }
     if (gb3 && threadIdx.x < A) {
         float sum = 0.f;
@@ -669,24 +745,39 @@ __device__ __forceinline__ void out_bwd(GLds& l, int ldB, const float* D, const 
     }
 }
 
-// first-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*K+j]*dz[r][k], db[k] = sum_r dz[r][k]
-__device__ __forceinline__ void l1_grads(const float* X, int K, const float* DZ, int ldz, int c0, int H,
-                                         float* __restrict__ gW, float* __restrict__ gb) {
+// first-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*K+j]*dz[r][k], db[k] = sum_r dz[r][k].
+// One column per thread; the K inputs go by in chunks of 4.
+__device__ __attribute__((noinline)) void l1_grads(const lds_f* X, int K, const lds_f* DZ, int ldz, int c0, int H, glb_f* __restrict__ gW,
+                                         glb_f* __restrict__ gb) {
     for (int k = threadIdx.x; k < H; k += NTHREADS) {
-        for (int j0 = 0; j0 < K; j0 += 8) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float sb = 0.f;
-            for (int r = 0; r < TILE; ++r) {
-                const float d = DZ[r * ldz + c0 + k];
-                sb += d;
+        const lds_f* dzk = DZ + c0 + k;
+        float sb = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < TILE; ++r) sb += dzk[r * ldz];
+        gb[k] = sb;
+#pragma nounroll
+        for (int j0 = 0; j0 < K; j0 += 4) {
+            int jx[4];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj)
-                    if (j0 + jj < K) acc[jj] = fmaf(X[r * K + j0 + jj], d, acc[jj]);
+            for (int jj = 0; jj < 4; ++jj) jx[jj] = min(j0 + jj, K - 1);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+            for (int rb = 0; rb < TILE; rb += 16) {  // operands of 16 rows first, then the FMAs (see l1_fwd)
+                float xv[16][4], dv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    dv[i] = dzk[(rb + i) * ldz];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(xv[i][jj], dv[i], acc[jj]);
             }
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
+            for (int jj = 0; jj < 4; ++jj)
                 if (j0 + jj < K) gW[(j0 + jj) * H + k] = acc[jj];
-            if (j0 == 0) gb[k] = sb;
         }
     }
 }
@@ -700,6 +791,14 @@ __device__ __forceinline__ float block_sum(const float* v, int n, float* red) { 
     lds_barrier();
     const float t = red[0] + red[1] + red[2] + red[3];
     lds_barrier();
+    return t;
+}
+
+// One load per 128-byte line of [lo, hi): pulls a network's small tensors (everything but W2) into L2 ahead of the passes
+// that read them a few values at a time -- cold, each such read is a serial trip to HBM.
+__device__ __forceinline__ float warm(const float* __restrict__ base, int lo, int hi) {
+    float t = 0.f;
+    for (int i = lo + threadIdx.x * 32; i < hi; i += NTHREADS * 32) t += base[i];
     return t;
 }
 
@@ -731,6 +830,17 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
         for (int i = L.cb3 + A; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
     }
 
+    {
+        float t = 0.f;
+        const int csz = L.theta_size - L.actor_size;
+        t += warm(tgt.th, 0, L.aW2) + warm(tgt.th, L.ab2, L.actor_size);
+        t += warm(tgt.th + L.actor_size, 0, L.cW2) + warm(tgt.th + L.actor_size, L.cb2, csz);
+        t += warm(net.th, 0, L.aW2) + warm(net.th, L.ab2, L.actor_size);
+        t += warm(net.th + L.actor_size, 0, L.cW2) + warm(net.th + L.actor_size, L.cb2, csz);
+        t += warm(net.st, 0, L.stats_size) + warm(tgt.st, 0, L.stats_size);
+        asm volatile("" ::"v"(t));  // keep the loads
+    }
+    PH_INIT();
     // pass 0: targets (y); 1: critic loss + gradient; 2: actor -> critic, gradient wrt the actions; 3: actor gradient
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
@@ -741,35 +851,45 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             for (int i = tid; i < TILE * S; i += NTHREADS) l.sX[i] = src[i];
             lds_barrier();
         }
+        PH(20);
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
             const float* th = n.th;
-            l1_fwd(l.sX, S, th + L.aW1, th + L.ab1, th + L.ag1, th + L.abe1, n.st + L.amm1, n.st + L.amv1, H1, l.bufA, ldA,
-                   0, l.invA, l.shA);
+            l1_fwd(LDSP(l.sX), S, CGLBP(th + L.aW1), CGLBP(th + L.ab1), CGLBP(th + L.ag1), CGLBP(th + L.abe1), CGLBP(n.st + L.amm1),
+                   CGLBP(n.st + L.amv1), H1, LDSP(l.bufA), ldA, 0, LDSP(l.invA), LDSP(l.shA));
+            PH(21);
             coefs_b(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, H2, l);
             lds_barrier();
+            PH(1);
             gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, H1, th + L.aW2, th + L.ab2, H2, l.bufB, ldB);
             lds_barrier();
-            out_fwd(l, ldB, th + L.aW3, th + L.ab3, H2, A, l.sQ);
+            PH(2);
+            out_fwd(LDSP(l.bufB), LDSP(l.invB), LDSP(l.shB), ldB, CGLBP(th + L.aW3), CGLBP(th + L.ab3), H2, A, LDSP(l.sQ));
             lds_barrier();
             for (int i = tid; i < TILE * A; i += NTHREADS) {
                 const float t = tanhf(l.sQ[i]);
                 l.sT[i] = t, l.sA1[i] = t * high;
             }
             lds_barrier();
+            PH(3);
         }
         if (it != 3) {  // ---- critic forward (agent/model.py:63-83)
             const float* th = n.th + L.actor_size;
             const float* act = (it == 1) ? l.sAct : l.sA1;
-            l1_fwd(l.sX, S, th + L.cWs, th + L.cbs, th + L.cgs, th + L.cbes, n.st + L.cmms, n.st + L.cmvs, H1, l.bufA, ldA,
-                   0, l.invA, l.shA);
-            l1_fwd(act, A, th + L.cWa, th + L.cba, th + L.cga, th + L.cbea, n.st + L.cmma, n.st + L.cmva, Ha, l.bufA, ldA,
-                   H1, l.invA, l.shA);
+            l1_fwd(LDSP(l.sX), S, CGLBP(th + L.cWs), CGLBP(th + L.cbs), CGLBP(th + L.cgs), CGLBP(th + L.cbes), CGLBP(n.st + L.cmms),
+                   CGLBP(n.st + L.cmvs), H1, LDSP(l.bufA), ldA, 0, LDSP(l.invA), LDSP(l.shA));
+            PH(22);
+            l1_fwd(LDSP(act), A, CGLBP(th + L.cWa), CGLBP(th + L.cba), CGLBP(th + L.cga), CGLBP(th + L.cbea), CGLBP(n.st + L.cmma),
+                   CGLBP(n.st + L.cmva), Ha, LDSP(l.bufA), ldA, H1, LDSP(l.invA), LDSP(l.shA));
+            PH(23);
             coefs_b(th + L.cg3, th + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, H2, l);
             lds_barrier();
+            PH(4);
             gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, KC, th + L.cW2, th + L.cb2, H2, l.bufB, ldB);
             lds_barrier();
-            out_fwd(l, ldB, th + L.cW3, th + L.cb3, H2, A, l.sQ);
+            PH(5);
+            out_fwd(LDSP(l.bufB), LDSP(l.invB), LDSP(l.shB), ldB, CGLBP(th + L.cW3), CGLBP(th + L.cb3), H2, A, LDSP(l.sQ));
             lds_barrier();
+            PH(6);
         }
         if (it == 0) {  // y = r + gamma * Q'(s2, mu'(s2)), r broadcast over the A outputs, no done mask (trainer.py:494)
             for (int i = tid; i < TILE * A; i += NTHREADS) l.sY[i] = fmaf(gamma, l.sQ[i], l.sR[i / A]);
@@ -798,15 +918,19 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
         const bool crit = (it != 3), wg = (it != 2);
         const float* wth = crit ? net.th + L.actor_size : net.th;
         float* gout = crit ? gc : ga;
-        out_bwd(l, ldB, l.sD, wth + (crit ? L.cW3 : L.aW3), H2, A, wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr,
-                wg ? gout + (crit ? L.cb3 : L.ab3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
-                gout + (crit ? L.cbe3 : L.abe2));
+        out_bwd(LDSP(l.bufB), LDSP(l.invB), LDSP(l.shB), LDSP(l.rsB), LDSP(l.mmB), ldB, LDSP(l.sD),
+                CGLBP(wth + (crit ? L.cW3 : L.aW3)), H2, A, GLBP(wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr),
+                GLBP(wg ? gout + (crit ? L.cb3 : L.ab3) : nullptr), GLBP(gout + (crit ? L.cg3 : L.ag2)),
+                GLBP(gout + (crit ? L.cbe3 : L.abe2)));
         lds_barrier();
+        PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
         if (wg) {
             col_sums(l.bufB, ldB, H2, l.db, gout + (crit ? L.cb2 : L.ab2));
             lds_barrier();
+            PH(it == 1 ? 8 : 16);
             gemm_dw(l.bufA, ldA, l.invA, l.shA, crit ? KC : H1, l.bufB, ldB, l.db, H2, gout + (crit ? L.cW2 : L.aW2));
             lds_barrier();
+            PH(it == 1 ? 9 : 17);
         }
         const float* w2 = wth + (crit ? L.cW2 : L.aW2);
         if (it != 2) {
@@ -823,9 +947,11 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
                        wg ? gc + L.cga : nullptr, wg ? gc + L.cbea : nullptr);
         }
         lds_barrier();
+        PH(it == 1 ? 10 : (it == 2 ? 13 : 18));
         if (it == 1) {
-            l1_grads(l.sX, S, l.bufA, ldA, 0, H1, gc + L.cWs, gc + L.cbs);
-            l1_grads(l.sAct, A, l.bufA, ldA, H1, Ha, gc + L.cWa, gc + L.cba);
+            l1_grads(LDSP(l.sX), S, LDSP(l.bufA), ldA, 0, H1, GLBP(gc + L.cWs), GLBP(gc + L.cbs));
+            l1_grads(LDSP(l.sAct), A, LDSP(l.bufA), ldA, H1, Ha, GLBP(gc + L.cWa), GLBP(gc + L.cba));
+            PH(11);
         } else if (it == 2) {  // da[r][a] = sum_j dza[r][j] * Wa[a][j]
             const float* cth = net.th + L.actor_size;
             for (int i = tid; i < TILE * A; i += NTHREADS) {
@@ -834,8 +960,10 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
                 for (int j = 0; j < Ha; ++j) acc = fmaf(l.bufA[rr * ldA + H1 + j], cth[L.cWa + aa * Ha + j], acc);
                 l.sDa[i] = acc;
             }
+            PH(14);
         } else {
-            l1_grads(l.sX, S, l.bufA, ldA, 0, H1, ga + L.aW1, ga + L.ab1);
+            l1_grads(LDSP(l.sX), S, LDSP(l.bufA), ldA, 0, H1, GLBP(ga + L.aW1), GLBP(ga + L.ab1));
+            PH(19);
         }
     }
 }

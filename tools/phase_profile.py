@@ -25,10 +25,12 @@ NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fw
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 FUSED = len(sys.argv) > 2 and sys.argv[2] == "fused"
+CENTRAL = len(sys.argv) > 2 and sys.argv[2] == "centralized"  # general kernel at S = 20, A = 5, widths x1.2
 conf = config.Config()
-grp = vec.AgentGroup(n, 4, 1, conf)
+S, A = (20, 5) if CENTRAL else (4, 1)
+grp = vec.AgentGroup(n, S, A, conf, hidd_mult=1.2 if CENTRAL else 1.0)
 f = lambda *s: torch.randn(*s, device="cuda")
-s, a, r, s2 = f(n, 64, 4), f(n, 64, 1), f(n, 64), f(n, 64, 4)
+s, a, r, s2 = f(n, 64, S), f(n, 64, A), f(n, 64), f(n, 64, S)
 lib = _hip.lib()
 lib.avd_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
@@ -44,5 +46,7 @@ lib.avd_debug_phase_cycles(buf, 0)
 tot = sum(buf)
 print(f"tiles={3 * n}  cycles/tile={tot / (3 * n):.0f}")
 NAMES.update({20: "  dx: issue next-tile loads", 21: "  dx: MFMA loop", 22: "  dx: BN epilogue", 23: "  dx: wait next tile (copy)"})
+if CENTRAL:  # the general kernel stamps its first-layer pieces under these ids (and they are NOT part of phases 1 / 4)
+    NAMES.update({20: "stage state batch", 21: "actor first layer", 22: "critic first layer (state)", 23: "critic first layer (action)"})
 for i in range(24):
     print(f"{i:2d} {NAMES[i]:38s} {buf[i] / (3 * n):9.0f} cyc/tile  {100 * buf[i] / tot:5.1f}%")
