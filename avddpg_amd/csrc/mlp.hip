@@ -176,64 +176,76 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FWD_RING = 4;  // B-operand register ring: blocks of 16 k in flight ahead of the MFMAs
 
+// One (16*MT rows) x 32 columns output tile of gemm_fwd_relu: rows (m0 + m) * 16 .., m < MT.
+template <int MT>
+__device__ __forceinline__ void fwd_relu_tile(const float* X, int ldx, const float* inv, const float* sh, int K,
+                                              const float* __restrict__ W, const float* __restrict__ b, int N, float* out,
+                                              int ldo, int n0, int m0) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int nblk = K >> 4;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (long)(4 * lg) * N + n0 + 2 * lr;  // row k = 16*blk + 4*lg + jj, columns n0+2lr, +1
+    f32x2 ring[FWD_RING][4];
+#pragma unroll
+    for (int d = 0; d < FWD_RING - 1; ++d)
+        if (d < nblk)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ring[d][jj] = *(const f32x2*)(wp + (long)(16 * d + jj) * N);
+    for (int kb = 0; kb < nblk; kb += FWD_RING) {
+#pragma unroll
+        for (int d = 0; d < FWD_RING; ++d) {
+            const int blk = kb + d;
+            if (blk < nblk) {
+                const int pre = blk + FWD_RING - 1;
+                if (pre < nblk)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        ring[(d + FWD_RING - 1) % FWD_RING][jj] = *(const f32x2*)(wp + (long)(16 * pre + jj) * N);
+                const int k4 = 16 * blk + 4 * lg;
+                const f32x4 iv = *(const f32x4*)(inv + k4);
+                const f32x4 sf = *(const f32x4*)(sh + k4);
+                f32x4 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f32x4 xv = *(const f32x4*)(X + ((m0 + m) * 16 + lr) * ldx + k4);
+                    a[m] = xv * iv + sf;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][0] = MFMA16(a[m][jj], ring[d][jj][0], acc[m][0]);
+                        acc[m][1] = MFMA16(a[m][jj], ring[d][jj][1], acc[m][1]);
+                    }
+            }
+        }
+    }
+    const f32x2 bc = *(const f32x2*)(b + n0 + 2 * lr);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 o;
+            o[0] = fmaxf(acc[m][0][j] + bc[0], 0.f);
+            o[1] = fmaxf(acc[m][1][j] + bc[1], 0.f);
+            *(f32x2*)(out + ((m0 + m) * 16 + lg * 4 + j) * ldo + n0 + 2 * lr) = o;
+        }
+}
+
 // Forward hidden layer: out[r][n] = relu(sum_k bn(X[r][k]) * W[k][n] + b[n]); X,out in LDS, W global [K][N].
-// K % 16 == 0, N % 32 == 0. Wave w owns columns [32w, 32w+32) (+128 per pass).
+// K % 16 == 0, N % 32 == 0. Full rounds: wave w owns the 64 x 32 tile of column group 4*round + w. The N/32 % 4 left-over
+// column groups are split by ROW tiles as well (16 x 32 pieces dealt over the four waves), so that e.g. N = 160 costs
+// 1.25 rounds, not 2 with three waves idle in the second.
 __device__ __forceinline__ void gemm_fwd_relu(const float* X, int ldx, const float* inv, const float* sh, int K,
                                               const float* __restrict__ W, const float* __restrict__ b, int N,
                                               float* out, int ldo) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    const int nblk = K >> 4;
-    for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wp = W + (long)(4 * lg) * N + n0 + 2 * lr;  // row k = 16*blk + 4*lg + jj, columns n0+2lr, +1
-        f32x2 ring[FWD_RING][4];
-#pragma unroll
-        for (int d = 0; d < FWD_RING - 1; ++d)
-            if (d < nblk)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) ring[d][jj] = *(const f32x2*)(wp + (long)(16 * d + jj) * N);
-        for (int kb = 0; kb < nblk; kb += FWD_RING) {
-#pragma unroll
-            for (int d = 0; d < FWD_RING; ++d) {
-                const int blk = kb + d;
-                if (blk < nblk) {
-                    const int pre = blk + FWD_RING - 1;
-                    if (pre < nblk)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            ring[(d + FWD_RING - 1) % FWD_RING][jj] = *(const f32x2*)(wp + (long)(16 * pre + jj) * N);
-                    const int k4 = 16 * blk + 4 * lg;
-                    const f32x4 iv = *(const f32x4*)(inv + k4);
-                    const f32x4 sf = *(const f32x4*)(sh + k4);
-                    f32x4 a[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const f32x4 xv = *(const f32x4*)(X + (m * 16 + lr) * ldx + k4);
-                        a[m] = xv * iv + sf;
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            acc[m][0] = MFMA16(a[m][jj], ring[d][jj][0], acc[m][0]);
-                            acc[m][1] = MFMA16(a[m][jj], ring[d][jj][1], acc[m][1]);
-                        }
-                }
-            }
-        }
-        const f32x2 bc = *(const f32x2*)(b + n0 + 2 * lr);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2 o;
-                o[0] = fmaxf(acc[m][0][j] + bc[0], 0.f);
-                o[1] = fmaxf(acc[m][1][j] + bc[1], 0.f);
-                *(f32x2*)(out + (m * 16 + lg * 4 + j) * ldo + n0 + 2 * lr) = o;
-            }
-    }
+    const int wave = threadIdx.x >> 6;
+    const int groups = N >> 5, full = groups >> 2, rem = groups & 3;
+    for (int rd = 0; rd < full; ++rd) fwd_relu_tile<4>(X, ldx, inv, sh, K, W, b, N, out, ldo, (rd * 4 + wave) * 32, 0);
+    for (int item = wave; item < rem * 4; item += 4)
+        fwd_relu_tile<1>(X, ldx, inv, sh, K, W, b, N, out, ldo, (full * 4 + (item >> 2)) * 32, item & 3);
 }
 
 // Weight gradient of a hidden layer fed by a BN output (all operands in LDS):
@@ -242,9 +254,13 @@ __device__ __forceinline__ void gemm_fwd_relu(const float* X, int ldx, const flo
 __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* inv, const float* sh, int K,
                                         const float* DZ, int ldz, const float* db, int N, float* __restrict__ gW) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
-    for (int n0 = wave * 32; n0 < N; n0 += 4 * 32) {
+    // (column group of 32, block of 64 feature rows) items dealt round-robin over the four waves
+    const int groups = N >> 5, kblocks = (K + 63) >> 6;
+    for (int item = wave; item < groups * kblocks; item += 4) {
+        const int n0 = (item % groups) * 32;
         const f32x2 dbc = *(const f32x2*)(db + n0 + 2 * lr);
-        for (int k0 = 0; k0 < K; k0 += 64) {
+        {
+            const int k0 = (item / groups) * 64;
             f32x4 acc[4][2];
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
