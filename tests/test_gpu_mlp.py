@@ -295,16 +295,17 @@ def test_full_size_learn_properties_20480_agents():
     assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-6)
 
 
-def test_centralized_shapes_forward_and_learn():
+@pytest.mark.parametrize("L", [3, 5])
+def test_centralized_shapes_forward_and_learn(L):
     """Centralized framework (SURVEY f-3; workers/trainer.py:80-87, 108-113): one agent per platoon with
     S = 4L states, A = L actions and widths int(256*1.2)/int(128*1.2)/int(48*1.2) = 307/153/57, held in slabs
     padded to 320/160/64. The critic has A outputs, the TD target broadcasts r over them (trainer.py:494) and
     both losses average over B*A."""
     need_gpu()
-    n_agents, L = 3, 3
-    S, A = 4 * L, L
+    n_agents = 3
+    S, A = 4 * L, L  # L = 5: two chunks of output-layer columns (4 + 1) and five chunks of inputs in the general kernel
     conf, grp = _perturbed_group(n_agents, S=S, A=A, hidd_mult=1.2, seed=41)
-    assert tuple(grp.dims) == (12, 3, 307, 153, 57) and (grp.lay.H1, grp.lay.H2, grp.lay.Ha) == (320, 160, 64)
+    assert tuple(grp.dims) == (S, A, 307, 153, 57) and (grp.lay.H1, grp.lay.H2, grp.lay.Ha) == (320, 160, 64)
     rs = np.random.RandomState(42)
     x = rs.normal(0, 1.5, size=(n_agents, S)).astype(np.float32)
     act = rs.uniform(-2.5, 2.5, size=(n_agents, A)).astype(np.float32)
