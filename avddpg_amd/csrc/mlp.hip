@@ -609,48 +609,50 @@ __device__ __forceinline__ GLds carve(float* p, const avd_mlp_layout& L) {
 }
 
 // first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k.
-// One column per thread, its 64 rows in registers; the K inputs go by in chunks of 4 whose weights are loaded together
-// (one L2 round trip per chunk, the next chunk's requested before the current one is used) -- a weight load inside the
-// row loop costs its full latency per use.
+// Work items are (column, quarter of the 64 rows), dealt round-robin: H = 320 columns are 1280 items = 5 per thread
+// (one column per thread would be two rounds with three waves idle in the second). The K inputs go by in chunks of 4
+// whose weights are loaded together, the next chunk's requested before the current one is used -- a weight load
+// inside the row loop costs its full latency per use; the operands of the 16 rows are read before the FMAs.
 __device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
                                        const glb_f* __restrict__ g, const glb_f* __restrict__ be,
                                        const glb_f* __restrict__ mm, const glb_f* __restrict__ mv, int H, lds_f* out,
                                        int ld, int col0, lds_f* inv, lds_f* sh) {
-    for (int k = threadIdx.x; k < H; k += NTHREADS) {
-        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
-        inv[col0 + k] = iv;
-        sh[col0 + k] = be[k] - mm[k] * iv;
+    constexpr int QR = TILE / 4;
+    for (int item = threadIdx.x; item < 4 * H; item += NTHREADS) {
+        const int q = item / H, k = item - q * H;
+        if (q == 0) {
+            const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+            inv[col0 + k] = iv;
+            sh[col0 + k] = be[k] - mm[k] * iv;
+        }
+        const lds_f* Xq = X + q * QR * K;
         const float bk = b[k];
-        float acc[TILE];
+        float acc[QR];
 #pragma unroll
-        for (int r = 0; r < TILE; ++r) acc[r] = bk;
+        for (int r = 0; r < QR; ++r) acc[r] = bk;
         float wn[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) wn[jj] = (jj < K) ? W[jj * H + k] : 0.f;
 #pragma nounroll
-        for (int j0 = 0; j0 < K; j0 += 4) {  // one chunk of weights serves all 64 rows: its successor's L2 round trip hides
-            float w[4];                      // under ~250 LDS reads + FMAs
+        for (int j0 = 0; j0 < K; j0 += 4) {
+            float w[4];
             int jx[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) w[jj] = wn[jj], jx[jj] = min(j0 + jj, K - 1);  // tail: weight 0, index clamped
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) wn[jj] = (j0 + 4 + jj < K) ? W[(j0 + 4 + jj) * H + k] : 0.f;
+            float xv[QR][4];
 #pragma unroll
-            for (int rb = 0; rb < TILE; rb += 8) {  // operands of 8 rows first, then the FMAs: a read -> use -> read
-                float xv[8][4];                      // chain pays one LDS round trip per value
+            for (int i = 0; i < QR; ++i)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int jj = 0; jj < 4; ++jj) xv[i][jj] = Xq[i * K + jx[jj]];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
+            for (int i = 0; i < QR; ++i)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[rb + i] = fmaf(xv[i][jj], w[jj], acc[rb + i]);
-                __builtin_amdgcn_sched_barrier(0);  // or the scheduler hoists all 256 reads of the chunk and spills them
-            }
+                for (int jj = 0; jj < 4; ++jj) acc[i] = fmaf(xv[i][jj], w[jj], acc[i]);
         }
 #pragma unroll
-        for (int r = 0; r < TILE; ++r) out[r * ld + col0 + k] = fmaxf(acc[r], 0.f);
+        for (int r = 0; r < QR; ++r) out[(q * QR + r) * ld + col0 + k] = fmaxf(acc[r], 0.f);
     }
 }
 
