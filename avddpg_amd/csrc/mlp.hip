@@ -764,39 +764,37 @@ __device__ __attribute__((noinline)) void out_bwd(lds_f* bufB, const lds_f* invB
 }
 
 // first-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*K+j]*dz[r][k], db[k] = sum_r dz[r][k].
-// One column per thread; the K inputs go by in chunks of 4.
+// Work items are (column, chunk of 4 inputs), dealt round-robin over the threads (see l1_fwd).
 __device__ __attribute__((noinline)) void l1_grads(const lds_f* X, int K, const lds_f* DZ, int ldz, int c0, int H, glb_f* __restrict__ gW,
                                          glb_f* __restrict__ gb) {
-    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+    const int chunks = (K + 3) >> 2;
+    for (int item = threadIdx.x; item < chunks * H; item += NTHREADS) {
+        const int ch = item / H, k = item - ch * H, j0 = 4 * ch;
         const lds_f* dzk = DZ + c0 + k;
-        float sb = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < TILE; ++r) sb += dzk[r * ldz];
-        gb[k] = sb;
+        int jx[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) jx[jj] = min(j0 + jj, K - 1);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
 #pragma nounroll
-        for (int j0 = 0; j0 < K; j0 += 4) {
-            int jx[4];
+        for (int rb = 0; rb < TILE; rb += 16) {  // operands of 16 rows first, then the FMAs (see l1_fwd)
+            float xv[16][4], dv[16];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) jx[jj] = min(j0 + jj, K - 1);
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma nounroll
-            for (int rb = 0; rb < TILE; rb += 16) {  // operands of 16 rows first, then the FMAs (see l1_fwd)
-                float xv[16][4], dv[16];
+            for (int i = 0; i < 16; ++i) {
+                dv[i] = dzk[(rb + i) * ldz];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    dv[i] = dzk[(rb + i) * ldz];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(xv[i][jj], dv[i], acc[jj]);
+                for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
             }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (j0 + jj < K) gW[(j0 + jj) * H + k] = acc[jj];
+            for (int i = 0; i < 16; ++i) {
+                sb += dv[i];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(xv[i][jj], dv[i], acc[jj]);
+            }
         }
+        if (ch == 0) gb[k] = sb;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (j0 + jj < K) gW[(j0 + jj) * H + k] = acc[jj];
     }
 }
 
