@@ -666,41 +666,39 @@ __device__ __forceinline__ void coefs_b(const float* __restrict__ g, const float
     }
 }
 
-// output layer, width A: out[r][a] = sum_k bn(P[r][k]) * W3[k*A+a] + b3[a].  4 lanes per batch row split k, partial sums
-// meet by shuffles. Outputs go by in chunks of 4 (uniform branch per chunk; inside a chunk every load is unconditional with
-// a clamped index -- a load under its own `if (a < A)` is waited for before the next one is issued).
-__device__ __attribute__((noinline)) void out_fwd(const lds_f* bufB, const lds_f* invB, const lds_f* shB, int ldB, const glb_f* __restrict__ W3,
-                                        const glb_f* __restrict__ b3, int H2, int A, lds_f* out) {
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-#pragma nounroll
-    for (int a0 = 0; a0 < A; a0 += 4) {
-        int ax[4];
+// Narrow GEMM on the matrix cores: out[r][a] = sum_k x(r, k) * W[k * wk + a * wa] (+ bias[a]) for a < A <= 16, K % 16 == 0,
+// x = X[r * ldx + k] * inv[k] + sh[k] (inv == nullptr: x = X). Used for the A-wide output layers (K = H2: W3[k][a]) and for
+// the gradient w.r.t. the actions (K = Ha: Wa[a][k]). Wave m owns batch rows 16m .. 16m+15; the A columns sit in a
+// 16-wide MFMA tile whose unused columns are fed zeros. All weight loads of the lane are issued up front with clamped
+// indices (K <= 256: at most 64) -- 64 rows x 160 x 5 as a scalar loop per output took ~29 k cycles, this takes ~3 k.
+__device__ __attribute__((noinline)) void narrow_gemm(const lds_f* X, int ldx, const lds_f* inv, const lds_f* sh, int K,
+                                                       const glb_f* __restrict__ W, int wk, int wa, int A,
+                                                       const glb_f* __restrict__ bias, lds_f* out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int nblk = K >> 4;
+    const float colmask = (lr < A) ? 1.f : 0.f;
+    const int ac = min(lr, A - 1);
+    float wv[16][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ax[i] = min(a0 + i, A - 1);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma nounroll
-        for (int k0 = part; k0 < H2; k0 += 32) {  // 8 k's per step: all operands first, then the FMAs
-            float y[8], wv[8][4];
+    for (int blk = 0; blk < 16; ++blk)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = min(k0 + 4 * u, H2 - 1);
-                const float ok = (k0 + 4 * u < H2) ? 1.f : 0.f;
-                y[u] = fmaf(bufB[r * ldB + k], invB[k], shB[k]) * ok;
+        for (int jj = 0; jj < 4; ++jj) wv[blk][jj] = W[min(16 * blk + 4 * lg + jj, K - 1) * wk + ac * wa] * colmask;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const lds_f* xr = X + (wave * 16 + lr) * ldx + 4 * lg;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wv[u][i] = W3[k * A + ax[i]];
-            }
+    for (int blk = 0; blk < 16; ++blk) {
+        if (blk < nblk) {
+            f32x4 x = *(const lds_f4*)(xr + 16 * blk);
+            if (inv) x = x * *(const lds_f4*)(inv + 16 * blk + 4 * lg) + *(const lds_f4*)(sh + 16 * blk + 4 * lg);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(y[u], wv[u][i], acc[i]);
+            for (int jj = 0; jj < 4; ++jj) acc = MFMA16(x[jj], wv[blk][jj], acc);
         }
+    }
+    if (lr < A) {
+        const float bb = bias ? bias[lr] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = acc[i];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            if (part == 0 && a0 + i < A) out[r * A + a0 + i] = v + b3[a0 + i];
-        }
+        for (int reg = 0; reg < 4; ++reg) out[(wave * 16 + 4 * lg + reg) * A + lr] = acc[reg] + bb;
     }
 }
 
@@ -879,7 +877,7 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, H1, th + L.aW2, th + L.ab2, H2, l.bufB, ldB);
             lds_barrier();
             PH(2);
-            out_fwd(LDSP(l.bufB), LDSP(l.invB), LDSP(l.shB), ldB, CGLBP(th + L.aW3), CGLBP(th + L.ab3), H2, A, LDSP(l.sQ));
+            narrow_gemm(LDSP(l.bufB), ldB, LDSP(l.invB), LDSP(l.shB), H2, CGLBP(th + L.aW3), A, 1, A, CGLBP(th + L.ab3), LDSP(l.sQ));
             lds_barrier();
             for (int i = tid; i < TILE * A; i += NTHREADS) {
                 const float t = tanhf(l.sQ[i]);
@@ -903,7 +901,7 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             gemm_fwd_relu(l.bufA, ldA, l.invA, l.shA, KC, th + L.cW2, th + L.cb2, H2, l.bufB, ldB);
             lds_barrier();
             PH(5);
-            out_fwd(LDSP(l.bufB), LDSP(l.invB), LDSP(l.shB), ldB, CGLBP(th + L.cW3), CGLBP(th + L.cb3), H2, A, LDSP(l.sQ));
+            narrow_gemm(LDSP(l.bufB), ldB, LDSP(l.invB), LDSP(l.shB), H2, CGLBP(th + L.cW3), A, 1, A, CGLBP(th + L.cb3), LDSP(l.sQ));
             lds_barrier();
             PH(6);
         }
@@ -970,12 +968,8 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             PH(11);
         } else if (it == 2) {  // da[r][a] = sum_j dza[r][j] * Wa[a][j]
             const float* cth = net.th + L.actor_size;
-            for (int i = tid; i < TILE * A; i += NTHREADS) {
-                const int rr = i / A, aa = i - rr * A;
-                float acc = 0.f;
-                for (int j = 0; j < Ha; ++j) acc = fmaf(l.bufA[rr * ldA + H1 + j], cth[L.cWa + aa * Ha + j], acc);
-                l.sDa[i] = acc;
-            }
+            narrow_gemm(LDSP(l.bufA + H1), ldA, (const lds_f*)nullptr, (const lds_f*)nullptr, Ha, CGLBP(cth + L.cWa), 1, Ha, A,
+                        (const glb_f*)nullptr, LDSP(l.sDa));
             PH(14);
         } else {
             l1_grads(LDSP(l.sX), S, LDSP(l.bufA), ldA, 0, H1, GLBP(ga + L.aW1), GLBP(ga + L.ab1));
