@@ -608,51 +608,51 @@ __device__ __forceinline__ GLds carve(float* p, const avd_mlp_layout& L) {
     return l;
 }
 
-// first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k.
-// Work items are (column, quarter of the 64 rows), dealt round-robin: H = 320 columns are 1280 items = 5 per thread
-// (one column per thread would be two rounds with three waves idle in the second). The K inputs go by in chunks of 4
-// whose weights are loaded together, the next chunk's requested before the current one is used -- a weight load
-// inside the row loop costs its full latency per use; the operands of the 16 rows are read before the FMAs.
+// first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k,
+// on the matrix cores: 16 x 16 output tiles (row tile, column tile) dealt over the waves, the K <= 64 inputs in MFMA steps
+// of 4 (indices past K are clamped and their operands zeroed). A tile's weight operands are all requested up front.
 __device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
                                        const glb_f* __restrict__ g, const glb_f* __restrict__ be,
                                        const glb_f* __restrict__ mm, const glb_f* __restrict__ mv, int H, lds_f* out,
                                        int ld, int col0, lds_f* inv, lds_f* sh) {
-    constexpr int QR = TILE / 4;
-    for (int item = threadIdx.x; item < 4 * H; item += NTHREADS) {
-        const int q = item / H, k = item - q * H;
-        if (q == 0) {
-            const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
-            inv[col0 + k] = iv;
-            sh[col0 + k] = be[k] - mm[k] * iv;
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
+        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+        inv[col0 + k] = iv;
+        sh[col0 + k] = be[k] - mm[k] * iv;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int steps = (K + 3) >> 2;
+    // a wave's items are the column tiles t = wave, wave + 4, ..; each serves the four row tiles with ONE set of weight
+    // operands, and the next column tile's are requested before the current one is used
+    const int ctiles = H >> 4;
+    float wn[16], bn_ = 0.f;
+    auto load_w = [&](int t, float(&w)[16], float& bc) {
+        const int col = 16 * min(t, ctiles - 1) + lr;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int j = 4 * st + lg;
+            w[st] = W[min(j, K - 1) * H + col] * (j < K ? 1.f : 0.f);
         }
-        const lds_f* Xq = X + q * QR * K;
-        const float bk = b[k];
-        float acc[QR];
+        bc = b[col];
+    };
+    load_w(wave, wn, bn_);
+    for (int t = wave; t < ctiles; t += 4) {
+        float wv[16];
 #pragma unroll
-        for (int r = 0; r < QR; ++r) acc[r] = bk;
-        float wn[4];
+        for (int st = 0; st < 16; ++st) wv[st] = wn[st];
+        const float bc = bn_;
+        load_w(t + 4, wn, bn_);
+        const int col = 16 * t + lr;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) wn[jj] = (jj < K) ? W[jj * H + k] : 0.f;
-#pragma nounroll
-        for (int j0 = 0; j0 < K; j0 += 4) {
-            float w[4];
-            int jx[4];
+        for (int m = 0; m < 4; ++m) {
+            const lds_f* xr = X + (16 * m + lr) * K;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) w[jj] = wn[jj], jx[jj] = min(j0 + jj, K - 1);  // tail: weight 0, index clamped
+            for (int st = 0; st < 16; ++st)
+                if (st < steps) acc = MFMA16(xr[min(4 * st + lg, K - 1)], wv[st], acc);  // (clamped x meets a zero weight)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) wn[jj] = (j0 + 4 + jj < K) ? W[(j0 + 4 + jj) * H + k] : 0.f;
-            float xv[QR][4];
-#pragma unroll
-            for (int i = 0; i < QR; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) xv[i][jj] = Xq[i * K + jx[jj]];
-#pragma unroll
-            for (int i = 0; i < QR; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i] = fmaf(xv[i][jj], w[jj], acc[i]);
+            for (int reg = 0; reg < 4; ++reg) out[(16 * m + 4 * lg + reg) * ld + col0 + col] = fmaxf(acc[reg] + bc, 0.f);
         }
-#pragma unroll
-        for (int r = 0; r < QR; ++r) out[(q * QR + r) * ld + col0 + k] = fmaxf(acc[r], 0.f);
     }
 }
 
@@ -762,37 +762,36 @@ __device__ __attribute__((noinline)) void out_bwd(lds_f* bufB, const lds_f* invB
 }
 
 // first-layer gradients from dz[r][c0..c0+H): dW[j][k] = sum_r X[r*K+j]*dz[r][k], db[k] = sum_r dz[r][k].
-// Work items are (column, chunk of 4 inputs), dealt round-robin over the threads (see l1_fwd).
+// dW = X^T dz on the matrix cores: (16 inputs) x (16 columns) tiles dealt over the waves, the 64 batch rows in 16 MFMA
+// steps; both operands come from LDS. db: one column per thread.
 __device__ __attribute__((noinline)) void l1_grads(const lds_f* X, int K, const lds_f* DZ, int ldz, int c0, int H, glb_f* __restrict__ gW,
                                          glb_f* __restrict__ gb) {
-    const int chunks = (K + 3) >> 2;
-    for (int item = threadIdx.x; item < chunks * H; item += NTHREADS) {
-        const int ch = item / H, k = item - ch * H, j0 = 4 * ch;
+    for (int k = threadIdx.x; k < H; k += NTHREADS) {
         const lds_f* dzk = DZ + c0 + k;
-        int jx[4];
+        float sb = 0.f;
+#pragma unroll 16
+        for (int r = 0; r < TILE; ++r) sb += dzk[r * ldz];
+        gb[k] = sb;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int jtiles = (K + 15) >> 4, ctiles = H >> 4;
+    for (int item = wave; item < jtiles * ctiles; item += 4) {
+        const int jt = item % jtiles, t = item / jtiles;
+        const int j = 16 * jt + lr;
+        const float jm = (j < K) ? 1.f : 0.f;
+        const lds_f* xc = X + min(j, K - 1);
+        const lds_f* dc = DZ + c0 + 16 * t + lr;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) jx[jj] = min(j0 + jj, K - 1);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
-#pragma nounroll
-        for (int rb = 0; rb < TILE; rb += 16) {  // operands of 16 rows first, then the FMAs (see l1_fwd)
-            float xv[16][4], dv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                dv[i] = dzk[(rb + i) * ldz];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) xv[i][jj] = X[(rb + i) * K + jx[jj]];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                sb += dv[i];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(xv[i][jj], dv[i], acc[jj]);
-            }
+        for (int st = 0; st < TILE / 4; ++st) {
+            const int r = 4 * st + lg;
+            acc = MFMA16(xc[r * K] * jm, dc[r * ldz], acc);
         }
-        if (ch == 0) gb[k] = sb;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            if (j0 + jj < K) gW[(j0 + jj) * H + k] = acc[jj];
+        for (int reg = 0; reg < 4; ++reg) {
+            const int jr = 16 * jt + 4 * lg + reg;
+            if (jr < K) gW[jr * H + 16 * t + lr] = acc[reg];
+        }
     }
 }
 
