@@ -1482,19 +1482,29 @@ __device__ __forceinline__ void gemm_dw_dx(float* P, const float* inv, const flo
     }
 }
 
-// Per-thread parameter columns of a network's first layers, loaded one phase before they are used.
+// Parameters of a network's first layers, loaded one phase before they are used: the BN parameters of the thread's own
+// column (coefficient tables) and, for the layer itself -- out = relu(X W + b), K = S or 1 inputs, ONE MFMA step per
+// 16 x 16 output tile -- the lane's weight / bias operands of the up to four column tiles its wave owns (tile t = wave +
+// 4 i). As a VALU loop (one column per thread, 64 rows x K FMAs, an LDS round trip per register block) the first layers
+// were 10 % of the kernel.
 template <int K>
 struct L1P {
-    float w[K], b, g, be, mm, mv;
+    float mw[4], mb[4], g, be, mm, mv;
 };
 template <int K>
 __device__ __forceinline__ L1P<K> l1p_load(const float* __restrict__ W, const float* __restrict__ b,
                                            const float* __restrict__ g, const float* __restrict__ be,
                                            const float* __restrict__ mm, const float* __restrict__ mv, int H, int k) {
+    static_assert(K <= 4, "one MFMA step");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     L1P<K> c;
 #pragma unroll
-    for (int j = 0; j < K; ++j) c.w[j] = W[j * H + k];
-    c.b = b[k], c.g = g[k], c.be = be[k], c.mm = mm[k], c.mv = mv[k];
+    for (int i = 0; i < 4; ++i) {
+        const int col = min(16 * (wave + 4 * i) + lr, H - 1);  // tiles past H: clamped loads, never used
+        c.mw[i] = W[min(lg, K - 1) * H + col] * (lg < K ? 1.f : 0.f);
+        c.mb[i] = b[col];
+    }
+    c.g = g[k], c.be = be[k], c.mm = mm[k], c.mv = mv[k];
     return c;
 }
 template <int K>
@@ -1503,24 +1513,24 @@ __device__ __forceinline__ void l1p_coefs(const L1P<K>& c, float* inv, float* sh
     inv[idx] = iv;
     sh[idx] = c.be - c.mm * iv;
 }
+// out[r][col0 + n] = relu(sum_j X[r*K + j] * W[j][n] + b[n]) for n < H: tile (m, t) -> rows 16m + 4lg + reg, column 16t + lr
 template <int K>
-__device__ __forceinline__ void l1p_rows(const L1P<K>& c, const float* X, float* out, int ld, int col, int r0,
-                                         int rstep) {
-    for (int rb = r0; rb < TILE; rb += RB * rstep) {  // register blocks of RB rows
-        float xv[RB][K];
+__device__ __forceinline__ void l1p_mfma(const L1P<K>& c, const float* X, float* out, int ld, int col0, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    float a[4];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = min(rb + i * rstep, TILE - 1);
+    for (int m = 0; m < 4; ++m) a[m] = X[(16 * m + lr) * K + min(lg, K - 1)];  // lanes lg >= K meet a zero weight
 #pragma unroll
-            for (int j = 0; j < K; ++j) xv[i][j] = X[r * K + j];
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave + 4 * i;
+        if (16 * t < H) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = rb + i * rstep;
-            float acc = c.b;
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 acc = MFMA16(a[m], c.mw[i], ((f32x4){0.f, 0.f, 0.f, 0.f}));
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc = fmaf(xv[i][j], c.w[j], acc);
-            if (r < TILE) out[r * ld + col] = fmaxf(acc, 0.f);
+                for (int reg = 0; reg < 4; ++reg)
+                    out[(16 * m + 4 * lg + reg) * ld + col0 + 16 * t + lr] = fmaxf(acc[reg] + c.mb[i], 0.f);
+            }
         }
     }
 }
@@ -1606,7 +1616,6 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
     constexpr float invn = 1.0f / (float)TILE;  // A == 1
     constexpr int LPR = FT / 64;                // lanes per batch row in the width-1 output layers
     // thread -> (column, row phase) maps of the first-layer phases
-    constexpr int sgroups = FT / H1, agroups = FT / HA;
     const int ks = tid % H1, rs0 = tid / H1;
     const int ka = tid % HA, ra = tid / HA;  // ra >= agroups: spare threads (they still load a valid column)
 
@@ -1671,7 +1680,7 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             if (it != 3) {  // pass 3: the first-layer activations and coefficients of pass 2 are still in bufA / invA / shA --
                             // pass 2's critic only touched the action columns (resumed GEMM, action-only dX)
                 if (rs0 == 0) l1p_coefs(pa.c1, l.invA, l.shA, ks);
-                l1p_rows<S>(pa.c1, X, l.bufA, LDA, ks, rs0, sgroups);
+                l1p_mfma<S>(pa.c1, X, l.bufA, LDA, 0, H1);
             }
             l2_store(pa.c2, l, H2, tid);
             lds_barrier();
@@ -1699,12 +1708,10 @@ __global__ __launch_bounds__(FT) void learn_kernel_t(avd_mlp_layout L, int set_m
             const float b3 = pc.b3;
             if (it != 2) {  // pass 2 resumes from pass 1's state-feature sums: no state first layer
                 if (rs0 == 0) l1p_coefs(pc.cs, l.invA, l.shA, ks);
-                l1p_rows<S>(pc.cs, X, l.bufA, LDA, ks, rs0, sgroups);
+                l1p_mfma<S>(pc.cs, X, l.bufA, LDA, 0, H1);
             }
-            if (ra < agroups) {
-                if (ra == 0) l1p_coefs(pc.ca, l.invA, l.shA, H1 + ka);
-                l1p_rows<1>(pc.ca, act, l.bufA, LDA, H1 + ka, ra, agroups);
-            }
+            if (ra == 0) l1p_coefs(pc.ca, l.invA, l.shA, H1 + ka);
+            l1p_mfma<1>(pc.ca, act, l.bufA, LDA, H1, HA);
             l2_store(pc.c2, l, H2, tid);
             __builtin_amdgcn_sched_barrier(0);
             // parameters of the next forwards (critic(net) of passes 1, 2; actor(net) of passes 2, 3)
