@@ -14,10 +14,10 @@ HIP extension is missing.
 Pinning status
 --------------
 * environment / reset / OU noise / replay buffer / trainer inner-loop RNG
-  interleaving: PINNED against golden vectors captured by importing the
-  reference's own NumPy code in the build container
-  (``tests/golden/make_golden.py`` -> ``tests/golden/g1..g6``), checked by
-  ``tests/test_oracle_golden.py``.
+  interleaving / evaluator rollout (decentralized and centralized): PINNED against
+  golden vectors captured by importing the reference's own NumPy code in the build
+  container (``tests/golden/make_golden.py`` -> ``tests/golden/g1..g6, g8, g9``),
+  checked by ``tests/test_oracle_golden.py``.
 * Dense / BatchNormalization / tanh / GradientTape / Adam / federated mean:
   **parity unpinned**.  That arithmetic lives in third-party
   ``tensorflow==2.4.1`` (reference ``requirements.txt:2``) which is absent from
