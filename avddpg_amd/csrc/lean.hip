@@ -1,0 +1,710 @@
+// learn_kernel_l -- Trainer.learn (workers/trainer.py:472-508), optionally fused with Adam x2 + update_target
+// (trainer.py:348-356, agent/ddpgagent.py:31-55), for one agent's batch of 64 rows per 256-thread workgroup, built so
+// that TWO workgroups share a CU (<= 80 KB of LDS, <= 256 registers per lane).
+//
+// Why: the fused form of learn_kernel_t (mlp.hip) alternates a matrix-core phase (~130 us per agent) with an HBM
+// stream phase (Adam/Polyak over 2.3 MB per agent, ~85 us); with one workgroup per CU nothing overlaps the two
+// (tools/probes/overlap.hip: 202 us per tile alone, 138 us per tile with a second workgroup on the CU). What kept
+// learn_kernel_t at one workgroup per CU is bufA, the [64][304] f32 image of the first-layer activations (79 KB).
+// Here those activations are never stored: the first layers have K = S <= 4 (state) or 1 (action) inputs, so
+// relu(x W1 + b1) costs S FMAs + add + max per element and is recomputed, in the lane that needs it, directly as
+// the MFMA operand of
+//   * the second-layer forward GEMMs   (A operand, row m*16+lr, features 16 blk + 4 lg + jj),
+//   * the weight-gradient GEMMs        (A operand, row 4 it + lg, features of the lane's output rows),
+//   * the BN/ReLU backward in the input-gradient epilogues (element (row, column) of the accumulator),
+// and the input gradient is reduced into the first-layer parameter gradients in that same epilogue instead of being
+// written back. What stays in LDS: the two [64][132] second-layer buffers, the batch (states padded to 4 floats),
+// the BN coefficient tables. The pass structure (targets / critic / actor-through-critic / actor, critic state blocks
+// of pass 1 resumed in pass 2, actor activations of pass 2 kept for pass 3) is that of learn_kernel_t.
+//
+// Weight-gradient tiles are laid out so that a lane owns 4 CONSECUTIVE columns of 8 rows: the fused Adam/Polyak
+// epilogue moves w, w_target, m, v with 16-byte accesses (learn_kernel_t: 8-byte).
+#undef AVD_PHASE_TIMING
+#include "learn_common.h"
+
+namespace avd {
+namespace lean {
+
+constexpr int FT = 256;  // 4 waves per workgroup; two workgroups per CU = 2 waves per SIMD
+constexpr int NW = FT / 64;
+constexpr int R = 3;     // W2-operand register ring depth (blocks of 16 k)
+
+struct Lds {
+    float *bufB, *bufC;          // [64][LDB] second-layer activations / gradients
+    float *xS, *xS2;             // [64][4] states, next states (columns >= S are zero)
+    float *invA, *shA;           // [H1 + HA] BN coefficients of the first-layer features
+    float *invB, *shB, *w3B, *rsB, *mmB, *db;  // [H2]
+    float *scr;                  // [3 * H2] reduction scratch (also the per-tile action-gradient partials)
+    float *sAct, *sR, *sY, *sQ, *sD, *sA1, *sT, *sDa;  // [64]
+    float *red;                  // [8]
+};
+__host__ __device__ constexpr int lds_floats(int KC, int H2) {
+    return 2 * TILE * ld_of(H2) + 2 * TILE * 4 + 2 * KC + 6 * H2 + 3 * H2 + 8 * TILE + 8;
+}
+__device__ __forceinline__ Lds carve(float* p, int KC, int H2) {
+    Lds l;
+    const int ldB = ld_of(H2);
+    l.bufB = p, p += TILE * ldB;
+    l.bufC = p, p += TILE * ldB;
+    l.xS = p, p += TILE * 4;
+    l.xS2 = p, p += TILE * 4;
+    l.invA = p, p += KC;
+    l.shA = p, p += KC;
+    l.invB = p, p += H2;
+    l.shB = p, p += H2;
+    l.w3B = p, p += H2;
+    l.rsB = p, p += H2;
+    l.mmB = p, p += H2;
+    l.db = p, p += H2;
+    l.scr = p, p += 3 * H2;
+    l.sAct = p, p += TILE;
+    l.sR = p, p += TILE;
+    l.sY = p, p += TILE;
+    l.sQ = p, p += TILE;
+    l.sD = p, p += TILE;
+    l.sA1 = p, p += TILE;
+    l.sT = p, p += TILE;
+    l.sDa = p, p += TILE;
+    l.red = p;
+    return l;
+}
+
+// A first layer (Dense + BN): parameters, and where its gradients go.
+struct L1Set {
+    const float *W1, *b1;             // [Kin][H], [H]
+    const float *g, *be, *mm, *mv;    // BN gamma, beta, moving mean, moving variance
+    float *gW1, *gb1, *gg, *gbe;      // gradient destinations
+    int H;
+};
+
+template <int W>
+__device__ __forceinline__ void ldv(float (&d)[W], const float* p) {
+    if constexpr (W == 4) {
+        const f32x4 v = *(const f32x4*)p;
+        d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
+    } else if constexpr (W == 2) {
+        const f32x2 v = *(const f32x2*)p;
+        d[0] = v[0], d[1] = v[1];
+    } else {
+        d[0] = p[0];
+    }
+}
+
+// first-layer weights of W consecutive features: w[j][e] = W1[j][k + e], b[e] = b1[k + e]
+template <int KIN, int W>
+struct FeatW {
+    float w[KIN][W], b[W];
+};
+template <int KIN, int W>
+__device__ __forceinline__ void featw_load(FeatW<KIN, W>& f, const float* __restrict__ W1, const float* __restrict__ b1,
+                                           int H, int k) {
+#pragma unroll
+    for (int j = 0; j < KIN; ++j) ldv<W>(f.w[j], W1 + j * H + k);
+    ldv<W>(f.b, b1 + k);
+}
+// relu(sum_j x[j] W1[j][k+e] + b1[k+e]): products summed in input order, bias last (Dense = matmul, then bias_add)
+template <int KIN, int W>
+__device__ __forceinline__ float feat(const FeatW<KIN, W>& f, const float (&x)[KIN], int e) {
+    float t = x[0] * f.w[0][e];
+#pragma unroll
+    for (int j = 1; j < KIN; ++j) t = fmaf(x[j], f.w[j][e], t);
+    return fmaxf(t + f.b[e], 0.f);
+}
+template <int KIN>
+__device__ __forceinline__ void ldx(float (&x)[KIN], const float* X, int r) {  // X: [64][4] (KIN > 1) or [64] (KIN == 1)
+    if constexpr (KIN == 1) {
+        x[0] = X[r];
+    } else {
+        const f32x4 v = *(const f32x4*)(X + 4 * r);
+#pragma unroll
+        for (int j = 0; j < KIN; ++j) x[j] = v[j];
+    }
+}
+
+__device__ __forceinline__ void l1_coefs(const L1Set& s, float* inv, float* sh, int k) {
+    const float iv = (1.0f / sqrtf(s.mv[k] + BN_EPS)) * s.g[k];
+    inv[k] = iv;
+    sh[k] = s.be[k] - s.mm[k] * iv;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[r][n] = relu(sum_k bn(feature(r, k)) * W2[k][n] + b2[n]), feature = first layer(s) recomputed on the fly.
+// Features [0, H1) come from `st` (inputs X4[r][0..S)), features [H1, H1 + HA) from `ac` (input act[r]) when CRITIC.
+// Wave w owns columns [32 w, 32 w + 32): MFMA tile t holds columns base + 2 lr + t; reduction index of the 4 MFMAs of
+// a 16-deep block: k = 16 blk + 4 lg + jj. BN is folded as in learn_kernel_t: p @ (inv (.) W2) + sh . W2.
+// FIRST / SNAP: see fast::gemm_fwd (critic state blocks of pass 1 snapshotted, pass 2 resumes with the action blocks).
+// ------------------------------------------------------------------------------------------
+template <int S, int H1, int HA, int H2, bool CRITIC, int FIRST, int SNAP>
+__device__ __forceinline__ void gemm_fwd(const float* X4, const float* act, const L1Set& st, const L1Set& ac,
+                                         const float* inv, const float* sh, const float* __restrict__ W2,
+                                         const float* __restrict__ b2, float* out, float* snap, float (&cs_snap)[2]) {
+    constexpr int NSB = H1 / 16, NBLK = CRITIC ? (H1 + HA) / 16 : H1 / 16, N = H2, LDO = ld_of(H2);
+    static_assert(N == 32 * NW, "two 16-column tiles per wave");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int col = wave * 32 + 2 * lr;
+    f32x4 acc[4][2];
+    float cs[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        cs[t] = (FIRST > 0) ? cs_snap[t] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (FIRST > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 v = *(const f32x2*)(snap + (m * 16 + lg * 4 + j) * LDO + col);
+                acc[m][0][j] = v[0], acc[m][1][j] = v[1];
+            }
+    }
+    float xr[4][S], ar[4][1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (FIRST < NSB) ldx<S>(xr[m], X4, m * 16 + lr);
+        if (CRITIC) ldx<1>(ar[m], act, m * 16 + lr);
+    }
+    const float* wl = W2 + (4 * lg) * N + col;
+    float ring[R][4][2];
+    auto load_blk = [&](float(&dst)[4][2], int blk) {
+        const float* p = wl + blk * (16 * N);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ldv<2>(dst[jj], p + jj * N);
+    };
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d)
+        if (FIRST + d < NBLK) load_blk(ring[(FIRST + d) % R], FIRST + d);
+    FeatW<S, 4> fs[2];
+    FeatW<1, 4> fa[2];
+    auto load_feat = [&](int blk) {
+        if (blk < NSB)
+            featw_load<S, 4>(fs[blk & 1], st.W1, st.b1, H1, 16 * blk + 4 * lg);
+        else
+            featw_load<1, 4>(fa[blk & 1], ac.W1, ac.b1, HA, 16 * (blk - NSB) + 4 * lg);
+    };
+    float a[2][4][4];
+    auto make_a = [&](int blk) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                a[blk & 1][m][jj] = (blk < NSB) ? feat<S, 4>(fs[blk & 1], xr[m], jj) : feat<1, 4>(fa[blk & 1], ar[m], jj);
+    };
+    load_feat(FIRST);
+    if (FIRST + 1 < NBLK) load_feat(FIRST + 1);
+    make_a(FIRST);
+    const float bc0 = b2[col], bc1 = b2[col + 1];
+#pragma unroll
+    for (int blk = FIRST; blk < NBLK; ++blk) {
+        if (SNAP > 0 && blk == SNAP && snap) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 v;
+                    v[0] = acc[m][0][j], v[1] = acc[m][1][j];
+                    *(f32x2*)(snap + (m * 16 + lg * 4 + j) * LDO + col) = v;
+                }
+            cs_snap[0] = cs[0], cs_snap[1] = cs[1];
+        }
+        if (blk + R - 1 < NBLK) load_blk(ring[(blk + R - 1) % R], blk + R - 1);
+        const f32x4 iv = *(const f32x4*)(inv + 16 * blk + 4 * lg);
+        const f32x4 sf = *(const f32x4*)(sh + 16 * blk + 4 * lg);
+        if (blk + 1 < NBLK) make_a(blk + 1);        // uses the feature weights loaded one block earlier
+        if (blk + 2 < NBLK) load_feat(blk + 2);     // into the buffer make_a(blk) has finished with
+        float bs[4][2];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bs[jj][t] = ring[blk % R][jj][t] * iv[jj];
+                cs[t] = fmaf(ring[blk % R][jj][t], sf[jj], cs[t]);
+            }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(a[blk & 1][m][jj], bs[jj][t], acc[m][t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        cs[t] += __shfl_xor(cs[t], 16);
+        cs[t] += __shfl_xor(cs[t], 32);
+    }
+    cs[0] += bc0, cs[1] += bc1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 o;
+            o[0] = fmaxf(acc[m][0][j] + cs[0], 0.f);
+            o[1] = fmaxf(acc[m][1][j] + cs[1], 0.f);
+            *(f32x2*)(out + (m * 16 + lg * 4 + j) * LDO + col) = o;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// One 16-column tile of the input gradient of a second layer, taken all the way to the first-layer parameter gradients:
+//   dy[r][c]   = sum_n DZ[r][n] * W2[c0g + lr][n]                  (c = this lane's column, r = 16 m + 4 lg + reg)
+//   dgamma[c]  = sum_r dy (p - mean) rs;   dbeta[c] = sum_r dy      p = relu(x[r] . W1[:, c] + b1[c]) recomputed
+//   dz1[r][c]  = dy * rs * gamma * (p > 0)
+//   dW1[j][c]  = sum_r x[r][j] dz1[r][c];  db1[c] = sum_r dz1[r][c]
+//   WANT_DA: dap[r] = sum_c dz1[r][c] * W1[0][c]  (KIN == 1: gradient w.r.t. the action input), this tile's share
+// cl = column index inside the layer `s` (c0g = cl + the layer's first row in W2).
+// ------------------------------------------------------------------------------------------
+template <int KIN, int N, int LDZ, bool WANT_DA, class Sink>
+__device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict__ W2row /* W2 + c0g * N */, const float* Xin,
+                                        const L1Set& s, int cl, bool write_grads, Sink sink, float* dap) {
+    constexpr int NB = N / 16;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    f32x4 wc[NB];
+    const float* wrow = W2row + lr * N + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) wc[q] = *(const f32x4*)(wrow + 16 * q);
+    const int c = cl + lr;
+    FeatW<KIN, 1> fw;
+    featw_load<KIN, 1>(fw, s.W1, s.b1, s.H, c);
+    const float gam = s.g[c], mean = s.mm[c], var = s.mv[c];
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[0][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 4 * lg);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        if (q + 1 < NB)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[(q + 1) & 1][m] = *(const f32x4*)(DZ + (m * 16 + lr) * LDZ + 16 * (q + 1) + 4 * lg);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[q & 1][m][jj], wc[q][jj], acc[m]);
+    }
+    const float rs = 1.0f / sqrtf(var + BN_EPS);
+    const float rg = rs * gam;
+    float sg = 0.f, sb = 0.f, ab = 0.f, aw[KIN];
+#pragma unroll
+    for (int j = 0; j < KIN; ++j) aw[j] = 0.f;
+    float da[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m * 16 + lg * 4 + j;
+            float x[KIN];
+            ldx<KIN>(x, Xin, r);
+            const float p = feat<KIN, 1>(fw, x, 0);
+            const float dy = acc[m][j];
+            sg = fmaf(dy * (p - mean), rs, sg);
+            sb += dy;
+            const float dz1 = (p > 0.f) ? dy * rg : 0.f;
+            ab += dz1;
+#pragma unroll
+            for (int i = 0; i < KIN; ++i) aw[i] = fmaf(x[i], dz1, aw[i]);
+            if (WANT_DA) da[m][j] = dz1 * fw.w[0][0];
+        }
+    if (write_grads) {
+        sg += __shfl_xor(sg, 16), sg += __shfl_xor(sg, 32);
+        sb += __shfl_xor(sb, 16), sb += __shfl_xor(sb, 32);
+        ab += __shfl_xor(ab, 16), ab += __shfl_xor(ab, 32);
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) aw[i] += __shfl_xor(aw[i], 16), aw[i] += __shfl_xor(aw[i], 32);
+        if (lg == 0) {
+            sink.put(s.gg + c, sg);
+            sink.put(s.gbe + c, sb);
+            sink.put(s.gb1 + c, ab);
+#pragma unroll
+            for (int i = 0; i < KIN; ++i) sink.put(s.gW1 + i * s.H + c, aw[i]);
+        }
+    }
+    if constexpr (WANT_DA) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = da[m][j];
+                v += __shfl_xor(v, 1), v += __shfl_xor(v, 2), v += __shfl_xor(v, 4), v += __shfl_xor(v, 8);
+                if (lr == 0) dap[m * 16 + lg * 4 + j] = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a second layer (+ fused Adam/Polyak) and its input gradient, interleaved per block of 64 features:
+//   dW2[k][n] = inv[k] * sum_r feature(r, k) * DZ[r][n] + sh[k] * db[n]
+// Wave w: column half ch = w & 1 (MFMA tile t holds columns 64 ch + 4 lr + t), row half rh = w >> 1 (tile ta holds the
+// features k0 + 32 rh + 2 i + ta, i = MFMA row). A lane ends up with rows k0 + 32 rh + 2 (4 lg + reg) + ta, 4 consecutive
+// columns each: 8 float4 pieces per array for the fused update.
+// The input-gradient tile of the block (columns k0 + 16 w .. + 15, dx_tile) follows the update: its W2 rows are the
+// ones the update has just pulled through L2 (learn_kernel_t's gemm_dw_dx).
+// ------------------------------------------------------------------------------------------
+template <int S, int H1, int HA, int H2, bool CRITIC, class Sink, class SmallSink>
+__device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, const L1Set& st, const L1Set& ac,
+                                           const float* inv, const float* sh, const float* DZ, const float* db,
+                                           float* __restrict__ gW, Sink sink, const float* __restrict__ W2,
+                                           SmallSink small) {
+    constexpr int N = H2, LDZ = ld_of(H2), K = CRITIC ? H1 + HA : H1;
+    constexpr bool kFused = !std::is_same<Sink, StoreSink>::value;
+    static_assert(N == 128 && H1 % 64 == 0 && HA <= 64 && HA % 16 == 0, "tile plan");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int ch = wave & 1, rh = wave >> 1;
+    const int col = 64 * ch + 4 * lr;
+    const f32x4 dbc = *(const f32x4*)(db + col);
+    const float* dp = DZ + lg * LDZ + col;
+#pragma nounroll
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const bool ablk = CRITIC && k0 >= H1;  // the critic's action features (their own first layer)
+        const int kl = k0 + 32 * rh;           // first feature row of this wave's half block
+        typename std::conditional<kFused, AdamSink::Quad4, int>::type q[8];
+        long base = 0;
+        if constexpr (kFused) {
+            base = (gW - sink.wo) + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+                    sink.load4(q[j * 2 + ta], base + (long)min(kl + 2 * (4 * lg + j) + ta, K - 1) * N);
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[ta][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mfma_it = [&](const float(&pa)[2], const f32x4& dz) {
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[ta][t] = MFMA16(pa[ta], dz[t], acc[ta][t]);
+        };
+        if (!ablk) {
+            FeatW<S, 2> fw;
+            featw_load<S, 2>(fw, st.W1, st.b1, H1, kl + 2 * lr);
+            float x[2][S];
+            f32x4 dz[2];
+            ldx<S>(x[0], X4, lg);
+            dz[0] = *(const f32x4*)dp;
+#pragma unroll
+            for (int it = 0; it < TILE / 4; ++it) {
+                if (it + 1 < TILE / 4) {
+                    ldx<S>(x[(it + 1) & 1], X4, 4 * (it + 1) + lg);
+                    dz[(it + 1) & 1] = *(const f32x4*)(dp + 4 * (it + 1) * LDZ);
+                }
+                float pa[2];
+                pa[0] = feat<S, 2>(fw, x[it & 1], 0), pa[1] = feat<S, 2>(fw, x[it & 1], 1);
+                mfma_it(pa, dz[it & 1]);
+            }
+        } else {
+            FeatW<1, 2> fw;
+            featw_load<1, 2>(fw, ac.W1, ac.b1, HA, min(kl - H1 + 2 * lr, HA - 2));  // rows past HA: clamped, never stored
+            float x[2][1];
+            f32x4 dz[2];
+            ldx<1>(x[0], act, lg);
+            dz[0] = *(const f32x4*)dp;
+#pragma unroll
+            for (int it = 0; it < TILE / 4; ++it) {
+                if (it + 1 < TILE / 4) {
+                    ldx<1>(x[(it + 1) & 1], act, 4 * (it + 1) + lg);
+                    dz[(it + 1) & 1] = *(const f32x4*)(dp + 4 * (it + 1) * LDZ);
+                }
+                float pa[2];
+                pa[0] = feat<1, 2>(fw, x[it & 1], 0), pa[1] = feat<1, 2>(fw, x[it & 1], 1);
+                mfma_it(pa, dz[it & 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta) {
+                const int k = kl + 2 * (4 * lg + j) + ta;
+                if (k < K) {
+                    const float iv = inv[k], sf = sh[k];
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = fmaf(iv, acc[ta][t][j], sf * dbc[t]);
+                    if constexpr (kFused) {
+                        sink.update4(q[j * 2 + ta], base + (long)k * N, o);
+                    } else {
+                        f32x4 ov;
+                        ov[0] = o[0], ov[1] = o[1], ov[2] = o[2], ov[3] = o[3];
+                        *(f32x4*)(gW + k * N + col) = ov;
+                    }
+                }
+            }
+        const int c0 = k0 + 16 * wave;
+        if (c0 < K) {
+            if (!ablk)
+                dx_tile<S, N, LDZ, false>(DZ, W2 + c0 * N, X4, st, c0, true, small, nullptr);
+            else
+                dx_tile<1, N, LDZ, false>(DZ, W2 + c0 * N, act, ac, c0 - H1, true, small, nullptr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// width-1 output layer backward through the BN below it (learn_common.h out_layer_backward with a 3*K scratch:
+// the two row halves meet through LDS, same summation order). Ends with a barrier.
+// ------------------------------------------------------------------------------------------
+template <int K, class Sink>
+__device__ __forceinline__ void out_backward(const float* P, int ldp, const float* inv, const float* sh, const float* d,
+                                             const float* w3, const float* rsl, const float* mml, float* DZ, int ldz,
+                                             float* scr, float* __restrict__ gW3, float* __restrict__ gg,
+                                             float* __restrict__ gbe, Sink sink) {
+    static_assert(2 * K == FT, "two row halves");
+    const int part = threadIdx.x / K, k = threadIdx.x - part * K;
+    float dw = 0.f, dgm = 0.f, dbt = 0.f;
+    const float wk = w3[k], iv = inv[k], s = sh[k], rs = rsl[k], mean = mml[k];
+    for (int rb = part * 32; rb < (part + 1) * 32; rb += 8) {
+        float pv[8], dv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[i] = P[(rb + i) * ldp + k], dv[i] = d[rb + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float p = pv[i], dr = dv[i];
+            dw = fmaf(fmaf(p, iv, s), dr, dw);
+            const float dy = dr * wk;
+            dgm = fmaf(dy * (p - mean), rs, dgm);
+            dbt += dy;
+            DZ[(rb + i) * ldz + k] = (p > 0.f) ? dy * iv : 0.f;
+        }
+    }
+    if (gW3) {
+        if (part == 1) scr[k] = dw, scr[K + k] = dgm, scr[2 * K + k] = dbt;
+        lds_barrier();
+        if (part == 0) {
+            sink.put(gW3 + k, (0.f + dw) + scr[k]);
+            sink.put(gg + k, (0.f + dgm) + scr[K + k]);
+            sink.put(gbe + k, (0.f + dbt) + scr[2 * K + k]);
+        }
+    }
+    lds_barrier();
+}
+
+__device__ __forceinline__ void l2_coefs(const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv,
+                                         const float* __restrict__ w3, Lds& l, int H2, int k) {
+    if (k < H2) {
+        const float rs = 1.0f / sqrtf(mv[k] + BN_EPS);
+        const float iv = rs * g[k];
+        l.invB[k] = iv, l.shB[k] = be[k] - mm[k] * iv, l.w3B[k] = w3[k], l.rsB[k] = rs, l.mmB[k] = mm[k];
+    }
+}
+
+template <int S, int H1, int H2, int HA, bool FUSED>
+__global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int set_mod, const float* __restrict__ theta,
+                                                         const float* __restrict__ stats, float* __restrict__ theta_t,
+                                                         float* __restrict__ stats_t, const float* __restrict__ s,
+                                                         const float* __restrict__ a, const float* __restrict__ r,
+                                                         const float* __restrict__ s2, float gamma, float high,
+                                                         float* __restrict__ grads, float* __restrict__ losses,
+                                                         UpdArgs upd) {
+    static_assert(H1 <= FT && HA <= FT && 2 * H2 == FT && S <= 4, "widths");
+    constexpr int KC = H1 + HA, LDB = ld_of(H2);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Lds l = carve(smem, KC, H2);
+    const int agent = blockIdx.x;
+    const int set = set_mod > 0 ? agent % set_mod : agent;
+    const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
+    const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+    float* g = grads + (long)agent * L.theta_size;
+    float* ga = g;
+    float* gc = g + L.actor_size;
+    const int tid = threadIdx.x;
+    const StoreSink sink;
+    typedef typename std::conditional<FUSED, AdamSink, StoreSink>::type BulkSink;
+    BulkSink bulk;
+    float* gw2 = g;
+    if constexpr (FUSED) {
+        const int t = upd.step[agent];
+        const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
+        const float root = sqrtf(1.0f - b2p);
+        const long o = (long)agent * L.theta_size;
+        gw2 = upd.theta_out + o;
+        bulk.wo = gw2, bulk.wi = net.th, bulk.wt = theta_t + o, bulk.m = upd.m + o, bulk.v = upd.v + o;
+        bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+        bulk.tau = upd.tau, bulk.omt = upd.omt, bulk.actor_size = L.actor_size;
+    }
+    constexpr float invn = 1.0f / (float)TILE;
+    constexpr int LPR = FT / 64;
+
+    for (int i = tid; i < TILE * 4; i += FT) {
+        const int rr = i >> 2, j = i & 3;
+        l.xS[i] = (j < S) ? s[(long)agent * TILE * S + rr * S + j] : 0.f;
+        l.xS2[i] = (j < S) ? s2[(long)agent * TILE * S + rr * S + j] : 0.f;
+    }
+    if (tid < TILE) {
+        l.sAct[tid] = a[(long)agent * TILE + tid];
+        l.sR[tid] = r[(long)agent * TILE + tid];
+    }
+    if (tid == 0) {  // alignment padding of the gradient slab
+        for (int i = L.ab3 + 1; i < L.actor_size; ++i) ga[i] = 0.f;
+        for (int i = L.cb3 + 1; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
+    }
+    float cs_snap[2] = {0.f, 0.f};  // lane-local shift sums of the critic's state blocks, pass 1 -> pass 2
+
+    // pass 0: targets (y); pass 1: critic loss + gradient; pass 2: actor -> critic, gradient wrt the action;
+    // pass 3: actor gradient (second-layer activations of pass 2 kept in bufB)      (workers/trainer.py:492-506)
+#pragma nounroll
+    for (int it = 0; it < 4; ++it) {
+        const Net n = (it == 0) ? tgt : net;
+        const float* X = (it == 0) ? l.xS2 : l.xS;
+        const float* ath = n.th;
+        const float* cth = n.th + L.actor_size;
+        // first layers of this pass's networks (gradient destinations only matter in passes 1 and 3)
+        const L1Set aL1 = {ath + L.aW1, ath + L.ab1, ath + L.ag1, ath + L.abe1, n.st + L.amm1, n.st + L.amv1,
+                           ga + L.aW1,  ga + L.ab1,  ga + L.ag1,  ga + L.abe1,  H1};
+        const L1Set cS1 = {cth + L.cWs, cth + L.cbs, cth + L.cgs, cth + L.cbes, n.st + L.cmms, n.st + L.cmvs,
+                           gc + L.cWs,  gc + L.cbs,  gc + L.cgs,  gc + L.cbes,  H1};
+        const L1Set cA1 = {cth + L.cWa, cth + L.cba, cth + L.cga, cth + L.cbea, n.st + L.cmma, n.st + L.cmva,
+                           gc + L.cWa,  gc + L.cba,  gc + L.cga,  gc + L.cbea,  HA};
+        float* const aP2 = l.bufB;
+        float* const cP2 = (it == 2) ? l.bufC : l.bufB;
+        float* const bP2 = (it == 2) ? l.bufC : l.bufB;
+        float* const bDZ = (it == 1) ? l.bufB : l.bufC;
+        if (it != 1) {  // ---- actor (agent/model.py:26-36); pass 3 only rebuilds the second layer's coefficient tables
+            if (it != 3 && tid < H1) l1_coefs(aL1, l.invA, l.shA, tid);
+            l2_coefs(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, l, H2, tid);
+            lds_barrier();
+            if (it != 3) {
+                gemm_fwd<S, H1, HA, H2, false, 0, 0>(X, nullptr, aL1, aL1, l.invA, l.shA, ath + L.aW2, ath + L.ab2, aP2,
+                                                     nullptr, cs_snap);
+                lds_barrier();
+                const float z = out_layer_row(aP2, LDB, l.invB, l.shB, l.w3B, ath[L.ab3], H2);
+                if (tid % LPR == 0) {
+                    const float t = tanhf(z);
+                    l.sT[tid / LPR] = t;
+                    l.sA1[tid / LPR] = t * high;
+                }
+                lds_barrier();
+            }
+        }
+        if (it != 3) {  // ---- critic (agent/model.py:63-83)
+            const float* act = (it == 1) ? l.sAct : l.sA1;
+            if (it != 2 && tid < H1) l1_coefs(cS1, l.invA, l.shA, tid);  // pass 2 keeps the ACTOR's state coefficients (pass 3)
+            if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
+            l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
+            lds_barrier();
+            if (it == 2)
+                gemm_fwd<S, H1, HA, H2, true, H1 / 16, 0>(X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cth + L.cb2, cP2,
+                                                          l.bufC, cs_snap);
+            else
+                gemm_fwd<S, H1, HA, H2, true, 0, H1 / 16>(X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cth + L.cb2, cP2,
+                                                          it == 1 ? l.bufC : nullptr, cs_snap);
+            lds_barrier();
+            const float q = out_layer_row(cP2, LDB, l.invB, l.shB, l.w3B, cth[L.cb3], H2);
+            if (tid % LPR == 0) l.sQ[tid / LPR] = q;
+            lds_barrier();
+        }
+        if (it == 0) {  // TD target, no done mask (trainer.py:494)
+            if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
+            if constexpr (FUSED) {  // the frozen BN statistics take part in the soft update too (ddpgagent.py:44-53)
+#pragma clang fp contract(off)
+                float* stt = stats_t + (long)set * L.stats_size;
+                for (int i = tid; i < L.stats_size; i += FT) stt[i] = net.st[i] * upd.tau + stt[i] * upd.omt;
+            }
+            lds_barrier();
+            continue;
+        }
+        // ---- d(loss)/d(output-layer input) for this pass
+        if (it == 1) {
+            if (tid < TILE) {
+                const float e = l.sY[tid] - l.sQ[tid];
+                l.sD[tid] = -2.0f * e * invn;
+                l.sT[tid] = e * e;
+            }
+            lds_barrier();
+            const float lc = block_sum64(l.sT, l.red) * invn;
+            const float db3 = block_sum64(l.sD, l.red);
+            if (tid == 0) {
+                sink.put(gc + L.cb3, db3);
+                if (losses) losses[(long)agent * 2 + 0] = lc;
+            }
+        } else if (it == 2) {
+            const float la = -block_sum64(l.sQ, l.red) * invn;
+            if (tid == 0 && losses) losses[(long)agent * 2 + 1] = la;
+            if (tid < TILE) l.sD[tid] = -invn;
+            lds_barrier();
+        } else {
+            if (tid < TILE) {
+                const float t = l.sT[tid];
+                l.sD[tid] = l.sDa[tid] * high * (1.0f - t * t);
+            }
+            lds_barrier();
+            const float db3 = block_sum64(l.sD, l.red);
+            if (tid == 0) sink.put(ga + L.ab3, db3);
+        }
+        const bool crit = (it != 3), wg = (it != 2);
+        float* gout = crit ? gc : ga;
+        out_backward<H2>(bP2, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, bDZ, LDB, l.scr,
+                         wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
+                         gout + (crit ? L.cbe3 : L.abe2), sink);
+        if (wg) {
+            col_sums(bDZ, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
+            lds_barrier();
+            if (crit)
+                gemm_dw_dx<S, H1, HA, H2, true>(X, l.sAct, cS1, cA1, l.invA, l.shA, bDZ, l.db,
+                                                gw2 + L.actor_size + L.cW2, bulk, cth + L.cW2, sink);
+            else
+                gemm_dw_dx<S, H1, HA, H2, false>(X, nullptr, aL1, aL1, l.invA, l.shA, bDZ, l.db, gw2 + L.aW2, bulk,
+                                                 ath + L.aW2, sink);
+            lds_barrier();
+        } else {  // pass 2: gradient w.r.t. the action only -- the critic's action-feature columns, three 16-column tiles
+            const int wave = tid >> 6;
+            if (wave < HA / 16)
+                dx_tile<1, H2, LDB, true>(bDZ, cth + L.cW2 + (H1 + 16 * wave) * H2, l.sA1, cA1, 16 * wave, false, sink,
+                                          l.scr + wave * TILE);
+            lds_barrier();
+            if (tid < TILE) {
+                float v = l.scr[tid];
+#pragma unroll
+                for (int w = 1; w < HA / 16; ++w) v += l.scr[w * TILE + tid];
+                l.sDa[tid] = v;
+            }
+            lds_barrier();
+        }
+    }
+}
+
+template <int S, bool FUSED>
+static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
+                  float* theta_t, float* stats_t, const float* s, const float* a, const float* r, const float* s2,
+                  float gamma, float high, float* grads, float* losses, UpdArgs upd, void* stream) {
+    constexpr int H1 = 256, H2 = 128, HA = 48;
+    const size_t lds = sizeof(float) * lds_floats(H1 + HA, H2);
+    static_assert(sizeof(float) * lds_floats(H1 + HA, H2) <= 80 * 1024, "two workgroups per CU");
+    hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_l<S, H1, H2, HA, FUSED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("lean_launch: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        return AVD_E_LAUNCH;
+    }
+    hipLaunchKernelGGL((learn_kernel_l<S, H1, H2, HA, FUSED>), dim3(n_agents), dim3(FT), lds, (hipStream_t)stream, *lay,
+                       set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, upd);
+    return check_launch(FUSED ? "avd_learn_update_f32 (lean)" : "avd_learn_f32 (lean)");
+}
+
+}  // namespace lean
+
+int lean_launch(const avd_mlp_layout* lay, bool fused, int n_agents, int set_mod, const float* theta, const float* stats,
+                float* theta_t, float* stats_t, const float* s, const float* a, const float* r, const float* s2,
+                float gamma, float high, float* grads, float* losses, UpdArgs upd, void* stream) {
+    if (!(lay->A == 1 && lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && (lay->S == 3 || lay->S == 4) &&
+          lay->B == TILE)) {
+        set_error("lean_launch: built for the reference widths 256/128/48, A=1, B=64, S in {3,4}");
+        return AVD_E_UNSUPPORTED;
+    }
+#define AVD_LEAN(SS, FF)                                                                                              \
+    return lean::launch<SS, FF>(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, \
+                                losses, upd, stream)
+    if (lay->S == 4) {
+        if (fused) AVD_LEAN(4, true);
+        AVD_LEAN(4, false);
+    }
+    if (fused) AVD_LEAN(3, true);
+    AVD_LEAN(3, false);
+#undef AVD_LEAN
+}
+
+}  // namespace avd

@@ -1,0 +1,158 @@
+// Probe (not product): does a second co-resident workgroup per CU hide the fused learn kernel's update stream?
+// Each "tile" models one agent of learn_kernel_t<fused>: a compute phase (f32 MFMAs at ~50 % pipe duty, registers only)
+// followed by a stream phase of 9 blocks [issue Adam operand loads | 160 MFMAs | update | stores] over the agent's
+// 9 x 64 x 128 floats of (w, w_target, m, v).  LDS per workgroup decides how many workgroups share a CU.
+//   overlap <lds_kb> <f4:0|1> <tiles> <compute_mfma_per_wave> <duty_sleep>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int BLK = 64 * 128;  // floats per block
+constexpr int NBLK = 9;
+
+__device__ __forceinline__ float upd(float w, float& t, float& m, float& v, float g) {
+#pragma clang fp contract(off)
+    m = m + (g - m) * 0.1f;
+    v = v + (g * g - v) * 0.001f;
+    const float wn = w - (m * 1e-3f) / (sqrtf(v) + 1e-7f);
+    t = wn * 0.001f + t * 0.999f;
+    return wn;
+}
+
+template <bool F4>
+__global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __restrict__ w, float* __restrict__ wo, float* __restrict__ t,
+                                                    float* __restrict__ m, float* __restrict__ v, int tiles_total,
+                                                    int compute_mfma, int duty_sleep, int do_stream, int* __restrict__ counter,
+                                                    float* __restrict__ sinkbuf) {
+    extern __shared__ float lds[];
+    __shared__ int s_tile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float av = 1e-3f * lane, bv = 1e-3f * (lane + 1);
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(counter, 1);
+        __syncthreads();
+        const int tile = s_tile;
+        __syncthreads();
+        if (tile >= tiles_total) break;
+        // ---- compute phase: bursts of 64 MFMAs, then idle (models VALU / LDS / barrier time of the real kernel)
+        for (int i = 0; i < compute_mfma; i += 64) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
+            for (int s = 0; s < duty_sleep; ++s) __builtin_amdgcn_s_sleep(16);
+        }
+        // ---- stream phase
+        const long abase = (long)tile * NBLK * BLK;
+        for (int b = 0; b < (do_stream ? NBLK : 0); ++b) {
+            const long bbase = abase + (long)b * BLK;
+            const float* w_ = w + bbase; float* wo_ = wo + bbase; float* t_ = t + bbase; float* m_ = m + bbase; float* v_ = v + bbase;
+            if constexpr (F4) {
+                const int col = 64 * (wave & 1) + 4 * lr, r0 = 32 * (wave >> 1);
+                f32x4 qw[8], qt[8], qm[8], qv[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) {
+                        const int o = (r0 + 2 * (4 * lg + j) + ta) * 128 + col;
+                        qw[j * 2 + ta] = *(const f32x4*)(w_ + o), qt[j * 2 + ta] = *(const f32x4*)(t_ + o);
+                        qm[j * 2 + ta] = *(const f32x4*)(m_ + o), qv[j * 2 + ta] = *(const f32x4*)(v_ + o);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 160; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) {
+                        const int q = j * 2 + ta;
+                        const int o = (r0 + 2 * (4 * lg + j) + ta) * 128 + col;
+                        f32x4 ow;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float tt = qt[q][e], mm = qm[q][e], vv = qv[q][e];
+                            ow[e] = upd(qw[q][e], tt, mm, vv, acc[q][e] + 1e-3f);
+                            qt[q][e] = tt, qm[q][e] = mm, qv[q][e] = vv;
+                        }
+                        *(f32x4*)(wo_ + o) = ow, *(f32x4*)(t_ + o) = qt[q], *(f32x4*)(m_ + o) = qm[q], *(f32x4*)(v_ + o) = qv[q];
+                    }
+            } else {
+                const int col = 32 * wave + 2 * lr;
+                f32x2 qw[16], qt[16], qm[16], qv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ta = 0; ta < 4; ++ta) {
+                        const int o = (4 * (lg * 4 + j) + ta) * 128 + col;
+                        qw[j * 4 + ta] = *(const f32x2*)(w_ + o), qt[j * 4 + ta] = *(const f32x2*)(t_ + o);
+                        qm[j * 4 + ta] = *(const f32x2*)(m_ + o), qv[j * 4 + ta] = *(const f32x2*)(v_ + o);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 160; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ta = 0; ta < 4; ++ta) {
+                        const int q = j * 4 + ta;
+                        const int o = (4 * (lg * 4 + j) + ta) * 128 + col;
+                        f32x2 ow;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                        {
+                            float tt = qt[q][e], mm = qm[q][e], vv = qv[q][e];
+                            ow[e] = upd(qw[q][e], tt, mm, vv, acc[q & 7][e] + 1e-3f);
+                            qt[q][e] = tt, qm[q][e] = mm, qv[q][e] = vv;
+                        }
+                        *(f32x2*)(wo_ + o) = ow, *(f32x2*)(t_ + o) = qt[q], *(f32x2*)(m_ + o) = qm[q], *(f32x2*)(v_ + o) = qv[q];
+                    }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) sinkbuf[threadIdx.x] = s + lds[threadIdx.x];
+}
+
+int main(int argc, char** argv) {
+    const int lds_kb = argc > 1 ? atoi(argv[1]) : 150;
+    const int f4 = argc > 2 ? atoi(argv[2]) : 0;
+    const int tiles = argc > 3 ? atoi(argv[3]) : 20480;
+    const int cm = argc > 4 ? atoi(argv[4]) : 4800;
+    const int duty = argc > 5 ? atoi(argv[5]) : 2;
+    const int stream = argc > 6 ? atoi(argv[6]) : 1;
+    const size_t n = (size_t)(stream ? tiles : 1) * NBLK * BLK;
+    float *w, *wo, *t, *m, *v, *sk;
+    int* counter;
+    hipMalloc(&w, n * 4), hipMalloc(&wo, n * 4), hipMalloc(&t, n * 4), hipMalloc(&m, n * 4), hipMalloc(&v, n * 4);
+    hipMalloc(&sk, 4096), hipMalloc(&counter, 4);
+    hipMemset(w, 0, n * 4), hipMemset(wo, 0, n * 4), hipMemset(t, 0, n * 4), hipMemset(m, 0, n * 4), hipMemset(v, 0, n * 4);
+    const int wgs_per_cu = lds_kb <= 53 ? 3 : (lds_kb <= 80 ? 2 : 1);
+    const int grid = 256 * wgs_per_cu;
+    auto k = f4 ? tile_kernel<true> : tile_kernel<false>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(counter, 0, 4);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_kb * 1024, 0, w, wo, t, m, v, tiles, cm, duty, stream, counter, sk);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double bytes = 8.0 * NBLK * BLK * 4 * tiles;
+    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
+           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
+    return 0;
+}
