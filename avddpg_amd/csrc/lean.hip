@@ -19,7 +19,6 @@
 //
 // Weight-gradient tiles are laid out so that a lane owns 4 CONSECUTIVE columns of 8 rows: the fused Adam/Polyak
 // epilogue moves w, w_target, m, v with 16-byte accesses (learn_kernel_t: 8-byte).
-#undef AVD_PHASE_TIMING
 #include "learn_common.h"
 
 namespace avd {
@@ -28,6 +27,10 @@ namespace lean {
 constexpr int FT = 256;  // 4 waves per workgroup; two workgroups per CU = 2 waves per SIMD
 constexpr int NW = FT / 64;
 constexpr int R = 3;     // W2-operand register ring depth (blocks of 16 k)
+
+// Lane index that LLVM cannot treat as invariant of the pass loop: without this, loop-invariant code motion hoists every
+// per-lane address of the loop body (hundreds of 32-bit offsets) above the loop and spills them (learn_common.h opaque_zero).
+__device__ __forceinline__ int tid_here() { return (int)threadIdx.x + opaque_zero(); }
 
 struct Lds {
     float *bufB, *bufC;          // [64][LDB] second-layer activations / gradients
@@ -69,12 +72,15 @@ __device__ __forceinline__ Lds carve(float* p, int KC, int H2) {
     return l;
 }
 
-// A first layer (Dense + BN): parameters, and where its gradients go.
+// A first layer (Dense + BN): where its parameters, BN statistics and gradients live. Three uniform base pointers plus
+// 32-bit offsets: the kernel keeps a handful of 64-bit bases in SGPRs and every per-lane address is base + u32.
 struct L1Set {
-    const float *W1, *b1;             // [Kin][H], [H]
-    const float *g, *be, *mm, *mv;    // BN gamma, beta, moving mean, moving variance
-    float *gW1, *gb1, *gg, *gbe;      // gradient destinations
-    int H;
+    const float* th;  // weight slab of the network (actor block or critic block)
+    const float* st;  // statistics slab
+    float* gr;        // gradient slab of the same block (same offsets as th)
+    unsigned oW1, ob1, og, obe;  // offsets into th / gr: W1 [Kin][H], b1, BN gamma, beta
+    unsigned omm, omv;           // offsets into st: moving mean, moving variance
+    unsigned H;
 };
 
 template <int W>
@@ -96,11 +102,10 @@ struct FeatW {
     float w[KIN][W], b[W];
 };
 template <int KIN, int W>
-__device__ __forceinline__ void featw_load(FeatW<KIN, W>& f, const float* __restrict__ W1, const float* __restrict__ b1,
-                                           int H, int k) {
+__device__ __forceinline__ void featw_load(FeatW<KIN, W>& f, const L1Set& s, unsigned k) {
 #pragma unroll
-    for (int j = 0; j < KIN; ++j) ldv<W>(f.w[j], W1 + j * H + k);
-    ldv<W>(f.b, b1 + k);
+    for (int j = 0; j < KIN; ++j) ldv<W>(f.w[j], (s.th + (s.oW1 + j * s.H)) + k);  // uniform pointer + u32 lane offset
+    ldv<W>(f.b, (s.th + s.ob1) + k);
 }
 // relu(sum_j x[j] W1[j][k+e] + b1[k+e]): products summed in input order, bias last (Dense = matmul, then bias_add)
 template <int KIN, int W>
@@ -121,10 +126,10 @@ __device__ __forceinline__ void ldx(float (&x)[KIN], const float* X, int r) {  /
     }
 }
 
-__device__ __forceinline__ void l1_coefs(const L1Set& s, float* inv, float* sh, int k) {
-    const float iv = (1.0f / sqrtf(s.mv[k] + BN_EPS)) * s.g[k];
+__device__ __forceinline__ void l1_coefs(const L1Set& s, float* inv, float* sh, unsigned k) {
+    const float iv = (1.0f / sqrtf(s.st[s.omv + k] + BN_EPS)) * s.th[s.og + k];
     inv[k] = iv;
-    sh[k] = s.be[k] - s.mm[k] * iv;
+    sh[k] = s.th[s.obe + k] - s.st[s.omm + k] * iv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -134,13 +139,47 @@ __device__ __forceinline__ void l1_coefs(const L1Set& s, float* inv, float* sh, 
 // a 16-deep block: k = 16 blk + 4 lg + jj. BN is folded as in learn_kernel_t: p @ (inv (.) W2) + sh . W2.
 // FIRST / SNAP: see fast::gemm_fwd (critic state blocks of pass 1 snapshotted, pass 2 resumes with the action blocks).
 // ------------------------------------------------------------------------------------------
+// Operands a forward GEMM needs before its first MFMA, requested one phase early (before the BN coefficient tables are
+// built and the barrier that publishes them): the first R-1 W2 blocks, the first-layer weights of the first two blocks,
+// the bias. Nothing here depends on LDS, so the cold HBM/L2 misses overlap the table phase.
+template <int S>
+struct FwdPre {
+    float ring[R][4][2];
+    FeatW<S, 4> fs[2];
+    FeatW<1, 4> fa[2];
+    float bc0, bc1;
+};
+template <int S, int H1, int HA, int H2, bool CRITIC, int FIRST>
+__device__ __forceinline__ void fwd_prefetch(FwdPre<S>& p, const L1Set& st, const L1Set& ac, const float* __restrict__ W2,
+                                             const float* __restrict__ b2) {
+    constexpr int NSB = H1 / 16, NBLK = CRITIC ? (H1 + HA) / 16 : H1 / 16, N = H2;
+    const int tx = tid_here(), wave = tx >> 6, lane = tx & 63, lr = lane & 15, lg = lane >> 4;
+    const unsigned col = wave * 32 + 2 * lr, wl = (4 * lg) * N + col;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int blk = FIRST + d;
+        if (blk < NBLK) {
+            if (blk < NSB)
+                featw_load<S, 4>(p.fs[blk & 1], st, 16 * blk + 4 * lg);
+            else
+                featw_load<1, 4>(p.fa[blk & 1], ac, 16 * (blk - NSB) + 4 * lg);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d)
+        if (FIRST + d < NBLK)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ldv<2>(p.ring[(FIRST + d) % R][jj], (W2 + ((FIRST + d) * 16 + jj) * N) + wl);
+    p.bc0 = b2[col], p.bc1 = (b2 + 1)[col];
+}
+
 template <int S, int H1, int HA, int H2, bool CRITIC, int FIRST, int SNAP>
-__device__ __forceinline__ void gemm_fwd(const float* X4, const float* act, const L1Set& st, const L1Set& ac,
-                                         const float* inv, const float* sh, const float* __restrict__ W2,
-                                         const float* __restrict__ b2, float* out, float* snap, float (&cs_snap)[2]) {
+__device__ __forceinline__ void gemm_fwd(FwdPre<S>& pre, const float* X4, const float* act, const L1Set& st,
+                                         const L1Set& ac, const float* inv, const float* sh,
+                                         const float* __restrict__ W2, float* out, float* snap, float (&cs_snap)[2]) {
     constexpr int NSB = H1 / 16, NBLK = CRITIC ? (H1 + HA) / 16 : H1 / 16, N = H2, LDO = ld_of(H2);
     static_assert(N == 32 * NW, "two 16-column tiles per wave");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int tx = tid_here(), wave = tx >> 6, lane = tx & 63, lr = lane & 15, lg = lane >> 4;
     const int col = wave * 32 + 2 * lr;
     f32x4 acc[4][2];
     float cs[2];
@@ -165,36 +204,30 @@ __device__ __forceinline__ void gemm_fwd(const float* X4, const float* act, cons
         if (FIRST < NSB) ldx<S>(xr[m], X4, m * 16 + lr);
         if (CRITIC) ldx<1>(ar[m], act, m * 16 + lr);
     }
-    const float* wl = W2 + (4 * lg) * N + col;
-    float ring[R][4][2];
+    const unsigned wl = (4 * lg) * N + col;  // lane part of every W2 address: the block / row parts are uniform
+    float(&ring)[R][4][2] = pre.ring;
     auto load_blk = [&](float(&dst)[4][2], int blk) {
-        const float* p = wl + blk * (16 * N);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ldv<2>(dst[jj], p + jj * N);
+        for (int jj = 0; jj < 4; ++jj) ldv<2>(dst[jj], (W2 + (blk * 16 + jj) * N) + wl);
     };
-#pragma unroll
-    for (int d = 0; d < R - 1; ++d)
-        if (FIRST + d < NBLK) load_blk(ring[(FIRST + d) % R], FIRST + d);
-    FeatW<S, 4> fs[2];
-    FeatW<1, 4> fa[2];
+    FeatW<S, 4>(&fs)[2] = pre.fs;
+    FeatW<1, 4>(&fa)[2] = pre.fa;
     auto load_feat = [&](int blk) {
         if (blk < NSB)
-            featw_load<S, 4>(fs[blk & 1], st.W1, st.b1, H1, 16 * blk + 4 * lg);
+            featw_load<S, 4>(fs[blk & 1], st, 16 * blk + 4 * lg);
         else
-            featw_load<1, 4>(fa[blk & 1], ac.W1, ac.b1, HA, 16 * (blk - NSB) + 4 * lg);
+            featw_load<1, 4>(fa[blk & 1], ac, 16 * (blk - NSB) + 4 * lg);
     };
-    float a[2][4][4];
-    auto make_a = [&](int blk) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                a[blk & 1][m][jj] = (blk < NSB) ? feat<S, 4>(fs[blk & 1], xr[m], jj) : feat<1, 4>(fa[blk & 1], ar[m], jj);
+    // a[m][jj]: this lane's A operands of the current block. The values of group jj are dead once its 8 MFMAs have been
+    // issued, so the next block's group jj is computed into the same registers right behind them (one buffer, not two).
+    float a[4][4];
+    auto feat_of = [&](int blk, int m, int jj) {
+        return (blk < NSB) ? feat<S, 4>(fs[blk & 1], xr[m], jj) : feat<1, 4>(fa[blk & 1], ar[m], jj);
     };
-    load_feat(FIRST);
-    if (FIRST + 1 < NBLK) load_feat(FIRST + 1);
-    make_a(FIRST);
-    const float bc0 = b2[col], bc1 = b2[col + 1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) a[m][jj] = feat_of(FIRST, m, jj);
 #pragma unroll
     for (int blk = FIRST; blk < NBLK; ++blk) {
         if (SNAP > 0 && blk == SNAP && snap) {
@@ -211,8 +244,6 @@ __device__ __forceinline__ void gemm_fwd(const float* X4, const float* act, cons
         if (blk + R - 1 < NBLK) load_blk(ring[(blk + R - 1) % R], blk + R - 1);
         const f32x4 iv = *(const f32x4*)(inv + 16 * blk + 4 * lg);
         const f32x4 sf = *(const f32x4*)(sh + 16 * blk + 4 * lg);
-        if (blk + 1 < NBLK) make_a(blk + 1);        // uses the feature weights loaded one block earlier
-        if (blk + 2 < NBLK) load_feat(blk + 2);     // into the buffer make_a(blk) has finished with
         float bs[4][2];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -222,18 +253,27 @@ __device__ __forceinline__ void gemm_fwd(const float* X4, const float* act, cons
                 cs[t] = fmaf(ring[blk % R][jj][t], sf[jj], cs[t]);
             }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(a[blk & 1][m][jj], bs[jj][t], acc[m][t]);
+                for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(a[m][jj], bs[jj][t], acc[m][t]);
+            if (blk + 1 < NBLK)  // next block's group jj (feature weights loaded one block earlier)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m][jj] = feat_of(blk + 1, m, jj);
+        }
+        if (blk + 2 < NBLK) load_feat(blk + 2);  // into the buffer block blk's operands came from
+        // pin the shift sums here: left alone, LLVM sinks the whole cs chain (only read after the last block) to the end
+        // of the GEMM and keeps -- i.e. spills -- every block's W2 operands and coefficients until then
+        asm volatile("" : "+v"(cs[0]), "+v"(cs[1]));
+        __builtin_amdgcn_sched_barrier(0);       // nothing moves across blocks: bounds the live ranges
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         cs[t] += __shfl_xor(cs[t], 16);
         cs[t] += __shfl_xor(cs[t], 32);
     }
-    cs[0] += bc0, cs[1] += bc1;
+    cs[0] += pre.bc0, cs[1] += pre.bc1;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -258,15 +298,15 @@ template <int KIN, int N, int LDZ, bool WANT_DA, class Sink>
 __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict__ W2row /* W2 + c0g * N */, const float* Xin,
                                         const L1Set& s, int cl, bool write_grads, Sink sink, float* dap) {
     constexpr int NB = N / 16;
-    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int lane = tid_here() & 63, lr = lane & 15, lg = lane >> 4;
     f32x4 wc[NB];
-    const float* wrow = W2row + lr * N + 4 * lg;
+    const unsigned wrow = lr * N + 4 * lg;
 #pragma unroll
-    for (int q = 0; q < NB; ++q) wc[q] = *(const f32x4*)(wrow + 16 * q);
-    const int c = cl + lr;
+    for (int q = 0; q < NB; ++q) wc[q] = *(const f32x4*)((W2row + 16 * q) + wrow);
+    const unsigned c = cl + lr;
     FeatW<KIN, 1> fw;
-    featw_load<KIN, 1>(fw, s.W1, s.b1, s.H, c);
-    const float gam = s.g[c], mean = s.mm[c], var = s.mv[c];
+    featw_load<KIN, 1>(fw, s, c);
+    const float gam = (s.th + s.og)[c], mean = (s.st + s.omm)[c], var = (s.st + s.omv)[c];
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -313,11 +353,11 @@ __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict
 #pragma unroll
         for (int i = 0; i < KIN; ++i) aw[i] += __shfl_xor(aw[i], 16), aw[i] += __shfl_xor(aw[i], 32);
         if (lg == 0) {
-            sink.put(s.gg + c, sg);
-            sink.put(s.gbe + c, sb);
-            sink.put(s.gb1 + c, ab);
+            sink.put((s.gr + s.og) + c, sg);
+            sink.put((s.gr + s.obe) + c, sb);
+            sink.put((s.gr + s.ob1) + c, ab);
 #pragma unroll
-            for (int i = 0; i < KIN; ++i) sink.put(s.gW1 + i * s.H + c, aw[i]);
+            for (int i = 0; i < KIN; ++i) sink.put((s.gr + (s.oW1 + i * s.H)) + c, aw[i]);
         }
     }
     if constexpr (WANT_DA) {
@@ -331,6 +371,11 @@ __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict
             }
     }
 }
+
+__device__ __forceinline__ const float* sink_base(const StoreSink&, const float* gW) { return gW; }
+__device__ __forceinline__ const float* sink_base(const AdamSink& s, const float*) { return s.wo; }
+__device__ __forceinline__ float alpha_of(const StoreSink&, bool) { return 0.f; }
+__device__ __forceinline__ float alpha_of(const AdamSink& s, bool critic) { return critic ? s.alpha_c : s.alpha_a; }
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient of a second layer (+ fused Adam/Polyak) and its input gradient, interleaved per block of 64 features:
@@ -349,7 +394,7 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
     constexpr int N = H2, LDZ = ld_of(H2), K = CRITIC ? H1 + HA : H1;
     constexpr bool kFused = !std::is_same<Sink, StoreSink>::value;
     static_assert(N == 128 && H1 % 64 == 0 && HA <= 64 && HA % 16 == 0, "tile plan");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int tx = tid_here(), wave = tx >> 6, lane = tx & 63, lr = lane & 15, lg = lane >> 4;
     const int ch = wave & 1, rh = wave >> 1;
     const int col = 64 * ch + 4 * lr;
     const f32x4 dbc = *(const f32x4*)(db + col);
@@ -359,14 +404,17 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
         const bool ablk = CRITIC && k0 >= H1;  // the critic's action features (their own first layer)
         const int kl = k0 + 32 * rh;           // first feature row of this wave's half block
         typename std::conditional<kFused, AdamSink::Quad4, int>::type q[8];
-        long base = 0;
+        // A lane's 8 rows are kl + 8 lg + {0..7}: one u32 lane offset, the row inside the group is an immediate. In the
+        // critic's last block the rows of whole lanes (lg >= 2 in the upper half) lie past K: those lanes are pointed at
+        // the rows of lg - 2 (valid memory, results never stored).
+        const bool lane_ok = kl + 8 * lg < K;
+        const unsigned lo = (unsigned)((kl + 8 * (lane_ok ? lg : lg - 2)) * N + col);
+        const long tens = gW - sink_base(sink, gW);  // position of this W2 tensor in the slab (uniform)
         if constexpr (kFused) {
-            base = (gW - sink.wo) + col;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ta = 0; ta < 2; ++ta)
-                    sink.load4(q[j * 2 + ta], base + (long)min(kl + 2 * (4 * lg + j) + ta, K - 1) * N);
+            for (int j = 0; j < 8; ++j)
+                AdamSink::load4p(q[j], (sink.wi + tens + j * N) + lo, (sink.wt + tens + j * N) + lo,
+                                 (sink.m + tens + j * N) + lo, (sink.v + tens + j * N) + lo);
         }
         f32x4 acc[2][4];
 #pragma unroll
@@ -381,7 +429,7 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
         };
         if (!ablk) {
             FeatW<S, 2> fw;
-            featw_load<S, 2>(fw, st.W1, st.b1, H1, kl + 2 * lr);
+            featw_load<S, 2>(fw, st, kl + 2 * lr);
             float x[2][S];
             f32x4 dz[2];
             ldx<S>(x[0], X4, lg);
@@ -398,7 +446,7 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
             }
         } else {
             FeatW<1, 2> fw;
-            featw_load<1, 2>(fw, ac.W1, ac.b1, HA, min(kl - H1 + 2 * lr, HA - 2));  // rows past HA: clamped, never stored
+            featw_load<1, 2>(fw, ac, min(kl - H1 + 2 * lr, HA - 2));  // rows past HA: clamped, never stored
             float x[2][1];
             f32x4 dz[2];
             ldx<1>(x[0], act, lg);
@@ -414,25 +462,28 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
                 mfma_it(pa, dz[it & 1]);
             }
         }
+        if (lane_ok) {
+            const float alpha = CRITIC ? alpha_of(sink, true) : alpha_of(sink, false);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta) {
-                const int k = kl + 2 * (4 * lg + j) + ta;
-                if (k < K) {
+                for (int ta = 0; ta < 2; ++ta) {
+                    const int k = kl + 2 * (4 * lg + j) + ta;
                     const float iv = inv[k], sf = sh[k];
                     float o[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = fmaf(iv, acc[ta][t][j], sf * dbc[t]);
+                    const int rj = 2 * j + ta;  // row inside the lane's group of 8
                     if constexpr (kFused) {
-                        sink.update4(q[j * 2 + ta], base + (long)k * N, o);
+                        sink.update4p(q[rj], alpha, (sink.wo + tens + rj * N) + lo, (sink.wt + tens + rj * N) + lo,
+                                      (sink.m + tens + rj * N) + lo, (sink.v + tens + rj * N) + lo, o);
                     } else {
                         f32x4 ov;
                         ov[0] = o[0], ov[1] = o[1], ov[2] = o[2], ov[3] = o[3];
-                        *(f32x4*)(gW + k * N + col) = ov;
+                        *(f32x4*)((gW + rj * N) + lo) = ov;
                     }
                 }
-            }
+        }
         const int c0 = k0 + 16 * wave;
         if (c0 < K) {
             if (!ablk)
@@ -453,7 +504,7 @@ __device__ __forceinline__ void out_backward(const float* P, int ldp, const floa
                                              float* scr, float* __restrict__ gW3, float* __restrict__ gg,
                                              float* __restrict__ gbe, Sink sink) {
     static_assert(2 * K == FT, "two row halves");
-    const int part = threadIdx.x / K, k = threadIdx.x - part * K;
+    const int tx = tid_here(), part = tx / K, k = tx - part * K;
     float dw = 0.f, dgm = 0.f, dbt = 0.f;
     const float wk = w3[k], iv = inv[k], s = sh[k], rs = rsl[k], mean = mml[k];
     for (int rb = part * 32; rb < (part + 1) * 32; rb += 8) {
@@ -542,60 +593,83 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
         for (int i = L.ab3 + 1; i < L.actor_size; ++i) ga[i] = 0.f;
         for (int i = L.cb3 + 1; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
     }
+    PH_INIT();
     float cs_snap[2] = {0.f, 0.f};  // lane-local shift sums of the critic's state blocks, pass 1 -> pass 2
 
     // pass 0: targets (y); pass 1: critic loss + gradient; pass 2: actor -> critic, gradient wrt the action;
     // pass 3: actor gradient (second-layer activations of pass 2 kept in bufB)      (workers/trainer.py:492-506)
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
+        const int tid = tid_here();
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.xS2 : l.xS;
         const float* ath = n.th;
         const float* cth = n.th + L.actor_size;
         // first layers of this pass's networks (gradient destinations only matter in passes 1 and 3)
-        const L1Set aL1 = {ath + L.aW1, ath + L.ab1, ath + L.ag1, ath + L.abe1, n.st + L.amm1, n.st + L.amv1,
-                           ga + L.aW1,  ga + L.ab1,  ga + L.ag1,  ga + L.abe1,  H1};
-        const L1Set cS1 = {cth + L.cWs, cth + L.cbs, cth + L.cgs, cth + L.cbes, n.st + L.cmms, n.st + L.cmvs,
-                           gc + L.cWs,  gc + L.cbs,  gc + L.cgs,  gc + L.cbes,  H1};
-        const L1Set cA1 = {cth + L.cWa, cth + L.cba, cth + L.cga, cth + L.cbea, n.st + L.cmma, n.st + L.cmva,
-                           gc + L.cWa,  gc + L.cba,  gc + L.cga,  gc + L.cbea,  HA};
+        const L1Set aL1 = {ath, n.st, ga, (unsigned)L.aW1, (unsigned)L.ab1, (unsigned)L.ag1, (unsigned)L.abe1,
+                           (unsigned)L.amm1, (unsigned)L.amv1, H1};
+        const L1Set cS1 = {cth, n.st, gc, (unsigned)L.cWs, (unsigned)L.cbs, (unsigned)L.cgs, (unsigned)L.cbes,
+                           (unsigned)L.cmms, (unsigned)L.cmvs, H1};
+        const L1Set cA1 = {cth, n.st, gc, (unsigned)L.cWa, (unsigned)L.cba, (unsigned)L.cga, (unsigned)L.cbea,
+                           (unsigned)L.cmma, (unsigned)L.cmva, HA};
         float* const aP2 = l.bufB;
         float* const cP2 = (it == 2) ? l.bufC : l.bufB;
         float* const bP2 = (it == 2) ? l.bufC : l.bufB;
         float* const bDZ = (it == 1) ? l.bufB : l.bufC;
-        if (it != 1) {  // ---- actor (agent/model.py:26-36); pass 3 only rebuilds the second layer's coefficient tables
-            if (it != 3 && tid < H1) l1_coefs(aL1, l.invA, l.shA, tid);
+        // Each forward is [request the GEMM's first operands | build the BN coefficient tables | barrier | GEMM]; the
+        // sequence is written out per variant so that the prefetched registers never meet at a control-flow join
+        // (joined, the register allocator spills them).
+        if (it == 3) {  // ---- pass 3: only the second layer's coefficient tables of the actor are rebuilt
             l2_coefs(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, l, H2, tid);
             lds_barrier();
-            if (it != 3) {
-                gemm_fwd<S, H1, HA, H2, false, 0, 0>(X, nullptr, aL1, aL1, l.invA, l.shA, ath + L.aW2, ath + L.ab2, aP2,
-                                                     nullptr, cs_snap);
-                lds_barrier();
-                const float z = out_layer_row(aP2, LDB, l.invB, l.shB, l.w3B, ath[L.ab3], H2);
-                if (tid % LPR == 0) {
-                    const float t = tanhf(z);
-                    l.sT[tid / LPR] = t;
-                    l.sA1[tid / LPR] = t * high;
-                }
-                lds_barrier();
+            PH(1);
+        } else if (it != 1) {  // ---- actor (agent/model.py:26-36)
+            FwdPre<S> fp;
+            fwd_prefetch<S, H1, HA, H2, false, 0>(fp, aL1, aL1, ath + L.aW2, ath + L.ab2);
+            if (tid < H1) l1_coefs(aL1, l.invA, l.shA, tid);
+            l2_coefs(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, l, H2, tid);
+            lds_barrier();
+            PH(1);
+            gemm_fwd<S, H1, HA, H2, false, 0, 0>(fp, X, nullptr, aL1, aL1, l.invA, l.shA, ath + L.aW2, aP2, nullptr, cs_snap);
+            lds_barrier();
+            PH(2);
+            const float z = out_layer_row(aP2, LDB, l.invB, l.shB, l.w3B, ath[L.ab3], H2);
+            if (tid % LPR == 0) {
+                const float t = tanhf(z);
+                l.sT[tid / LPR] = t;
+                l.sA1[tid / LPR] = t * high;
             }
+            lds_barrier();
+            PH(3);
         }
         if (it != 3) {  // ---- critic (agent/model.py:63-83)
             const float* act = (it == 1) ? l.sAct : l.sA1;
-            if (it != 2 && tid < H1) l1_coefs(cS1, l.invA, l.shA, tid);  // pass 2 keeps the ACTOR's state coefficients (pass 3)
-            if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
-            l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
-            lds_barrier();
-            if (it == 2)
-                gemm_fwd<S, H1, HA, H2, true, H1 / 16, 0>(X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cth + L.cb2, cP2,
-                                                          l.bufC, cs_snap);
-            else
-                gemm_fwd<S, H1, HA, H2, true, 0, H1 / 16>(X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cth + L.cb2, cP2,
+            if (it == 2) {  // resumes from pass 1's state-block sums; the ACTOR's state coefficients stay in invA/shA (pass 3)
+                FwdPre<S> fp;
+                fwd_prefetch<S, H1, HA, H2, true, H1 / 16>(fp, cS1, cA1, cth + L.cW2, cth + L.cb2);
+                if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
+                l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
+                lds_barrier();
+                PH(4);
+                gemm_fwd<S, H1, HA, H2, true, H1 / 16, 0>(fp, X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cP2, l.bufC,
+                                                          cs_snap);
+            } else {
+                FwdPre<S> fp;
+                fwd_prefetch<S, H1, HA, H2, true, 0>(fp, cS1, cA1, cth + L.cW2, cth + L.cb2);
+                if (tid < H1) l1_coefs(cS1, l.invA, l.shA, tid);
+                if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
+                l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
+                lds_barrier();
+                PH(4);
+                gemm_fwd<S, H1, HA, H2, true, 0, H1 / 16>(fp, X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cP2,
                                                           it == 1 ? l.bufC : nullptr, cs_snap);
+            }
             lds_barrier();
+            PH(5);
             const float q = out_layer_row(cP2, LDB, l.invB, l.shB, l.w3B, cth[L.cb3], H2);
             if (tid % LPR == 0) l.sQ[tid / LPR] = q;
             lds_barrier();
+            PH(6);
         }
         if (it == 0) {  // TD target, no done mask (trainer.py:494)
             if (tid < TILE) l.sY[tid] = fmaf(gamma, l.sQ[tid], l.sR[tid]);
@@ -640,9 +714,11 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
         out_backward<H2>(bP2, LDB, l.invB, l.shB, l.sD, l.w3B, l.rsB, l.mmB, bDZ, LDB, l.scr,
                          wg ? gout + (crit ? L.cW3 : L.aW3) : nullptr, gout + (crit ? L.cg3 : L.ag2),
                          gout + (crit ? L.cbe3 : L.abe2), sink);
+        PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
         if (wg) {
             col_sums(bDZ, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
             lds_barrier();
+            PH(it == 1 ? 8 : 16);
             if (crit)
                 gemm_dw_dx<S, H1, HA, H2, true>(X, l.sAct, cS1, cA1, l.invA, l.shA, bDZ, l.db,
                                                 gw2 + L.actor_size + L.cW2, bulk, cth + L.cW2, sink);
@@ -650,12 +726,14 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
                 gemm_dw_dx<S, H1, HA, H2, false>(X, nullptr, aL1, aL1, l.invA, l.shA, bDZ, l.db, gw2 + L.aW2, bulk,
                                                  ath + L.aW2, sink);
             lds_barrier();
+            PH(it == 1 ? 9 : 17);
         } else {  // pass 2: gradient w.r.t. the action only -- the critic's action-feature columns, three 16-column tiles
             const int wave = tid >> 6;
             if (wave < HA / 16)
                 dx_tile<1, H2, LDB, true>(bDZ, cth + L.cW2 + (H1 + 16 * wave) * H2, l.sA1, cA1, 16 * wave, false, sink,
                                           l.scr + wave * TILE);
             lds_barrier();
+            PH(13);
             if (tid < TILE) {
                 float v = l.scr[tid];
 #pragma unroll
@@ -663,6 +741,7 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
                 l.sDa[tid] = v;
             }
             lds_barrier();
+            PH(14);
         }
     }
 }
@@ -672,7 +751,8 @@ static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const fl
                   float* theta_t, float* stats_t, const float* s, const float* a, const float* r, const float* s2,
                   float gamma, float high, float* grads, float* losses, UpdArgs upd, void* stream) {
     constexpr int H1 = 256, H2 = 128, HA = 48;
-    const size_t lds = sizeof(float) * lds_floats(H1 + HA, H2);
+    size_t lds = sizeof(float) * lds_floats(H1 + HA, H2);
+    if (const char* kb = getenv("AVD_LEAN_LDS_KB")) lds = (size_t)atoi(kb) * 1024;  // diagnostics: force 1 workgroup per CU
     static_assert(sizeof(float) * lds_floats(H1 + HA, H2) <= 80 * 1024, "two workgroups per CU");
     hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_l<S, H1, H2, HA, FUSED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -686,6 +766,19 @@ static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const fl
 }
 
 }  // namespace lean
+
+#ifdef AVD_PHASE_TIMING
+}  // namespace avd
+extern "C" int avd_debug_phase_cycles_lean(unsigned long long* h_out, int reset) {
+    if (h_out) (void)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
+    if (reset) {
+        unsigned long long z[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(avd::g_phase_cycles), z, sizeof(z));
+    }
+    return 0;
+}
+namespace avd {
+#endif
 
 int lean_launch(const avd_mlp_layout* lay, bool fused, int n_agents, int set_mod, const float* theta, const float* stats,
                 float* theta_t, float* stats_t, const float* s, const float* a, const float* r, const float* s2,

@@ -135,6 +135,26 @@ struct AdamSink {
         *(f32x4*)(m + off) = om;
         *(f32x4*)(v + off) = ov;
     }
+    // Pointer form (lean.hip): the caller passes uniform base + per-lane u32 offset addresses, one per array.
+    __device__ __forceinline__ static void load4p(Quad4& q, const float* pw, const float* pt, const float* pm, const float* pv) {
+        q.w = *(const f32x4*)pw, q.t = *(const f32x4*)pt, q.m = *(const f32x4*)pm, q.v = *(const f32x4*)pv;
+    }
+    __device__ __forceinline__ void update4p(const Quad4& q, float alpha, float* pwo, float* pt, float* pm, float* pv,
+                                             const float (&g)[4]) const {
+#pragma clang fp contract(off)
+        f32x4 ow, ot, om, ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mm = q.m[e] + (g[e] - q.m[e]) * (1.0f - 0.9f);
+            const float vv = q.v[e] + (g[e] * g[e] - q.v[e]) * (1.0f - 0.999f);
+            const float w = q.w[e] - (mm * alpha) / (sqrtf(vv) + 1e-7f);
+            om[e] = mm, ov[e] = vv, ow[e] = w, ot[e] = w * tau + q.t[e] * omt;
+        }
+        *(f32x4*)pwo = ow;
+        *(f32x4*)pt = ot;
+        *(f32x4*)pm = om;
+        *(f32x4*)pv = ov;
+    }
 };
 
 struct Net {  // pointers into one weight set

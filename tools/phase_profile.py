@@ -24,7 +24,9 @@ NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fw
          18: "actor dX GEMM + BN bwd", 19: "actor L1 grads"}
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-FUSED = len(sys.argv) > 2 and sys.argv[2] == "fused"
+FUSED = len(sys.argv) > 2 and sys.argv[2] in ("fused", "lean-fused")
+LEAN = len(sys.argv) > 2 and sys.argv[2].startswith("lean")  # learn_kernel_l (lean.hip); else learn_kernel_t
+os.environ["AVD_LEARN_KERNEL"] = "lean" if LEAN else "fast"
 CENTRAL = len(sys.argv) > 2 and sys.argv[2] == "centralized"  # general kernel at S = 20, A = 5, widths x1.2
 conf = config.Config()
 S, A = (20, 5) if CENTRAL else (4, 1)
@@ -32,20 +34,24 @@ grp = vec.AgentGroup(n, S, A, conf, hidd_mult=1.2 if CENTRAL else 1.0)
 f = lambda *s: torch.randn(*s, device="cuda")
 s, a, r, s2 = f(n, 64, S), f(n, 64, A), f(n, 64), f(n, 64, S)
 lib = _hip.lib()
-lib.avd_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dbg = lib.avd_debug_phase_cycles_lean if LEAN else lib.avd_debug_phase_cycles
+dbg.argtypes = [ctypes.c_void_p, ctypes.c_int]
 gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
 run = (lambda: grp.learn_update(s, a, r, s2, gscr)) if FUSED else (lambda: grp.learn(s, a, r, s2, 0))
 run()
 torch.cuda.synchronize()
-lib.avd_debug_phase_cycles(None, 1)
+dbg(None, 1)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
-lib.avd_debug_phase_cycles(buf, 0)
+dbg(buf, 0)
 tot = sum(buf)
 print(f"tiles={3 * n}  cycles/tile={tot / (3 * n):.0f}")
 NAMES.update({20: "  dx: issue next-tile loads", 21: "  dx: MFMA loop", 22: "  dx: BN epilogue", 23: "  dx: wait next tile (copy)"})
+if LEAN:
+    NAMES.update({1: "actor BN coefficient tables", 4: "critic BN coefficient tables", 9: "critic dW2 + dX (+update)",
+                  10: "-", 11: "-", 17: "actor dW2 + dX (+update)", 18: "-", 19: "-"})
 if CENTRAL:  # the general kernel stamps its first-layer pieces under these ids (and they are NOT part of phases 1 / 4)
     NAMES.update({20: "stage state batch", 21: "actor first layer", 22: "critic first layer (state)", 23: "critic first layer (action)"})
 for i in range(24):
