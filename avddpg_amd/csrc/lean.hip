@@ -294,19 +294,30 @@ __device__ __forceinline__ void gemm_fwd(FwdPre<S>& pre, const float* X4, const 
 //   WANT_DA: dap[r] = sum_c dz1[r][c] * W1[0][c]  (KIN == 1: gradient w.r.t. the action input), this tile's share
 // cl = column index inside the layer `s` (c0g = cl + the layer's first row in W2).
 // ------------------------------------------------------------------------------------------
+// dx_load requests the tile's operands (the 16 W2 rows, the columns' first-layer weights and BN parameters), dx_run does the
+// rest: callers put other work between the two.
+template <int KIN, int N>
+struct DxOps {
+    f32x4 wc[N / 16];
+    FeatW<KIN, 1> fw;
+    float gam, mean, var;
+};
+template <int KIN, int N>
+__device__ __forceinline__ void dx_load(DxOps<KIN, N>& o, const float* __restrict__ W2row /* W2 + c0g * N */, const L1Set& s,
+                                        int cl) {
+    const int lane = tid_here() & 63, lr = lane & 15, lg = lane >> 4;
+    const unsigned wrow = lr * N + 4 * lg, c = cl + lr;
+#pragma unroll
+    for (int q = 0; q < N / 16; ++q) o.wc[q] = *(const f32x4*)((W2row + 16 * q) + wrow);
+    featw_load<KIN, 1>(o.fw, s, c);
+    o.gam = (s.th + s.og)[c], o.mean = (s.st + s.omm)[c], o.var = (s.st + s.omv)[c];
+}
 template <int KIN, int N, int LDZ, bool WANT_DA, class Sink>
-__device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict__ W2row /* W2 + c0g * N */, const float* Xin,
-                                        const L1Set& s, int cl, bool write_grads, Sink sink, float* dap) {
+__device__ __forceinline__ void dx_run(const DxOps<KIN, N>& o, const float* DZ, const float* Xin, const L1Set& s, int cl,
+                                       bool write_grads, Sink sink, float* dap) {
     constexpr int NB = N / 16;
     const int lane = tid_here() & 63, lr = lane & 15, lg = lane >> 4;
-    f32x4 wc[NB];
-    const unsigned wrow = lr * N + 4 * lg;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) wc[q] = *(const f32x4*)((W2row + 16 * q) + wrow);
     const unsigned c = cl + lr;
-    FeatW<KIN, 1> fw;
-    featw_load<KIN, 1>(fw, s, c);
-    const float gam = (s.th + s.og)[c], mean = (s.st + s.omm)[c], var = (s.st + s.omv)[c];
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -321,10 +332,10 @@ __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[q & 1][m][jj], wc[q][jj], acc[m]);
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(a[q & 1][m][jj], o.wc[q][jj], acc[m]);
     }
-    const float rs = 1.0f / sqrtf(var + BN_EPS);
-    const float rg = rs * gam;
+    const float rs = 1.0f / sqrtf(o.var + BN_EPS), mean = o.mean;
+    const float rg = rs * o.gam;
     float sg = 0.f, sb = 0.f, ab = 0.f, aw[KIN];
 #pragma unroll
     for (int j = 0; j < KIN; ++j) aw[j] = 0.f;
@@ -336,7 +347,7 @@ __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict
             const int r = m * 16 + lg * 4 + j;
             float x[KIN];
             ldx<KIN>(x, Xin, r);
-            const float p = feat<KIN, 1>(fw, x, 0);
+            const float p = feat<KIN, 1>(o.fw, x, 0);
             const float dy = acc[m][j];
             sg = fmaf(dy * (p - mean), rs, sg);
             sb += dy;
@@ -344,7 +355,7 @@ __device__ __forceinline__ void dx_tile(const float* DZ, const float* __restrict
             ab += dz1;
 #pragma unroll
             for (int i = 0; i < KIN; ++i) aw[i] = fmaf(x[i], dz1, aw[i]);
-            if (WANT_DA) da[m][j] = dz1 * fw.w[0][0];
+            if (WANT_DA) da[m][j] = dz1 * o.fw.w[0][0];
         }
     if (write_grads) {
         sg += __shfl_xor(sg, 16), sg += __shfl_xor(sg, 32);
@@ -381,10 +392,13 @@ __device__ __forceinline__ float alpha_of(const AdamSink& s, bool critic) { retu
 // Weight gradient of a second layer (+ fused Adam/Polyak) and its input gradient, interleaved per block of 64 features:
 //   dW2[k][n] = inv[k] * sum_r feature(r, k) * DZ[r][n] + sh[k] * db[n]
 // Wave w: column half ch = w & 1 (MFMA tile t holds columns 64 ch + 4 lr + t), row half rh = w >> 1 (tile ta holds the
-// features k0 + 32 rh + 2 i + ta, i = MFMA row). A lane ends up with rows k0 + 32 rh + 2 (4 lg + reg) + ta, 4 consecutive
+// features k0 + 32 rh + 2 i + ta, i = MFMA row). A lane ends up with rows k0 + 32 rh + 8 lg + {0..7}, 4 consecutive
 // columns each: 8 float4 pieces per array for the fused update.
-// The input-gradient tile of the block (columns k0 + 16 w .. + 15, dx_tile) follows the update: its W2 rows are the
-// ones the update has just pulled through L2 (learn_kernel_t's gemm_dw_dx).
+// Order inside a block, chosen for the in-order vmcnt counter (a wait for a load also waits for every older load AND
+// store):  [first-layer weights of the NEXT block | Adam operands of this block]  MFMA loop  [operands of the block's
+// input-gradient tile (columns k0 + 16 w .., dx_load): W2 rows the update is pulling through L2 right now]
+// update + stores  |  input-gradient tile (dx_run).  The MFMA loop thus never waits behind the operand stream, and the
+// next block's loop starts on weights that arrived a block ago, underneath this block's stores.
 // ------------------------------------------------------------------------------------------
 template <int S, int H1, int HA, int H2, bool CRITIC, class Sink, class SmallSink>
 __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, const L1Set& st, const L1Set& ac,
@@ -399,97 +413,109 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
     const int col = 64 * ch + 4 * lr;
     const f32x4 dbc = *(const f32x4*)(db + col);
     const float* dp = DZ + lg * LDZ + col;
-#pragma nounroll
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const bool ablk = CRITIC && k0 >= H1;  // the critic's action features (their own first layer)
-        const int kl = k0 + 32 * rh;           // first feature row of this wave's half block
-        typename std::conditional<kFused, AdamSink::Quad4, int>::type q[8];
-        // A lane's 8 rows are kl + 8 lg + {0..7}: one u32 lane offset, the row inside the group is an immediate. In the
-        // critic's last block the rows of whole lanes (lg >= 2 in the upper half) lie past K: those lanes are pointed at
-        // the rows of lg - 2 (valid memory, results never stored).
-        const bool lane_ok = kl + 8 * lg < K;
-        const unsigned lo = (unsigned)((kl + 8 * (lane_ok ? lg : lg - 2)) * N + col);
-        const long tens = gW - sink_base(sink, gW);  // position of this W2 tensor in the slab (uniform)
+    const long tens = gW - sink_base(sink, gW);  // position of this W2 tensor in the slab (uniform)
+    const float alpha = alpha_of(sink, CRITIC);
+    typedef typename std::conditional<kFused, AdamSink::Quad4, int>::type QuadT;
+
+    // A lane's 8 rows are kl + 8 lg + {0..7}: one u32 lane offset `lo`, the row inside the group is an immediate.
+    auto load_quads = [&](QuadT(&q)[8], unsigned lo) {
         if constexpr (kFused) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 AdamSink::load4p(q[j], (sink.wi + tens + j * N) + lo, (sink.wt + tens + j * N) + lo,
                                  (sink.m + tens + j * N) + lo, (sink.v + tens + j * N) + lo);
         }
-        f32x4 acc[2][4];
+    };
+    auto mfma_loop = [&](f32x4(&acc)[2][4], const auto& fw, const float* Xin, auto kin_tag) {
+        constexpr int KIN = decltype(kin_tag)::value;
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[ta][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto mfma_it = [&](const float(&pa)[2], const f32x4& dz) {
+        float x[2][KIN];
+        f32x4 dz[2];
+        ldx<KIN>(x[0], Xin, lg);
+        dz[0] = *(const f32x4*)dp;
+#pragma unroll
+        for (int it = 0; it < TILE / 4; ++it) {
+            if (it + 1 < TILE / 4) {
+                ldx<KIN>(x[(it + 1) & 1], Xin, 4 * (it + 1) + lg);
+                dz[(it + 1) & 1] = *(const f32x4*)(dp + 4 * (it + 1) * LDZ);
+            }
+            float pa[2];
+            pa[0] = feat<KIN, 2>(fw, x[it & 1], 0), pa[1] = feat<KIN, 2>(fw, x[it & 1], 1);
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[ta][t] = MFMA16(pa[ta], dz[t], acc[ta][t]);
-        };
-        if (!ablk) {
-            FeatW<S, 2> fw;
-            featw_load<S, 2>(fw, st, kl + 2 * lr);
-            float x[2][S];
-            f32x4 dz[2];
-            ldx<S>(x[0], X4, lg);
-            dz[0] = *(const f32x4*)dp;
+                for (int t = 0; t < 4; ++t) acc[ta][t] = MFMA16(pa[ta], dz[it & 1][t], acc[ta][t]);
+        }
+    };
+    // rows [R0, R1) of the lane's group of 8 (row rj = 2 j + ta holds feature kl + 8 lg + rj)
+    auto epilogue = [&](const f32x4(&acc)[2][4], const QuadT(&q)[8], int kl, unsigned lo, auto r0_tag, auto r1_tag) {
+        constexpr int R0 = decltype(r0_tag)::value, R1 = decltype(r1_tag)::value;
+        const f32x4 iv0 = *(const f32x4*)(inv + kl + 8 * lg), iv1 = *(const f32x4*)(inv + kl + 8 * lg + 4);
+        const f32x4 sf0 = *(const f32x4*)(sh + kl + 8 * lg), sf1 = *(const f32x4*)(sh + kl + 8 * lg + 4);
 #pragma unroll
-            for (int it = 0; it < TILE / 4; ++it) {
-                if (it + 1 < TILE / 4) {
-                    ldx<S>(x[(it + 1) & 1], X4, 4 * (it + 1) + lg);
-                    dz[(it + 1) & 1] = *(const f32x4*)(dp + 4 * (it + 1) * LDZ);
-                }
-                float pa[2];
-                pa[0] = feat<S, 2>(fw, x[it & 1], 0), pa[1] = feat<S, 2>(fw, x[it & 1], 1);
-                mfma_it(pa, dz[it & 1]);
-            }
-        } else {
-            FeatW<1, 2> fw;
-            featw_load<1, 2>(fw, ac, min(kl - H1 + 2 * lr, HA - 2));  // rows past HA: clamped, never stored
-            float x[2][1];
-            f32x4 dz[2];
-            ldx<1>(x[0], act, lg);
-            dz[0] = *(const f32x4*)dp;
+        for (int rj = R0; rj < R1; ++rj) {
+            const int j = rj >> 1, ta = rj & 1;
+            const float iv = rj < 4 ? iv0[rj & 3] : iv1[rj & 3], sf = rj < 4 ? sf0[rj & 3] : sf1[rj & 3];
+            float o[4];
 #pragma unroll
-            for (int it = 0; it < TILE / 4; ++it) {
-                if (it + 1 < TILE / 4) {
-                    ldx<1>(x[(it + 1) & 1], act, 4 * (it + 1) + lg);
-                    dz[(it + 1) & 1] = *(const f32x4*)(dp + 4 * (it + 1) * LDZ);
-                }
-                float pa[2];
-                pa[0] = feat<1, 2>(fw, x[it & 1], 0), pa[1] = feat<1, 2>(fw, x[it & 1], 1);
-                mfma_it(pa, dz[it & 1]);
+            for (int t = 0; t < 4; ++t) o[t] = fmaf(iv, acc[ta][t][j], sf * dbc[t]);
+            if constexpr (kFused) {
+                sink.update4p(q[rj], alpha, (sink.wo + tens + rj * N) + lo, (sink.wt + tens + rj * N) + lo,
+                              (sink.m + tens + rj * N) + lo, (sink.v + tens + rj * N) + lo, o);
+            } else {
+                f32x4 ov;
+                ov[0] = o[0], ov[1] = o[1], ov[2] = o[2], ov[3] = o[3];
+                *(f32x4*)((gW + rj * N) + lo) = ov;
             }
         }
-        if (lane_ok) {
-            const float alpha = CRITIC ? alpha_of(sink, true) : alpha_of(sink, false);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ta = 0; ta < 2; ++ta) {
-                    const int k = kl + 2 * (4 * lg + j) + ta;
-                    const float iv = inv[k], sf = sh[k];
-                    float o[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) o[t] = fmaf(iv, acc[ta][t][j], sf * dbc[t]);
-                    const int rj = 2 * j + ta;  // row inside the lane's group of 8
-                    if constexpr (kFused) {
-                        sink.update4p(q[rj], alpha, (sink.wo + tens + rj * N) + lo, (sink.wt + tens + rj * N) + lo,
-                                      (sink.m + tens + rj * N) + lo, (sink.v + tens + rj * N) + lo, o);
-                    } else {
-                        f32x4 ov;
-                        ov[0] = o[0], ov[1] = o[1], ov[2] = o[2], ov[3] = o[3];
-                        *(f32x4*)((gW + rj * N) + lo) = ov;
-                    }
-                }
-        }
-        const int c0 = k0 + 16 * wave;
-        if (c0 < K) {
-            if (!ablk)
-                dx_tile<S, N, LDZ, false>(DZ, W2 + c0 * N, X4, st, c0, true, small, nullptr);
-            else
-                dx_tile<1, N, LDZ, false>(DZ, W2 + c0 * N, act, ac, c0 - H1, true, small, nullptr);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 8> I8;
+
+    FeatW<S, 2> fw;
+    featw_load<S, 2>(fw, st, 32 * rh + 2 * lr);
+#pragma nounroll
+    for (int k0 = 0; k0 < H1; k0 += 64) {  // blocks of state features
+        const int kl = k0 + 32 * rh;       // first feature row of this wave's half block
+        const unsigned lo = (unsigned)((kl + 8 * lg) * N + col);
+        FeatW<S, 2> fwn;
+        featw_load<S, 2>(fwn, st, min(kl + 64, H1 - 64 + 32 * rh) + 2 * lr);  // next block's (the last block reloads its own)
+        QuadT q[8];
+        load_quads(q, lo);
+        f32x4 acc[2][4];
+        mfma_loop(acc, fw, X4, std::integral_constant<int, S>());
+        // the tile operands are requested once two rows of the epilogue have retired their registers: ahead of the other
+        // six rows' stores in vmcnt order, and over W2 rows the update has just read
+        epilogue(acc, q, kl, lo, I0(), I2());
+        DxOps<S, N> dxo;
+        dx_load<S, N>(dxo, W2 + (k0 + 16 * wave) * N, st, k0 + 16 * wave);
+        epilogue(acc, q, kl, lo, I2(), I8());
+        dx_run<S, N, LDZ, false>(dxo, DZ, X4, st, k0 + 16 * wave, true, small, nullptr);
+        fw = fwn;
+    }
+    if constexpr (CRITIC) {  // the critic's action features (their own first layer): rows H1 .. H1 + HA of W2
+        const int kl = H1 + 32 * rh;
+        // rows of whole lanes (lg >= (HA - 32) / 8 in the upper half) lie past K: those lanes work on the rows of the lower
+        // lanes again (valid memory) and store nothing
+        const bool lane_ok = kl + 8 * lg < K;
+        const int lge = lane_ok ? lg : lg - 2;
+        const unsigned lo = (unsigned)((kl + 8 * lge) * N + col);
+        FeatW<1, 2> fwa;
+        featw_load<1, 2>(fwa, ac, min(32 * rh + 2 * lr, HA - 2));  // rows past HA: clamped, never stored
+        QuadT q[8];
+        load_quads(q, lo);
+        f32x4 acc[2][4];
+        mfma_loop(acc, fwa, act, std::integral_constant<int, 1>());
+        const bool have = H1 + 16 * wave < K;
+        if (lane_ok) epilogue(acc, q, kl, lo, I0(), I8());
+        if (have) {
+            DxOps<1, N> dxo;
+            dx_load<1, N>(dxo, W2 + (H1 + 16 * wave) * N, ac, 16 * wave);
+            dx_run<1, N, LDZ, false>(dxo, DZ, act, ac, 16 * wave, true, small, nullptr);
         }
     }
 }
@@ -729,9 +755,11 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
             PH(it == 1 ? 9 : 17);
         } else {  // pass 2: gradient w.r.t. the action only -- the critic's action-feature columns, three 16-column tiles
             const int wave = tid >> 6;
-            if (wave < HA / 16)
-                dx_tile<1, H2, LDB, true>(bDZ, cth + L.cW2 + (H1 + 16 * wave) * H2, l.sA1, cA1, 16 * wave, false, sink,
-                                          l.scr + wave * TILE);
+            if (wave < HA / 16) {
+                DxOps<1, H2> dxo;
+                dx_load<1, H2>(dxo, cth + L.cW2 + (H1 + 16 * wave) * H2, cA1, 16 * wave);
+                dx_run<1, H2, LDB, true>(dxo, bDZ, l.sA1, cA1, 16 * wave, false, sink, l.scr + wave * TILE);
+            }
             lds_barrier();
             PH(13);
             if (tid < TILE) {

@@ -1462,7 +1462,7 @@ extern "C" int avd_mlp_layout_init(avd_mlp_layout* o, int S, int A, int H1, int 
 // AVD_LEARN_KERNEL=fast asks for learn_kernel_t (one workgroup per CU, first-layer activations in LDS).
 static bool use_lean_kernel() {
     const char* k = getenv("AVD_LEARN_KERNEL");
-    return k && !strcmp(k, "lean");
+    return !(k && !strcmp(k, "fast"));
 }
 
 static int check_mlp_dims(const avd_mlp_layout* L, const char* who, bool rows_only = false) {

@@ -251,10 +251,13 @@ def test_model_a_and_weighted_interfrl_trainer_paths_run():
     assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
 
 
-@pytest.mark.parametrize("model", ["ModelB", "ModelA"])
-def test_fused_learn_update_is_bitwise_learn_then_apply(model):
+@pytest.mark.parametrize("model,kernel", [("ModelB", "lean"), ("ModelA", "lean"), ("ModelB", "fast"), ("ModelA", "fast")])
+def test_fused_learn_update_is_bitwise_learn_then_apply(model, kernel, monkeypatch):
     """avd_learn_update_f32 (Adam + Polyak applied where each gradient is produced, theta ping-pong) gives exactly
-    the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32."""
+    the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32 -- for learn_kernel_l (default)
+    and for learn_kernel_t (AVD_LEARN_KERNEL=fast)."""
+    if kernel == "fast":
+        monkeypatch.setenv("AVD_LEARN_KERNEL", "fast")
     conf = config.Config(num_platoons=21, pl_size=3, buffer_size=128, model=model)
     runs = []
     for fused in (False, True):

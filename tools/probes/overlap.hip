@@ -22,7 +22,7 @@ __device__ __forceinline__ float upd(float w, float& t, float& m, float& v, floa
     return wn;
 }
 
-template <bool F4>
+template <bool F4, int ROWMAP>
 __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __restrict__ w, float* __restrict__ wo, float* __restrict__ t,
                                                     float* __restrict__ m, float* __restrict__ v, int tiles_total,
                                                     int compute_mfma, int duty_sleep, int do_stream, int* __restrict__ counter,
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __re
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int ta = 0; ta < 2; ++ta) {
-                        const int o = (r0 + 2 * (4 * lg + j) + ta) * 128 + col;
+                        const int rj = 2 * j + ta;
+                        const int o = (r0 + (ROWMAP ? 4 * rj + lg : 8 * lg + rj)) * 128 + col;
                         qw[j * 2 + ta] = *(const f32x4*)(w_ + o), qt[j * 2 + ta] = *(const f32x4*)(t_ + o);
                         qm[j * 2 + ta] = *(const f32x4*)(m_ + o), qv[j * 2 + ta] = *(const f32x4*)(v_ + o);
                     }
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __re
 #pragma unroll
                     for (int ta = 0; ta < 2; ++ta) {
                         const int q = j * 2 + ta;
-                        const int o = (r0 + 2 * (4 * lg + j) + ta) * 128 + col;
+                        const int rj = 2 * j + ta;
+                        const int o = (r0 + (ROWMAP ? 4 * rj + lg : 8 * lg + rj)) * 128 + col;
                         f32x4 ow;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -128,6 +130,7 @@ int main(int argc, char** argv) {
     const int cm = argc > 4 ? atoi(argv[4]) : 4800;
     const int duty = argc > 5 ? atoi(argv[5]) : 2;
     const int stream = argc > 6 ? atoi(argv[6]) : 1;
+    const int rowmap = argc > 7 ? atoi(argv[7]) : 0;
     const size_t n = (size_t)(stream ? tiles : 1) * NBLK * BLK;
     float *w, *wo, *t, *m, *v, *sk;
     int* counter;
@@ -136,7 +139,7 @@ int main(int argc, char** argv) {
     hipMemset(w, 0, n * 4), hipMemset(wo, 0, n * 4), hipMemset(t, 0, n * 4), hipMemset(m, 0, n * 4), hipMemset(v, 0, n * 4);
     const int wgs_per_cu = lds_kb <= 53 ? 3 : (lds_kb <= 80 ? 2 : 1);
     const int grid = 256 * wgs_per_cu;
-    auto k = f4 ? tile_kernel<true> : tile_kernel<false>;
+    auto k = f4 ? (rowmap ? tile_kernel<true, 1> : tile_kernel<true, 0>) : tile_kernel<false, 0>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -152,7 +155,7 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double bytes = 8.0 * NBLK * BLK * 4 * tiles;
-    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
-           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
+    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d rowmap=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
+           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, rowmap, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
     return 0;
 }
