@@ -58,8 +58,10 @@ def set_args_to_config(args, conf):
     return conf.refresh()
 
 
-def main(argv=None):
-    conf = Config()
+def main(argv=None, conf=None):
+    """conf: the Config the flags override (the reference edits src/config.py for anything the CLI has no flag for,
+    e.g. ``framework``); default Config()."""
+    conf = Config() if conf is None else conf
     args, conf = get_cmdl_args(sys.argv[1:] if argv is None else argv, conf)
     if args.mode == "tr":
         import numpy as np
@@ -77,10 +79,13 @@ def main(argv=None):
     elif args.mode == "esim":
         from . import artifacts, evaluator, vec
         conf = artifacts.config_loader(os.path.join(args.exp_path, "conf.json"), Config)
-        S = 3 if conf.model == conf.modelA else 4
+        # model count and shapes as the trainer derives them (workers/evaluator.py:48-66): L models of S states / 1 action
+        # decentralized, ONE model of 4L states / L actions and widths x1.2 centralized (src/environment.py:35-52)
+        shape = vec.VecPlatoon(1, conf.pl_size, conf, rng="device")  # device RNG: consumes no np.random draws
+        M = shape.num_models
         for p in range(1, conf.num_platoons + 1):
-            grp = vec.AgentGroup(conf.pl_size, S, 1, conf)
-            for m in range(conf.pl_size):
+            grp = vec.AgentGroup(M, shape.num_states, shape.num_actions, conf, hidd_mult=shape.hidden_multiplier)
+            for m in range(M):
                 grp.set_weights(m, "actor", artifacts.load_actor_weights(args.exp_path, p, m + 1))
             rew, _ = evaluator.run(conf=conf, actors=grp, pl_idx=p, manual_timestep_override=args.n_timesteps)
             print(f"platoon {p}: cumulative platoon reward {rew}")

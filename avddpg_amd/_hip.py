@@ -58,6 +58,7 @@ _PROTOS = {
     "avd_ou_step_f32": [_i, _P, _P, _f, _f, _f, _f, _u64, _u64, _P],
     "avd_policy_f32": [_i, _P, _P, _f, _f, _P, _P],
     "avd_normal_f32": [_i, _P, _f, _u64, _u64, _P],
+    "avd_uniform_f32": [_i, _P, _f, _u64, _u64, _P],
     "avd_replay_add_f32": [_i, _i, _i, _i, _P, _i64, _P, _P, _i, _P, _P, _P],
     "avd_replay_indices": [_i, _i, _i, _u64, _u64, _P, _P],
     "avd_replay_gather_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P],

@@ -199,6 +199,13 @@ __global__ void normal_kernel(int n, float* __restrict__ out, float std_dev, uin
     out[i] = box_muller(r.x, r.y, nullptr) * std_dev;
 }
 
+__global__ void uniform_kernel(int n, float* __restrict__ out, float half_width, uint64_t seed, uint64_t counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 r = philox_at(seed, counter, (uint32_t)i, STREAM_NORMAL);  // same stream slot as normal_kernel: one or the other
+    out[i] = uniform_pm1(r.x) * half_width;
+}
+
 }  // namespace avd
 
 using namespace avd;
@@ -253,4 +260,11 @@ extern "C" int avd_normal_f32(int n, float* out, float std_dev, uint64_t seed, u
     hipLaunchKernelGGL(normal_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, out, std_dev, seed,
                        counter);
     return check_launch("avd_normal_f32");
+}
+
+extern "C" int avd_uniform_f32(int n, float* out, float half_width, uint64_t seed, uint64_t counter, void* stream) {
+    AVD_REQUIRE(n > 0 && out, "avd_uniform_f32: n=%d", n);
+    hipLaunchKernelGGL(uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, out, half_width, seed,
+                       counter);
+    return check_launch("avd_uniform_f32");
 }

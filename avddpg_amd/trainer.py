@@ -64,10 +64,13 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
-                 pipeline_chunks=1, fused_update=False, shared_engine=None):
+                 pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
-        sync per step); needs rng='device'."""
+        sync per step); needs rng='device'.
+        seed: this rank's env / noise / replay stream seed (give every rank its own). init_seed: seed of the initial
+        weights, ``conf.random_seed`` by default -- rank-INVARIANT: every agent on every rank starts from the same
+        weights (workers/trainer.py:121-131); with a group they are broadcast from rank 0 as well."""
         conf.refresh()
         self.conf, self.rng, self.group = conf, rng, group
         self.device = torch.device(device if device is not None else "cuda")
@@ -97,8 +100,13 @@ class VecTrainer:
         if self.shared and not can_share:
             raise ValueError("shared weight sets are only exact for interfrl+gradients with every step federated")
         self.set_mod = self.M if self.shared else 0
-        self.agents = vec.AgentGroup(self.M if self.shared else n_agents, self.S, self.A, conf, self.device, seed=seed,
+        self.agents = vec.AgentGroup(self.M if self.shared else n_agents, self.S, self.A, conf, self.device,
+                                     seed=conf.random_seed if init_seed is None else init_seed,
                                      hidd_mult=self.env.hidden_multiplier)
+        from . import dist as _dist
+        _dist.broadcast_agents(self.agents, group)
+        # platoons over all ranks: a constant, reduced once here (the federated mean's divisor)
+        self.total_platoons = _dist.total_platoons(self.P, group, self.device)
         self.replay = vec.VecReplay(n_agents, conf.buffer_size, conf.batch_size, self.S, self.A, self.device, rng=rng,
                                     seed=seed)
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -127,6 +135,12 @@ class VecTrainer:
         self.auto_reset = auto_reset
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
+        if auto_reset and fed and conf.weighted_average_enabled:
+            # the federated weights are |1 / mean(last episodic rewards)| (trainer.py:385-398); auto_reset keeps no
+            # per-episode reward history on the host, so there is nothing to compute them from
+            raise ValueError("auto_reset (device-side episode bookkeeping) cannot be combined with a federated method and "
+                             "weighted_average_enabled: the weights need the per-episode reward lists; run the episode "
+                             "loop (VecTrainer.run) or set weighted_average_enabled=False")
         self.fused_update = bool(fused_update)  # nofrl + reference widths: avd_learn_update_f32
         if self.fused_update and self.centralized:
             raise ValueError("fused_update is specialised for the decentralized reference widths")
@@ -179,8 +193,9 @@ class VecTrainer:
             self.leader_exog.copy_(torch.from_numpy(exog.astype(np.float32)))
         else:
             noise = self.ou()
-            call("avd_normal_f32", P, ptr(self.leader_exog), conf.reset_max_u, self.seed, self.exog_calls,
-                 stream_handle())
+            # util.get_random_val(conf.rand_gen, reset_max_u) (trainer.py:291-295): U(-u, u) or N(0, u)
+            call("avd_uniform_f32" if conf.rand_gen == conf.uniform else "avd_normal_f32", P, ptr(self.leader_exog),
+                 conf.reset_max_u, self.seed, self.exog_calls, stream_handle())
             self.exog_calls += 1
         if self.A > 1:  # one scalar OU process per model, broadcast over its A actions (ddpgagent.py:22)
             noise = noise.view(-1, 1).expand(-1, self.A).contiguous()
@@ -194,7 +209,13 @@ class VecTrainer:
         w = np.empty((self.P, self.M), dtype=np.float32)
         for p in range(self.P):
             for m in range(self.M):
-                w[p, m] = abs(1 / np.mean(self.all_ep_reward_lists[p][m][-self.conf.weighted_window:]))
+                hist = self.all_ep_reward_lists[p][m][-self.conf.weighted_window:]
+                if not hist:
+                    raise RuntimeError(f"weighted federated averaging at episode {ep} needs the episodic rewards of agent "
+                                       f"({p}, {m}), but none were recorded (update_reward_list is called by run())")
+                w[p, m] = abs(1 / np.mean(hist))
+        if not np.all(np.isfinite(w)):
+            raise FloatingPointError(f"non-finite federated weights at episode {ep} (an episodic-reward mean of 0?)")
         return torch.from_numpy(w).to(self.device)
 
     def _train(self, ep, i):
@@ -259,7 +280,7 @@ class VecTrainer:
             from .dist import exchange_fed_sums
             # local (weighted) mean -> local (weighted) sum over platoons, all-reduce, divide by the global count / weight
             self.set_grads.mul_(float(P) if wsum is None else wsum.view(M, 1))
-            total = exchange_fed_sums(self.set_grads, wsum, P, self.group)
+            total = exchange_fed_sums(self.set_grads, wsum, P, self.group, total=self.total_platoons)
             self.set_grads.div_(total if wsum is None else wsum.view(M, 1))
 
     def _update(self, ep, i, fed):
@@ -277,7 +298,8 @@ class VecTrainer:
             weights = self.fed_weights[1]
         method = conf.fed_method
         if is_valid_step_for_federated_training_with_gradients(conf, ep, i):
-            avg = vec.fed_mean(self.grads, P, M, weights=weights, group=self.group, method=method)
+            avg = vec.fed_mean(self.grads, P, M, weights=weights, group=self.group, method=method,
+                               total=self.total_platoons)
             if self.shared:
                 self.agents.apply(avg)
             else:
@@ -303,8 +325,9 @@ class VecTrainer:
             if self.shared:
                 raise RuntimeError("weights aggregation needs per-agent weight sets")
             ag = self.agents
-            avg_th = vec.fed_mean(ag.theta, P, M, weights=weights, group=self.group, method=method)[0]
-            avg_st = vec.fed_mean(ag.stats, P, M, weights=weights, group=self.group, method=method)[0]
+            tp = self.total_platoons
+            avg_th = vec.fed_mean(ag.theta, P, M, weights=weights, group=self.group, method=method, total=tp)[0]
+            avg_st = vec.fed_mean(ag.stats, P, M, weights=weights, group=self.group, method=method, total=tp)[0]
             directional = method == conf.intrafrl and conf.intra_directional_averaging
             for dst, src in ((ag.theta, avg_th), (ag.theta_t, avg_th), (ag.stats, avg_st), (ag.stats_t, avg_st)):
                 view = dst.view(P, M, -1)

@@ -422,7 +422,7 @@ class AgentGroup:
                 params.unpack(self.lay, g, dummy, "actor", trainable_only=True, dims=self.dims))
 
 
-def fed_mean(grads, P, M, weights=None, group=None, method="interfrl"):
+def fed_mean(grads, P, M, weights=None, group=None, method="interfrl", total=None):
     """Federated average of per-agent rows grads[P*M, n] (agent id v = p*M + m)
     (reference src/server/federated.py:47-63 / :99-118).
       interfrl: mean over platoons  -> [M, n];  intrafrl: mean over a platoon's vehicles -> [P, n].
@@ -441,7 +441,7 @@ def fed_mean(grads, P, M, weights=None, group=None, method="interfrl"):
     count = float(n_in)
     if group is not None and method == "interfrl":
         from .dist import exchange_fed_sums
-        count = exchange_fed_sums(out, wsum, n_in, group)
+        count = exchange_fed_sums(out, wsum, n_in, group, total=total)  # total: cached platoon count over all ranks
     call("avd_fed_finalize_f32", n_out, n, ptr(out), count, ptr(wsum), stream_handle())
     return out
 

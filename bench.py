@@ -112,7 +112,7 @@ def main():
     P, L = args.platoons, args.pl_size
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
                          fed_method="interfrl" if args.mode == "interfrl" else "normal",
-                         weighted_average_enabled=False, random_seed=1 + rank, framework=args.framework)
+                         weighted_average_enabled=False, random_seed=1, framework=args.framework)  # random_seed: initial weights, the same on every rank
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,

@@ -127,6 +127,10 @@ int avd_policy_f32(int n, const float* actor_out, const float* noise, float lo, 
 /* Leader exogenous input N(0, std) per platoon per step (workers/trainer.py:291-295), device Philox. */
 int avd_normal_f32(int n, float* out, float std_dev, uint64_t seed, uint64_t counter, void* stream);
 
+/* The same draw when conf.rand_gen == 'uniform': U(-half_width, half_width) (src/util.py:55-70 get_random_val,
+ * workers/trainer.py:291-295), device Philox, same (seed, counter, index) addressing as avd_normal_f32. */
+int avd_uniform_f32(int n, float* out, float half_width, uint64_t seed, uint64_t counter, void* stream);
+
 /* ---- replay buffer (src/replaybuffer.py:5-63) ----------------------------------
  * ring [n_agents][cap][row] float32, row = [s(S) a(A) r(1) s2(S)], row = 2S+A+1.
  * add: writes slot (counter % cap) of every agent (:40-47).

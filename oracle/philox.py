@@ -55,3 +55,14 @@ def box_muller(a, b):
 def normals(n, seed, counter, stream):
     w = philox_at(seed, counter, np.arange(n), stream)
     return box_muller(w[0], w[1])[0]
+
+
+def uniform_pm1(a):
+    """common.h uniform_pm1: U[-1, 1) from the top 24 bits of one word."""
+    return (a >> np.uint64(8)).astype(np.float32) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+
+
+def uniforms(n, seed, counter, stream, half_width):
+    """avd_uniform_f32: U(-half_width, half_width) per index (word x of the block)."""
+    w = philox_at(seed, counter, np.arange(n), stream)
+    return (uniform_pm1(w[0]) * np.float32(half_width)).astype(np.float32)

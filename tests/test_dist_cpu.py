@@ -50,7 +50,12 @@ def _worker(rank, world, port, P_total, M, n, weighted, q):
             ws = torch.from_numpy(wl.sum(axis=0, dtype=np.float32))
         else:
             out, ws = torch.from_numpy(gl.sum(axis=0, dtype=np.float32)), None
-        count = adist.exchange_fed_sums(out, ws, hi - lo, dist.group.WORLD)
+        total = adist.total_platoons(hi - lo, dist.group.WORLD)  # reduced once (trainer construction)
+        out0, ws0 = out.clone(), (None if ws is None else ws.clone())
+        count = adist.exchange_fed_sums(out, ws, hi - lo, dist.group.WORLD, total=total)  # one collective, no host sync
+        # the uncached form (count reduced inside) gives the same sums and count
+        assert adist.exchange_fed_sums(out0, ws0, hi - lo, dist.group.WORLD) == count and torch.equal(out0, out)
+        assert ws is None or torch.equal(ws0, ws)
         avg = (out * (1.0 / ws)[:, None]) if weighted else out / count  # avd_fed_finalize_f32
         flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
         q.put((rank, count, avg.numpy(), adist.any_terminal(flag, dist.group.WORLD),
@@ -85,3 +90,44 @@ def test_interfrl_exchange_world2_matches_oracle_mean_over_all_platoons(weighted
         for m in range(M):
             assert np.allclose(avg[m], ref[m][0], rtol=1e-5, atol=1e-6)
     assert np.array_equal(res[0][2], res[1][2])  # every rank ends with the identical average (bit-equal weights)
+
+
+class _Sets:
+    def __init__(self, rank):
+        g = torch.Generator().manual_seed(100 + rank)  # every rank starts from DIFFERENT values
+        self.theta = torch.randn(5, 40, generator=g)[0:1].repeat(5, 1)
+        self.stats = torch.randn(5, 8, generator=g)[0:1].repeat(5, 1)
+        self.theta_t, self.stats_t = self.theta.clone(), self.stats.clone()
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = _Sets(rank)
+        adist.broadcast_agents(s, dist.group.WORLD)
+        q.put((rank, s.theta.numpy(), s.stats.numpy(), s.theta_t.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_agents_world2_gives_every_rank_rank0_weight_sets():
+    """ranks must not keep rank-specific initial weights -- after broadcast_agents every set on every rank is
+    rank 0's set 0 (the reference starts all agents from agent (0,0)'s weights, workers/trainer.py:121-131)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _Sets(0)
+    for rank, th, st, tht in res:
+        assert np.array_equal(th, want.theta.numpy()) and np.array_equal(st, want.stats.numpy())
+        assert np.array_equal(tht, want.theta_t.numpy())
+    assert not np.array_equal(_Sets(1).theta.numpy(), want.theta.numpy())  # they did differ before

@@ -349,9 +349,11 @@ def test_episode_reward_curve_matches_oracle_loop_config1():
     assert tr.engine.updates == ref.updates
 
 
-def test_cli_train_then_esim_roundtrip(tmp_path, capsys):
+@pytest.mark.parametrize("framework", ["decentralized", "centralized"])
+def test_cli_train_then_esim_roundtrip(tmp_path, capsys, framework):
     """`python -m avddpg_amd tr` writes reward CSVs, conf.json and Keras-ordered checkpoints; `esim` reloads the
-    actors from them and reproduces the evaluator reward of the in-memory agents."""
+    actors from them and reproduces the evaluator reward of the in-memory agents. Centralized runs save ONE model per
+    platoon (S = 4L, A = L, widths x1.2) and esim must rebuild exactly that shape."""
     import glob
     import os
 
@@ -359,13 +361,15 @@ def test_cli_train_then_esim_roundtrip(tmp_path, capsys):
     from avddpg_amd import artifacts, evaluator
     from avddpg_amd.config import Config
 
+    cent = framework == "centralized"
+    # the reference CLI has no --framework flag (src/cmd/api.py:60-81): it is a Config field
     cli.main(["tr", "--pl_num", "2", "--pl_size", "2", "--total_time_steps", "1200", "--buffer_size", "500", "--out",
-              str(tmp_path)])
+              str(tmp_path)], conf=Config(framework=framework))
     base = capsys.readouterr().out.strip().splitlines()[-1]
     assert os.path.exists(os.path.join(base, "ep_reward__seed1.csv")) and os.path.exists(os.path.join(base, "conf.json"))
-    assert len(glob.glob(os.path.join(base, "*.npz"))) == 2 * 2 * 4
+    assert len(glob.glob(os.path.join(base, "*.npz"))) == 2 * (1 if cent else 2) * 4
     w = artifacts.load_actor_weights(base, 2, 1)
-    assert [x.shape for x in w][:3] == [(4, 256), (256,), (256,)] and len(w) == 14
+    assert [x.shape for x in w][:3] == ([(8, 307), (307,), (307,)] if cent else [(4, 256), (256,), (256,)]) and len(w) == 14
     cli.main(["esim", base, "--n_timesteps", "60"])
     out = capsys.readouterr().out
     assert "platoon 1: cumulative platoon reward" in out and "platoon 2:" in out
@@ -455,3 +459,49 @@ def test_centralized_evaluator_rollout_matches_reference_golden_and_oracle():
     assert abs(pl_rew - o_rew) <= 2e-3 and np.abs(o_tr["inputs"]).max() > 0.05
     assert np.allclose(tr["inputs"], o_tr["inputs"], atol=5e-5)
     assert np.allclose(tr["states"], o_tr["states"].reshape(100, L, 4), atol=2e-4, rtol=1e-4)
+
+
+def test_initial_weights_do_not_depend_on_the_stream_seed():
+    """Multi-GPU interfrl: every rank passes its own stream seed (env / noise / replay) but must start from the SAME
+    weights -- the reference starts every agent from agent (0,0)'s (workers/trainer.py:121-131) and the federated
+    arithmetic assumes identical sets on all ranks. The init seed is conf.random_seed, independent of `seed`."""
+    conf = config.Config(num_platoons=6, pl_size=3, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+    a = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1)
+    b = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=2)
+    assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
+    assert torch.equal(a.agents.stats, b.agents.stats) and a.total_platoons == 6.0
+    a.reset_episode(), b.reset_episode()
+    assert not torch.equal(a.env.x, b.env.x)  # the streams do differ
+    c = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1, init_seed=7)
+    assert not torch.equal(a.agents.theta, c.agents.theta)
+
+
+def test_auto_reset_refuses_weighted_federated_averaging():
+    """auto_reset keeps no per-episode reward history, which the federated weights |1 / mean(rewards)| need
+    (trainer.py:385-398): the combination must fail at construction, not poison the weights with NaN later."""
+    conf = config.Config(num_platoons=4, pl_size=2, buffer_size=128, fed_method="interfrl", weighted_average_enabled=True)
+    with pytest.raises(ValueError, match="weighted_average_enabled"):
+        trainer.VecTrainer(conf, rng="device", auto_reset=True)
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=False)  # the episode loop is fine ...
+    with pytest.raises(RuntimeError, match="episodic rewards"):       # ... but weights without any recorded episode are not
+        vt._weights_for_fed(conf.weighted_window)
+
+
+def test_device_rng_leader_exog_honours_rand_gen():
+    """util.get_random_val(conf.rand_gen, reset_max_u) (trainer.py:291-295): the device-RNG path draws U(-u, u) when
+    rand_gen == 'uniform' (avd_uniform_f32, bit-checked against the oracle's Philox restatement), N(0, u) otherwise."""
+    from oracle import philox as ophilox
+
+    for gen in ("uniform", "normal"):
+        conf = config.Config(num_platoons=8192, pl_size=2, buffer_size=128, rand_gen=gen)
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=9)
+        vt.reset_episode()
+        vt.step()
+        ex = vt.leader_exog.cpu().numpy()
+        u = conf.reset_max_u
+        if gen == "uniform":
+            assert np.abs(ex).max() <= u and abs(ex.std() - u / np.sqrt(3)) < 0.02 * u and abs(ex.mean()) < 0.05 * u
+            want = ophilox.uniforms(8192, 9, 0, ophilox.STREAM_NORMAL, u)
+            assert np.array_equal(ex, want)
+        else:
+            assert np.abs(ex).max() > u and abs(ex.std() / u - 1) < 0.05
