@@ -473,7 +473,6 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
         }
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 8> I8;
 
     FeatW<S, 2> fw;
@@ -482,20 +481,20 @@ __device__ __forceinline__ void gemm_dw_dx(const float* X4, const float* act, co
     for (int k0 = 0; k0 < H1; k0 += 64) {  // blocks of state features
         const int kl = k0 + 32 * rh;       // first feature row of this wave's half block
         const unsigned lo = (unsigned)((kl + 8 * lg) * N + col);
-        FeatW<S, 2> fwn;
-        featw_load<S, 2>(fwn, st, min(kl + 64, H1 - 64 + 32 * rh) + 2 * lr);  // next block's (the last block reloads its own)
+        // the input-gradient tile's W2 rows are requested together with the Adam operands, which cover the same rows: the
+        // two requests meet on the same in-flight L2 lines (with 64 workgroups per XCD streaming, a line fetched now is
+        // gone from the 4 MB L2 a few microseconds later: requested after the update, these rows came from HBM again)
+        DxOps<S, N> dxo;
+        dx_load<S, N>(dxo, W2 + (k0 + 16 * wave) * N, st, k0 + 16 * wave);
         QuadT q[8];
         load_quads(q, lo);
         f32x4 acc[2][4];
         mfma_loop(acc, fw, X4, std::integral_constant<int, S>());
-        // the tile operands are requested once two rows of the epilogue have retired their registers: ahead of the other
-        // six rows' stores in vmcnt order, and over W2 rows the update has just read
-        epilogue(acc, q, kl, lo, I0(), I2());
-        DxOps<S, N> dxo;
-        dx_load<S, N>(dxo, W2 + (k0 + 16 * wave) * N, st, k0 + 16 * wave);
-        epilogue(acc, q, kl, lo, I2(), I8());
+        epilogue(acc, q, kl, lo, I0(), I8());
+        // next block's first-layer weights (the last block reloads its own): behind this block's stores in vmcnt order, with
+        // the input-gradient tile between them and their first use
+        featw_load<S, 2>(fw, st, min(kl + 64, H1 - 64 + 32 * rh) + 2 * lr);
         dx_run<S, N, LDZ, false>(dxo, DZ, X4, st, k0 + 16 * wave, true, small, nullptr);
-        fw = fwn;
     }
     if constexpr (CRITIC) {  // the critic's action features (their own first layer): rows H1 .. H1 + HA of W2
         const int kl = H1 + 32 * rh;
@@ -570,7 +569,7 @@ __device__ __forceinline__ void l2_coefs(const float* __restrict__ g, const floa
 }
 
 template <int S, int H1, int H2, int HA, bool FUSED>
-__global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int set_mod, const float* __restrict__ theta,
+__global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, int set_mod, const float* __restrict__ theta,
                                                          const float* __restrict__ stats, float* __restrict__ theta_t,
                                                          float* __restrict__ stats_t, const float* __restrict__ s,
                                                          const float* __restrict__ a, const float* __restrict__ r,
@@ -579,6 +578,12 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
                                                          UpdArgs upd) {
     static_assert(H1 <= FT && HA <= FT && 2 * H2 == FT && S <= 4, "widths");
     constexpr int KC = H1 + HA, LDB = ld_of(H2);
+    // The layout (43 offsets) is the kernel's FIRST argument, i.e. the first bytes of the kernarg segment. It is read
+    // through that pointer, re-derived inside each pass behind an opaque zero: as a plain by-value argument LLVM loads
+    // every field it will ever need up front and keeps ~40 SGPRs alive -- and spilled into VGPR lanes -- all kernel long.
+    const avd_mlp_layout* const Lk = (const avd_mlp_layout*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)L_arg;
+    const avd_mlp_layout& L = *Lk;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Lds l = carve(smem, KC, H2);
     const int agent = blockIdx.x;
@@ -594,13 +599,10 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
     BulkSink bulk;
     float* gw2 = g;
     if constexpr (FUSED) {
-        const int t = upd.step[agent];
-        const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
-        const float root = sqrtf(1.0f - b2p);
         const long o = (long)agent * L.theta_size;
         gw2 = upd.theta_out + o;
         bulk.wo = gw2, bulk.wi = net.th, bulk.wt = theta_t + o, bulk.m = upd.m + o, bulk.v = upd.v + o;
-        bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+        bulk.alpha_a = bulk.alpha_c = 0.f;  // Adam step sizes: computed where the update runs (passes 1 and 3)
         bulk.tau = upd.tau, bulk.omt = upd.omt, bulk.actor_size = L.actor_size;
     }
     constexpr float invn = 1.0f / (float)TILE;
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
         const int tid = tid_here();
+        const avd_mlp_layout& L = *(const avd_mlp_layout*)((const char*)Lk + opaque_zero());  // re-read per pass, see above
         const Net n = (it == 0) ? tgt : net;
         const float* X = (it == 0) ? l.xS2 : l.xS;
         const float* ath = n.th;
@@ -743,6 +746,12 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L, int se
         PH(it == 1 ? 7 : (it == 2 ? 12 : 15));
         if (wg) {
             col_sums(bDZ, LDB, H2, l.db, gout + (crit ? L.cb2 : L.ab2), sink);
+            if constexpr (FUSED) {  // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), as adam_polyak_kernel (optim.hip) computes it
+                const int t = upd.step[agent];
+                const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
+                const float root = sqrtf(1.0f - b2p);
+                bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+            }
             lds_barrier();
             PH(it == 1 ? 8 : 16);
             if (crit)
