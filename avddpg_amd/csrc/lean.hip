@@ -750,7 +750,12 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
                 const int t = upd.step[agent];
                 const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
                 const float root = sqrtf(1.0f - b2p);
-                bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+                // wave-uniform values computed on the vector unit: moved to SGPRs so that they cost no vector register for
+                // the rest of the kernel
+                bulk.alpha_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                    __builtin_bit_cast(int, (upd.actor_lr * root) / (1.0f - b1p))));
+                bulk.alpha_c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                    __builtin_bit_cast(int, (upd.critic_lr * root) / (1.0f - b1p))));
             }
             lds_barrier();
             PH(it == 1 ? 8 : 16);
@@ -779,6 +784,36 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
             }
             lds_barrier();
             PH(14);
+        }
+    }
+    if constexpr (FUSED) {
+        // Adam + Polyak of the small tensors (biases, BN gamma/beta, first and output layers: everything outside the two W2
+        // matrices, ~6 % of the parameters), whose gradients the passes above left in this agent's gradient slab. Same
+        // arithmetic, element for element, as adam_polyak_ranges_kernel (optim.hip), which learn_kernel_t launches for this.
+#pragma clang fp contract(off)
+        __syncthreads();  // every wave's gradient stores are visible to the workgroup
+        const int tid = tid_here();
+        const int T = L.theta_size, a0 = L.aW2, a1 = L.aW2 + H1 * H2, c0 = L.actor_size + L.cW2, c1 = c0 + KC * H2;
+        const int n0 = a0 / 4, n1 = (c0 - a1) / 4, n2 = (T - c1) / 4;
+        const f32x4* g4 = (const f32x4*)g;
+        const f32x4* wi4 = (const f32x4*)bulk.wi;
+        f32x4* wo4 = (f32x4*)bulk.wo;
+        f32x4* wt4 = (f32x4*)bulk.wt;
+        f32x4* m4 = (f32x4*)bulk.m;
+        f32x4* v4 = (f32x4*)bulk.v;
+        for (int j = tid; j < n0 + n1 + n2; j += FT) {
+            const unsigned i = j < n0 ? j : (j < n0 + n1 ? a1 / 4 + (j - n0) : c1 / 4 + (j - n0 - n1));
+            const float alpha = ((int)i * 4 < L.actor_size) ? bulk.alpha_a : bulk.alpha_c;
+            const f32x4 gg = g4[i];
+            f32x4 w = wi4[i], wt = wt4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mm[k] = mm[k] + (gg[k] - mm[k]) * (1.0f - 0.9f);
+                vv[k] = vv[k] + (gg[k] * gg[k] - vv[k]) * (1.0f - 0.999f);
+                w[k] = w[k] - (mm[k] * alpha) / (sqrtf(vv[k]) + 1e-7f);
+                wt[k] = w[k] * bulk.tau + wt[k] * bulk.omt;
+            }
+            wo4[i] = w, wt4[i] = wt, m4[i] = mm, v4[i] = vv;
         }
     }
 }

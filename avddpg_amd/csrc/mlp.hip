@@ -1585,10 +1585,10 @@ extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, con
         return AVD_E_UNSUPPORTED;
     }
     const UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau)};
-    if (use_lean_kernel())
-        rc = lean_launch(lay, true, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads_scratch,
-                         losses, upd, stream);
-    else if (lay->S == 4)
+    if (use_lean_kernel())  // learn_kernel_l applies the small tensors' update itself: one launch for the whole update
+        return lean_launch(lay, true, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads_scratch,
+                           losses, upd, stream);
+    if (lay->S == 4)
         rc = fast::launch<4, 256, 128, 48, true>(lay, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma,
                                                  high, grads_scratch, losses, upd, stream);
     else

@@ -177,13 +177,16 @@ def main():
         assert abs(flop_per_sample - LEARN_FLOP_PER_SAMPLE) < 0.01 * LEARN_FLOP_PER_SAMPLE
         assert abs(adam_bytes - ADAM_BYTES_PER_AGENT) < 0.01 * ADAM_BYTES_PER_AGENT
     roofs = []
+    # the reference widths run learn_kernel_l (lean.hip: two workgroups per CU) unless AVD_LEARN_KERNEL=fast (learn_kernel_t)
+    lk = "learn_kernel_t" if os.environ.get("AVD_LEARN_KERNEL") == "fast" else "learn_kernel_l"
+    fused_name = lk + "<fused> + adam_polyak_ranges_kernel"
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
         t = stage_ms["learn+update"] / 1e3
-        mf = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / t / 1e12,
+        mf = {"kernel": fused_name, "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / t / 1e12,
               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-        hb = {"kernel": "learn_kernel_t<fused> + adam_polyak_ranges_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / t / 1e9,
+        hb = {"kernel": fused_name, "bound": "hbm", "achieved": adam_bytes * n_agents / t / 1e9,
               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         roofs = [mf, hb]
     elif batched:
@@ -199,7 +202,7 @@ def main():
     else:
         learn_s = stage_ms["learn"] / 1e3
         upd_s = stage_ms["update"] / 1e3
-        roofs.append({"kernel": "learn_kernel" if args.framework == "decentralized" else "gen::learn_kernel_g", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
+        roofs.append({"kernel": lk if args.framework == "decentralized" else "gen::learn_kernel_g", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "_t": learn_s})
         if args.mode == "nofrl":
             roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,
@@ -209,8 +212,7 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
     if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
         pmc = json.load(open(pmc_path))["kernels"]
-        want = {"learn_kernel_t<fused> + adam_polyak_ranges_kernel": ("learn_kernel_t", "adam_polyak_ranges"),
-                "learn_kernel": ("learn_kernel_t",), "adam_polyak_kernel": ("adam_polyak_kernel",)}
+        want = {fused_name: (lk, "adam_polyak_ranges"), lk: (lk,), "adam_polyak_kernel": ("adam_polyak_kernel",)}
         for r in roofs:
             per_unit = [next((v["hbm_bytes_per_unit"] for k, v in pmc.items() if s in k), None) for s in want[r["kernel"]]]
             if all(per_unit):
@@ -253,7 +255,7 @@ def main():
                        "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
             "stages_ms": stage_ms,
-            "pipeline": ("fused learn+Adam+Polyak kernel (avd_learn_update_f32)" if fused else
+            "pipeline": (f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
                          (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
                           "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else
                          ("batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
