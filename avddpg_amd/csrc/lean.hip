@@ -228,6 +228,11 @@ __device__ __forceinline__ void gemm_fwd(FwdPre<S>& pre, const float* X4, const 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) a[m][jj] = feat_of(FIRST, m, jj);
+    // BN coefficients of the block's 4 features per lane: read one block ahead (the per-block scheduling fence below would
+    // otherwise leave every block waiting on its own LDS round trip)
+    f32x4 ivs[2], sfs[2];
+    ivs[FIRST & 1] = *(const f32x4*)(inv + 16 * FIRST + 4 * lg);
+    sfs[FIRST & 1] = *(const f32x4*)(sh + 16 * FIRST + 4 * lg);
 #pragma unroll
     for (int blk = FIRST; blk < NBLK; ++blk) {
         if (SNAP > 0 && blk == SNAP && snap) {
@@ -241,9 +246,17 @@ __device__ __forceinline__ void gemm_fwd(FwdPre<S>& pre, const float* X4, const 
                 }
             cs_snap[0] = cs[0], cs_snap[1] = cs[1];
         }
+        // Issue order matters: vmcnt retires in order, so a wait for the first-layer weights (L2 hits, needed next block)
+        // also waits for every load issued BEFORE them. They go first, the W2 block (HBM, needed R-1 blocks from now)
+        // after them; the fence keeps the compiler from sinking either below the MFMAs.
+        if (blk + 2 < NBLK) load_feat(blk + 2);  // into the buffer block blk's operands came from
         if (blk + R - 1 < NBLK) load_blk(ring[(blk + R - 1) % R], blk + R - 1);
-        const f32x4 iv = *(const f32x4*)(inv + 16 * blk + 4 * lg);
-        const f32x4 sf = *(const f32x4*)(sh + 16 * blk + 4 * lg);
+        if (blk + 1 < NBLK) {
+            ivs[(blk + 1) & 1] = *(const f32x4*)(inv + 16 * (blk + 1) + 4 * lg);
+            sfs[(blk + 1) & 1] = *(const f32x4*)(sh + 16 * (blk + 1) + 4 * lg);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 iv = ivs[blk & 1], sf = sfs[blk & 1];
         float bs[4][2];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -262,7 +275,6 @@ __device__ __forceinline__ void gemm_fwd(FwdPre<S>& pre, const float* X4, const 
 #pragma unroll
                 for (int m = 0; m < 4; ++m) a[m][jj] = feat_of(blk + 1, m, jj);
         }
-        if (blk + 2 < NBLK) load_feat(blk + 2);  // into the buffer block blk's operands came from
         // pin the shift sums here: left alone, LLVM sinks the whole cs chain (only read after the last block) to the end
         // of the GEMM and keeps -- i.e. spills -- every block's W2 operands and coefficients until then
         asm volatile("" : "+v"(cs[0]), "+v"(cs[1]));
