@@ -126,10 +126,21 @@ __device__ __forceinline__ void ldx(float (&x)[KIN], const float* X, int r) {  /
     }
 }
 
-__device__ __forceinline__ void l1_coefs(const L1Set& s, float* inv, float* sh, unsigned k) {
-    const float iv = (1.0f / sqrtf(s.st[s.omv + k] + BN_EPS)) * s.th[s.og + k];
-    inv[k] = iv;
-    sh[k] = s.th[s.obe + k] - s.st[s.omm + k] * iv;
+// BN coefficient tables, in two steps so that the parameter loads can be issued BEFORE a forward GEMM's operand prefetch
+// (in-order vmcnt: requested after it, the table phase would wait for the prefetch's HBM round trip) and consumed after it.
+struct BnRaw {
+    float g, be, mm, mv;
+};
+__device__ __forceinline__ BnRaw l1_raw(const L1Set& s, unsigned k, unsigned H) {
+    const unsigned kk = k < H ? k : H - 1;  // threads past the layer load a valid column and store nothing
+    return {(s.th + s.og)[kk], (s.th + s.obe)[kk], (s.st + s.omm)[kk], (s.st + s.omv)[kk]};
+}
+__device__ __forceinline__ void l1_coefs(const BnRaw& r, float* inv, float* sh, unsigned k, unsigned H) {
+    if (k < H) {
+        const float iv = (1.0f / sqrtf(r.mv + BN_EPS)) * r.g;
+        inv[k] = iv;
+        sh[k] = r.be - r.mm * iv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -570,13 +581,20 @@ __device__ __forceinline__ void out_backward(const float* P, int ldp, const floa
     lds_barrier();
 }
 
-__device__ __forceinline__ void l2_coefs(const float* __restrict__ g, const float* __restrict__ be,
-                                         const float* __restrict__ mm, const float* __restrict__ mv,
-                                         const float* __restrict__ w3, Lds& l, int H2, int k) {
+struct L2Raw {
+    float g, be, mm, mv, w3;
+};
+__device__ __forceinline__ L2Raw l2_raw(const float* __restrict__ g, const float* __restrict__ be,
+                                        const float* __restrict__ mm, const float* __restrict__ mv,
+                                        const float* __restrict__ w3, unsigned H2, unsigned k) {
+    const unsigned kk = k < H2 ? k : H2 - 1;
+    return {g[kk], be[kk], mm[kk], mv[kk], w3[kk]};
+}
+__device__ __forceinline__ void l2_coefs(const L2Raw& r, Lds& l, unsigned H2, unsigned k) {
     if (k < H2) {
-        const float rs = 1.0f / sqrtf(mv[k] + BN_EPS);
-        const float iv = rs * g[k];
-        l.invB[k] = iv, l.shB[k] = be[k] - mm[k] * iv, l.w3B[k] = w3[k], l.rsB[k] = rs, l.mmB[k] = mm[k];
+        const float rs = 1.0f / sqrtf(r.mv + BN_EPS);
+        const float iv = rs * r.g;
+        l.invB[k] = iv, l.shB[k] = r.be - r.mm * iv, l.w3B[k] = r.w3, l.rsB[k] = rs, l.mmB[k] = r.mm;
     }
 }
 
@@ -661,14 +679,16 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
         // sequence is written out per variant so that the prefetched registers never meet at a control-flow join
         // (joined, the register allocator spills them).
         if (it == 3) {  // ---- pass 3: only the second layer's coefficient tables of the actor are rebuilt
-            l2_coefs(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, l, H2, tid);
+            l2_coefs(l2_raw(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, H2, tid), l, H2, tid);
             lds_barrier();
             PH(1);
         } else if (it != 1) {  // ---- actor (agent/model.py:26-36)
+            const BnRaw r1 = l1_raw(aL1, tid, H1);
+            const L2Raw r2 = l2_raw(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, H2, tid);
             FwdPre<S> fp;
             fwd_prefetch<S, H1, HA, H2, false, 0>(fp, aL1, aL1, ath + L.aW2, ath + L.ab2);
-            if (tid < H1) l1_coefs(aL1, l.invA, l.shA, tid);
-            l2_coefs(ath + L.ag2, ath + L.abe2, n.st + L.amm2, n.st + L.amv2, ath + L.aW3, l, H2, tid);
+            l1_coefs(r1, l.invA, l.shA, tid, H1);
+            l2_coefs(r2, l, H2, tid);
             lds_barrier();
             PH(1);
             gemm_fwd<S, H1, HA, H2, false, 0, 0>(fp, X, nullptr, aL1, aL1, l.invA, l.shA, ath + L.aW2, aP2, nullptr, cs_snap);
@@ -686,20 +706,24 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
         if (it != 3) {  // ---- critic (agent/model.py:63-83)
             const float* act = (it == 1) ? l.sAct : l.sA1;
             if (it == 2) {  // resumes from pass 1's state-block sums; the ACTOR's state coefficients stay in invA/shA (pass 3)
+                const BnRaw ra = l1_raw(cA1, tid, HA);
+                const L2Raw r2 = l2_raw(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, H2, tid);
                 FwdPre<S> fp;
                 fwd_prefetch<S, H1, HA, H2, true, H1 / 16>(fp, cS1, cA1, cth + L.cW2, cth + L.cb2);
-                if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
-                l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
+                l1_coefs(ra, l.invA + H1, l.shA + H1, tid, HA);
+                l2_coefs(r2, l, H2, tid);
                 lds_barrier();
                 PH(4);
                 gemm_fwd<S, H1, HA, H2, true, H1 / 16, 0>(fp, X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cP2, l.bufC,
                                                           cs_snap);
             } else {
+                const BnRaw rs1 = l1_raw(cS1, tid, H1), ra = l1_raw(cA1, tid, HA);
+                const L2Raw r2 = l2_raw(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, H2, tid);
                 FwdPre<S> fp;
                 fwd_prefetch<S, H1, HA, H2, true, 0>(fp, cS1, cA1, cth + L.cW2, cth + L.cb2);
-                if (tid < H1) l1_coefs(cS1, l.invA, l.shA, tid);
-                if (tid < HA) l1_coefs(cA1, l.invA + H1, l.shA + H1, tid);
-                l2_coefs(cth + L.cg3, cth + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, cth + L.cW3, l, H2, tid);
+                l1_coefs(rs1, l.invA, l.shA, tid, H1);
+                l1_coefs(ra, l.invA + H1, l.shA + H1, tid, HA);
+                l2_coefs(r2, l, H2, tid);
                 lds_barrier();
                 PH(4);
                 gemm_fwd<S, H1, HA, H2, true, 0, H1 / 16>(fp, X, act, cS1, cA1, l.invA, l.shA, cth + L.cW2, cP2,
