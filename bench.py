@@ -179,7 +179,8 @@ def main():
     roofs = []
     # the reference widths run learn_kernel_l (lean.hip: two workgroups per CU) unless AVD_LEARN_KERNEL=fast (learn_kernel_t)
     lk = "learn_kernel_t" if os.environ.get("AVD_LEARN_KERNEL") == "fast" else "learn_kernel_l"
-    fused_name = lk + "<fused> + adam_polyak_ranges_kernel"
+    # learn_kernel_l<fused> updates the small tensors itself (one launch); learn_kernel_t leaves them to a second kernel
+    fused_name = lk + "<fused>" + ("" if lk == "learn_kernel_l" else " + adam_polyak_ranges_kernel")
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
@@ -212,7 +213,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
     if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
         pmc = json.load(open(pmc_path))["kernels"]
-        want = {fused_name: (lk, "adam_polyak_ranges"), lk: (lk,), "adam_polyak_kernel": ("adam_polyak_kernel",)}
+        want = {fused_name: (lk,) if lk == "learn_kernel_l" else (lk, "adam_polyak_ranges"), lk: (lk,),
+                "adam_polyak_kernel": ("adam_polyak_kernel",)}
         for r in roofs:
             per_unit = [next((v["hbm_bytes_per_unit"] for k, v in pmc.items() if s in k), None) for s in want[r["kernel"]]]
             if all(per_unit):
