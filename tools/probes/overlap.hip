@@ -22,8 +22,8 @@ __device__ __forceinline__ float upd(float w, float& t, float& m, float& v, floa
     return wn;
 }
 
-template <bool F4, int ROWMAP>
-__global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __restrict__ w, float* __restrict__ wo, float* __restrict__ t,
+template <bool F4, int ROWMAP, int HALF = 0>
+__global__ __launch_bounds__(256, F4 ? (HALF ? 3 : 2) : 1) void tile_kernel(const float* w, float* wo, float* __restrict__ t,
                                                     float* __restrict__ m, float* __restrict__ v, int tiles_total,
                                                     int compute_mfma, int duty_sleep, int do_stream, int* __restrict__ counter,
                                                     float* __restrict__ sinkbuf) {
@@ -42,9 +42,13 @@ __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __re
         if (tile >= tiles_total) break;
         // ---- compute phase: bursts of 64 MFMAs, then idle (models VALU / LDS / barrier time of the real kernel)
         for (int i = 0; i < compute_mfma; i += 64) {
+            if (duty_sleep >= 0) {
 #pragma unroll
-            for (int k = 0; k < 64; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
-            for (int s = 0; s < duty_sleep; ++s) __builtin_amdgcn_s_sleep(16);
+                for (int k = 0; k < 64; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
+                for (int s = 0; s < duty_sleep; ++s) __builtin_amdgcn_s_sleep(16);
+            } else {  // duty_sleep < 0: the compute phase idles for the same time (no matrix work at all)
+                for (int s = 0; s < 2 - duty_sleep; ++s) __builtin_amdgcn_s_sleep(16);
+            }
         }
         // ---- stream phase
         const long abase = (long)tile * NBLK * BLK;
@@ -53,26 +57,24 @@ __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __re
             const float* w_ = w + bbase; float* wo_ = wo + bbase; float* t_ = t + bbase; float* m_ = m + bbase; float* v_ = v + bbase;
             if constexpr (F4) {
                 const int col = 64 * (wave & 1) + 4 * lr, r0 = 32 * (wave >> 1);
-                f32x4 qw[8], qt[8], qm[8], qv[8];
+                constexpr int NQ = HALF ? 4 : 8;  // rows per lane and sub-block
+#pragma unroll 1
+                for (int h = 0; h < (HALF ? 2 : 1); ++h) {
+                    f32x4 qw[NQ], qt[NQ], qm[NQ], qv[NQ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ta = 0; ta < 2; ++ta) {
-                        const int rj = 2 * j + ta;
+                    for (int q = 0; q < NQ; ++q) {
+                        const int rj = h * 4 + q;
                         const int o = (r0 + (ROWMAP ? 4 * rj + lg : 8 * lg + rj)) * 128 + col;
-                        qw[j * 2 + ta] = *(const f32x4*)(w_ + o), qt[j * 2 + ta] = *(const f32x4*)(t_ + o);
-                        qm[j * 2 + ta] = *(const f32x4*)(m_ + o), qv[j * 2 + ta] = *(const f32x4*)(v_ + o);
+                        qw[q] = *(const f32x4*)(w_ + o), qt[q] = *(const f32x4*)(t_ + o);
+                        qm[q] = *(const f32x4*)(m_ + o), qv[q] = *(const f32x4*)(v_ + o);
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 160; ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < (HALF ? 80 : 160); ++k) acc[k & 7] = MFMA16(av, bv, acc[k & 7]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ta = 0; ta < 2; ++ta) {
-                        const int q = j * 2 + ta;
-                        const int rj = 2 * j + ta;
+                    for (int q = 0; q < NQ; ++q) {
+                        const int rj = h * 4 + q;
                         const int o = (r0 + (ROWMAP ? 4 * rj + lg : 8 * lg + rj)) * 128 + col;
                         f32x4 ow;
 #pragma unroll
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256, F4 ? 2 : 1) void tile_kernel(const float* __re
                         }
                         *(f32x4*)(wo_ + o) = ow, *(f32x4*)(t_ + o) = qt[q], *(f32x4*)(m_ + o) = qm[q], *(f32x4*)(v_ + o) = qv[q];
                     }
+                }
             } else {
                 const int col = 32 * wave + 2 * lr;
                 f32x2 qw[16], qt[16], qm[16], qv[16];
@@ -131,6 +134,7 @@ int main(int argc, char** argv) {
     const int duty = argc > 5 ? atoi(argv[5]) : 2;
     const int stream = argc > 6 ? atoi(argv[6]) : 1;
     const int rowmap = argc > 7 ? atoi(argv[7]) : 0;
+    const int inplace = argc > 8 ? atoi(argv[8]) : 0;  // 1: updated weights written over the old ones (4 streams, not 5)
     const size_t n = (size_t)(stream ? tiles : 1) * NBLK * BLK;
     float *w, *wo, *t, *m, *v, *sk;
     int* counter;
@@ -139,7 +143,7 @@ int main(int argc, char** argv) {
     hipMemset(w, 0, n * 4), hipMemset(wo, 0, n * 4), hipMemset(t, 0, n * 4), hipMemset(m, 0, n * 4), hipMemset(v, 0, n * 4);
     const int wgs_per_cu = lds_kb <= 53 ? 3 : (lds_kb <= 80 ? 2 : 1);
     const int grid = 256 * wgs_per_cu;
-    auto k = f4 ? (rowmap ? tile_kernel<true, 1> : tile_kernel<true, 0>) : tile_kernel<false, 0>;
+    auto k = f4 == 2 ? tile_kernel<true, 0, 1> : f4 ? (rowmap ? tile_kernel<true, 1> : tile_kernel<true, 0>) : tile_kernel<false, 0>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -147,7 +151,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(counter, 0, 4);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_kb * 1024, 0, w, wo, t, m, v, tiles, cm, duty, stream, counter, sk);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_kb * 1024, 0, w, inplace ? w : wo, t, m, v, tiles, cm, duty, stream, counter, sk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -155,7 +159,7 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double bytes = 8.0 * NBLK * BLK * 4 * tiles;
-    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d rowmap=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
-           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, rowmap, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
+    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d rowmap=%d inplace=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
+           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, rowmap, inplace, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
     return 0;
 }
