@@ -5,9 +5,10 @@ import os
 import sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avddpg_amd import config, trainer
-for kw, fused, steps in ((dict(), True, 1500), (dict(fed_method="interfrl", weighted_average_enabled=False), False, 600), (dict(fed_method="interfrl"), False, 600)):
+for kw, fused, eng, steps in ((dict(), True, None, 1500),
+                             (dict(fed_method="interfrl", weighted_average_enabled=False), False, "batched", 600),
+                             (dict(fed_method="interfrl", weighted_average_enabled=False), False, "per_agent", 600)):
     conf = config.Config(num_platoons=256, pl_size=5, buffer_size=2000, **kw)
-    eng = "batched" if kw else None
     vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, fused_update=fused, shared_engine=eng)
     vt.reset_episode()
     t0 = time.time()
@@ -16,6 +17,14 @@ for kw, fused, steps in ((dict(), True, 1500), (dict(fed_method="interfrl", weig
         if i % 300 == 299:
             torch.cuda.synchronize()
             th = vt.agents.theta
-            print(kw, fused, i + 1, "finite", bool(torch.isfinite(th).all()), "max|w|", float(th.abs().max()), "episodes", vt.episode,
+            print(kw, fused, eng, i + 1, "finite", bool(torch.isfinite(th).all()), "max|w|", float(th.abs().max()), "episodes", vt.episode,
                   "mean reward/step", float(vt.env.reward.mean()), flush=True)
     print("time", round(time.time() - t0, 1))
+# weighted federated averaging needs the per-episode reward history: the episode loop (run), past the weighting window
+conf = config.Config(num_platoons=16, pl_size=3, buffer_size=500, fed_method="interfrl", weighted_average_enabled=True,
+                     weighted_window=3, total_time_steps=8 * 600)
+vt = trainer.VecTrainer(conf, rng="device", auto_reset=False)
+ep, avg = vt.run()
+th = vt.agents.theta
+print("weighted interfrl via run():", len(ep[0][0]), "episodes, finite", bool(torch.isfinite(th).all()), "max|w|", float(th.abs().max()),
+      "weights used from episode", conf.weighted_window, "last avg reward", float(avg[0][0][-1]))
