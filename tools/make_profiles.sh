@@ -16,6 +16,7 @@ python bench.py --pl-size 10 --buffer-size 50000 --steps 5 --warmup 2 --no-cpu-b
 python bench.py --framework centralized --no-cpu-baseline > $OUT/${TAG}_bench_centralized_4096x5.json 2>/dev/null
 python tools/phase_profile.py 4096 lean > $OUT/${TAG}_phase_profile_learn_kernel_l.txt 2>/dev/null
 python tools/phase_profile.py 4096 lean-fused > $OUT/${TAG}_phase_profile_learn_kernel_l_fused.txt 2>/dev/null
+[ -x tools/probes/overlap ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -Wno-unused-value tools/probes/overlap.hip -o tools/probes/overlap
 # model of the fused tile: <lds KB> <0: 8-byte, 1: 16-byte operand accesses, 2: 16-byte + half blocks (3 WG/CU fit)> <tiles>
 # <MFMAs per wave in the compute phase> <sleeps per 64 MFMAs; negative: the compute phase only idles> <stream> <rowmap> <in place>
 (cd tools/probes && for a in "150 0 20480 4800 2 1 0 0" "150 1 20480 4800 2 1 0 0" "75 1 20480 4800 2 1 0 0" "75 1 20480 4800 2 1 0 1" \

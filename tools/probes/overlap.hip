@@ -13,6 +13,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BLK = 64 * 128;  // floats per block
 constexpr int NBLK = 9;
 
+#ifdef CHEAP_UPDATE
+__device__ __forceinline__ float upd(float w, float& t, float& m, float& v, float g) {  // no division / square root
+    m = m + g * 0.1f, v = v + g * 0.001f;
+    const float wn = w - m * 1e-3f;
+    t = wn * 0.001f + t * 0.999f;
+    return wn;
+}
+#else
 __device__ __forceinline__ float upd(float w, float& t, float& m, float& v, float g) {
 #pragma clang fp contract(off)
     m = m + (g - m) * 0.1f;
@@ -21,6 +29,7 @@ __device__ __forceinline__ float upd(float w, float& t, float& m, float& v, floa
     t = wn * 0.001f + t * 0.999f;
     return wn;
 }
+#endif
 
 template <bool F4, int ROWMAP, int HALF = 0>
 __global__ __launch_bounds__(256, F4 ? (HALF ? 3 : 2) : 1) void tile_kernel(const float* w, float* wo, float* __restrict__ t,
