@@ -85,6 +85,33 @@ def cpu_baseline(seconds, pl_size):
                       "does not depend on the number of platoons"}
 
 
+def _cpu_worker(seconds, pl_size, q):
+    r = cpu_baseline(seconds, pl_size)
+    q.put((r["value"], r["updates_per_s"]))
+
+
+def cpu_baseline_all_cores(seconds, pl_size):
+    """platoons are independent, so the host's whole-socket figure is N independent single-thread copies of
+    the reference-shaped loop, N = the cores this process may run on. Reported beside the 1-thread figure, never as it."""
+    import multiprocessing as mp
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(seconds, pl_size, q)) for _ in range(n)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=seconds * 3 + 90) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+    return {"value": sum(r[0] for r in res), "unit": "env-steps/s", "updates_per_s": sum(r[1] for r in res), "cores": n,
+            "sample": f"{n} independent single-thread processes of the same loop, {seconds:.0f} s each, throughputs summed"}
+
+
 def main():
     args = parse()
     import torch
@@ -265,6 +292,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
+            try:  # the whole host beside the reference's own 1-thread setting
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), L)
+            except Exception as e:  # never let the side figure break the bench line
+                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
