@@ -19,8 +19,9 @@ python tools/phase_profile.py 4096 lean-fused > $OUT/${TAG}_phase_profile_learn_
 [ -x tools/probes/overlap ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -Wno-unused-value tools/probes/overlap.hip -o tools/probes/overlap
 # model of the fused tile: <lds KB> <0: 8-byte, 1: 16-byte operand accesses, 2: 16-byte + half blocks (3 WG/CU fit)> <tiles>
 # <MFMAs per wave in the compute phase> <sleeps per 64 MFMAs; negative: the compute phase only idles> <stream> <rowmap> <in place>
+# <start delay of every second workgroup of a CU, x 8128 cycles>
 (cd tools/probes && for a in "150 0 20480 4800 2 1 0 0" "150 1 20480 4800 2 1 0 0" "75 1 20480 4800 2 1 0 0" "75 1 20480 4800 2 1 0 1" \
-   "75 1 20480 4800 -2 1 0 0" "75 2 20480 4800 2 1 0 0" "50 2 20480 4800 2 1 0 0" "150 1 20480 0 0 1 0 0" "75 1 20480 0 0 1 0 0" "50 2 20480 0 0 1 0 0"; do ./overlap $a; done) > $OUT/${TAG}_overlap_probe.txt 2>/dev/null
+   "75 1 20480 4800 -2 1 0 0" "75 1 20480 4800 2 1 0 0 20" "75 2 20480 4800 2 1 0 0" "50 2 20480 4800 2 1 0 0" "150 1 20480 0 0 1 0 0" "75 1 20480 0 0 1 0 0" "50 2 20480 0 0 1 0 0"; do ./overlap $a; done) > $OUT/${TAG}_overlap_probe.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fused -o run -- $B > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null

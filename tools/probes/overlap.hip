@@ -34,7 +34,7 @@ __device__ __forceinline__ float upd(float w, float& t, float& m, float& v, floa
 template <bool F4, int ROWMAP, int HALF = 0>
 __global__ __launch_bounds__(256, F4 ? (HALF ? 3 : 2) : 1) void tile_kernel(const float* w, float* wo, float* __restrict__ t,
                                                     float* __restrict__ m, float* __restrict__ v, int tiles_total,
-                                                    int compute_mfma, int duty_sleep, int do_stream, int* __restrict__ counter,
+                                                    int compute_mfma, int duty_sleep, int do_stream, int stagger, int* __restrict__ slots, int* __restrict__ counter,
                                                     float* __restrict__ sinkbuf) {
     extern __shared__ float lds[];
     __shared__ int s_tile;
@@ -43,6 +43,17 @@ __global__ __launch_bounds__(256, F4 ? (HALF ? 3 : 2) : 1) void tile_kernel(cons
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float av = 1e-3f * lane, bv = 1e-3f * (lane + 1);
+    if (stagger > 0) {  // every second workgroup that lands on a CU starts `stagger` x 8128 cycles late (anti-phase)
+        __shared__ int s_par;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+            s_par = atomicAdd(&slots[((xcc & 15) << 8) | ((hw >> 8) & 0xFF)], 1) & 1;
+        }
+        __syncthreads();
+        if (s_par)
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (;;) {
         if (threadIdx.x == 0) s_tile = atomicAdd(counter, 1);
         __syncthreads();
@@ -143,12 +154,15 @@ int main(int argc, char** argv) {
     const int duty = argc > 5 ? atoi(argv[5]) : 2;
     const int stream = argc > 6 ? atoi(argv[6]) : 1;
     const int rowmap = argc > 7 ? atoi(argv[7]) : 0;
-    const int inplace = argc > 8 ? atoi(argv[8]) : 0;  // 1: updated weights written over the old ones (4 streams, not 5)
+    const int inplace = argc > 8 ? atoi(argv[8]) : 0;
+    const int stagger = argc > 9 ? atoi(argv[9]) : 0;  // start delay of every second workgroup on a CU, in units of 8128 cycles  // 1: updated weights written over the old ones (4 streams, not 5)
     const size_t n = (size_t)(stream ? tiles : 1) * NBLK * BLK;
     float *w, *wo, *t, *m, *v, *sk;
     int* counter;
     hipMalloc(&w, n * 4), hipMalloc(&wo, n * 4), hipMalloc(&t, n * 4), hipMalloc(&m, n * 4), hipMalloc(&v, n * 4);
     hipMalloc(&sk, 4096), hipMalloc(&counter, 4);
+    int* slots;
+    hipMalloc(&slots, 4096 * 4);
     hipMemset(w, 0, n * 4), hipMemset(wo, 0, n * 4), hipMemset(t, 0, n * 4), hipMemset(m, 0, n * 4), hipMemset(v, 0, n * 4);
     const int wgs_per_cu = lds_kb <= 53 ? 3 : (lds_kb <= 80 ? 2 : 1);
     const int grid = 256 * wgs_per_cu;
@@ -159,8 +173,9 @@ int main(int argc, char** argv) {
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(counter, 0, 4);
+        hipMemset(slots, 0, 4096 * 4);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_kb * 1024, 0, w, inplace ? w : wo, t, m, v, tiles, cm, duty, stream, counter, sk);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_kb * 1024, 0, w, inplace ? w : wo, t, m, v, tiles, cm, duty, stream, stagger, slots, counter, sk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -168,7 +183,7 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double bytes = 8.0 * NBLK * BLK * 4 * tiles;
-    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d rowmap=%d inplace=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
-           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, rowmap, inplace, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
+    printf("lds=%3d KB (%d WG/CU) f4=%d tiles=%d compute_mfma/wave=%d duty_sleep=%d stream=%d rowmap=%d inplace=%d stagger=%d: %.3f ms  %.1f us/tile/CU  %.2f TB/s (r+w)\n",
+           lds_kb, wgs_per_cu, f4, tiles, cm, duty, stream, rowmap, inplace, stagger, best, best * 1e3 * 256 / tiles, bytes / best * 1e-9);
     return 0;
 }
