@@ -63,9 +63,11 @@ _PROTOS = {
     "avd_replay_indices": [_i, _i, _i, _u64, _u64, _P, _P],
     "avd_replay_gather_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "avd_actor_forward_f32": [_LP, _i, _i, _P, _P, _P, _i, _f, _P, _P],
+    "avd_actor_forward_cond_f32": [_LP, _i, _i, _P, _P, _P, _i, _f, _P, _P, _P],
     "avd_critic_forward_f32": [_LP, _i, _i, _P, _P, _P, _i, _P, _P, _P],
     "avd_learn_f32": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P],
     "avd_learn_update_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _d, _P, _P, _P],
+    "avd_learn_update_act_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _d, _P, _P, _P, _i, _P, _P],
     "avd_adam_polyak_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
     "avd_polyak_f32": [_i64, _P, _P, _d, _P],
     "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],

@@ -851,6 +851,27 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
             }
             wo4[i] = w, wt4[i] = wt, m4[i] = mm, v4[i] = vv;
         }
+        if (upd.act_out) {
+            // The agent's NEXT action, actor(next state) with the weights this workgroup has just written (still in L2; the
+            // separate launch re-reads 143 KB per agent from HBM): the building blocks and the summation order of
+            // mlp_rows_kernel, so the value is the same bit for bit. bufB / bufC are free by now.
+            __syncthreads();
+            float* h1 = l.bufB;           // H1
+            float* h2 = h1 + H1;          // H2
+            float* part = h2 + H2;        // 256
+            float* xin = part + NTHREADS; // S
+            const float* tho = bulk.wo;
+            if (threadIdx.x < S) xin[threadIdx.x] = upd.act_x[(long)agent * upd.act_x_stride + threadIdx.x];
+            __syncthreads();
+            gemv_relu(xin, S, tho + L.aW1, tho + L.ab1, H1, part, h1);
+            bn_apply(h1, H1, tho + L.ag1, tho + L.abe1, net.st + L.amm1, net.st + L.amv1);
+            __syncthreads();
+            gemv_relu(h1, H1, tho + L.aW2, tho + L.ab2, H2, part, h2);
+            bn_apply(h2, H2, tho + L.ag2, tho + L.abe2, net.st + L.amm2, net.st + L.amv2);
+            __syncthreads();
+            const float z = block_dot(h2, tho + L.aW3, 1, H2, part) + tho[L.ab3];
+            if (threadIdx.x == 0) upd.act_out[agent] = tanhf(z) * high;
+        }
     }
 }
 

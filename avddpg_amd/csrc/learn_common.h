@@ -584,12 +584,64 @@ __device__ __forceinline__ float block_sum64(const float* v, float* red) {
 }
 
 
+// ---- batch-1 forward building blocks (mlp_rows_kernel; the next-action epilogue of learn_kernel_l<fused>) ----
+// y[n] = relu(sum_k x[k]*W[k][n] + b[n]) for n < N with x in LDS (already BN'ed); 256 threads split K.
+__device__ __forceinline__ void gemv_relu(const float* x, int K, const float* __restrict__ W,
+                                          const float* __restrict__ b, int N, float* part, float* y) {
+    const int cols = N < NTHREADS ? N : NTHREADS;
+    const int ksplit = NTHREADS / cols;
+    for (int n0 = 0; n0 < N; n0 += cols) {
+        const int n = n0 + (threadIdx.x % cols);
+        const int kh = threadIdx.x / cols;
+        float acc = 0.f;
+        if (kh < ksplit && n < N) {
+            const int kb = (K * kh) / ksplit, ke = (K * (kh + 1)) / ksplit;
+#pragma unroll 8
+            for (int k = kb; k < ke; ++k) acc = fmaf(x[k], W[(long)k * N + n], acc);
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < cols && n < N) {
+            float sum = b[n];
+            for (int h = 0; h < ksplit; ++h) sum += part[h * cols + threadIdx.x];
+            y[n] = fmaxf(sum, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void bn_apply(float* y, int n, const float* __restrict__ g, const float* __restrict__ be,
+                                         const float* __restrict__ mm, const float* __restrict__ mv) {
+    for (int k = threadIdx.x; k < n; k += NTHREADS) {
+        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
+        y[k] = fmaf(y[k], iv, be[k] - mm[k] * iv);
+    }
+}
+
+__device__ __forceinline__ float block_dot(const float* x, const float* __restrict__ w, int wstride, int n,
+                                           float* part) {
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < n; k += NTHREADS) acc = fmaf(x[k], w[(long)k * wstride], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float r = part[0] + part[1] + part[2] + part[3];
+    __syncthreads();
+    return r;
+}
+
+
 // Extra arguments of the fused learn+update form (FUSED): Adam + Polyak are applied where each gradient is produced.
 struct UpdArgs {
     float* theta_out;  // [n_agents][theta_size]: updated weights (theta itself stays pre-update for the whole step)
     float *m, *v;      // Adam moments, in place
     const int32_t* step;  // [n_agents] Adam iteration count AFTER this update
     float actor_lr, critic_lr, tau, omt;
+    // optional: act_out[agent][0] = actor(act_x[agent * act_x_stride ..]) with the UPDATED weights (avd_learn_update_act_f32)
+    const float* act_x;
+    int act_x_stride;
+    float* act_out;
 };
 
 // lean.hip: learn_kernel_l (two workgroups per CU; layer-1 activations recomputed on the fly). Same contract as

@@ -1316,59 +1316,15 @@ static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const fl
 // ------------------------------------------------------------------------------------------
 // batch-1 forward per agent (act / Q read-out): one workgroup per agent row, weights streamed once
 // ------------------------------------------------------------------------------------------
-// y[n] = relu(sum_k x[k]*W[k][n] + b[n]) for n < N with x in LDS (already BN'ed); 256 threads split K.
-__device__ __forceinline__ void gemv_relu(const float* x, int K, const float* __restrict__ W,
-                                          const float* __restrict__ b, int N, float* part, float* y) {
-    const int cols = N < NTHREADS ? N : NTHREADS;
-    const int ksplit = NTHREADS / cols;
-    for (int n0 = 0; n0 < N; n0 += cols) {
-        const int n = n0 + (threadIdx.x % cols);
-        const int kh = threadIdx.x / cols;
-        float acc = 0.f;
-        if (kh < ksplit && n < N) {
-            const int kb = (K * kh) / ksplit, ke = (K * (kh + 1)) / ksplit;
-#pragma unroll 8
-            for (int k = kb; k < ke; ++k) acc = fmaf(x[k], W[(long)k * N + n], acc);
-        }
-        part[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x < cols && n < N) {
-            float sum = b[n];
-            for (int h = 0; h < ksplit; ++h) sum += part[h * cols + threadIdx.x];
-            y[n] = fmaxf(sum, 0.f);
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void bn_apply(float* y, int n, const float* __restrict__ g, const float* __restrict__ be,
-                                         const float* __restrict__ mm, const float* __restrict__ mv) {
-    for (int k = threadIdx.x; k < n; k += NTHREADS) {
-        const float iv = (1.0f / sqrtf(mv[k] + BN_EPS)) * g[k];
-        y[k] = fmaf(y[k], iv, be[k] - mm[k] * iv);
-    }
-}
-
-__device__ __forceinline__ float block_dot(const float* x, const float* __restrict__ w, int wstride, int n,
-                                           float* part) {
-    float acc = 0.f;
-    for (int k = threadIdx.x; k < n; k += NTHREADS) acc = fmaf(x[k], w[(long)k * wstride], acc);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    const float r = part[0] + part[1] + part[2] + part[3];
-    __syncthreads();
-    return r;
-}
-
 // mode 0: actor, out[agent][a] = tanh(.)*high ; mode 1: critic, out[agent][a] = q      (A = num_actions outputs)
 __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, int mode, int set_mod,
                                                              const float* __restrict__ theta,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ state, int x_stride,
                                                              const float* __restrict__ action, float high,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out,
+                                                             const int32_t* __restrict__ run_if_nonzero) {
+    if (run_if_nonzero && *run_if_nonzero == 0) return;  // uniform across the grid: `out` already holds the result
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* h1 = smem;                    // H1 + Ha
     float* h2 = h1 + L.H1 + L.Ha;        // H2
@@ -1485,7 +1441,7 @@ static int check_mlp_dims(const avd_mlp_layout* L, const char* who, bool rows_on
 
 static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int set_mod, const float* theta,
                        const float* stats, const float* state, int x_stride, const float* action, float high,
-                       float* out, void* stream, const char* who) {
+                       float* out, void* stream, const char* who, const int32_t* run_if_nonzero = nullptr) {
     int rc = check_mlp_dims(lay, who, true);
     if (rc) return rc;
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0 && x_stride >= lay->S, "%s: n_agents=%d set_mod=%d x_stride=%d", who,
@@ -1499,7 +1455,7 @@ static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int se
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)mlp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mlp_rows_kernel, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, mode, set_mod,
-                       theta, stats, state, x_stride, action, high, out);
+                       theta, stats, state, x_stride, action, high, out, run_if_nonzero);
     return check_launch(who);
 }
 
@@ -1508,6 +1464,14 @@ extern "C" int avd_actor_forward_f32(const avd_mlp_layout* lay, int n_agents, in
                                      void* stream) {
     return launch_rows(lay, 0, n_agents, set_mod, theta, stats, state, x_stride, nullptr, high, out, stream,
                        "avd_actor_forward_f32");
+}
+
+extern "C" int avd_actor_forward_cond_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                                          const float* stats, const float* state, int x_stride, float high, float* out,
+                                          const int32_t* run_if_nonzero, void* stream) {
+    AVD_REQUIRE(run_if_nonzero, "avd_actor_forward_cond_f32: null flag");
+    return launch_rows(lay, 0, n_agents, set_mod, theta, stats, state, x_stride, nullptr, high, out, stream,
+                       "avd_actor_forward_cond_f32", run_if_nonzero);
 }
 
 extern "C" int avd_critic_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
@@ -1567,11 +1531,37 @@ int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float
                               float actor_lr, float critic_lr, double tau, int skip_a0, int skip_a1, int skip_c0,
                               int skip_c1, void* stream);
 
+static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                             float* theta_out, float* theta_t, float* stats_t, float* m, float* v, const int32_t* step,
+                             const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
+                             float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
+                             const float* next_state, int x_stride, float* next_action, void* stream);
+
 extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
                                     float* theta_out, float* theta_t, float* stats_t, float* m, float* v,
                                     const int32_t* step, const float* s, const float* a, const float* r,
                                     const float* s2, float gamma, float high, float actor_lr, float critic_lr,
                                     double tau, float* grads_scratch, float* losses, void* stream) {
+    return learn_update_impl(lay, n_agents, theta, stats, theta_out, theta_t, stats_t, m, v, step, s, a, r, s2, gamma, high,
+                             actor_lr, critic_lr, tau, grads_scratch, losses, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int avd_learn_update_act_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                                        float* theta_out, float* theta_t, float* stats_t, float* m, float* v,
+                                        const int32_t* step, const float* s, const float* a, const float* r,
+                                        const float* s2, float gamma, float high, float actor_lr, float critic_lr,
+                                        double tau, float* grads_scratch, float* losses, const float* next_state,
+                                        int x_stride, float* next_action, void* stream) {
+    AVD_REQUIRE(next_state && next_action && lay && x_stride >= lay->S, "avd_learn_update_act_f32: next_state / x_stride");
+    return learn_update_impl(lay, n_agents, theta, stats, theta_out, theta_t, stats_t, m, v, step, s, a, r, s2, gamma, high,
+                             actor_lr, critic_lr, tau, grads_scratch, losses, next_state, x_stride, next_action, stream);
+}
+
+static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                             float* theta_out, float* theta_t, float* stats_t, float* m, float* v, const int32_t* step,
+                             const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
+                             float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
+                             const float* next_state, int x_stride, float* next_action, void* stream) {
     int rc = check_mlp_dims(lay, "avd_learn_update_f32");
     if (rc) return rc;
     AVD_REQUIRE(n_agents > 0, "avd_learn_update_f32: n_agents=%d", n_agents);
@@ -1584,10 +1574,14 @@ extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, con
                   lay->H1, lay->H2, lay->Ha, lay->B, lay->S);
         return AVD_E_UNSUPPORTED;
     }
-    const UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau)};
-    if (use_lean_kernel())  // learn_kernel_l applies the small tensors' update itself: one launch for the whole update
+    UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau), nullptr, 0, nullptr};
+    if (use_lean_kernel()) {
+        // learn_kernel_l applies the small tensors' update itself and, on request, evaluates the updated actor on the
+        // agent's next state while its weights are still in L2: one launch for the whole update
+        upd.act_x = next_state, upd.act_x_stride = x_stride, upd.act_out = next_action;
         return lean_launch(lay, true, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads_scratch,
                            losses, upd, stream);
+    }
     if (lay->S == 4)
         rc = fast::launch<4, 256, 128, 48, true>(lay, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma,
                                                  high, grads_scratch, losses, upd, stream);
@@ -1598,6 +1592,9 @@ extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, con
     // the small tensors: everything outside the two W2 matrices (which the learn kernel has already updated)
     const int a0 = lay->aW2, a1 = lay->aW2 + lay->H1 * lay->H2;
     const int c0 = lay->actor_size + lay->cW2, c1 = c0 + (lay->H1 + lay->Ha) * lay->H2;
-    return launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads_scratch, step, actor_lr,
-                                     critic_lr, tau, a0, a1, c0, c1, stream);
+    rc = launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads_scratch, step, actor_lr, critic_lr,
+                                   tau, a0, a1, c0, c1, stream);
+    if (rc || !next_action) return rc;
+    return launch_rows(lay, 0, n_agents, 0, theta_out, stats, next_state, x_stride, nullptr, high, next_action, stream,
+                       "avd_learn_update_act_f32(actor)");
 }

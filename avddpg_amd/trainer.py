@@ -142,6 +142,10 @@ class VecTrainer:
                              "weighted_average_enabled: the weights need the per-episode reward lists; run the episode "
                              "loop (VecTrainer.run) or set weighted_average_enabled=False")
         self.fused_update = bool(fused_update)  # nofrl + reference widths: avd_learn_update_f32
+        # fused_update also has the learn kernel evaluate the UPDATED actor on the state the next step acts from
+        # (workers/trainer.py:287-289): self.actor_out then already holds the next step's actor outputs unless the states
+        # were reset in between (device flag env.any_done / a host-side reset clears _act_ready)
+        self._act_ready = False
         if self.fused_update and self.centralized:
             raise ValueError("fused_update is specialised for the decentralized reference widths")
         self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
@@ -164,6 +168,7 @@ class VecTrainer:
 
     def reset_episode(self):
         """trainer.py:244-249"""
+        self._act_ready = False  # new states: the actor outputs left by the last fused update are stale
         self.env.reset()
         self.ep_reward.zero_()
         self.ep_step = 0
@@ -178,6 +183,11 @@ class VecTrainer:
             sm = self.env.x.view(P, M, 4)[..., :self.S].transpose(0, 1).contiguous()  # set-major [M, P, S]
             o = self.agents.actor_shared(sm, P * M)
             self.actor_out.copy_(o.transpose(0, 1).reshape(P * M, 1))
+        elif self._act_ready:
+            # the last fused update left actor(states) in actor_out; recompute only if the episode ended since (any platoon
+            # terminal resets ALL platoons, :268-269 -- the flag of the previous step is still set at this point)
+            self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out,
+                              run_if_nonzero=self.env.any_done)
         else:
             self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out)
         if self.rng == "host":
@@ -242,7 +252,11 @@ class VecTrainer:
         self.updates += self.n_agents
         if not fed and self.fused_update:
             # nofrl: learn + Adam x2 + Polyak of every agent in one kernel (no gradient slab round trip)
-            self._timed("learn+update", self.agents.learn_update, s, a, r, s2, self.grads, self.losses)
+            nxt = self.A == 1 and self.auto_reset  # the episode loop's host-side resets go through reset_episode()
+            self._timed("learn+update", self.agents.learn_update, s, a, r, s2, self.grads, self.losses,
+                        next_states=env.x.view(P * M, self.x_stride) if nxt else None, x_stride=self.x_stride,
+                        next_actions=self.actor_out.view(-1) if nxt else None)
+            self._act_ready = nxt
             return
         if not fed and self.pipeline_chunks > 1:
             # nofrl: every agent learns and updates locally -> software-pipeline the two kernels over agent slices
@@ -347,6 +361,7 @@ class VecTrainer:
             # any platoon terminal ends the episode for ALL platoons (:268-269); so does the step limit
             if self.ep_step >= self.conf.steps_per_episode:
                 self.env.reset()
+                self._act_ready = False
                 self.ep_step = 0
                 self.episode += 1
             else:

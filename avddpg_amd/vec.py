@@ -262,15 +262,21 @@ class AgentGroup:
         self.stats_t.copy_(self.stats)
 
     # -- forward ----------------------------------------------------------------------------------
-    def actor(self, states, set_mod, x_stride=None, out=None, target=False):
-        """states [n_agents, x_stride] -> tanh(.)*high [n_agents] ([n_agents, A] when A > 1) (agent/model.py:26-36)."""
+    def actor(self, states, set_mod, x_stride=None, out=None, target=False, run_if_nonzero=None):
+        """states [n_agents, x_stride] -> tanh(.)*high [n_agents] ([n_agents, A] when A > 1) (agent/model.py:26-36).
+        run_if_nonzero: int32[1] device flag; the launch is a no-op when it reads 0 (`out` then keeps what a fused update
+        left there, see learn_update)."""
         n_agents = states.shape[0]
         x_stride = states.shape[-1] if x_stride is None else x_stride
         shape = (n_agents,) if self.lay.A == 1 else (n_agents, self.lay.A)
         out = torch.empty(*shape, dtype=torch.float32, device=self.device) if out is None else out
         th, st = (self.theta_t, self.stats_t) if target else (self.theta, self.stats)
-        call("avd_actor_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
-             self.high, ptr(out), stream_handle())
+        if run_if_nonzero is not None:
+            call("avd_actor_forward_cond_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
+                 self.high, ptr(out), ptr(run_if_nonzero), stream_handle())
+        else:
+            call("avd_actor_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
+                 self.high, ptr(out), stream_handle())
         return out
 
     def critic(self, states, actions, set_mod, x_stride=None, out=None, target=False):
@@ -337,11 +343,13 @@ class AgentGroup:
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())
 
-    def learn_update(self, s, a, r, s2, grads, losses=None):
+    def learn_update(self, s, a, r, s2, grads, losses=None, next_states=None, x_stride=None, next_actions=None):
         """Fused Trainer.learn + Adam x2 + update_target for per-agent weight sets (reference nofrl,
         workers/trainer.py:325-356) in ONE kernel: every gradient is consumed where it is produced, the updated
         weights go to the alternate slab (theta ping-pong: all forward/backward passes of the step read the
-        pre-update weights, trainer.py:492-506). Same result as learn() followed by apply()."""
+        pre-update weights, trainer.py:492-506). Same result as learn() followed by apply().
+        next_states [n, x_stride] + next_actions [n]: also leaves actor(next_states) of the UPDATED weights in next_actions
+        (bit-identical to actor() called afterwards; saves that launch's re-read of every actor from HBM)."""
         n = self.n_sets
         if s.shape[0] != n:
             raise _hip.AvdError("learn_update needs one weight set per agent (set_mod == 0)")
@@ -349,10 +357,17 @@ class AgentGroup:
             self.theta_alt = self.theta.clone()  # alignment padding stays zero in both slabs
         c = self.config
         self.step += 1
-        call("avd_learn_update_f32", self._layp, n, ptr(self.theta), ptr(self.stats), ptr(self.theta_alt),
-             ptr(self.theta_t), ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(self.step), ptr(s), ptr(a), ptr(r),
-             ptr(s2), c.gamma, self.high, c.actor_lr, c.critic_lr, float(c.tau), ptr(grads), ptr(losses),
-             stream_handle())
+        args = (self._layp, n, ptr(self.theta), ptr(self.stats), ptr(self.theta_alt), ptr(self.theta_t), ptr(self.stats_t),
+                ptr(self.m), ptr(self.v), ptr(self.step), ptr(s), ptr(a), ptr(r), ptr(s2), c.gamma, self.high, c.actor_lr,
+                c.critic_lr, float(c.tau), ptr(grads), ptr(losses))
+        if next_actions is not None:
+            # + the agents' next actions actor(next_states) with the updated weights, from the workgroup that wrote them
+            if self.lay.A != 1:
+                raise _hip.AvdError("next-action epilogue: A == 1 only")
+            xs = next_states.shape[-1] if x_stride is None else x_stride
+            call("avd_learn_update_act_f32", *args, ptr(next_states), xs, ptr(next_actions), stream_handle())
+        else:
+            call("avd_learn_update_f32", *args, stream_handle())
         self.theta, self.theta_alt = self.theta_alt, self.theta
 
     def learn_apply(self, s, a, r, s2, grads, losses=None, chunks=4, timers=None):

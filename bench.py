@@ -284,7 +284,11 @@ def main():
                        "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
             "stages_ms": stage_ms,
-            "pipeline": (f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
+            "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
+                          "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
+                          "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
+                         if (fused and getattr(vt, "_act_ready", False)) else
+                         f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
                          (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
                           "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else
                          ("batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),

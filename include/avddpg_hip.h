@@ -158,6 +158,13 @@ int avd_replay_gather_f32(int n_agents, int cap, int S, int A, int B, const floa
 int avd_actor_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats,
                           const float* state, int x_stride, float high, float* out, void* stream);
 
+/* The same, executed only when *run_if_nonzero != 0 (a device flag, e.g. the any-terminal flag of the previous step):
+ * when a fused update has already left actor(next state) in `out` (avd_learn_update_act_f32) and no reset has changed
+ * the states since, the launch returns at once and `out` stays. */
+int avd_actor_forward_cond_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
+                               const float* stats, const float* state, int x_stride, float high, float* out,
+                               const int32_t* run_if_nonzero, void* stream);
+
 /* critic([state, action]) -> q[n_agents][A] (agent/model.py:63-83; the output width is num_actions, :80);
  * action [n_agents][A]; rows as above, batch 1 per agent. */
 int avd_critic_forward_f32(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta,
@@ -188,7 +195,8 @@ int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, flo
  *   theta_out  [n_agents][theta_size] receives the updated weights; must not alias theta (callers ping-pong)
  *   theta_t, stats_t, m, v  updated in place;  step [n_agents] = Adam iteration AFTER this update;
  *   grads_scratch [n_agents][theta_size] workspace: receives only the gradients of the small tensors (biases, BN
- *              gamma/beta, first/last layers, ~6 % of the slab), which a second, range-restricted launch consumes;
+ *              gamma/beta, first/last layers, ~6 % of the slab), consumed at the end of the same launch (learn_kernel_l)
+ *              or by a second, range-restricted launch (learn_kernel_t);
  *   losses [n_agents][2] or NULL.  Same result as the two separate calls. Reference widths only
  *   (256/128/48, B = 64, S in {3,4}); otherwise AVD_E_UNSUPPORTED. */
 int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
@@ -196,6 +204,15 @@ int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* t
                          const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
                          float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
                          void* stream);
+
+/* avd_learn_update_f32 plus the agents' NEXT actions (workers/trainer.py:287-289 of the following step, before noise
+ * and clipping): next_action[v] = actor(next_state[v * x_stride ..]) with the UPDATED weights, evaluated by the
+ * workgroup that has just written them (A = 1). Bit-identical to avd_actor_forward_f32 on theta_out afterwards. */
+int avd_learn_update_act_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
+                             float* theta_out, float* theta_t, float* stats_t, float* m, float* v, const int32_t* step,
+                             const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
+                             float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
+                             const float* next_state, int x_stride, float* next_action, void* stream);
 
 /* update_target alone (agent/ddpgagent.py:31-55): t = w*tau + t*(1-tau) over n floats. */
 int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream);

@@ -349,3 +349,29 @@ def test_centralized_shapes_forward_and_learn(L):
         gcW2 = gh[v, lay.actor_size + lay.cW2:lay.actor_size + lay.cW2 + 384 * 160].reshape(384, 160)
         assert np.all(gcW2[307:320] == 0) and np.all(gcW2[377:] == 0) and np.all(gcW2[:, 153:] == 0)
         assert np.all(gh[v, lay.ag1 + 307:lay.ag1 + 320] == 0) and np.all(gh[v, lay.abe2 + 153:lay.abe2 + 160] == 0)
+
+
+def test_learn_update_next_action_epilogue_and_conditional_actor():
+    """avd_learn_update_act_f32: next_action = actor(next_state) with the updated weights, bit-identical to the actor
+    launch on the updated slab; avd_actor_forward_cond_f32 runs only when its device flag is non-zero."""
+    need_gpu()
+    n = 37
+    conf, grp = _perturbed_group(n, S=4, seed=31)
+    rs = np.random.RandomState(32)
+    s = t(rs.normal(0, 1.5, size=(n, 64, 4)).astype(np.float32))
+    a = t(rs.uniform(-2.5, 2.5, size=(n, 64, 1)).astype(np.float32))
+    r = t(-np.abs(rs.normal(0, 0.3, size=(n, 64))).astype(np.float32))
+    s2 = t(rs.normal(0, 1.5, size=(n, 64, 4)).astype(np.float32))
+    nxt = t(rs.normal(0, 1.5, size=(n, 4)).astype(np.float32))
+    scratch = torch.zeros(n, grp.lay.theta_size, device="cuda")
+    out = torch.full((n,), 7.0, device="cuda")
+    grp.learn_update(s, a, r, s2, scratch, next_states=nxt, next_actions=out)
+    want = grp.actor(nxt, 0)  # grp.theta is the updated slab now
+    assert torch.equal(out, want) and float(out.abs().max()) <= conf.action_high
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    keep = torch.full((n,), 3.0, device="cuda")
+    grp.actor(nxt, 0, out=keep, run_if_nonzero=flag)
+    assert torch.all(keep == 3.0)                      # flag 0: nothing written
+    flag.fill_(1)
+    grp.actor(nxt, 0, out=keep, run_if_nonzero=flag)
+    assert torch.equal(keep, want)

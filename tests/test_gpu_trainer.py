@@ -505,3 +505,28 @@ def test_device_rng_leader_exog_honours_rand_gen():
             assert np.array_equal(ex, want)
         else:
             assert np.abs(ex).max() > u and abs(ex.std() / u - 1) < 0.05
+
+
+def test_fused_update_next_action_epilogue_survives_episode_resets():
+    """fused_update has the learn kernel leave actor(next state) of the UPDATED weights in actor_out, and the next step's
+    actor launch runs only if the episode ended in between (device flag). With tight termination bounds episodes end
+    every few steps: the trajectory must stay bit-identical to the two-kernel path, which calls the actor every step."""
+    conf = config.Config(num_platoons=33, pl_size=3, buffer_size=128, max_ep=5.5, max_ev=5.5)
+    runs = []
+    for fused in (False, True):
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, fused_update=fused, seed=11)
+        vt.reset_episode()
+        ends = 0
+        for _ in range(140):
+            vt.step()
+            ends += int(vt.env.done.any().item())
+        torch.cuda.synchronize()
+        runs.append((vt, ends))
+    (a, ea), (b, eb) = runs
+    assert ea == eb and 5 <= ea <= 135, ea          # episodes do end, but not on every step: both branches are exercised
+    assert b._act_ready and not a._act_ready
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.actions, b.actions)  # same actions taken on every step
+    assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
+    # b.actor_out already holds the NEXT step's actor outputs (unless that step must recompute them after a reset)
+    nxt = a.agents.actor(a.env.x.view(-1, a.x_stride), 0, x_stride=a.x_stride)
+    assert bool(b.env.done.any()) or torch.equal(b.actor_out.view(-1), nxt)
