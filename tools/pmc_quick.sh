@@ -11,5 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 f() { find $OUT/$1 -name "*counter_collection.csv" | head -1; }
-python tools/pmc_summary.py "$(f FETCH_SIZE)" "$(f WRITE_SIZE)" $OUT/pmc_traffic.json 2>&1 | grep -i "learn\|adam\|correction"
+python tools/pmc_summary.py "$(f FETCH_SIZE)" "$(f WRITE_SIZE)" $OUT/pmc_traffic.json 2>&1 | grep -i "learn\|adam\|correction\|rows"
 rm -rf $OUT/FETCH_SIZE $OUT/WRITE_SIZE

@@ -45,8 +45,15 @@ def main():
         actor_bytes = (4 * 256 + 3 * 256 + 256 * 128 + 3 * 128 + 128 + 1 + 2 * 256 + 2 * 128) * 4
         cals.append(actor_bytes * f[rows][2] / f[rows][0])
         res["fetch_correction"]["mlp_rows_4B_per_lane"] = cals[-1]
-    corr = sum(cals) / len(cals)
+    # a calibration kernel that did no real work in this run (e.g. mlp_rows_kernel when the conditional actor launch
+    # returned at once every step) gives a meaningless factor: keep only plausible ones, else the guide's 2.0
+    res["fetch_correction"]["candidates"] = list(cals)
+    cals = [c for c in cals if 1.8 <= c <= 2.2]
+    corr = sum(cals) / len(cals) if cals else 2.0
     res["fetch_correction"]["applied"] = corr
+    res["fetch_correction"]["source"] = "calibrated on kernels of known read bytes" if cals else \
+        "MI355X_MICROARCH.md: FETCH_SIZE reports exactly 1/2 of coalesced streaming reads on gfx950"
+
     for k in f:
         if not k.startswith("avd::"):
             continue
