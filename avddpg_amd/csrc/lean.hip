@@ -612,7 +612,7 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
     // through that pointer, re-derived inside each pass behind an opaque zero: as a plain by-value argument LLVM loads
     // every field it will ever need up front and keeps ~40 SGPRs alive -- and spilled into VGPR lanes -- all kernel long.
     const avd_mlp_layout* const Lk = (const avd_mlp_layout*)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)L_arg;
+    if (L_arg.theta_size != Lk->theta_size || L_arg.stats_size != Lk->stats_size) __builtin_trap();  // the layout IS argument 0
     const avd_mlp_layout& L = *Lk;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Lds l = carve(smem, KC, H2);
