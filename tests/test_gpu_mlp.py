@@ -375,3 +375,34 @@ def test_learn_update_next_action_epilogue_and_conditional_actor():
     flag.fill_(1)
     grp.actor(nxt, 0, out=keep, run_if_nonzero=flag)
     assert torch.equal(keep, want)
+
+
+def test_full_size_fused_update_is_bitwise_the_two_kernel_update_20480_agents():
+    """BASELINE configs[1] size: avd_learn_update_act_f32 (learn_kernel_l<fused>: learn + Adam x2 + Polyak + next action, one
+    launch) leaves exactly the weights, targets, moments and next actions of avd_learn_f32 + avd_adam_polyak_f32 +
+    avd_actor_forward_f32 for all 20480 agents, two steps in a row (the second reads the ping-ponged slab)."""
+    need_gpu()
+    n = 4096 * 5
+    conf = config.Config()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    grp_a, grp_b = (vec.AgentGroup(n, 4, 1, conf, seed=11) for _ in range(2))
+    grp_a.theta.add_(torch.randn(grp_a.theta.shape, device="cuda", generator=g) * 0.01 * (grp_a.theta != 0))
+    grp_a.theta_t.copy_(grp_a.theta)
+    grp_b.theta.copy_(grp_a.theta), grp_b.theta_t.copy_(grp_a.theta_t)
+    scratch = torch.zeros(n, grp_a.lay.theta_size, device="cuda")
+    grads = torch.zeros(n, grp_a.lay.theta_size, device="cuda")
+    nxt_act = torch.zeros(n, device="cuda")
+    for step in range(2):
+        s = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+        a = torch.rand(n, 64, 1, device="cuda", generator=g) * 5 - 2.5
+        r = -torch.rand(n, 64, device="cuda", generator=g)
+        s2 = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+        nxt = torch.randn(n, 4, device="cuda", generator=g) * 1.5
+        grp_a.learn_update(s, a, r, s2, scratch, next_states=nxt, next_actions=nxt_act)
+        grp_b.learn(s, a, r, s2, 0, grads=grads)
+        grp_b.apply(grads)
+        for x, y in ((grp_a.theta, grp_b.theta), (grp_a.theta_t, grp_b.theta_t), (grp_a.m, grp_b.m), (grp_a.v, grp_b.v),
+                     (grp_a.stats_t, grp_b.stats_t)):
+            assert torch.equal(x, y), step
+        assert torch.equal(nxt_act, grp_b.actor(nxt, 0))
+    assert int(grp_a.step[0]) == int(grp_b.step[-1]) == 2 and torch.isfinite(grp_a.theta).all()

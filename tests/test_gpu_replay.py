@@ -96,3 +96,40 @@ def test_normal_kernel_matches_oracle_philox():
     ref = ophilox.normals(10000, seed=42, counter=7, stream=ophilox.STREAM_NORMAL) * np.float32(0.1)
     assert np.allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-6)  # libm vs device log/cos: few ulp of 0.4
     assert abs(out.std().item() / 0.1 - 1) < 0.03
+
+
+def test_full_capacity_ring_of_20480_agents_wraps_at_100000_rows():
+    """BASELINE configs[1] at the reference's buffer_size (src/config.py:107): 20480 rings x 100000 rows x 10 floats = 82 GB
+    in HBM. The write index wraps at capacity (replaybuffer.py:40), the sample range saturates at it (:52), indices stay in
+    range and the gather returns the rows it indexed."""
+    need_gpu()
+    n, cap, B, S, A = 4096 * 5, 100000, 64, 4, 1
+    if torch.cuda.mem_get_info()[0] < 100 * 2**30:
+        pytest.skip("needs ~85 GB of free HBM")
+    rb = vec.VecReplay(n, cap, B, S, A, rng="device", seed=3)
+    assert rb.ring.numel() * 4 == n * cap * (2 * S + A + 1) * 4 == 81_920_000_000
+    rb.buffer_counter = cap - 2  # as after cap - 2 adds
+    rows = []
+    for k in range(5):  # slots cap-2, cap-1, 0, 1, 2
+        sp = torch.full((n, S), float(10 + k), device="cuda") + torch.arange(n, device="cuda").view(n, 1) * 1e-3
+        ac = torch.full((n, A), float(-k), device="cuda")
+        rw = torch.full((n,), 0.5 * k, device="cuda")
+        sn = sp + 0.25
+        assert oreplay.ring_index(rb.buffer_counter, cap) == (cap - 2 + k) % cap
+        rb.add(sp, ac, rw, sn, S)
+        rows.append((sp, ac, rw, sn))
+    assert rb.buffer_counter == cap + 3 and rb.sample_range() == oreplay.sample_range(cap + 3, cap) == cap
+    for k, slot in enumerate((cap - 2, cap - 1, 0, 1, 2)):
+        sp, ac, rw, sn = rows[k]
+        for ag in (0, 12345, n - 1):
+            row = rb.ring[ag, slot]
+            assert torch.equal(row[:S], sp[ag]) and torch.equal(row[S:S + A], ac[ag]) and row[S + A] == rw[ag]
+            assert torch.equal(row[S + A + 1:], sn[ag])
+    assert float(rb.ring[77, 3].abs().sum()) == 0.0  # untouched slots stay as allocated
+    s, a, r, s2 = rb.sample()
+    idx = rb.idx
+    assert int(idx.min()) >= 0 and int(idx.max()) < cap
+    assert np.array_equal(idx[:64].cpu().numpy(), ophilox.replay_indices(n, B, cap, seed=3, counter=0)[:64])
+    for ag in (0, 9999, n - 1):
+        got = rb.ring[ag][idx[ag].long()]
+        assert torch.equal(s[ag], got[:, :S]) and torch.equal(r[ag], got[:, S + A]) and torch.equal(s2[ag], got[:, S + A + 1:])
