@@ -286,8 +286,13 @@ __device__ __forceinline__ void gemm_fwd_relu(const float* X, int ldx, const flo
 // Weight gradient of a hidden layer fed by a BN output (all operands in LDS):
 //   dW[k][n] = inv[k] * sum_r P[r][k]*DZ[r][n] + sh[k]*db[n]   for k < K, n < N  -> global gW[k*N + n]
 // Output tile (ta, tb) of a 64x32 block holds rows k0 + 4*i + ta (i = 4*lg + reg) and columns n0 + 2*lr + tb.
+// Sink = AdamSink: gW is the tensor's position in the OUTPUT weight slab and every element is updated where it is produced
+// (the 16 (row, column-pair) operand groups of a block are requested before its MFMA loop, consumed after it).
+template <class Sink = StoreSink>
 __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* inv, const float* sh, int K,
-                                        const float* DZ, int ldz, const float* db, int N, float* __restrict__ gW) {
+                                        const float* DZ, int ldz, const float* db, int N, float* __restrict__ gW,
+                                        Sink sink = Sink()) {
+    constexpr bool kFused = !std::is_same<Sink, StoreSink>::value;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
     // (column group of 32, block of 64 feature rows) items dealt round-robin over the four waves
     const int groups = N >> 5, kblocks = (K + 63) >> 6;
@@ -296,6 +301,16 @@ __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* in
         const f32x2 dbc = *(const f32x2*)(db + n0 + 2 * lr);
         {
             const int k0 = (item / groups) * 64;
+            typename std::conditional<kFused, AdamSink::Quad, int>::type q[16];
+            long base = 0;
+            if constexpr (kFused) {
+                base = (gW - sink.wo) + n0 + 2 * lr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ta = 0; ta < 4; ++ta)  // clamped: loads for rows past K stay inside the tensor, never used
+                        sink.load2(q[j * 4 + ta], base + (long)(min(k0 + 4 * (lg * 4 + j), K - 4) + ta) * N);
+            }
             f32x4 acc[4][2];
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -319,10 +334,16 @@ __device__ __forceinline__ void gemm_dw(const float* P, int ldp, const float* in
                     const f32x4 sf = *(const f32x4*)(sh + kbase);
 #pragma unroll
                     for (int ta = 0; ta < 4; ++ta) {
-                        f32x2 o;
-                        o[0] = fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]);
-                        o[1] = fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1]);
-                        *(f32x2*)(gW + (long)(kbase + ta) * N + n0 + 2 * lr) = o;
+                        if constexpr (kFused) {
+                            const float o[2] = {fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]),
+                                                fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1])};
+                            sink.update2(q[j * 4 + ta], base + (long)(kbase + ta) * N, o);
+                        } else {
+                            f32x2 o;
+                            o[0] = fmaf(iv[ta], acc[ta][0][j], sf[ta] * dbc[0]);
+                            o[1] = fmaf(iv[ta], acc[ta][1][j], sf[ta] * dbc[1]);
+                            *(f32x2*)(gW + (long)(kbase + ta) * N + n0 + 2 * lr) = o;
+                        }
                     }
                 }
             }

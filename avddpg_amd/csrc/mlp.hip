@@ -282,15 +282,19 @@ __device__ __forceinline__ float warm(const float* __restrict__ base, int lo, in
     return t;
 }
 
+// FUSED (avd_learn_update_f32 for general widths): Adam + Polyak of the two W2 matrices in the epilogue of the weight-
+// gradient GEMM that produces their gradient, theta ping-pong as in learn_kernel_t; the small tensors go through the gradient
+// slab and adam_polyak_ranges_kernel.
+template <bool FUSED>
 __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int set_mod,
                                                             const float* __restrict__ theta,
                                                             const float* __restrict__ stats,
-                                                            const float* __restrict__ theta_t,
-                                                            const float* __restrict__ stats_t,
+                                                            float* __restrict__ theta_t,
+                                                            float* __restrict__ stats_t,
                                                             const float* __restrict__ s, const float* __restrict__ a,
                                                             const float* __restrict__ r, const float* __restrict__ s2,
                                                             float gamma, float high, float* __restrict__ grads,
-                                                            float* __restrict__ losses) {
+                                                            float* __restrict__ losses, UpdArgs upd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GLds l = carve(smem, L);
     const int S = L.S, A = L.A, H1 = L.H1, H2 = L.H2, Ha = L.Ha, KC = H1 + Ha;
@@ -302,6 +306,19 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
     float* ga = grads + (long)agent * L.theta_size;
     float* gc = ga + L.actor_size;
     const float invn = 1.0f / (float)(TILE * A);
+    typedef typename std::conditional<FUSED, AdamSink, StoreSink>::type BulkSink;
+    BulkSink bulk;
+    float* gw2 = ga;  // where gemm_dw "stores": the gradient slab, or the agent's slab of theta_out
+    if constexpr (FUSED) {
+        const int t = upd.step[agent];
+        const float b1p = (float)pow((double)0.9f, (double)t), b2p = (float)pow((double)0.999f, (double)t);
+        const float root = sqrtf(1.0f - b2p);
+        const long o = (long)agent * L.theta_size;
+        gw2 = upd.theta_out + o;
+        bulk.wo = gw2, bulk.wi = net.th, bulk.wt = theta_t + o, bulk.m = upd.m + o, bulk.v = upd.v + o;
+        bulk.alpha_a = (upd.actor_lr * root) / (1.0f - b1p), bulk.alpha_c = (upd.critic_lr * root) / (1.0f - b1p);
+        bulk.tau = upd.tau, bulk.omt = upd.omt, bulk.actor_size = L.actor_size;
+    }
 
     if (tid < TILE) l.sR[tid] = r[(long)agent * TILE + tid];
     for (int i = tid; i < TILE * A; i += NTHREADS) l.sAct[i] = a[(long)agent * TILE * A + i];
@@ -373,6 +390,11 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
         }
         if (it == 0) {  // y = r + gamma * Q'(s2, mu'(s2)), r broadcast over the A outputs, no done mask (trainer.py:494)
             for (int i = tid; i < TILE * A; i += NTHREADS) l.sY[i] = fmaf(gamma, l.sQ[i], l.sR[i / A]);
+            if constexpr (FUSED) {  // the frozen BN statistics take part in the soft update too (ddpgagent.py:44-53)
+#pragma clang fp contract(off)
+                float* stt = stats_t + (long)set * L.stats_size;
+                for (int i = tid; i < L.stats_size; i += NTHREADS) stt[i] = net.st[i] * upd.tau + stt[i] * upd.omt;
+            }
             continue;
         }
         if (it == 1) {  // Lc = mean((y - q)^2) over B*A (trainer.py:496)
@@ -408,7 +430,8 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             col_sums(l.bufB, ldB, H2, l.db, gout + (crit ? L.cb2 : L.ab2));
             lds_barrier();
             PH(it == 1 ? 8 : 16);
-            gemm_dw(l.bufA, ldA, l.invA, l.shA, crit ? KC : H1, l.bufB, ldB, l.db, H2, gout + (crit ? L.cW2 : L.aW2));
+            gemm_dw(l.bufA, ldA, l.invA, l.shA, crit ? KC : H1, l.bufB, ldB, l.db, H2,
+                    gw2 + (crit ? L.actor_size + L.cW2 : L.aW2), bulk);
             lds_barrier();
             PH(it == 1 ? 9 : 17);
         }
@@ -1514,14 +1537,14 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
                   lay->A, lay->H1, lay->H2, lay->Ha, lds);
         return AVD_E_UNSUPPORTED;
     }
-    hipError_t e = hipFuncSetAttribute((const void*)gen::learn_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)gen::learn_kernel_g<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
         set_error("avd_learn_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         return AVD_E_LAUNCH;
     }
-    hipLaunchKernelGGL(gen::learn_kernel_g, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod, theta,
-                       stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses);
+    hipLaunchKernelGGL(gen::learn_kernel_g<false>, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, set_mod,
+                       theta, stats, (float*)theta_t, (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, UpdArgs{});
     return check_launch("avd_learn_f32");
 }
 
@@ -1568,11 +1591,37 @@ static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const floa
     AVD_REQUIRE(theta && stats && theta_out && theta_t && stats_t && m && v && step && s && a && r && s2 && grads_scratch,
                 "avd_learn_update_f32: null pointer");
     AVD_REQUIRE(theta_out != theta, "avd_learn_update_f32: theta_out must not alias theta (every pass reads pre-update weights)");
-    if (!(lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && lay->B == TILE && (lay->S == 3 || lay->S == 4))) {
-        set_error("avd_learn_update_f32: the fused kernel is built for the reference widths 256/128/48, B=64, S in {3,4} "
-                  "(got %d/%d/%d, B=%d, S=%d); use avd_learn_f32 + avd_adam_polyak_f32",
-                  lay->H1, lay->H2, lay->Ha, lay->B, lay->S);
+    const int a0 = lay->aW2, a1 = lay->aW2 + lay->H1 * lay->H2;  // the two W2 matrices: updated inside the learn kernels
+    const int c0 = lay->actor_size + lay->cW2, c1 = c0 + (lay->H1 + lay->Ha) * lay->H2;
+    if (lay->B != TILE) {
+        set_error("avd_learn_update_f32: batch_size=%d; the tile kernels implement B == %d", lay->B, TILE);
         return AVD_E_UNSUPPORTED;
+    }
+    if (!(lay->A == 1 && lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && (lay->S == 3 || lay->S == 4)) ||
+        getenv("AVD_LEARN_GENERAL")) {
+        // any other shape the general kernel serves (centralized framework, non-default widths): its fused form
+        const size_t lds = sizeof(float) * gen::lds_floats(*lay);
+        if (lds > 160 * 1024) {
+            set_error("avd_learn_update_f32: S=%d A=%d H1=%d H2=%d Ha=%d need %zu B of LDS per 64-row tile (> 160 KiB)", lay->S,
+                      lay->A, lay->H1, lay->H2, lay->Ha, lds);
+            return AVD_E_UNSUPPORTED;
+        }
+        hipError_t e = hipFuncSetAttribute((const void*)gen::learn_kernel_g<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) {
+            set_error("avd_learn_update_f32: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+            return AVD_E_LAUNCH;
+        }
+        const UpdArgs updg = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau), nullptr, 0, nullptr};
+        hipLaunchKernelGGL(gen::learn_kernel_g<true>, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, 0, theta,
+                           stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads_scratch, losses, updg);
+        rc = check_launch("avd_learn_update_f32 (general)");
+        if (rc) return rc;
+        rc = launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads_scratch, step, actor_lr,
+                                       critic_lr, tau, a0, a1, c0, c1, stream);
+        if (rc || !next_action) return rc;
+        return launch_rows(lay, 0, n_agents, 0, theta_out, stats, next_state, x_stride, nullptr, high, next_action, stream,
+                           "avd_learn_update_act_f32(actor)");
     }
     UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau), nullptr, 0, nullptr};
     if (use_lean_kernel()) {
@@ -1590,8 +1639,6 @@ static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const floa
                                                  high, grads_scratch, losses, upd, stream);
     if (rc) return rc;
     // the small tensors: everything outside the two W2 matrices (which the learn kernel has already updated)
-    const int a0 = lay->aW2, a1 = lay->aW2 + lay->H1 * lay->H2;
-    const int c0 = lay->actor_size + lay->cW2, c1 = c0 + (lay->H1 + lay->Ha) * lay->H2;
     rc = launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads_scratch, step, actor_lr, critic_lr,
                                    tau, a0, a1, c0, c1, stream);
     if (rc || !next_action) return rc;

@@ -141,13 +141,11 @@ class VecTrainer:
             raise ValueError("auto_reset (device-side episode bookkeeping) cannot be combined with a federated method and "
                              "weighted_average_enabled: the weights need the per-episode reward lists; run the episode "
                              "loop (VecTrainer.run) or set weighted_average_enabled=False")
-        self.fused_update = bool(fused_update)  # nofrl + reference widths: avd_learn_update_f32
+        self.fused_update = bool(fused_update)  # nofrl (any framework / widths the learn kernels serve): avd_learn_update_f32
         # fused_update also has the learn kernel evaluate the UPDATED actor on the state the next step acts from
         # (workers/trainer.py:287-289): self.actor_out then already holds the next step's actor outputs unless the states
         # were reset in between (device flag env.any_done / a host-side reset clears _act_ready)
         self._act_ready = False
-        if self.fused_update and self.centralized:
-            raise ValueError("fused_update is specialised for the decentralized reference widths")
         self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
         self.timers = None
         self.episode, self.ep_step = 0, 0

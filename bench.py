@@ -144,7 +144,7 @@ def main():
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
                             seed=1 + rank, pipeline_chunks=args.chunks,
-                            fused_update=(args.mode == "nofrl" and not args.no_fused and args.framework == "decentralized"),
+                            fused_update=(args.mode == "nofrl" and not args.no_fused),
                             shared_engine=args.engine if args.mode == "interfrl" else None)
     batched = vt.shared and vt.shared_engine == "batched"
     # synthetic steady state: replay rings full of random-init-platoon-like rows
@@ -208,6 +208,8 @@ def main():
     lk = "learn_kernel_t" if os.environ.get("AVD_LEARN_KERNEL") == "fast" else "learn_kernel_l"
     # learn_kernel_l<fused> updates the small tensors itself (one launch); learn_kernel_t leaves them to a second kernel
     fused_name = lk + "<fused>" + ("" if lk == "learn_kernel_l" else " + adam_polyak_ranges_kernel")
+    if args.framework != "decentralized":
+        lk, fused_name = "gen::learn_kernel_g", "gen::learn_kernel_g<fused> + adam_polyak_ranges_kernel"
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
@@ -230,7 +232,7 @@ def main():
     else:
         learn_s = stage_ms["learn"] / 1e3
         upd_s = stage_ms["update"] / 1e3
-        roofs.append({"kernel": lk if args.framework == "decentralized" else "gen::learn_kernel_g", "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
+        roofs.append({"kernel": lk, "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "_t": learn_s})
         if args.mode == "nofrl":
             roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,

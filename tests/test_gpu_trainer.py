@@ -251,14 +251,19 @@ def test_model_a_and_weighted_interfrl_trainer_paths_run():
     assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
 
 
-@pytest.mark.parametrize("model,kernel", [("ModelB", "lean"), ("ModelA", "lean"), ("ModelB", "fast"), ("ModelA", "fast")])
+@pytest.mark.parametrize("model,kernel", [("ModelB", "lean"), ("ModelA", "lean"), ("ModelB", "fast"), ("ModelA", "fast"),
+                                          ("ModelB", "general"), ("ModelB", "centralized")])
 def test_fused_learn_update_is_bitwise_learn_then_apply(model, kernel, monkeypatch):
     """avd_learn_update_f32 (Adam + Polyak applied where each gradient is produced, theta ping-pong) gives exactly
-    the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32 -- for learn_kernel_l (default)
-    and for learn_kernel_t (AVD_LEARN_KERNEL=fast)."""
+    the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32 -- for learn_kernel_l (default),
+    learn_kernel_t (AVD_LEARN_KERNEL=fast) and the general kernel (AVD_LEARN_GENERAL=1 at the reference widths; the
+    centralized framework: S = 12, A = 3, widths 307/153/57 padded to 320/160/64)."""
     if kernel == "fast":
         monkeypatch.setenv("AVD_LEARN_KERNEL", "fast")
-    conf = config.Config(num_platoons=21, pl_size=3, buffer_size=128, model=model)
+    if kernel == "general":
+        monkeypatch.setenv("AVD_LEARN_GENERAL", "1")
+    conf = config.Config(num_platoons=21, pl_size=3, buffer_size=128, model=model,
+                         framework="centralized" if kernel == "centralized" else "decentralized")
     runs = []
     for fused in (False, True):
         vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, fused_update=fused, seed=4)
@@ -274,8 +279,8 @@ def test_fused_learn_update_is_bitwise_learn_then_apply(model, kernel, monkeypat
     assert torch.equal(a.agents.stats_t, b.agents.stats_t) and torch.equal(a.env.x, b.env.x)
     assert torch.equal(a.losses, b.losses)
     lay = b.agents.lay
-    assert torch.all(b.agents.theta[:, lay.ab3 + 1:lay.actor_size] == 0)  # padding untouched in both slabs
-    assert torch.all(b.agents.theta_alt[:, lay.ab3 + 1:lay.actor_size] == 0)
+    assert torch.all(b.agents.theta[:, lay.ab3 + lay.A:lay.actor_size] == 0)  # padding untouched in both slabs
+    assert torch.all(b.agents.theta_alt[:, lay.ab3 + lay.A:lay.actor_size] == 0)
 
 
 def test_intrafrl_directional_and_weights_aggregation_semantics():
