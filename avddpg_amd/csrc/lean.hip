@@ -652,6 +652,7 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
         for (int i = L.cb3 + 1; i < L.theta_size - L.actor_size; ++i) gc[i] = 0.f;
     }
     PH_INIT();
+    PH_CLK_INIT();
     float cs_snap[2] = {0.f, 0.f};  // lane-local shift sums of the critic's state blocks, pass 1 -> pass 2
 
     // pass 0: targets (y); pass 1: critic loss + gradient; pass 2: actor -> critic, gradient wrt the action;
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(FT, 2) void learn_kernel_l(avd_mlp_layout L_arg, in
             if (threadIdx.x == 0) upd.act_out[agent] = tanhf(z) * high;
         }
     }
+    PH_CLK_END();
 }
 
 template <int S, bool FUSED>

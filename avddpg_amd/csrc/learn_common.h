@@ -43,7 +43,21 @@ static __device__ unsigned long long g_phase_cycles[32];  // per translation uni
     } while (0)
 #define PH_ARG , unsigned long long& ph_last
 #define PH_PASS , ph_last
+// In-kernel clock (MI355X_MICROARCH.md, DVFS item 6): slot 30 sums the shader-cycle counter (s_memtime), slot 31 the
+// constant 100 MHz counter (s_memrealtime) over each workgroup's lifetime; clock = 100 MHz * [30] / [31].
+#define PH_CLK_INIT()                                                   \
+    const unsigned long long ph_c0 = __builtin_amdgcn_s_memtime();     \
+    const unsigned long long ph_r0 = __builtin_amdgcn_s_memrealtime()
+#define PH_CLK_END()                                                                        \
+    do {                                                                                    \
+        if (threadIdx.x == 0) {                                                             \
+            atomicAdd(&g_phase_cycles[30], __builtin_amdgcn_s_memtime() - ph_c0);           \
+            atomicAdd(&g_phase_cycles[31], __builtin_amdgcn_s_memrealtime() - ph_r0);       \
+        }                                                                                   \
+    } while (0)
 #else
+#define PH_CLK_INIT()
+#define PH_CLK_END()
 #define PH_INIT()
 #define PHX_T0()
 #define PHX(id)

@@ -40,13 +40,24 @@ gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
 run = (lambda: grp.learn_update(s, a, r, s2, gscr)) if FUSED else (lambda: grp.learn(s, a, r, s2, 0))
 run()
 torch.cuda.synchronize()
+import time
+t_warm = time.time()
+while time.time() - t_warm < 2.0:  # the chip settles on the clock it holds under this load (DVFS) before anything is counted
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
 dbg(None, 1)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 dbg(buf, 0)
-tot = sum(buf)
+tot = sum(buf[:30])
+if buf[31]:  # learn_kernel_l stamps its lifetime with both counters: the clock the chip held while it ran
+    print(f"in-kernel clock = {100e6 * buf[30] / buf[31] / 1e9:.3f} GHz (sum of s_memtime / sum of s_memrealtime x 100 MHz over all workgroups)")
+    print(f"workgroup lifetime = {buf[30] / (3 * n):.0f} cyc/tile = {buf[31] / (3 * n) / 100:.1f} us/tile "
+          f"(stamped phases below cover {100 * tot / buf[30]:.1f} % of it; the rest is the batch staging before the first stamp and, "
+          f"fused, the small-tensor update + next-action epilogue after the last)")
 print(f"tiles={3 * n}  cycles/tile={tot / (3 * n):.0f}")
 NAMES.update({20: "  dx: issue next-tile loads", 21: "  dx: MFMA loop", 22: "  dx: BN epilogue", 23: "  dx: wait next tile (copy)"})
 if LEAN:
