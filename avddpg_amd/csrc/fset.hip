@@ -1,0 +1,960 @@
+// Fused shared-weight-set learner ("fset"): Trainer.learn (workers/trainer.py:472-508) + the federated mean over the
+// platoons (src/server/federated.py:47-63, 99-118; workers/trainer.py:400-431) for agents that SHARE their networks
+// (interfrl with every step federated: the P copies of vehicle m's networks stay identical, trainer.py:121-128), at the
+// reference widths 256 / 128 / 48 (src/config.py:112-117), as a chain of PERSISTENT kernels that keep one weight matrix
+// in registers and stream the agents' 64-row batches through it.
+//
+// Why: the layer-wise GEMM chain of wide.hip moves every activation of the P x 64 rows of a set through HBM (8.4 ms at
+// 4096 x 5 agents, 4 % of the bf16 matrix peak), and the per-agent f32 kernel (lean.hip) is bound by the f32 MFMA rate
+// (8.2 ms). Here a workgroup (8 waves, one per CU, 256 registers per lane) is bound to ONE weight set for its whole life:
+//   * the BN-folded second-layer weights sit in each wave's registers as bf16 MFMA fragments (64 / 76 registers for its
+//     32 output columns) -- no weight traffic at all after the first tile;
+//   * the first layers (K = S or 1 inputs) are evaluated ON the matrix cores with split operands
+//     [x_hi | x_lo | x_hi | 1 | 1] . [w_hi | w_hi | w_lo | b_hi | b_lo] (one v_mfma_f32_32x32x16_bf16 per 32 x 32 tile,
+//     products exact, 2^-16 relative), in whichever orientation the consumer needs: written to LDS as the bf16 operand of
+//     the second-layer GEMM (head_kernel), or used directly as the A operand of the weight-gradient product (an accumulator
+//     tile IS the operand of a product that sums over its rows: dw_kernel, dx_kernel);
+//   * gradients never leave the registers per tile: W2 gradients (76 / 64 accumulator registers per lane), first-layer and
+//     BN gradients and the output-layer sums are accumulated over all the tiles a workgroup sees and written ONCE, as one
+//     partial per workgroup; finalize_* sums the partials of a set in a fixed order (deterministic) and applies the BN folds.
+// Between kernels only per-row scalars (target action, TD target, mu, dmu) and the bf16 second-layer gradient dZ2
+// (16 KB per agent) go through HBM.
+//
+// Passes (one launch each; "head" = first layer + second-layer GEMM + output layer [+ its backward]):
+//   1 head  target actor(s')                    -> a'                       4 head  critic(s, a), seed 2(q-y)/N -> dZ2c, sums
+//   2 head  target critic(s', a')  -> y = r+g*q                             5 dw    critic: G  += P1^T . dZ2c
+//   3 head  actor(s)               -> mu                                    6 dx    critic: first-layer/BN grads (state, action)
+//   7 head  critic(s, mu), seed -1/N -> dZ2'    8 dx(action cols, transposed) -> dmu
+//   9 head  actor(s), seed dmu*high*(1-t^2) -> dZ2a, sums     10 dw actor     11 dx actor     12 finalize
+// GEMM operands are bf16 (8 significant bits), accumulation / parameters / gradients f32: the same numerics class as
+// avd_learn_shared_bf16 (wide.hip), against which and against the float64 oracle it is tested (tests/test_gpu_fset.py).
+#include "common.h"
+
+namespace avd {
+namespace fset {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float BN_EPS = 1e-3f;  // tf.keras BatchNormalization default epsilon (agent/model.py:28)
+constexpr int TILE = 64, H1 = 256, H2 = 128, HA = 48, NT = 512, VEC = 264;
+#ifndef FSET_EXP
+#define FSET_EXP 0  // timing experiments only (wrong results): 1 no first-layer LDS stores, 2 no GEMM, 4 no output tail, 8 no first layer
+#endif
+
+struct Actor {
+    static constexpr int K = 256, KP = 256, NFT = 8;
+    static constexpr bool critic = false;
+};
+struct Critic {
+    static constexpr int K = 304, KP = 320, NFT = 10;  // 256 state + 48 action features, padded to 10 tiles of 32
+    static constexpr bool critic = true;
+};
+
+// row (M index) of accumulator register i of a 32x32 MFMA result in lane half h; the column is lane & 31
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// relu as one v_med3_f32 (fmaxf also quiets NaNs: two instructions per element)
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- first layer on the matrix cores -------------------------------------------------------------------------------
+// z1[row][f] = sum_k x[row][k] W1[k][f] + b1[f] as ONE 32x32x16 bf16 MFMA with both operands split into bf16 pairs:
+//   k slot      0..3        4..7        8..11       12     13     14 15
+//   input  x:   x_hi        x_lo        x_hi        1      1      0  0        (lane half 0 holds slots 0..7, half 1 8..15)
+//   weight w:   w_hi        w_hi        w_lo        b_hi   b_lo   0  0
+// Every product of two bf16 numbers is exact in f32; what is dropped is x_lo*w_lo and the third bf16 of each split:
+// 2^-16 relative. The same fragment serves as the A or as the B operand (row / column = lane & 31 either way).
+__device__ __forceinline__ bf16x8 make_xf(float x0, float x1, float x2, float x3, int h) {
+    const bf16 a0 = (bf16)x0, a1 = (bf16)x1, a2 = (bf16)x2, a3 = (bf16)x3;
+    const bf16 l0 = (bf16)(x0 - (float)a0), l1 = (bf16)(x1 - (float)a1), l2 = (bf16)(x2 - (float)a2), l3 = (bf16)(x3 - (float)a3);
+    const bf16 one = (bf16)1.f, zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = a0, v[1] = a1, v[2] = a2, v[3] = a3;
+    v[4] = h ? one : l0, v[5] = h ? one : l1, v[6] = h ? zero : l2, v[7] = h ? zero : l3;
+    return v;
+}
+__device__ __forceinline__ bf16x8 make_wf(float w0, float w1, float w2, float w3, float b, int h) {
+    const bf16 a0 = (bf16)w0, a1 = (bf16)w1, a2 = (bf16)w2, a3 = (bf16)w3, bh = (bf16)b;
+    const bf16 l0 = (bf16)(w0 - (float)a0), l1 = (bf16)(w1 - (float)a1), l2 = (bf16)(w2 - (float)a2), l3 = (bf16)(w3 - (float)a3);
+    const bf16 bl = (bf16)(b - (float)bh), zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = h ? l0 : a0, v[1] = h ? l1 : a1, v[2] = h ? l2 : a2, v[3] = h ? l3 : a3;
+    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? zero : a2, v[7] = h ? zero : a3;
+    return v;
+}
+
+// one network's operands (device pointers; `th` already points at the net's block of the slab of set 0)
+struct NetP {
+    const float* th;  // theta or theta_t (+ actor_size for a critic); set stride th_stride
+    const float* st;  // stats or stats_t; set stride st_stride
+    long th_stride, st_stride;
+    int oW1, ob1;     // first (state) layer weights [S][H1] / bias, offsets into th
+    int oWa, oba;     // critic action layer [1][HA] / bias (critic only)
+    int oga, omva;    // critic action-branch BN gamma (th) / moving variance (st): dx_kernel's action-gradient mode
+    const bf16* W2T;  // [sets][H2][KP]  bf16(inv1[f] * W2[f][n]) transposed: head_kernel's resident operand
+    const bf16* W2R;  // [sets][KP][H2]  bf16(W2[f][n]), rows >= K zero: dx_kernel's resident operand (online nets only)
+    const float* vec; // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3
+};
+
+// feature tile `ft` (32 features) of a net's first layer as a weight fragment; tiles >= 8 are the critic's action layer
+template <int S, class NET>
+__device__ __forceinline__ bf16x8 layer1_wf(const NetP& n, const float* th, int ft, int r, int h) {
+    if (NET::critic && ft >= 8) {
+        const int f = 32 * (ft - 8) + r;
+        const bool ok = f < HA;
+        return make_wf(ok ? th[n.oWa + f] : 0.f, 0.f, 0.f, 0.f, ok ? th[n.oba + f] : 0.f, h);
+    }
+    const int f = 32 * ft + r;
+    const float* W = th + n.oW1;
+    return make_wf(W[f], W[H1 + f], W[2 * H1 + f], S > 3 ? W[3 * H1 + f] : 0.f, th[n.ob1 + f], h);
+}
+
+template <int S>
+__device__ __forceinline__ void load_x(const float* xa, int row, float (&x)[4]) {
+    if (S == 4) {
+        const float4 v = *(const float4*)(xa + 4 * row);
+        x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = k < S ? xa[S * row + k] : 0.f;
+    }
+}
+
+// The first-layer input fragments of every batch row, built ONCE per learn call (every pass of the chain and each of the 8
+// waves of a workgroup would otherwise redo the split): out[row][h] = make_xf(x[row], h), 32 bytes per row.
+template <int S>
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, long rows, bf16* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * rows) return;
+    float v[4];
+    load_x<S>(x, (int)(i >> 1), v);
+    *(bf16x8*)(out + 8 * i) = make_xf(v[0], v[1], v[2], v[3], (int)(i & 1));
+}
+
+// ---- operand preparation: one block per (output column n, net, set) ---------------------------------------------------
+struct PrepArgs {
+    avd_mlp_layout L;
+    const float *theta, *stats, *theta_t, *stats_t;
+    bf16* W2T[4];  // net 0 actor, 1 critic, 2 target actor, 3 target critic
+    bf16* W2R[4];  // online nets only
+    float* vec[4];
+};
+__global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
+    __shared__ float red[320];
+    const int n = blockIdx.x, net = blockIdx.y, set = blockIdx.z, f = threadIdx.x;
+    const bool critic = net & 1, target = net >= 2;
+    const avd_mlp_layout& L = a.L;
+    const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
+    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP;
+    const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2, oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
+    float shw = 0.f;
+    if (f < KP) {
+        float w = 0.f, inv = 0.f;
+        if (f < K) {
+            int og, obe, omm, omv, ff = f;
+            if (!critic) og = L.ag1, obe = L.abe1, omm = L.amm1, omv = L.amv1;
+            else if (f < H1) og = L.cgs, obe = L.cbes, omm = L.cmms, omv = L.cmvs;
+            else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, ff = f - H1;
+            inv = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff];
+            const float sh = th[obe + ff] - st[omm + ff] * inv;
+            w = th[oW2 + (long)f * H2 + n];
+            shw = sh * w;
+        }
+        a.W2T[net][((long)set * H2 + n) * KP + f] = (bf16)(inv * w);
+        if (!target) a.W2R[net][((long)set * KP + f) * H2 + n] = (bf16)w;
+    }
+    red[f] = shw;
+    __syncthreads();
+    if (f < 64) red[f] += red[f + 256];  // 320 = 256 + 64
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (f < o) red[f] += red[f + o];
+        __syncthreads();
+    }
+    float* vec = a.vec[net] + (long)set * VEC;
+    const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
+    if (f == 0) {
+        vec[n] = th[ob2 + n] + red[0];
+        const float inv2 = (1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n];
+        vec[H2 + n] = inv2 * th[oW3 + n];
+    }
+    if (n == 0) {  // d3 = b3 + sum_n sh2[n] w3[n]
+        __syncthreads();
+        float v = 0.f;
+        if (f < H2) {
+            const float inv2 = (1.0f / sqrtf(st[omv2 + f] + BN_EPS)) * th[og2 + f];
+            v = (th[obe2 + f] - st[omm2 + f] * inv2) * th[oW3 + f];
+        }
+        red[f] = v;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) {
+            if (f < o) red[f] += red[f + o];
+            __syncthreads();
+        }
+        if (f == 0) vec[2 * H2] = th[ob3] + red[0];
+    }
+}
+
+// ---- head: first layer -> second-layer GEMM -> output layer [-> its backward] ------------------------------------------
+enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4 };
+struct HeadArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const bf16* xf;    // [n_agents][64][2][8] packed first-layer input fragments of the states (pack_x_kernel)
+    const float* act;  // [n_agents][64] the critic's action input (a, a' or mu)
+    const float* r;    // OUT_TD: rewards [n_agents][64]
+    const float* yin;  // HEAD_CRITIC: TD targets; HEAD_ACTOR: dmu
+    const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
+    float* out;        // OUT_*: per-row result
+    bf16* dz;          // HEAD_*: dZ2 [n_agents][64][128]
+    float* part;       // HEAD_*: [grid][2][2][128] sums T1 (seed * p2), T2 (seed * mask) per output column
+    float* part_s;     // HEAD_*: [grid][2][2] sums of the seeds and of the loss terms
+    float gamma, high, inv_n;
+};
+
+// Wave w = (wm, wn): rows [32 wm, +32) x columns [32 wn, +32) of the tile's second layer, transposed orientation
+// (A = resident weights, B = activations from LDS): lane = batch row, registers = 16 output columns, so that the output
+// layer is a per-lane dot product and dZ2 is stored 4 consecutive columns at a time. Two barriers per tile: first-layer
+// image complete; per-row output-layer partials of the 4 column quarters complete.
+template <int S, class NET, int MODE>
+__global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
+    constexpr int K = NET::K, KP = NET::KP, NS = K / 16, LD = KP + 8;  // LD/2 = 4 (mod 8) dwords: conflict-free b128 rows
+    __shared__ __attribute__((aligned(16))) bf16 img[2][TILE * LD];
+    __shared__ float zpart[2][4][TILE];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = w >> 2, wn = w & 3;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const float* th = p.net.th + (long)set * p.net.th_stride;
+
+    bf16x8 w2[NS];
+    {
+        const bf16* src = p.net.W2T + ((long)set * H2 + 32 * wn + r) * KP + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w2[s] = *(const bf16x8*)(src + 16 * s);
+    }
+    const float* vec = p.net.vec + (long)set * VEC;
+    f32x16 b2r;
+    float c3r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = 32 * wn + acc_row(i, h);
+        b2r[i] = vec[n], c3r[i] = vec[H2 + n];
+    }
+    const float d3 = vec[2 * H2];
+    const bf16x8 wf = layer1_wf<S, NET>(p.net, th, w, r, h);
+    bf16x8 wfa = wf;
+    if (NET::critic && w < 2) wfa = layer1_wf<S, NET>(p.net, th, 8 + w, r, h);
+
+    float T1[16], T2[16], Dacc = 0.f, Lacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T1[i] = 0.f, T2[i] = 0.f;
+    const f32x16 zero16 = {};
+    const int row = 32 * wm + r;
+
+    // inputs of a tile, requested one tile ahead (a load issued where it is used costs a full memory latency per tile)
+    bf16x8 nx0 = {}, nx1 = {};
+    float na0 = 0.f, na1 = 0.f, ny = 0.f, nw = 1.f;
+    auto fetch_in = [&](int pi) {
+        const int agent = pi * p.n_sets + set;
+        const bf16x8* xa = (const bf16x8*)p.xf + (long)agent * TILE * 2;
+        nx0 = xa[2 * r + h], nx1 = xa[2 * (32 + r) + h];
+        if (NET::critic && w < 2) na0 = p.act[(long)agent * TILE + r], na1 = p.act[(long)agent * TILE + 32 + r];
+        if (MODE == OUT_TD) ny = p.r[(long)agent * TILE + row];
+        if (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR) ny = p.yin[(long)agent * TILE + row];
+        if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
+    };
+    auto store_l1 = [&](bf16* im, const f32x16& acc, int rw, int f0) {  // relu, bf16, 4 consecutive features per 8-byte store
+        bf16* dst = im + rw * LD + f0 + 4 * h;
+        if (FSET_EXP & 1) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (bf16)relu(acc[4 * g + j]);
+            *(bf16x4*)(dst + 8 * g) = v;
+        }
+    };
+    auto layer1 = [&](bf16* im) {  // the wave's feature tile(s) of all 64 rows, from the prefetched inputs
+        if (FSET_EXP & 8) return;
+        store_l1(im, mfma(wf, nx0, zero16), r, 32 * w);
+        store_l1(im, mfma(wf, nx1, zero16), 32 + r, 32 * w);
+        if (NET::critic && w < 2) {
+            store_l1(im, mfma(wfa, make_xf(na0, 0.f, 0.f, 0.f, h), zero16), r, H1 + 32 * w);
+            store_l1(im, mfma(wfa, make_xf(na1, 0.f, 0.f, 0.f, h), zero16), 32 + r, H1 + 32 * w);
+        }
+    };
+    // Software pipeline, ONE barrier per tile: [GEMM(t) | output-layer partials(t) | first layer(t+1) -> other image] barrier
+    // [output layer + backward(t)]. The barrier publishes both the partials of tile t and the image of tile t+1; images and
+    // partials alternate between two buffers, so nothing written before barrier t+1 is still being read by a slower wave.
+    float cy = 0.f, cw = 1.f;
+    if (j0 < P) {
+        fetch_in(j0);
+        layer1(img[0]);
+        cy = ny, cw = nw;
+        if (j0 + J < P) fetch_in(j0 + J);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
+        const int agent = pi * p.n_sets + set;
+        const float ty = cy, tw = cw;
+        f32x16 acc;
+        auto gemm_part = [&]() {
+            const bf16* arow = img[buf] + (32 * wm + r) * LD + 8 * h;
+            acc = mfma(w2[0], *(const bf16x8*)arow, b2r);  // the folded bias b2' is the C operand of the first step
+#pragma unroll
+            for (int s = 1; s < ((FSET_EXP & 2) ? 1 : NS); ++s) acc = mfma(w2[s], *(const bf16x8*)(arow + 16 * s), acc);
+            float zp = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = relu(acc[i]);
+                zp = fmaf(acc[i], c3r[i], zp);
+            }
+            zp += __shfl_xor(zp, 32);
+            if (h == 0) zpart[buf][wn][row] = zp;
+        };
+        auto l1_part = [&]() {
+            if (pi + J < P) {
+                layer1(img[buf ^ 1]);
+                cy = ny, cw = nw;
+                if (pi + 2 * J < P) fetch_in(pi + 2 * J);
+            }
+        };
+        // the two waves of a SIMD (w and w + 4: wm = 0 / 1) run the two halves in opposite order: one streams its first-layer
+        // tile into LDS (VALU + the slow LDS store path) while the other holds the matrix pipe, then they swap
+        if (wm == 0) {
+            l1_part();
+            gemm_part();
+        } else {
+            gemm_part();
+            l1_part();
+        }
+        __syncthreads();
+        const float z = d3 + ((zpart[buf][0][row] + zpart[buf][1][row]) + (zpart[buf][2][row] + zpart[buf][3][row]));
+        const long ri = (long)agent * TILE + row;
+        if (FSET_EXP & 4) {
+            if (z == 12345.f) p.out[ri] = acc[0];
+            continue;
+        }
+        if (MODE == OUT_TANH) {
+            if (wn == 0) {
+                const float o = tanhf(z) * p.high;
+                if (h == 0) p.out[ri] = o;
+            }
+        } else if (MODE == OUT_TD) {
+            if (wn == 0 && h == 0) p.out[ri] = ty + p.gamma * z;
+        } else {
+            float g3, loss;
+            if (MODE == HEAD_CRITIC) {
+                const float diff = z - ty;
+                g3 = 2.f * diff * p.inv_n * tw, loss = diff * diff;
+            } else if (MODE == HEAD_CONST) {
+                g3 = -p.inv_n * tw, loss = z;
+            } else {
+                const float t = tanhf(z);
+                g3 = ty * p.high * (1.f - t * t), loss = 0.f;
+            }
+            // dZ2 row-major: the lane holds columns 8g + 4h + j of its row; the two lanes of a row trade groups (1 <-> 0', 3 <-> 2')
+            // so that each owns 8 consecutive columns twice: 16-byte stores, 32 contiguous bytes per row and instruction
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const bool m = acc[i] > 0.f;
+                    if (MODE != HEAD_CONST) {
+                        T1[i] = fmaf(g3, acc[i], T1[i]);
+                        T2[i] += m ? g3 : 0.f;
+                    }
+                    v[j] = (bf16)(m ? g3 * c3r[i] : 0.f);
+                }
+                const uint2 u = __builtin_bit_cast(uint2, v);
+                pk[g][0] = u.x, pk[g][1] = u.y;
+            }
+            bf16* dst = p.dz + ri * H2 + 32 * wn + 8 * h;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {  // after the swap: h = 0 holds columns 16gg + [0, 8), h = 1 holds 16gg + [8, 16)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                uint4 o;
+                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                *(uint4*)(dst + 16 * gg) = o;
+            }
+            if (wn == 0 && h == 0) Dacc += g3, Lacc += loss;
+        }
+    }
+    if (MODE >= HEAD_CRITIC) {
+        // one partial per workgroup: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                T1[i] += __shfl_xor(T1[i], o);
+                T2[i] += __shfl_xor(T2[i], o);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            Dacc += __shfl_xor(Dacc, o);
+            Lacc += __shfl_xor(Lacc, o);
+        }
+        float* pt = p.part + ((long)blockIdx.x * 2 + wm) * 2 * H2;
+        if (MODE != HEAD_CONST && r == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = 32 * wn + acc_row(i, h);
+                pt[n] = T1[i], pt[H2 + n] = T2[i];
+            }
+        }
+        if (wn == 0 && lane == 0) {
+            p.part_s[((long)blockIdx.x * 2 + wm) * 2] = Dacc;
+            p.part_s[((long)blockIdx.x * 2 + wm) * 2 + 1] = Lacc;
+        }
+    }
+}
+
+// ---- dw: G[f][n] += sum_rows P1[row][f] dZ2[row][n] over all tiles of the workgroup -------------------------------------
+struct DwArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const bf16* xf;  // packed state fragments (pack_x_kernel)
+    const float* act;
+    const bf16* dz;
+    float* partG;  // [grid][KP][128]
+};
+// Wave w = (fg, wn): feature tiles fg*NFT/2 .. of column quarter wn. The first-layer tile is computed with the batch rows as
+// the M index (result: feature on the lane, rows in the registers) and used straight as the A operand of G = P1^T . dZ2
+// (k order permuted, tools/probes/mfma_layout.hip); the dZ2 tile goes through LDS (row stride 320 B: conflict-free for
+// ds_read_b64_tr_b16, which delivers it reduction-contiguous in exactly that order). One barrier per tile.
+template <int S, class NET>
+__global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
+    constexpr int KP = NET::KP, NFW = NET::NFT / 2, LDZ = 160;
+    __shared__ __attribute__((aligned(16))) bf16 dzimg[2][TILE * LDZ];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wn = w & 3, fg = w >> 2;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const float* th = p.net.th + (long)set * p.net.th_stride;
+    bf16x8 wf[NFW];
+    f32x16 G[NFW];
+    const f32x16 zero16 = {};
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) wf[i] = layer1_wf<S, NET>(p.net, th, fg * NFW + i, r, h), G[i] = zero16;
+    const bool act_tiles = NET::critic && fg == 1;  // feature tiles 8, 9 (i = 3, 4) take the action as their input
+
+    const int srow = tid >> 3, sch = tid & 7;  // staging: 64 rows x 8 chunks of 32 bytes
+    uint4 d0 = {}, d1 = {};
+    auto fetch = [&](int agent) {
+        const uint4* src = (const uint4*)(p.dz + ((long)agent * TILE + srow) * H2 + 16 * sch);
+        d0 = src[0], d1 = src[1];
+    };
+    auto stage = [&](int buf) {
+        uint4* dst = (uint4*)(dzimg[buf] + srow * LDZ + 16 * sch);
+        dst[0] = d0, dst[1] = d1;
+    };
+    bf16x8 nx0 = {}, nx1 = {};  // the next tile's inputs, requested a tile ahead like its dZ2
+    float na0 = 0.f, na1 = 0.f;
+    auto fetch_x = [&](int agent) {
+        const bf16x8* xa = (const bf16x8*)p.xf + (long)agent * TILE * 2;
+        nx0 = xa[2 * r + h], nx1 = xa[2 * (32 + r) + h];
+        if (act_tiles) na0 = p.act[(long)agent * TILE + r], na1 = p.act[(long)agent * TILE + 32 + r];
+    };
+    if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0);
+    __syncthreads();
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    int buf = 0;
+    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
+        const bool more = pi + J < P;
+        const bf16x8 xs0 = nx0, xs1 = nx1;
+        const bf16x8 xa0 = make_xf(na0, 0.f, 0.f, 0.f, h), xa1 = make_xf(na1, 0.f, 0.f, 0.f, h);
+        if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
+        bf16x8 bfr[2][2];
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int R0 = 32 * rh + 16 * s + 8 * hf + 4 * (g4 >> 1);
+                    const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(dzimg[buf] + (R0 + q) * LDZ + 32 * wn + 16 * (g4 & 1) + 4 * pp));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bfr[rh][s][4 * hf + j] = t[j];
+                }
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const bool at = act_tiles && i >= 3;
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const bf16x8 xf = rh ? (at ? xa1 : xs1) : (at ? xa0 : xs0);
+                const f32x16 p1 = mfma(xf, wf[i], zero16);  // [row][feature]: feature on the lane
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 xo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xo[j] = (bf16)relu(p1[8 * s + j]);
+                    G[i] = mfma(xo, bfr[rh][s], G[i]);
+                }
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+        float* dst = p.partG + ((long)blockIdx.x * KP + 32 * (fg * NFW + i)) * H2 + 32 * wn + r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G[i][k];
+    }
+}
+
+// ---- dx: dC = dZ2 . W2^T, BN/ReLU backward of the first layer and its parameter sums; or the action gradient -----------
+struct DxArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const bf16* xf;  // packed state fragments (pack_x_kernel), feature tiles < 8
+    const float* x;  // feature tiles >= 8: the per-row action input [n_agents][64]
+    const bf16* dz;
+    float* partU;    // [grid][2 rh][2 h][KP][2]   sum dC, sum dC * p1 per feature
+    float* partV;    // [grid][2 rh][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
+    float* dmu;      // ACTGRAD: [n_agents][64], accumulated with atomics (two addends per row), zeroed by the caller
+};
+// Wave w = (rh, fg): row half rh of feature tiles FT0 + fg + 4 i. Resident: the raw W2 rows of its tiles as B fragments
+// (reduction over the 128 columns). dC comes out [row][feature] (feature on the lane), like the recomputed first layer:
+// the per-feature sums over rows are per-lane sums over the registers, and the masked gradient tile is the A operand of
+// V = (dC*mask)^T . [x_hi | x_lo | 1], which yields dW1 and db1 (k order permuted as in dw_kernel; the [k][row] image of the
+// inputs is the wave's own LDS area).
+// ACTGRAD (critic action tiles, pass 8): operands swapped -> [feature][row] with the row on the lane; per lane
+// dmu[row] = sum_f dC * inv_a[f] * (pa > 0) * wa[f] over its 16 features, the other 48 arrive by shuffle / atomics.
+template <int S, class NET, int FT0, int NFTOT, bool ACTGRAD>
+__global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
+    constexpr int KP = NET::KP, NF = (NFTOT + 3) / 4, LDZ = 136;  // 272-byte rows: conflict-free b128 row reads
+    constexpr bool ACT_IN = FT0 >= 8;                               // this launch's first layer reads the action
+    __shared__ __attribute__((aligned(16))) bf16 dzimg[2][TILE * LDZ];
+    __shared__ __attribute__((aligned(16))) bf16 xt[8][2][32 * 32];  // per wave, per buffer: [k column][row of its half]
+    __shared__ float ctab[64][4];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, rh = w & 1, fg = w >> 1;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const float* th = p.net.th + (long)set * p.net.th_stride;
+    const f32x16 zero16 = {};
+    bf16x8 w2[NF][8], wf[NF];
+    f32x16 V[NF];
+    float U0[NF], U1[NF];
+    bool valid[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        valid[i] = fg + 4 * i < NFTOT;
+        const int ft = FT0 + (valid[i] ? fg + 4 * i : 0);
+        const bf16* src = p.net.W2R + ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w2[i][s] = *(const bf16x8*)(src + 16 * s);
+        wf[i] = layer1_wf<S, NET>(p.net, th, ft, r, h);
+        V[i] = zero16, U0[i] = 0.f, U1[i] = 0.f;
+    }
+    if (ACTGRAD) {
+        if (tid < 64) {
+            const bool ok = tid < HA;
+            const float* st = p.net.st + (long)set * p.net.st_stride;
+            const float wa = ok ? th[p.net.oWa + tid] : 0.f, ba = ok ? th[p.net.oba + tid] : 0.f;
+            const float ia = ok ? (1.0f / sqrtf(st[p.net.omva + tid] + BN_EPS)) * th[p.net.oga + tid] : 0.f;
+            ctab[tid][0] = wa, ctab[tid][1] = ba, ctab[tid][2] = ia * wa, ctab[tid][3] = 0.f;
+        }
+    } else {
+        for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
+            const int k = (i >> 5) & 31;
+            xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
+        }
+    }
+    const int srow = tid >> 3, sch = tid & 7;
+    uint4 d0 = {}, d1 = {};
+    auto fetch = [&](int agent) {
+        const uint4* src = (const uint4*)(p.dz + ((long)agent * TILE + srow) * H2 + 16 * sch);
+        d0 = src[0], d1 = src[1];
+    };
+    auto stage = [&](int buf) {
+        uint4* dst = (uint4*)(dzimg[buf] + srow * LDZ + 16 * sch);
+        dst[0] = d0, dst[1] = d1;
+    };
+    float an = 0.f;      // ACT_IN: the row's action input
+    bf16x8 xfn = {};     // the row's input fragment [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1)
+    auto fetch_x = [&](int agent) {
+        if (ACT_IN) {
+            an = p.x[(long)agent * TILE + 32 * rh + r];
+            xfn = make_xf(an, 0.f, 0.f, 0.f, h);
+        } else {
+            xfn = ((const bf16x8*)p.xf)[((long)agent * TILE + 32 * rh + r) * 2 + h];
+        }
+    };
+    auto stage_x = [&](int buf) {  // [k][row] image of [x_hi | x_lo] of the wave's 32 rows: the h = 0 fragment, transposed
+        if (!ACTGRAD && h == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xt[w][buf][k * 32 + r] = xfn[k];
+        }
+    };
+    __syncthreads();  // the zero / ones fill above before the first stage_x
+    if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0), stage_x(0);
+    __syncthreads();
+    int buf = 0;
+    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
+        const int agent = pi * p.n_sets + set;
+        const bool more = pi + J < P;
+        const bf16x8 xf = xfn;
+        const float mu_r = an;
+        if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
+        bf16x8 dzf[8];
+        const bf16* arow = dzimg[buf] + (32 * rh + r) * LDZ + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dzf[s] = *(const bf16x8*)(arow + 16 * s);
+        if (ACTGRAD) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                if (!valid[i]) continue;
+                f32x16 dct = zero16;  // [feature][row]: row on the lane
+#pragma unroll
+                for (int s = 0; s < 8; ++s) dct = mfma(w2[i][s], dzf[s], dct);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 c = *(const float4*)ctab[32 * (fg + 4 * i) + acc_row(k, h)];
+                    const float pa = fmaf(mu_r, c.x, c.y);
+                    sum += pa > 0.f ? dct[k] * c.z : 0.f;
+                }
+            }
+            sum += __shfl_xor(sum, 32);
+            if (h == 0 && valid[0]) atomicAdd(&p.dmu[(long)agent * TILE + 32 * rh + r], sum);
+        } else {
+            bf16x8 xb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
+                const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                if (!valid[i]) continue;
+                f32x16 dc = zero16;  // [row][feature]: feature on the lane
+#pragma unroll
+                for (int s = 0; s < 8; ++s) dc = mfma(dzf[s], w2[i][s], dc);
+                const f32x16 p1 = mfma(xf, wf[i], zero16);
+                float u0 = 0.f, u1 = 0.f;
+                bf16x8 va[2];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float pr = relu(p1[k]);
+                    u0 += dc[k];
+                    u1 = fmaf(dc[k], pr, u1);
+                    va[k >> 3][k & 7] = (bf16)(pr > 0.f ? dc[k] : 0.f);
+                }
+                U0[i] += u0, U1[i] += u1;
+                V[i] = mfma(va[0], xb[0], V[i]);
+                V[i] = mfma(va[1], xb[1], V[i]);
+            }
+        }
+        if (more) stage(buf ^ 1), stage_x(buf ^ 1);
+        __syncthreads();
+    }
+    if (!ACTGRAD) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if (!valid[i]) continue;
+            const int ft = FT0 + fg + 4 * i;
+            float* pu = p.partU + ((((long)blockIdx.x * 2 + rh) * 2 + h) * KP + 32 * ft + r) * 2;
+            pu[0] = U0[i], pu[1] = U1[i];
+            if (r < 16) {
+                float* pv = p.partV + (((long)blockIdx.x * 2 + rh) * KP + 32 * ft) * 16 + r;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[i][k];
+            }
+        }
+    }
+}
+
+// ---- finalize: sum the workgroups' partials of a set (fixed order), apply the BN folds, write the gradient slab -------
+struct FinArgs {
+    avd_mlp_layout L;
+    int n_sets, J, S;  // J = workgroups per set; workgroup j of set m has block index j * n_sets + m
+    const float *theta, *stats;
+    const float* partH[2];   // [0] actor (pass 9), [1] critic (pass 4)
+    const float* partHs[2];
+    const float* partLa;     // pass 7's part_s (actor loss sums)
+    const float* partU[2];
+    const float* partV[2];
+    const float* partG[2];
+    float* grads;   // [n_sets][theta_size]
+    float* losses;  // [n_sets][2] or NULL
+    float inv_n;
+};
+// One item per 32 lanes: output column n (items 0..127: output layer, BN2, b2) or first-layer feature f (items 128..):
+// lane jl sums the partials of workgroups jl, jl + 32, .. of the set, then a fixed shuffle tree combines the 32 lanes.
+__global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
+    const int set = blockIdx.x, net = blockIdx.y, tid = threadIdx.x, jl = tid & 31;
+    const int item = blockIdx.z * 16 + (tid >> 5);
+    const bool critic = net;
+    const avd_mlp_layout& L = a.L;
+    const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = a.stats + (long)set * L.stats_size;
+    float* g = a.grads + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP;
+    auto allsum = [&](float v) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    if (item < H2) {
+        const int n = item;
+        const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
+        const int oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3, ob2 = critic ? L.cb2 : L.ab2;
+        float T1 = 0.f, T2 = 0.f, D = 0.f, Lc = 0.f, La = 0.f;
+        for (int j = jl; j < a.J; j += 32) {
+            const long wg = (long)j * a.n_sets + set;
+            for (int wm = 0; wm < 2; ++wm) {
+                const float* pt = a.partH[net] + (wg * 2 + wm) * 2 * H2;
+                T1 += pt[n], T2 += pt[H2 + n];
+                D += a.partHs[net][(wg * 2 + wm) * 2];
+                if (critic && n == 0) Lc += a.partHs[1][(wg * 2 + wm) * 2 + 1], La += a.partLa[(wg * 2 + wm) * 2 + 1];
+            }
+        }
+        T1 = allsum(T1), T2 = allsum(T2), D = allsum(D);
+        if (critic && n == 0) Lc = allsum(Lc), La = allsum(La);
+        if (jl == 0) {
+            const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
+            const float sh2 = th[obe2 + n] - mm2 * inv2, w3 = th[oW3 + n];
+            g[oW3 + n] = inv2 * T1 + sh2 * D;
+            g[obe2 + n] = w3 * D;
+            g[og2 + n] = w3 * rs2 * (T1 - mm2 * D);
+            g[ob2 + n] = inv2 * w3 * T2;
+            if (n == 0) g[ob3] = D;
+            if (critic && n == 0 && a.losses) a.losses[2 * set] = Lc * a.inv_n, a.losses[2 * set + 1] = -La * a.inv_n;
+        }
+        return;
+    }
+    const int f = item - H2;
+    if (f >= K) return;
+    float U0 = 0.f, U1 = 0.f, V[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) V[k] = 0.f;
+    for (int j = jl; j < a.J; j += 32) {
+        const long wg = (long)j * a.n_sets + set;
+        for (int rh = 0; rh < 2; ++rh) {
+            for (int h = 0; h < 2; ++h) {
+                const float* pu = a.partU[net] + ((((wg * 2 + rh) * 2 + h) * KP) + f) * 2;
+                U0 += pu[0], U1 += pu[1];
+            }
+            const float* pv = a.partV[net] + ((wg * 2 + rh) * KP + f) * 16;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) V[k] += pv[k];
+        }
+    }
+    U0 = allsum(U0), U1 = allsum(U1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) V[k] = allsum(V[k]);
+    if (jl == 0) {
+        int og, obe, omm, omv, oW, ob, ff = f, ld = H1, sin = a.S;
+        if (!critic) og = L.ag1, obe = L.abe1, omm = L.amm1, omv = L.amv1, oW = L.aW1, ob = L.ab1;
+        else if (f < H1) og = L.cgs, obe = L.cbes, omm = L.cmms, omv = L.cmvs, oW = L.cWs, ob = L.cbs;
+        else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, oW = L.cWa, ob = L.cba, ff = f - H1, ld = HA, sin = 1;
+        const float rs1 = 1.0f / sqrtf(st[omv + ff] + BN_EPS), inv1 = rs1 * th[og + ff], mm1 = st[omm + ff];
+        g[obe + ff] = U0;
+        g[og + ff] = rs1 * (U1 - mm1 * U0);
+        g[ob + ff] = inv1 * V[8];
+        for (int k = 0; k < sin; ++k) g[oW + k * ld + ff] = inv1 * (V[k] + V[4 + k]);
+    }
+}
+// W2 gradients: dW2[f][n] = inv1[f] * G[f][n] + sh1[f] * db2[n] (db2 read back from the slab finalize_small wrote)
+__global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
+    const int f = blockIdx.x, set = blockIdx.y, net = blockIdx.z, n = threadIdx.x;
+    const bool critic = net;
+    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP;
+    if (f >= K) return;
+    const avd_mlp_layout& L = a.L;
+    const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = a.stats + (long)set * L.stats_size;
+    float* g = a.grads + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    int og, obe, omm, omv, ff = f;
+    if (!critic) og = L.ag1, obe = L.abe1, omm = L.amm1, omv = L.amv1;
+    else if (f < H1) og = L.cgs, obe = L.cbes, omm = L.cmms, omv = L.cmvs;
+    else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, ff = f - H1;
+    const float inv1 = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff], sh1 = th[obe + ff] - st[omm + ff] * inv1;
+    float G = 0.f;
+    for (int j = 0; j < a.J; ++j) G += a.partG[net][(((long)j * a.n_sets + set) * KP + f) * H2 + n];
+    const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
+    g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+struct Plan {
+    int grid, J;
+    size_t W2T[4], W2R[2], vec[4], a2, y, mu, dmu, dz, xfs, xfs2, partH[2], partHs[3], partU[2], partV[2], partG[2], total;
+};
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+static Plan make_plan(int n_agents, int n_sets) {
+    Plan pl;
+    const int P = n_agents / n_sets;
+    int J = cu_count() / n_sets;  // one 512-thread workgroup per CU, every workgroup bound to one set
+    if (J < 1) J = 1;
+    if (J > P) J = P;
+    pl.J = J, pl.grid = J * n_sets;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    for (int i = 0; i < 4; ++i) {
+        const int KP = (i & 1) ? Critic::KP : Actor::KP;
+        pl.W2T[i] = take(sizeof(bf16) * (size_t)n_sets * H2 * KP);
+        pl.vec[i] = take(sizeof(float) * (size_t)n_sets * VEC);
+        if (i < 2) pl.W2R[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2);
+    }
+    const size_t rows = (size_t)n_agents * TILE;
+    pl.a2 = take(4 * rows), pl.y = take(4 * rows), pl.mu = take(4 * rows), pl.dmu = take(4 * rows);
+    pl.dz = take(sizeof(bf16) * rows * H2);
+    pl.xfs = take(sizeof(bf16) * rows * 16), pl.xfs2 = take(sizeof(bf16) * rows * 16);
+    for (int i = 0; i < 2; ++i) {
+        const int KP = i ? Critic::KP : Actor::KP;
+        pl.partH[i] = take(4 * (size_t)pl.grid * 2 * 2 * H2);
+        pl.partU[i] = take(4 * (size_t)pl.grid * 2 * 2 * KP * 2);
+        pl.partV[i] = take(4 * (size_t)pl.grid * 2 * KP * 16);
+        pl.partG[i] = take(4 * (size_t)pl.grid * KP * H2);
+    }
+    for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 2 * 2);
+    pl.total = o;
+    return pl;
+}
+static int check_fset(const avd_mlp_layout* L, int n_agents, int n_sets, const char* who) {
+    AVD_REQUIRE(L, "%s: null layout", who);
+    if (L->H1 != H1 || L->H2 != H2 || L->Ha != HA || L->A != 1 || (L->S != 3 && L->S != 4) || L->B != TILE) {
+        set_error("%s: serves the reference widths only (layer1 256, layer2 128, action layer 48, A = 1, S in {3, 4}, B = 64); "
+                  "got H1=%d H2=%d Ha=%d A=%d S=%d B=%d (avd_learn_shared_bf16 takes other widths)",
+                  who, L->H1, L->H2, L->Ha, L->A, L->S, L->B);
+        return AVD_E_UNSUPPORTED;
+    }
+    AVD_REQUIRE(n_sets > 0 && n_sets <= 64 && n_agents > 0 && n_agents % n_sets == 0, "%s: n_agents=%d n_sets=%d", who, n_agents,
+                n_sets);
+    return AVD_OK;
+}
+
+template <int S>
+static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* theta, const float* stats, const float* theta_t,
+               const float* stats_t, const float* s, const float* a, const float* r, const float* s2, const float* aw, float gamma,
+               float high, float* grads, float* losses, unsigned char* ws, const Plan& pl, hipStream_t st) {
+    PrepArgs pa;
+    pa.L = L, pa.theta = theta, pa.stats = stats, pa.theta_t = theta_t, pa.stats_t = stats_t;
+    NetP net[4];
+    for (int i = 0; i < 4; ++i) {
+        const bool critic = i & 1, target = i >= 2;
+        pa.W2T[i] = (bf16*)(ws + pl.W2T[i]), pa.vec[i] = (float*)(ws + pl.vec[i]);
+        pa.W2R[i] = i < 2 ? (bf16*)(ws + pl.W2R[i]) : nullptr;
+        NetP& n = net[i];
+        n.th = (target ? theta_t : theta) + (critic ? L.actor_size : 0), n.st = target ? stats_t : stats;
+        n.th_stride = L.theta_size, n.st_stride = L.stats_size;
+        n.oW1 = critic ? L.cWs : L.aW1, n.ob1 = critic ? L.cbs : L.ab1;
+        n.oWa = critic ? L.cWa : 0, n.oba = critic ? L.cba : 0, n.oga = critic ? L.cga : 0, n.omva = critic ? L.cmva : 0;
+        n.W2T = pa.W2T[i], n.W2R = pa.W2R[i], n.vec = pa.vec[i];
+    }
+    hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
+    const long nrows = (long)n_agents * TILE;
+    bf16 *xfs = (bf16*)(ws + pl.xfs), *xfs2 = (bf16*)(ws + pl.xfs2);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, nrows, xfs);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, nrows, xfs2);
+    const int P = n_agents / n_sets;
+    const float inv_n = 1.0f / ((float)P * TILE);
+    float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
+    bf16* dz = (bf16*)(ws + pl.dz);
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    const dim3 grid(pl.grid), block(NT);
+    HeadArgs h;
+    h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.dz = dz;
+    auto head = [&](auto kern, int ni, const bf16* x, const float* act, const float* rr, const float* yin, float* out, float* part,
+                    float* part_s) {
+        h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
+        hipLaunchKernelGGL(kern, grid, block, 0, st, h);
+    };
+    DwArgs dw;
+    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.dz = dz;
+    DxArgs dx;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.dz = dz, dx.dmu = dmu;
+    // 1-2: targets
+    head(head_kernel<S, Actor, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+    head(head_kernel<S, Critic, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+    // 3: mu (independent of the critic passes)
+    head(head_kernel<S, Actor, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+    // 4-6: critic loss and gradients
+    head(head_kernel<S, Critic, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    dw.net = net[1], dw.xf = xfs, dw.act = a, dw.partG = F(pl.partG[1]);
+    hipLaunchKernelGGL((dw_kernel<S, Critic>), grid, block, 0, st, dw);
+    dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]);
+    dx.xf = xfs, dx.x = nullptr;
+    hipLaunchKernelGGL((dx_kernel<S, Critic, 0, 8, false>), grid, block, 0, st, dx);
+    dx.x = a;
+    hipLaunchKernelGGL((dx_kernel<S, Critic, 8, 2, false>), grid, block, 0, st, dx);
+    // 7-8: actor loss through the critic, gradient w.r.t. the action
+    head(head_kernel<S, Critic, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
+    (void)hipMemsetAsync(dmu, 0, sizeof(float) * (size_t)n_agents * TILE, st);
+    dx.x = mu;
+    hipLaunchKernelGGL((dx_kernel<S, Critic, 8, 2, true>), grid, block, 0, st, dx);
+    // 9-11: actor gradients
+    head(head_kernel<S, Actor, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
+    dw.net = net[0], dw.xf = xfs, dw.act = nullptr, dw.partG = F(pl.partG[0]);
+    hipLaunchKernelGGL((dw_kernel<S, Actor>), grid, block, 0, st, dw);
+    dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.x = nullptr;
+    hipLaunchKernelGGL((dx_kernel<S, Actor, 0, 8, false>), grid, block, 0, st, dx);
+    // 12: finalize
+    FinArgs fa;
+    fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
+    fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]);
+    for (int i = 0; i < 2; ++i)
+        fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
+        fa.partG[i] = F(pl.partG[i]);
+    hipLaunchKernelGGL(finalize_small_kernel, dim3(n_sets, 2, (H2 + Critic::K + 15) / 16), dim3(512), 0, st, fa);
+    hipLaunchKernelGGL(finalize_w2_kernel, dim3(Critic::K, n_sets, 2), dim3(H2), 0, st, fa);
+    return check_launch("avd_learn_set_fused_bf16");
+}
+
+}  // namespace fset
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_learn_set_fused_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes) {
+    int rc = fset::check_fset(lay, n_agents, n_sets, "avd_learn_set_fused_workspace");
+    if (rc) return rc;
+    AVD_REQUIRE(bytes, "avd_learn_set_fused_workspace: null pointer");
+    *bytes = fset::make_plan(n_agents, n_sets).total;
+    return AVD_OK;
+}
+
+extern "C" int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                                        const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                                        const float* s2, const float* agent_weight, float gamma, float high, float* grads,
+                                        float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = fset::check_fset(lay, n_agents, n_sets, "avd_learn_set_fused_bf16");
+    if (rc) return rc;
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads && workspace,
+                "avd_learn_set_fused_bf16: null pointer");
+    const fset::Plan pl = fset::make_plan(n_agents, n_sets);
+    AVD_REQUIRE(workspace_bytes >= pl.total, "avd_learn_set_fused_bf16: workspace %zu B < %zu B", workspace_bytes, pl.total);
+    // (padding floats of the slab are never written by finalize: keep them zero like every other gradient producer)
+    (void)hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream);
+    if (lay->S == 4)
+        return fset::run<4>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
+                            losses, (unsigned char*)workspace, pl, (hipStream_t)stream);
+    return fset::run<3>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads, losses,
+                        (unsigned char*)workspace, pl, (hipStream_t)stream);
+}

@@ -112,18 +112,20 @@ class VecTrainer:
         f32 = dict(dtype=torch.float32, device=self.device)
         # Shared weight sets: "per_agent" = the f32 LDS-resident kernel per agent + fed_sum (exact f32, widths up to
         # 256); "batched" = one learn over each set's P x 64 rows as bf16 MFMA GEMMs (csrc/wide.hip; any width multiple
-        # of 64, e.g. BASELINE config 5's 1024). Default: per_agent where it exists.
+        # of 64, e.g. BASELINE config 5's 1024); "fused" = the same quantity at the reference widths as persistent
+        # register-resident-weight kernels (csrc/fset.hip; bf16 operands, deterministic, agent-major batches).
+        # Default: per_agent where it exists.
         lay = self.agents.lay
         fits = lay.H2 <= 256
         self.shared_engine = shared_engine or ("batched" if (self.shared and not fits) else "per_agent")
-        if self.shared_engine not in ("per_agent", "batched"):
+        if self.shared_engine not in ("per_agent", "batched", "fused"):
             raise ValueError(f"shared_engine={shared_engine!r}")
-        if self.shared_engine == "batched" and not self.shared:
-            raise ValueError("the batched learner needs shared weight sets (interfrl + gradients, every step federated)")
+        if self.shared_engine in ("batched", "fused") and not self.shared:
+            raise ValueError("the batched learners need shared weight sets (interfrl + gradients, every step federated)")
         self.actor_out = torch.zeros(n_agents, self.A, **f32)
         self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)
-        batched = self.shared and self.shared_engine == "batched"  # no per-agent gradient slab (188 GB at hidden 1024)
+        batched = self.shared and self.shared_engine in ("batched", "fused")  # no per-agent gradient slab (188 GB at hidden 1024)
         self.grads = None if batched else torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
         self.losses = torch.zeros(n_agents, 2, **f32)
         self.ep_reward = torch.zeros(self.P, self.M, **f32)  # float32 accumulators (trainer.py:249, 321)
@@ -261,7 +263,7 @@ class VecTrainer:
             self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,
                                     timers=self.timers)
             return
-        if self.shared and self.shared_engine == "batched":
+        if self.shared and self.shared_engine in ("batched", "fused"):
             weights = None
             if is_weighted_fed_enabled(conf, ep):
                 if self.fed_weights is None or self.fed_weights[0] != ep:
@@ -283,11 +285,16 @@ class VecTrainer:
             self.set_grads = torch.empty(M, self.agents.lay.theta_size, dtype=torch.float32, device=self.device)
             self.set_losses = torch.zeros(M, 2, dtype=torch.float32, device=self.device)
         rw = wsum = None
-        if weights is not None:  # [P, M] -> per-row factors w_p * P / sum_p w_p, set-major (federated.py:99-118)
+        if weights is not None:  # [P, M] -> factors w_p * P / sum_p w_p (federated.py:99-118)
             wsum = weights.sum(dim=0)  # [M]
-            rw = (weights * (float(P) / wsum)).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()
-        self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses,
-                                 row_weight=rw)
+        if self.shared_engine == "fused":  # agent-major batches as sampled, one factor per agent
+            aw = None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous()
+            self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw)
+        else:
+            if weights is not None:  # per-row factors, set-major
+                rw = (weights * (float(P) / wsum)).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()
+            self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses,
+                                     row_weight=rw)
         if self.group is not None:
             from .dist import exchange_fed_sums
             # local (weighted) mean -> local (weighted) sum over platoons, all-reduce, divide by the global count / weight

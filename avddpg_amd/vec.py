@@ -319,6 +319,25 @@ class AgentGroup:
              self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
+    def learn_set_fused(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None):
+        """Trainer.learn + federated mean for agents that SHARE this group's ``n_sets`` weight sets, at the reference
+        widths, as persistent register-resident-weight kernels (csrc/fset.hip). Batches are AGENT-MAJOR as sampled
+        (agent v = p*n_sets + m uses set m): s, s2 [n_agents, B, S], a [n_agents, B(, 1)], r [n_agents, B].
+        agent_weight [n_agents] (optional): w_p * P / sum(w) per agent = the weighted federated mean.
+        Returns the mean gradient per set [n_sets, theta_size]."""
+        import ctypes
+        if grads is None:
+            grads = torch.empty(self.n_sets, self.lay.theta_size, dtype=torch.float32, device=self.device)
+        need = ctypes.c_size_t(0)
+        call("avd_learn_set_fused_workspace", self._layp, n_agents, self.n_sets, ctypes.byref(need))
+        ws = getattr(self, "_fset_ws", None)
+        if ws is None or ws.numel() < need.value:
+            ws = self._fset_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        call("avd_learn_set_fused_bf16", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
+             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma,
+             self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
+        return grads
+
     def actor_shared(self, states_set_major, n_agents, out=None):
         """actor(state) for agents sharing this group's weight sets as one bf16 GEMM chain per set (csrc/wide.hip):
         states [n_sets, rows, S] set-major, tightly packed -> [n_sets, rows]."""

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
     ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
-    ap.add_argument("--engine", choices=["per_agent", "batched"], default=None,
+    ap.add_argument("--engine", choices=["per_agent", "batched", "fused"], default=None,
                     help="interfrl: per_agent = f32 LDS-resident learn kernel per agent + federated sum; batched = one "
                          "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist)")
     ap.add_argument("--hidden", type=int, default=None,
@@ -146,7 +146,8 @@ def main():
                             seed=1 + rank, pipeline_chunks=args.chunks,
                             fused_update=(args.mode == "nofrl" and not args.no_fused),
                             shared_engine=args.engine if args.mode == "interfrl" else None)
-    batched = vt.shared and vt.shared_engine == "batched"
+    batched = vt.shared and vt.shared_engine in ("batched", "fused")
+    fset = vt.shared and vt.shared_engine == "fused"
     # synthetic steady state: replay rings full of random-init-platoon-like rows
     ring = vt.replay.ring
     chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
@@ -226,7 +227,10 @@ def main():
         H1, H2, KC, rows = lay.H1, lay.H2, lay.H1 + lay.Ha, 64 * n_agents
         flops = 2.0 * rows * H2 * ((2 * H1 + 3 * KC) + (KC + H1) + (KC + lay.Ha + H1))  # actor fwd x2, critic fwd x3
         learn_s = stage_ms["learn"] / 1e3
-        roofs.append({"kernel": "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)", "bound": "mfma",
+        if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
+            flops = flop_per_sample * 64 * n_agents
+        roofs.append({"kernel": ("avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x4 persistent kernels + finalize)" if fset else
+                                 "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)"), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})
     else:
@@ -293,7 +297,9 @@ def main():
                          f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
                          (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
                           "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else
-                         ("batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
+                         ("fused shared-set learner (avd_learn_set_fused_bf16: second-layer weights resident in registers, first layers on "
+                           "the matrix cores, per-workgroup gradient partials) + Adam/Polyak on the sets" if fset else
+                          "batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
             "kernels": [r for r in (roof_learn, roof_upd) if r],
         }
         if world == 1 and not args.no_cpu_baseline:

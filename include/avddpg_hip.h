@@ -254,6 +254,21 @@ int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, c
                           const float* s2, const float* row_weight, float gamma, float high, float* grads, float* losses,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same quantity -- Trainer.learn (workers/trainer.py:472-508) + federated mean over the platoons
+ * (src/server/federated.py:47-63, 99-118; workers/trainer.py:400-431) for agents sharing n_sets weight sets -- at the
+ * REFERENCE widths (layer1 256, layer2 128, action layer 48; src/config.py:112-117), as persistent kernels that keep the
+ * second-layer weights in registers and stream the agents' batches through them (csrc/fset.hip). Differences from
+ * avd_learn_shared_bf16: batches are AGENT-MAJOR, exactly what avd_replay_gather_f32 writes
+ *   s, s2 [n_agents][B][S], a [n_agents][B], r [n_agents][B]; agent v uses weight set v % n_sets;
+ *   agent_weight [n_agents] or NULL: factor on both loss seeds of the agent's rows (w_p * P / sum_p w_p = the weighted mean);
+ * the result is deterministic (per-workgroup partial sums combined in a fixed order, no float atomics on the gradients).
+ * bf16 GEMM operands, f32 accumulation / parameters / gradients. Other widths: AVD_E_UNSUPPORTED. */
+int avd_learn_set_fused_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
+int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                             const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                             const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* actor(state) (agent/model.py:26-36, workers/trainer.py:286-289) for agents that share n_sets weight sets, as the same
  * bf16 GEMM chain: state [n_sets][rows][S] SET-MAJOR (rows = n_agents / n_sets, tightly packed S floats per row),
  * out [n_sets][rows] = tanh(.) * high. */
