@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shared, q):
+def _worker(rank, world, port, shared, q, engine=None):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +34,7 @@ def _worker(rank, world, port, shared, q):
         conf = config.Config(num_platoons=5 + rank, pl_size=3, buffer_size=128, fed_method="interfrl",
                              weighted_average_enabled=False)  # unequal shards on purpose
         vt = trainer.VecTrainer(conf, rng="device", group=dist.group.WORLD, auto_reset=True, seed=1 + rank,
-                                shared_sets=shared)
+                                shared_sets=shared, shared_engine=engine)
         th0 = vt.agents.theta.clone()
         vt.reset_episode()
         for _ in range(70):  # the strict gate opens with the 65th add: 6 federated updates
@@ -47,8 +47,12 @@ def _worker(rank, world, port, shared, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("shared", [True, False, "fused"])
 def test_two_rank_interfrl_weight_sets_stay_identical(shared):
+    """shared = "fused": shared sets with the fused bf16 set learner (csrc/fset.hip): each rank's mean gradient is scaled to a
+    sum over its platoons, all-reduced, divided by the global platoon count -- deterministic, so the ranks stay bit-identical."""
+    engine = "fused" if shared == "fused" else None
+    shared = bool(shared)
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
@@ -57,7 +61,7 @@ def test_two_rank_interfrl_weight_sets_stay_identical(shared):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shared, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shared, q, engine)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])

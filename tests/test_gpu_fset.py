@@ -150,3 +150,56 @@ def test_full_size_fused_set_learner_is_the_mean_of_its_halves_and_tracks_the_la
         assert (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item() <= 1e-3 * scale, lo
         assert (full[:, lo:hi] - wide[:, lo:hi]).abs().max().item() <= 2e-2 * scale, lo
     assert not torch.allclose(halves[0], halves[1])  # the halves are different batches
+
+
+def test_trainer_fused_engine_tracks_per_agent_engine_under_interfrl():
+    """VecTrainer with shared weight sets: the fused set learner against the exact f32 per-agent kernel + fed_sum, same host
+    RNG stream (parity mode). Before the first update the trajectories are identical; afterwards they differ by bf16 rounding
+    of the gradients, amplified by Adam's normalisation (|dw| <= lr per step either way)."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    P, L, steps = 6, 3, 72
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+    runs = []
+    for engine in ("per_agent", "fused"):
+        np.random.seed(11)
+        vt = trainer.VecTrainer(conf, rng="host", shared_sets=True, shared_engine=engine)
+        vt.reset_episode()
+        traj = []
+        for i in range(steps):
+            vt.step(0, i)
+            traj.append((vt.actions.cpu().numpy().copy(), vt.env.x.cpu().numpy().copy()))
+        runs.append((vt, traj))
+    (a, ta), (b, tb) = runs
+    assert b.grads is None and b.shared_engine == "fused" and a.updates == b.updates == (steps - 64) * P * L
+    for i in range(steps):
+        tol = 0.0 if i < 65 else 5e-3
+        assert np.abs(ta[i][0] - tb[i][0]).max() <= tol * 2.5, i
+        assert np.abs(ta[i][1] - tb[i][1]).max() <= tol * max(1.0, np.abs(ta[i][1]).max()), i
+    n_upd = steps - 64
+    for lr, lo, hi in ((conf.actor_lr, 0, a.agents.lay.actor_size), (conf.critic_lr, a.agents.lay.actor_size, a.agents.lay.theta_size)):
+        d = (a.agents.theta[:, lo:hi] - b.agents.theta[:, lo:hi]).abs()
+        assert d.max().item() <= 2 * lr * n_upd and d.mean().item() <= 0.1 * lr * n_upd
+    assert torch.isfinite(b.agents.theta).all() and int(b.agents.step[0]) == n_upd
+
+
+def test_trainer_fused_engine_weighted_federation_runs_model_a():
+    """Weighted interfrl (workers/trainer.py:385-398) + Model A (S = 3) through the fused engine: the weights of episode 3
+    come from episodes 1-2 and reach the kernel as per-agent factors; finite, learning."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    conf = config.Config(num_platoons=4, pl_size=2, buffer_size=128, fed_method="interfrl", weighted_average_enabled=True,
+                         weighted_window=2, episode_sim_time=3.0, model="ModelA")  # 30-step episodes
+    np.random.seed(2)
+    vt = trainer.VecTrainer(conf, rng="host", shared_engine="fused")
+    assert vt.shared and vt.shared_engine == "fused" and vt.agents.lay.S == 3
+    th0 = vt.agents.theta.clone()
+    vt.run(number_of_episodes=4)
+    assert vt.fed_weights is not None and vt.fed_weights[0] == 3
+    w = vt.fed_weights[1].cpu().numpy()
+    ref = np.array([[abs(1 / np.mean(vt.all_ep_reward_lists[p][m][-2 - 1:-1])) for m in range(2)] for p in range(4)])
+    assert np.allclose(w, ref, rtol=1e-6)
+    assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
+    assert not torch.equal(vt.agents.theta, th0)
