@@ -55,8 +55,10 @@ struct Critic {
 // row (M index) of accumulator register i of a 32x32 MFMA result in lane half h; the column is lane & 31
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// relu as one v_med3_f32 (fmaxf also quiets NaNs: two instructions per element)
-__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// relu: ONE v_max_f32 when the file is compiled with -fno-honor-nans (Makefile); otherwise fmaxf is lowered to
+// canonicalize + max (it must quiet signalling NaNs) -- two VALU instructions per element in loops whose VALU count bounds
+// them. (Inline assembly is not an option: hipcc does not pad the MFMA -> VALU read hazard for an opaque instruction.)
+__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
