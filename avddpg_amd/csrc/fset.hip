@@ -39,16 +39,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float BN_EPS = 1e-3f;  // tf.keras BatchNormalization default epsilon (agent/model.py:28)
 constexpr int TILE = 64, H1 = 256, H2 = 128, HA = 48, NT = 512, VEC = 264;
-#ifndef FSET_EXP
-#define FSET_EXP 0  // timing experiments only (wrong results): 1 no first-layer LDS stores, 2 no GEMM, 4 no output tail, 8 no first layer
-#endif
 
+// K features enter the second layer; KP = K rounded up to feature tiles of 32 (dx operands); KW = K + 16: the head's weight
+// image with the folded bias as feature K; NFT first-layer tiles; dw also accumulates a constant-one feature K (its G row is
+// the column sum of dZ2 = the gradient of b2): NGT tiles, KG rows.
 struct Actor {
-    static constexpr int K = 256, KP = 256, NFT = 8;
+    static constexpr int K = 256, KP = 256, KW = 272, NFT = 8, NGT = 9, KG = 288;
     static constexpr bool critic = false;
 };
 struct Critic {
-    static constexpr int K = 304, KP = 320, NFT = 10;  // 256 state + 48 action features, padded to 10 tiles of 32
+    static constexpr int K = 304, KP = 320, KW = 320, NFT = 10, NGT = 10, KG = 320;  // 256 state + 48 action features
     static constexpr bool critic = true;
 };
 
@@ -98,18 +98,20 @@ struct NetP {
     int oW1, ob1;     // first (state) layer weights [S][H1] / bias, offsets into th
     int oWa, oba;     // critic action layer [1][HA] / bias (critic only)
     int oga, omva;    // critic action-branch BN gamma (th) / moving variance (st): dx_kernel's action-gradient mode
-    const bf16* W2T;  // [sets][H2][KP]  bf16(inv1[f] * W2[f][n]) transposed: head_kernel's resident operand
+    const bf16* W2T;  // [sets][H2][KW]  bf16(inv1[f] * W2[f][n]) transposed, feature K = b2' (folded bias): head_kernel's LDS image
     const bf16* W2R;  // [sets][KP][H2]  bf16(W2[f][n]), rows >= K zero: dx_kernel's resident operand (online nets only)
     const float* vec; // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3
 };
 
 // feature tile `ft` (32 features) of a net's first layer as a weight fragment; tiles >= 8 are the critic's action layer
 template <int S, class NET>
-__device__ __forceinline__ bf16x8 layer1_wf(const NetP& n, const float* th, int ft, int r, int h) {
+__device__ __forceinline__ bf16x8 layer1_wf(const NetP& n, const float* th, int ft, int r, int h, bool with_one = false) {
+    if (32 * ft + r >= NET::K) {  // past the real features: zeros, or (dw_kernel) the constant-one feature K = relu(0 x + 1)
+        return make_wf(0.f, 0.f, 0.f, 0.f, (with_one && 32 * ft + r == NET::K) ? 1.f : 0.f, h);
+    }
     if (NET::critic && ft >= 8) {
         const int f = 32 * (ft - 8) + r;
-        const bool ok = f < HA;
-        return make_wf(ok ? th[n.oWa + f] : 0.f, 0.f, 0.f, 0.f, ok ? th[n.oba + f] : 0.f, h);
+        return make_wf(th[n.oWa + f], 0.f, 0.f, 0.f, th[n.oba + f], h);
     }
     const int f = 32 * ft + r;
     const float* W = th + n.oW1;
@@ -153,10 +155,10 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     const avd_mlp_layout& L = a.L;
     const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
     const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
-    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP;
+    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP, KW = critic ? Critic::KW : Actor::KW;
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2, oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
     float shw = 0.f;
-    if (f < KP) {
+    {
         float w = 0.f, inv = 0.f;
         if (f < K) {
             int og, obe, omm, omv, ff = f;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             w = th[oW2 + (long)f * H2 + n];
             shw = sh * w;
         }
-        a.W2T[net][((long)set * H2 + n) * KP + f] = (bf16)(inv * w);
-        if (!target) a.W2R[net][((long)set * KP + f) * H2 + n] = (bf16)w;
+        if (f < KW && f != K) a.W2T[net][((long)set * H2 + n) * KW + f] = (bf16)(inv * w);  // (feature K: the folded bias, below)
+        if (!target && f < KP) a.W2R[net][((long)set * KP + f) * H2 + n] = (bf16)w;
     }
     red[f] = shw;
     __syncthreads();
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
     if (f == 0) {
         vec[n] = th[ob2 + n] + red[0];
+        a.W2T[net][((long)set * H2 + n) * KW + K] = (bf16)vec[n];
         const float inv2 = (1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n];
         vec[H2 + n] = inv2 * th[oW3 + n];
     }
@@ -215,141 +218,175 @@ struct HeadArgs {
     const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
     float* out;        // OUT_*: per-row result
     bf16* dz;          // HEAD_*: dZ2 [n_agents][64][128]
-    float* part;       // HEAD_*: [grid][2][2][128] sums T1 (seed * p2), T2 (seed * mask) per output column
-    float* part_s;     // HEAD_*: [grid][2][2] sums of the seeds and of the loss terms
+    float* part;       // HEAD_*: [grid][8 waves][128] sums T1 = sum_rows seed * p2 per output column
+    float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float gamma, high, inv_n;
 };
 
-// Wave w = (wm, wn): rows [32 wm, +32) x columns [32 wn, +32) of the tile's second layer, transposed orientation
-// (A = resident weights, B = activations from LDS): lane = batch row, registers = 16 output columns, so that the output
-// layer is a per-lane dot product and dZ2 is stored 4 consecutive columns at a time. Two barriers per tile: first-layer
-// image complete; per-row output-layer partials of the 4 column quarters complete.
+// The set's BN-folded second-layer weights sit in LDS for the workgroup's whole life (bf16, [column n][feature f], plus the
+// folded bias b2' as feature K: 70 / 82 KB); after the one barrier behind that load the 8 waves never synchronise again:
+// wave w owns rows [32 (w & 1), +32) of every 4th tile of the workgroup. Per feature tile it evaluates the first layer for
+// ITS rows on the matrix cores (lane = batch row, registers = features), trades feature groups between the two lanes of a
+// row (v_permlane32_swap) so that each holds 8 consecutive features -- which IS the B operand of the second-layer MFMA,
+// no LDS round trip for activations -- and multiplies it into all four 32-column tiles (A = weight fragments from LDS, one
+// ds_read_b128 per MFMA). Result: lane = batch row, 64 registers = its second-layer outputs, so the output layer is a
+// per-lane dot product (+ one exchange with the partner lane) and dZ2 leaves in 16-byte row-major pieces.
 template <int S, class NET, int MODE>
 __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
-    constexpr int K = NET::K, KP = NET::KP, NS = K / 16, LD = KP + 8;  // LD/2 = 4 (mod 8) dwords: conflict-free b128 rows
-    __shared__ __attribute__((aligned(16))) bf16 img[2][TILE * LD];
-    __shared__ float zpart[2][4][TILE];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = w >> 2, wn = w & 3;
+    constexpr int K = NET::K, KW = NET::KW, NKS = K / 16, NFT = NET::NFT, LD = KW + 8;  // LD/2 = 4 (mod 8) dwords: conflict-free b128
+    __shared__ __attribute__((aligned(16))) bf16 wimg[H2 * LD];
+    __shared__ __attribute__((aligned(16))) float c3s[H2];
+    __shared__ __attribute__((aligned(16))) bf16x8 wfs[NFT * 64];  // first-layer weight fragments [tile][lane] (registers are short)
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, q = w >> 1, rh = w & 1;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const float* th = p.net.th + (long)set * p.net.th_stride;
-
-    bf16x8 w2[NS];
     {
-        const bf16* src = p.net.W2T + ((long)set * H2 + 32 * wn + r) * KP + 8 * h;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) w2[s] = *(const bf16x8*)(src + 16 * s);
+        const bf16* src = p.net.W2T + (long)set * H2 * KW;
+        for (int i = tid; i < H2 * (KW / 8); i += NT) {
+            const int n = i / (KW / 8), c = i - n * (KW / 8);
+            *(uint4*)(wimg + n * LD + 8 * c) = *(const uint4*)(src + (long)n * KW + 8 * c);
+        }
     }
     const float* vec = p.net.vec + (long)set * VEC;
-    f32x16 b2r;
-    float c3r[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int n = 32 * wn + acc_row(i, h);
-        b2r[i] = vec[n], c3r[i] = vec[H2 + n];
-    }
+    if (tid < H2) c3s[tid] = vec[H2 + tid];
     const float d3 = vec[2 * H2];
-    const bf16x8 wf = layer1_wf<S, NET>(p.net, th, w, r, h);
-    bf16x8 wfa = wf;
-    if (NET::critic && w < 2) wfa = layer1_wf<S, NET>(p.net, th, 8 + w, r, h);
-
-    float T1[16], T2[16], Dacc = 0.f, Lacc = 0.f;
+    for (int ft = w; ft < NFT; ft += 8) wfs[ft * 64 + lane] = layer1_wf<S, NET>(p.net, th, ft, r, h);
+    bf16x8 onef;  // activation fragment of the bias step: feature K = 1, features K+1.. = 0
 #pragma unroll
-    for (int i = 0; i < 16; ++i) T1[i] = 0.f, T2[i] = 0.f;
+    for (int j = 0; j < 8; ++j) onef[j] = (bf16)((j == 0 && h == 0) ? 1.f : 0.f);
     const f32x16 zero16 = {};
-    const int row = 32 * wm + r;
+    float T1[4][16], Dacc = 0.f, Lacc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T1[t][i] = 0.f;
+    __syncthreads();
 
-    // inputs of a tile, requested one tile ahead (a load issued where it is used costs a full memory latency per tile)
-    bf16x8 nx0 = {}, nx1 = {};
-    float na0 = 0.f, na1 = 0.f, ny = 0.f, nw = 1.f;
-    auto fetch_in = [&](int pi) {
-        const int agent = pi * p.n_sets + set;
-        const bf16x8* xa = (const bf16x8*)p.xf + (long)agent * TILE * 2;
-        nx0 = xa[2 * r + h], nx1 = xa[2 * (32 + r) + h];
-        if (NET::critic && w < 2) na0 = p.act[(long)agent * TILE + r], na1 = p.act[(long)agent * TILE + 32 + r];
-        if (MODE == OUT_TD) ny = p.r[(long)agent * TILE + row];
-        if (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR) ny = p.yin[(long)agent * TILE + row];
+    const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;  // tiles of this workgroup: j0, j0 + J, ..
+    const int row = 32 * rh + r;
+    bf16x8 nx = {};
+    float na = 0.f, ny = 0.f, nw = 1.f;
+    auto fetch_in = [&](int k) {  // one unit (32 rows of a tile) ahead
+        const int agent = (j0 + k * J) * p.n_sets + set;
+        const long ri = (long)agent * TILE + row;
+        nx = ((const bf16x8*)p.xf)[2 * ri + h];
+        if (NET::critic) na = p.act[ri];
+        if (MODE == OUT_TD) ny = p.r[ri];
+        if (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR) ny = p.yin[ri];
         if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
     };
-    auto store_l1 = [&](bf16* im, const f32x16& acc, int rw, int f0) {  // relu, bf16, 4 consecutive features per 8-byte store
-        bf16* dst = im + rw * LD + f0 + 4 * h;
-        if (FSET_EXP & 1) return;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (bf16)relu(acc[4 * g + j]);
-            *(bf16x4*)(dst + 8 * g) = v;
-        }
-    };
-    auto layer1 = [&](bf16* im) {  // the wave's feature tile(s) of all 64 rows, from the prefetched inputs
-        if (FSET_EXP & 8) return;
-        store_l1(im, mfma(wf, nx0, zero16), r, 32 * w);
-        store_l1(im, mfma(wf, nx1, zero16), 32 + r, 32 * w);
-        if (NET::critic && w < 2) {
-            store_l1(im, mfma(wfa, make_xf(na0, 0.f, 0.f, 0.f, h), zero16), r, H1 + 32 * w);
-            store_l1(im, mfma(wfa, make_xf(na1, 0.f, 0.f, 0.f, h), zero16), 32 + r, H1 + 32 * w);
-        }
-    };
-    // Software pipeline, ONE barrier per tile: [GEMM(t) | output-layer partials(t) | first layer(t+1) -> other image] barrier
-    // [output layer + backward(t)]. The barrier publishes both the partials of tile t and the image of tile t+1; images and
-    // partials alternate between two buffers, so nothing written before barrier t+1 is still being read by a slower wave.
-    float cy = 0.f, cw = 1.f;
-    if (j0 < P) {
-        fetch_in(j0);
-        layer1(img[0]);
-        cy = ny, cw = nw;
-        if (j0 + J < P) fetch_in(j0 + J);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
-        const int agent = pi * p.n_sets + set;
-        const float ty = cy, tw = cw;
-        f32x16 acc;
-        auto gemm_part = [&]() {
-            const bf16* arow = img[buf] + (32 * wm + r) * LD + 8 * h;
-            acc = mfma(w2[0], *(const bf16x8*)arow, b2r);  // the folded bias b2' is the C operand of the first step
-#pragma unroll
-            for (int s = 1; s < ((FSET_EXP & 2) ? 1 : NS); ++s) acc = mfma(w2[s], *(const bf16x8*)(arow + 16 * s), acc);
-            float zp = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[i] = relu(acc[i]);
-                zp = fmaf(acc[i], c3r[i], zp);
-            }
-            zp += __shfl_xor(zp, 32);
-            if (h == 0) zpart[buf][wn][row] = zp;
-        };
-        auto l1_part = [&]() {
-            if (pi + J < P) {
-                layer1(img[buf ^ 1]);
-                cy = ny, cw = nw;
-                if (pi + 2 * J < P) fetch_in(pi + 2 * J);
-            }
-        };
-        // the two waves of a SIMD (w and w + 4: wm = 0 / 1) run the two halves in opposite order: one streams its first-layer
-        // tile into LDS (VALU + the slow LDS store path) while the other holds the matrix pipe, then they swap
-        if (wm == 0) {
-            l1_part();
-            gemm_part();
-        } else {
-            gemm_part();
-            l1_part();
-        }
-        __syncthreads();
-        const float z = d3 + ((zpart[buf][0][row] + zpart[buf][1][row]) + (zpart[buf][2][row] + zpart[buf][3][row]));
+    if (q < ntile) fetch_in(q);
+    const bf16* wrow = wimg + r * LD + 8 * h;  // + 32 nt LD + 16 ks
+    for (int k = q; k < ntile; k += 4) {
+        const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
-        if (FSET_EXP & 4) {
-            if (z == 12345.f) p.out[ri] = acc[0];
-            continue;
-        }
-        if (MODE == OUT_TANH) {
-            if (wn == 0) {
-                const float o = tanhf(z) * p.high;
-                if (h == 0) p.out[ri] = o;
+        const bf16x8 xs = nx, xa = make_xf(na, 0.f, 0.f, 0.f, h);
+        const float ty = ny, tw = nw;
+        if (k + 4 < ntile) fetch_in(k + 4);
+        f32x16 acc[4] = {zero16, zero16, zero16, zero16};
+        // relu + bf16 of a first-layer tile [feature][row] (row on the lane): 4 groups of 4 consecutive features
+        auto pack = [&](const f32x16& p1, unsigned (&pk)[4][2]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (bf16)relu(p1[4 * g + j]);
+                const uint2 u = __builtin_bit_cast(uint2, v);
+                pk[g][0] = u.x, pk[g][1] = u.y;
             }
+        };
+        // Software pipeline over the feature tiles: [first-layer MFMA of tile ft+1] [8 second-layer MFMAs of tile ft]
+        // [relu/bf16 of tile ft+1]. The VALU part then runs in the shadow of MFMAs already issued (this wave's and its SIMD
+        // partner's); issued where its result is consumed, the first-layer MFMA queues behind the partner's eight and the
+        // two waves of a SIMD serialise (measured: 31 of 101 us).
+        unsigned pk[4][2];
+        pack(mfma(wfs[lane], xs, zero16), pk);
+        bf16x8 wfq = wfs[64 + lane], wfq2 = wfq;  // first-layer weights of tile ft + 1, read a tile ahead as well
+        // weight fragments of a feature tile (2 k-steps x 4 column tiles), read one tile ahead: a ds_read_b128 issued right in
+        // front of the MFMA that consumes it exposes the LDS latency four times per tile
+        // (the modes that carry the 64 T1 accumulators have no registers for all 8 fragments of the next tile: they read its
+        //  first k-step ahead and the second k-step of the current tile in front of the first k-step's four MFMAs)
+        constexpr bool HALF = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR);
+        bf16x8 wcur[2][4], wnxt[HALF ? 1 : 2][4];
+        auto read_w1 = [&](int ft, int gg, bf16x8 (&dst)[4]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (2 * ft + gg < NKS) dst[t] = *(const bf16x8*)(wrow + 32 * t * LD + 16 * (2 * ft + gg));
+        };
+        auto read_w = [&](int ft, bf16x8 (&dst)[HALF ? 1 : 2][4]) {
+            read_w1(ft, 0, dst[0]);
+            if (!HALF) read_w1(ft, 1, dst[HALF ? 0 : 1]);
+        };
+        read_w1(0, 0, wcur[0]);
+        if (!HALF) read_w1(0, 1, wcur[1]);
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            f32x16 p1n = zero16;
+            if (ft + 1 < NFT) {
+                p1n = mfma(wfq, (NET::critic && ft + 1 >= 8) ? xa : xs, zero16);
+                read_w(ft + 1, wnxt);
+                if (ft + 2 < NFT) wfq2 = wfs[(ft + 2) * 64 + lane];
+            }
+            if (HALF) read_w1(ft, 1, wcur[1]);
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int ks = 2 * ft + gg;
+                if (ks >= NKS) continue;  // (the critic's last tile holds only 16 features)
+                // the lane holds features 8g + 4h + j; after the swap h = 0 holds 16gg + [0, 8), h = 1 holds 16gg + [8, 16)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                uint4 o;
+                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma(wcur[gg][t], bfrag, acc[t]);
+            }
+            if (ft + 1 < NFT) {
+                pack(p1n, pk);
+#pragma unroll
+                for (int gg = 0; gg < (HALF ? 1 : 2); ++gg)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wcur[gg][t] = wnxt[gg][t];
+                wfq = wfq2;
+            }
+            // Issue order inside the tile: an MFMA holds the SIMD's issue port for 8 of its 32 cycles, so the next tile's
+            // relu/bf16 conversions (24 VALU) and weight reads go INTO the gaps between this tile's 8 second-layer MFMAs -- a
+            // wave is in-order: VALU placed behind the MFMAs waits for all of them to be issued (measured: VALU-active 28 % +
+            // issue-stalled 44 % of the wave's cycles, the matrix pipe 48 % busy).
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // first-layer MFMA of the next tile
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // the four lane-half swaps
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            // (tiles stay in program order: the scheduler otherwise hoists every tile's first-layer MFMA and weight reads to
+            //  the top and spills hundreds of registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma(*(const bf16x8*)(wrow + 32 * t * LD + 16 * NKS), onef, acc[t]);  // + b2'
+        float zp = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[t][4 * g + j] = relu(acc[t][4 * g + j]);
+                    zp = fmaf(acc[t][4 * g + j], cc[j], zp);
+                }
+            }
+        zp += __shfl_xor(zp, 32);
+        const float z = d3 + zp;
+        if (MODE == OUT_TANH) {
+            const float o = tanhf(z) * p.high;
+            if (h == 0) p.out[ri] = o;
         } else if (MODE == OUT_TD) {
-            if (wn == 0 && h == 0) p.out[ri] = ty + p.gamma * z;
+            if (h == 0) p.out[ri] = ty + p.gamma * z;
         } else {
             float g3, loss;
             if (MODE == HEAD_CRITIC) {
@@ -361,63 +398,59 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
                 const float t = tanhf(z);
                 g3 = ty * p.high * (1.f - t * t), loss = 0.f;
             }
-            // dZ2 row-major: the lane holds columns 8g + 4h + j of its row; the two lanes of a row trade groups (1 <-> 0', 3 <-> 2')
-            // so that each owns 8 consecutive columns twice: 16-byte stores, 32 contiguous bytes per row and instruction
-            unsigned pk[4][2];
+            bf16* dst = p.dz + ri * H2 + 8 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
+            for (int t = 0; t < 4; ++t) {
+                unsigned pk[4][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    const bool m = acc[i] > 0.f;
-                    if (MODE != HEAD_CONST) {
-                        T1[i] = fmaf(g3, acc[i], T1[i]);
-                        T2[i] += m ? g3 : 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                    const float cc[4] = {c.x, c.y, c.z, c.w};
+                    bf16x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        if (MODE != HEAD_CONST) T1[t][i] = fmaf(g3, acc[t][i], T1[t][i]);
+                        v[j] = (bf16)(acc[t][i] > 0.f ? g3 * cc[j] : 0.f);
                     }
-                    v[j] = (bf16)(m ? g3 * c3r[i] : 0.f);
+                    const uint2 u = __builtin_bit_cast(uint2, v);
+                    pk[g][0] = u.x, pk[g][1] = u.y;
                 }
-                const uint2 u = __builtin_bit_cast(uint2, v);
-                pk[g][0] = u.x, pk[g][1] = u.y;
-            }
-            bf16* dst = p.dz + ri * H2 + 32 * wn + 8 * h;
 #pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {  // after the swap: h = 0 holds columns 16gg + [0, 8), h = 1 holds 16gg + [8, 16)
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                uint4 o;
-                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
-                *(uint4*)(dst + 16 * gg) = o;
+                for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                    uint4 o;
+                    o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                    *(uint4*)(dst + 32 * t + 16 * gg) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one column tile at a time (register pressure)
             }
-            if (wn == 0 && h == 0) Dacc += g3, Lacc += loss;
+            if (h == 0) Dacc += g3, Lacc += loss;
         }
     }
     if (MODE >= HEAD_CRITIC) {
-        // one partial per workgroup: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
+        // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
+        if (MODE != HEAD_CONST) {
+            float* pt = p.part + ((long)blockIdx.x * 8 + w) * H2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                T1[i] += __shfl_xor(T1[i], o);
-                T2[i] += __shfl_xor(T2[i], o);
-            }
+                for (int i = 0; i < 16; ++i) {
+                    float v = T1[t][i];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+                    if (r == 0) pt[32 * t + acc_row(i, h)] = v;
+                }
         }
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
             Dacc += __shfl_xor(Dacc, o);
             Lacc += __shfl_xor(Lacc, o);
         }
-        float* pt = p.part + ((long)blockIdx.x * 2 + wm) * 2 * H2;
-        if (MODE != HEAD_CONST && r == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = 32 * wn + acc_row(i, h);
-                pt[n] = T1[i], pt[H2 + n] = T2[i];
-            }
-        }
-        if (wn == 0 && lane == 0) {
-            p.part_s[((long)blockIdx.x * 2 + wm) * 2] = Dacc;
-            p.part_s[((long)blockIdx.x * 2 + wm) * 2 + 1] = Lacc;
+        if (lane == 0) {
+            p.part_s[((long)blockIdx.x * 8 + w) * 2] = Dacc;
+            p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc;
         }
     }
 }
@@ -429,7 +462,7 @@ struct DwArgs {
     const bf16* xf;  // packed state fragments (pack_x_kernel)
     const float* act;
     const bf16* dz;
-    float* partG;  // [grid][KP][128]
+    float* partG;  // [grid][KG][128] (row K: the constant-one feature = column sums of dZ2)
 };
 // Wave w = (fg, wn): feature tiles fg*NFT/2 .. of column quarter wn. The first-layer tile is computed with the batch rows as
 // the M index (result: feature on the lane, rows in the registers) and used straight as the A operand of G = P1^T . dZ2
@@ -437,7 +470,7 @@ struct DwArgs {
 // ds_read_b64_tr_b16, which delivers it reduction-contiguous in exactly that order). One barrier per tile.
 template <int S, class NET>
 __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
-    constexpr int KP = NET::KP, NFW = NET::NFT / 2, LDZ = 160;
+    constexpr int KG = NET::KG, NGT = NET::NGT, NFW = (NGT + 1) / 2, LDZ = 160;
     __shared__ __attribute__((aligned(16))) bf16 dzimg[2][TILE * LDZ];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wn = w & 3, fg = w >> 2;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
@@ -446,7 +479,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     f32x16 G[NFW];
     const f32x16 zero16 = {};
 #pragma unroll
-    for (int i = 0; i < NFW; ++i) wf[i] = layer1_wf<S, NET>(p.net, th, fg * NFW + i, r, h), G[i] = zero16;
+    for (int i = 0; i < NFW; ++i) wf[i] = layer1_wf<S, NET>(p.net, th, fg * NFW + i, r, h, true), G[i] = zero16;
     const bool act_tiles = NET::critic && fg == 1;  // feature tiles 8, 9 (i = 3, 4) take the action as their input
 
     const int srow = tid >> 3, sch = tid & 7;  // staging: 64 rows x 8 chunks of 32 bytes
@@ -490,6 +523,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
                 }
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
+            if (fg * NFW + i >= NGT) continue;
             const bool at = act_tiles && i >= 3;
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -509,7 +543,8 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < NFW; ++i) {
-        float* dst = p.partG + ((long)blockIdx.x * KP + 32 * (fg * NFW + i)) * H2 + 32 * wn + r;
+        if (fg * NFW + i >= NGT) continue;
+        float* dst = p.partG + ((long)blockIdx.x * KG + 32 * (fg * NFW + i)) * H2 + 32 * wn + r;
 #pragma unroll
         for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G[i][k];
     }
@@ -713,17 +748,18 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
         const int n = item;
         const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
         const int oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3, ob2 = critic ? L.cb2 : L.ab2;
-        float T1 = 0.f, T2 = 0.f, D = 0.f, Lc = 0.f, La = 0.f;
+        const int KG = critic ? Critic::KG : Actor::KG;
+        float T1 = 0.f, S2 = 0.f, D = 0.f, Lc = 0.f, La = 0.f;
         for (int j = jl; j < a.J; j += 32) {
             const long wg = (long)j * a.n_sets + set;
-            for (int wm = 0; wm < 2; ++wm) {
-                const float* pt = a.partH[net] + (wg * 2 + wm) * 2 * H2;
-                T1 += pt[n], T2 += pt[H2 + n];
-                D += a.partHs[net][(wg * 2 + wm) * 2];
-                if (critic && n == 0) Lc += a.partHs[1][(wg * 2 + wm) * 2 + 1], La += a.partLa[(wg * 2 + wm) * 2 + 1];
+            for (int w = 0; w < 8; ++w) {
+                T1 += a.partH[net][(wg * 8 + w) * H2 + n];
+                D += a.partHs[net][(wg * 8 + w) * 2];
+                if (critic && n == 0) Lc += a.partHs[1][(wg * 8 + w) * 2 + 1], La += a.partLa[(wg * 8 + w) * 2 + 1];
             }
+            S2 += a.partG[net][(wg * KG + K) * H2 + n];  // dw_kernel's constant-one feature: sum over rows of dZ2 = db2
         }
-        T1 = allsum(T1), T2 = allsum(T2), D = allsum(D);
+        T1 = allsum(T1), S2 = allsum(S2), D = allsum(D);
         if (critic && n == 0) Lc = allsum(Lc), La = allsum(La);
         if (jl == 0) {
             const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
@@ -731,7 +767,7 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
             g[oW3 + n] = inv2 * T1 + sh2 * D;
             g[obe2 + n] = w3 * D;
             g[og2 + n] = w3 * rs2 * (T1 - mm2 * D);
-            g[ob2 + n] = inv2 * w3 * T2;
+            g[ob2 + n] = S2;
             if (n == 0) g[ob3] = D;
             if (critic && n == 0 && a.losses) a.losses[2 * set] = Lc * a.inv_n, a.losses[2 * set + 1] = -La * a.inv_n;
         }
@@ -773,7 +809,7 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
 __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     const int f = blockIdx.x, set = blockIdx.y, net = blockIdx.z, n = threadIdx.x;
     const bool critic = net;
-    const int K = critic ? Critic::K : Actor::K, KP = critic ? Critic::KP : Actor::KP;
+    const int K = critic ? Critic::K : Actor::K, KG = critic ? Critic::KG : Actor::KG;
     if (f >= K) return;
     const avd_mlp_layout& L = a.L;
     const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
@@ -785,7 +821,7 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, ff = f - H1;
     const float inv1 = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff], sh1 = th[obe + ff] - st[omm + ff] * inv1;
     float G = 0.f;
-    for (int j = 0; j < a.J; ++j) G += a.partG[net][(((long)j * a.n_sets + set) * KP + f) * H2 + n];
+    for (int j = 0; j < a.J; ++j) G += a.partG[net][(((long)j * a.n_sets + set) * KG + f) * H2 + n];
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
     g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
 }
@@ -819,8 +855,8 @@ static Plan make_plan(int n_agents, int n_sets) {
         return at;
     };
     for (int i = 0; i < 4; ++i) {
-        const int KP = (i & 1) ? Critic::KP : Actor::KP;
-        pl.W2T[i] = take(sizeof(bf16) * (size_t)n_sets * H2 * KP);
+        const int KP = (i & 1) ? Critic::KP : Actor::KP, KW = (i & 1) ? Critic::KW : Actor::KW;
+        pl.W2T[i] = take(sizeof(bf16) * (size_t)n_sets * H2 * KW);
         pl.vec[i] = take(sizeof(float) * (size_t)n_sets * VEC);
         if (i < 2) pl.W2R[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2);
     }
@@ -829,13 +865,13 @@ static Plan make_plan(int n_agents, int n_sets) {
     pl.dz = take(sizeof(bf16) * rows * H2);
     pl.xfs = take(sizeof(bf16) * rows * 16), pl.xfs2 = take(sizeof(bf16) * rows * 16);
     for (int i = 0; i < 2; ++i) {
-        const int KP = i ? Critic::KP : Actor::KP;
-        pl.partH[i] = take(4 * (size_t)pl.grid * 2 * 2 * H2);
+        const int KP = i ? Critic::KP : Actor::KP, KG = i ? Critic::KG : Actor::KG;
+        pl.partH[i] = take(4 * (size_t)pl.grid * 8 * H2);
         pl.partU[i] = take(4 * (size_t)pl.grid * 2 * 2 * KP * 2);
         pl.partV[i] = take(4 * (size_t)pl.grid * 2 * KP * 16);
-        pl.partG[i] = take(4 * (size_t)pl.grid * KP * H2);
+        pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
     }
-    for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 2 * 2);
+    for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 8 * 2);
     pl.total = o;
     return pl;
 }
