@@ -1,33 +1,38 @@
 // Fused shared-weight-set learner ("fset"): Trainer.learn (workers/trainer.py:472-508) + the federated mean over the
 // platoons (src/server/federated.py:47-63, 99-118; workers/trainer.py:400-431) for agents that SHARE their networks
 // (interfrl with every step federated: the P copies of vehicle m's networks stay identical, trainer.py:121-128), at the
-// reference widths 256 / 128 / 48 (src/config.py:112-117), as a chain of PERSISTENT kernels that keep one weight matrix
-// in registers and stream the agents' 64-row batches through it.
+// reference widths 256 / 128 / 48 (src/config.py:112-117), as a chain of PERSISTENT kernels: a workgroup (8 waves, one per
+// CU) is bound to ONE weight set for its whole life, keeps that set's weights on chip and streams the agents' 64-row
+// batches through them.
 //
 // Why: the layer-wise GEMM chain of wide.hip moves every activation of the P x 64 rows of a set through HBM (8.4 ms at
 // 4096 x 5 agents, 4 % of the bf16 matrix peak), and the per-agent f32 kernel (lean.hip) is bound by the f32 MFMA rate
-// (8.2 ms). Here a workgroup (8 waves, one per CU, 256 registers per lane) is bound to ONE weight set for its whole life:
-//   * the BN-folded second-layer weights sit in each wave's registers as bf16 MFMA fragments (64 / 76 registers for its
-//     32 output columns) -- no weight traffic at all after the first tile;
+// (8.2 ms). Here
+//   * weights never move after the first tile: the BN-folded second-layer weights (+ the folded bias as one more feature)
+//     sit in LDS (head_kernel, 70 / 82 KB) or in the waves' registers as MFMA fragments (dx_kernel, dxa_kernel);
 //   * the first layers (K = S or 1 inputs) are evaluated ON the matrix cores with split operands
 //     [x_hi | x_lo | x_hi | 1 | 1] . [w_hi | w_hi | w_lo | b_hi | b_lo] (one v_mfma_f32_32x32x16_bf16 per 32 x 32 tile,
-//     products exact, 2^-16 relative), in whichever orientation the consumer needs: written to LDS as the bf16 operand of
-//     the second-layer GEMM (head_kernel), or used directly as the A operand of the weight-gradient product (an accumulator
-//     tile IS the operand of a product that sums over its rows: dw_kernel, dx_kernel);
-//   * gradients never leave the registers per tile: W2 gradients (76 / 64 accumulator registers per lane), first-layer and
-//     BN gradients and the output-layer sums are accumulated over all the tiles a workgroup sees and written ONCE, as one
-//     partial per workgroup; finalize_* sums the partials of a set in a fixed order (deterministic) and applies the BN folds.
+//     products exact, 2^-16 relative), in whichever orientation the consumer needs, and never touch memory: as the B operand
+//     of the second-layer MFMA after one exchange between the two lanes of a row (head_kernel), or directly as the A operand
+//     of a product that sums over the tile's rows (an accumulator tile IS that operand: dw_kernel, dx_kernel);
+//   * gradients never leave the registers per tile: W2 gradients (80 accumulator registers per lane), first-layer and BN
+//     gradients and the output-layer sums are accumulated over all the tiles a workgroup sees and written ONCE, as one
+//     partial per workgroup / wave; finalize_* sums the partials of a set in a fixed order (deterministic) and applies the
+//     BN folds.
 // Between kernels only per-row scalars (target action, TD target, mu, dmu) and the bf16 second-layer gradient dZ2
 // (16 KB per agent) go through HBM.
 //
 // Passes (one launch each; "head" = first layer + second-layer GEMM + output layer [+ its backward]):
-//   1 head  target actor(s')                    -> a'                       4 head  critic(s, a), seed 2(q-y)/N -> dZ2c, sums
-//   2 head  target critic(s', a')  -> y = r+g*q                             5 dw    critic: G  += P1^T . dZ2c
-//   3 head  actor(s)               -> mu                                    6 dx    critic: first-layer/BN grads (state, action)
-//   7 head  critic(s, mu), seed -1/N -> dZ2'    8 dx(action cols, transposed) -> dmu
-//   9 head  actor(s), seed dmu*high*(1-t^2) -> dZ2a, sums     10 dw actor     11 dx actor     12 finalize
+//   0 prep (bf16 weight images, folded vectors), pack (split input fragments of s and s')
+//   1 head  target actor(s')                -> a'                   5 dw   critic: G += P1^T . dZ2c (+ column sums = db2)
+//   2 head  target critic(s', a')           -> y = r + gamma q      6 dx   critic state tiles, dxa critic action tiles:
+//   3 head  actor(s)                        -> mu                          first-layer / BN gradient sums
+//   4 head  critic(s, a), seed 2(q-y)/N     -> dZ2c, T1, loss       7 head critic(s, mu), seed -1/N -> dmu (the product with
+//   8 head  actor(s), seed dmu*high*(1-t^2) -> dZ2a, T1                    the action rows of W2 taken from registers), loss
+//   9 dw actor     10 dx actor     11 finalize_small, finalize_w2
 // GEMM operands are bf16 (8 significant bits), accumulation / parameters / gradients f32: the same numerics class as
-// avd_learn_shared_bf16 (wide.hip), against which and against the float64 oracle it is tested (tests/test_gpu_fset.py).
+// avd_learn_shared_bf16 (wide.hip), against which, against the exact f32 per-agent kernel + federated mean and against the
+// float64 oracle it is tested (tests/test_gpu_fset.py).
 #include "common.h"
 
 namespace avd {
@@ -217,7 +222,8 @@ struct HeadArgs {
     const float* yin;  // HEAD_CRITIC: TD targets; HEAD_ACTOR: dmu
     const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
     float* out;        // OUT_*: per-row result
-    bf16* dz;          // HEAD_*: dZ2 [n_agents][64][128]
+    bf16* dz;          // HEAD_CRITIC / HEAD_ACTOR: dZ2 [n_agents][64][128]
+    float* dmu;        // HEAD_CONST: dLa/dmu per row [n_agents][64] (the action gradient, through the critic's action branch)
     float* part;       // HEAD_*: [grid][8 waves][128] sums T1 = sum_rows seed * p2 per output column
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float gamma, high, inv_n;
@@ -237,6 +243,10 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 wimg[H2 * LD];
     __shared__ __attribute__((aligned(16))) float c3s[H2];
     __shared__ __attribute__((aligned(16))) bf16x8 wfs[NFT * 64];  // first-layer weight fragments [tile][lane] (registers are short)
+    constexpr bool AG = (MODE == HEAD_CONST);  // action-gradient epilogue (pass 7; the critic)
+    constexpr int LDA = H2 + 8;
+    __shared__ __attribute__((aligned(16))) bf16 w2a[AG ? 64 * LDA : 8];  // raw W2 rows of the 48 action features (+ 16 zero rows)
+    __shared__ __attribute__((aligned(16))) float ctab[AG ? 64 : 1][4];    // per action feature: wa, ba, inv_a * wa
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, q = w >> 1, rh = w & 1;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const float* th = p.net.th + (long)set * p.net.th_stride;
@@ -250,6 +260,20 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     const float* vec = p.net.vec + (long)set * VEC;
     if (tid < H2) c3s[tid] = vec[H2 + tid];
     const float d3 = vec[2 * H2];
+    if (AG) {
+        const bf16* src = p.net.W2R + ((long)set * NET::KP + H1) * H2;
+        for (int i = tid; i < 64 * (H2 / 8); i += NT) {
+            const int f = i / (H2 / 8), c = i - f * (H2 / 8);
+            *(uint4*)(w2a + f * LDA + 8 * c) = *(const uint4*)(src + (long)f * H2 + 8 * c);
+        }
+        if (tid < 64) {
+            const bool ok = tid < HA;
+            const float* st = p.net.st + (long)set * p.net.st_stride;
+            const float wa = ok ? th[p.net.oWa + tid] : 0.f, ba = ok ? th[p.net.oba + tid] : 0.f;
+            const float ia = ok ? (1.0f / sqrtf(st[p.net.omva + tid] + BN_EPS)) * th[p.net.oga + tid] : 0.f;
+            ctab[tid][0] = wa, ctab[tid][1] = ba, ctab[tid][2] = ia * wa, ctab[tid][3] = 0.f;
+        }
+    }
     for (int ft = w; ft < NFT; ft += 8) wfs[ft * 64 + lane] = layer1_wf<S, NET>(p.net, th, ft, r, h);
     bf16x8 onef;  // activation fragment of the bias step: feature K = 1, features K+1.. = 0
 #pragma unroll
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
         const bf16x8 xs = nx, xa = make_xf(na, 0.f, 0.f, 0.f, h);
-        const float ty = ny, tw = nw;
+        const float ty = ny, tw = nw, ta = na;
         if (k + 4 < ntile) fetch_in(k + 4);
         f32x16 acc[4] = {zero16, zero16, zero16, zero16};
         // relu + bf16 of a first-layer tile [feature][row] (row on the lane): 4 groups of 4 consecutive features
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
                 g3 = ty * p.high * (1.f - t * t), loss = 0.f;
             }
             bf16* dst = p.dz + ri * H2 + 8 * h;
+            f32x16 dct[2] = {zero16, zero16};  // AG: dC^T [action feature][row], row on the lane
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned pk[4][2];
@@ -422,9 +447,33 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
                     uint4 o;
                     o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
-                    *(uint4*)(dst + 32 * t + 16 * gg) = o;
+                    if (AG) {
+                        // dZ2' never leaves the registers: these 8 consecutive columns of the lane's row ARE the B operand
+                        // (k-step 2t + gg of the 128-column reduction) of dC^T = W2[action rows] . dZ2'^T
+                        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl)
+                            dct[fl] = mfma(*(const bf16x8*)(w2a + (32 * fl + r) * LDA + 16 * (2 * t + gg) + 8 * h), bfrag, dct[fl]);
+                    } else {
+                        *(uint4*)(dst + 32 * t + 16 * gg) = o;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one column tile at a time (register pressure)
+            }
+            if (AG) {
+                // dmu[row] = sum_f dC[row][f] * inv_a[f] * (pa[f] > 0) * wa[f], pa = relu(mu wa + ba): BN / ReLU backward of the
+                // action layer and its 1-wide input; the lane holds 16 + 16 features of its row, its partner the others
+                float sum = 0.f;
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float4 c = *(const float4*)ctab[32 * fl + acc_row(i, h)];
+                        const float pa = fmaf(ta, c.x, c.y);
+                        sum += pa > 0.f ? dct[fl][i] * c.z : 0.f;
+                    }
+                sum += __shfl_xor(sum, 32);
+                if (h == 0) p.dmu[ri] = sum;
             }
             if (h == 0) Dacc += g3, Lacc += loss;
         }
@@ -554,27 +603,22 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 struct DxArgs {
     NetP net;
     int n_agents, n_sets;
-    const bf16* xf;  // packed state fragments (pack_x_kernel), feature tiles < 8
-    const float* x;  // feature tiles >= 8: the per-row action input [n_agents][64]
+    const bf16* xf;  // dx_kernel: packed state fragments (pack_x_kernel)
+    const float* x;  // dxa_kernel: the per-row action input [n_agents][64]
     const bf16* dz;
     float* partU;    // [grid][2 rh][2 h][KP][2]   sum dC, sum dC * p1 per feature
     float* partV;    // [grid][2 rh][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
-    float* dmu;      // ACTGRAD: [n_agents][64], accumulated with atomics (two addends per row), zeroed by the caller
 };
-// Wave w = (rh, fg): row half rh of feature tiles FT0 + fg + 4 i. Resident: the raw W2 rows of its tiles as B fragments
-// (reduction over the 128 columns). dC comes out [row][feature] (feature on the lane), like the recomputed first layer:
-// the per-feature sums over rows are per-lane sums over the registers, and the masked gradient tile is the A operand of
-// V = (dC*mask)^T . [x_hi | x_lo | 1], which yields dW1 and db1 (k order permuted as in dw_kernel; the [k][row] image of the
-// inputs is the wave's own LDS area).
-// ACTGRAD (critic action tiles, pass 8): operands swapped -> [feature][row] with the row on the lane; per lane
-// dmu[row] = sum_f dC * inv_a[f] * (pa > 0) * wa[f] over its 16 features, the other 48 arrive by shuffle / atomics.
-template <int S, class NET, int FT0, int NFTOT, bool ACTGRAD>
+// Wave w = (rh, fg): row half rh of feature tiles fg + 4 i (the 8 state tiles; the critic's action tiles: dxa_kernel).
+// Resident: the raw W2 rows of its tiles as B fragments (reduction over the 128 columns). dC comes out [row][feature] (feature
+// on the lane), like the recomputed first layer: the per-feature sums over rows are per-lane sums over the registers, and
+// the masked gradient tile is the A operand of V = (dC*mask)^T . [x_hi | x_lo | 1], which yields dW1 and db1 (k order
+// permuted as in dw_kernel; the [k][row] image of the inputs is the wave's own LDS area).
+template <int S, class NET>
 __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
-    constexpr int KP = NET::KP, NF = (NFTOT + 3) / 4, LDZ = 136;  // 272-byte rows: conflict-free b128 row reads
-    constexpr bool ACT_IN = FT0 >= 8;                               // this launch's first layer reads the action
+    constexpr int KP = NET::KP, NF = 2, LDZ = 136;  // 272-byte rows: conflict-free b128 row reads
     __shared__ __attribute__((aligned(16))) bf16 dzimg[2][TILE * LDZ];
     __shared__ __attribute__((aligned(16))) bf16 xt[8][2][32 * 32];  // per wave, per buffer: [k column][row of its half]
-    __shared__ float ctab[64][4];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, rh = w & 1, fg = w >> 1;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const float* th = p.net.th + (long)set * p.net.th_stride;
@@ -582,30 +626,18 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     bf16x8 w2[NF][8], wf[NF];
     f32x16 V[NF];
     float U0[NF], U1[NF];
-    bool valid[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-        valid[i] = fg + 4 * i < NFTOT;
-        const int ft = FT0 + (valid[i] ? fg + 4 * i : 0);
+        const int ft = fg + 4 * i;
         const bf16* src = p.net.W2R + ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) w2[i][s] = *(const bf16x8*)(src + 16 * s);
         wf[i] = layer1_wf<S, NET>(p.net, th, ft, r, h);
         V[i] = zero16, U0[i] = 0.f, U1[i] = 0.f;
     }
-    if (ACTGRAD) {
-        if (tid < 64) {
-            const bool ok = tid < HA;
-            const float* st = p.net.st + (long)set * p.net.st_stride;
-            const float wa = ok ? th[p.net.oWa + tid] : 0.f, ba = ok ? th[p.net.oba + tid] : 0.f;
-            const float ia = ok ? (1.0f / sqrtf(st[p.net.omva + tid] + BN_EPS)) * th[p.net.oga + tid] : 0.f;
-            ctab[tid][0] = wa, ctab[tid][1] = ba, ctab[tid][2] = ia * wa, ctab[tid][3] = 0.f;
-        }
-    } else {
-        for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
-            const int k = (i >> 5) & 31;
-            xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
-        }
+    for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
+        const int k = (i >> 5) & 31;
+        xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
     }
     const int srow = tid >> 3, sch = tid & 7;
     uint4 d0 = {}, d1 = {};
@@ -617,18 +649,10 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         uint4* dst = (uint4*)(dzimg[buf] + srow * LDZ + 16 * sch);
         dst[0] = d0, dst[1] = d1;
     };
-    float an = 0.f;      // ACT_IN: the row's action input
-    bf16x8 xfn = {};     // the row's input fragment [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1)
-    auto fetch_x = [&](int agent) {
-        if (ACT_IN) {
-            an = p.x[(long)agent * TILE + 32 * rh + r];
-            xfn = make_xf(an, 0.f, 0.f, 0.f, h);
-        } else {
-            xfn = ((const bf16x8*)p.xf)[((long)agent * TILE + 32 * rh + r) * 2 + h];
-        }
-    };
+    bf16x8 xfn = {};  // the row's input fragment [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1)
+    auto fetch_x = [&](int agent) { xfn = ((const bf16x8*)p.xf)[((long)agent * TILE + 32 * rh + r) * 2 + h]; };
     auto stage_x = [&](int buf) {  // [k][row] image of [x_hi | x_lo] of the wave's 32 rows: the h = 0 fragment, transposed
-        if (!ACTGRAD && h == 0) {
+        if (h == 0) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) xt[w][buf][k * 32 + r] = xfn[k];
         }
@@ -638,77 +662,150 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     __syncthreads();
     int buf = 0;
     for (int pi = j0; pi < P; pi += J, buf ^= 1) {
-        const int agent = pi * p.n_sets + set;
         const bool more = pi + J < P;
         const bf16x8 xf = xfn;
-        const float mu_r = an;
         if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
         bf16x8 dzf[8];
         const bf16* arow = dzimg[buf] + (32 * rh + r) * LDZ + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) dzf[s] = *(const bf16x8*)(arow + 16 * s);
-        if (ACTGRAD) {
-            float sum = 0.f;
+        bf16x8 xb[2];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                if (!valid[i]) continue;
-                f32x16 dct = zero16;  // [feature][row]: row on the lane
+        for (int s = 0; s < 2; ++s) {
+            const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
+            const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) dct = mfma(w2[i][s], dzf[s], dct);
+            for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
+        }
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 c = *(const float4*)ctab[32 * (fg + 4 * i) + acc_row(k, h)];
-                    const float pa = fmaf(mu_r, c.x, c.y);
-                    sum += pa > 0.f ? dct[k] * c.z : 0.f;
-                }
+        for (int i = 0; i < NF; ++i) {
+            f32x16 dc = zero16;  // [row][feature]: feature on the lane
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dc = mfma(dzf[s], w2[i][s], dc);
+            const f32x16 p1 = mfma(xf, wf[i], zero16);
+            float u0 = 0.f, u1 = 0.f;
+            bf16x8 va[2];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float pr = relu(p1[k]);
+                u0 += dc[k];
+                u1 = fmaf(dc[k], pr, u1);
+                va[k >> 3][k & 7] = (bf16)(pr > 0.f ? dc[k] : 0.f);
             }
-            sum += __shfl_xor(sum, 32);
-            if (h == 0 && valid[0]) atomicAdd(&p.dmu[(long)agent * TILE + 32 * rh + r], sum);
-        } else {
-            bf16x8 xb[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
-                const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
-            }
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                if (!valid[i]) continue;
-                f32x16 dc = zero16;  // [row][feature]: feature on the lane
-#pragma unroll
-                for (int s = 0; s < 8; ++s) dc = mfma(dzf[s], w2[i][s], dc);
-                const f32x16 p1 = mfma(xf, wf[i], zero16);
-                float u0 = 0.f, u1 = 0.f;
-                bf16x8 va[2];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float pr = relu(p1[k]);
-                    u0 += dc[k];
-                    u1 = fmaf(dc[k], pr, u1);
-                    va[k >> 3][k & 7] = (bf16)(pr > 0.f ? dc[k] : 0.f);
-                }
-                U0[i] += u0, U1[i] += u1;
-                V[i] = mfma(va[0], xb[0], V[i]);
-                V[i] = mfma(va[1], xb[1], V[i]);
-            }
+            U0[i] += u0, U1[i] += u1;
+            V[i] = mfma(va[0], xb[0], V[i]);
+            V[i] = mfma(va[1], xb[1], V[i]);
         }
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
         __syncthreads();
     }
-    if (!ACTGRAD) {
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            if (!valid[i]) continue;
-            const int ft = FT0 + fg + 4 * i;
-            float* pu = p.partU + ((((long)blockIdx.x * 2 + rh) * 2 + h) * KP + 32 * ft + r) * 2;
-            pu[0] = U0[i], pu[1] = U1[i];
-            if (r < 16) {
-                float* pv = p.partV + (((long)blockIdx.x * 2 + rh) * KP + 32 * ft) * 16 + r;
+    for (int i = 0; i < NF; ++i) {
+        const int ft = fg + 4 * i;
+        float* pu = p.partU + ((((long)blockIdx.x * 2 + rh) * 2 + h) * KP + 32 * ft + r) * 2;
+        pu[0] = U0[i], pu[1] = U1[i];
+        if (r < 16) {
+            float* pv = p.partV + (((long)blockIdx.x * 2 + rh) * KP + 32 * ft) * 16 + r;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[i][k];
-            }
+            for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[i][k];
+        }
+    }
+}
+
+// ---- dxa: the critic's ACTION feature tiles (48 features = tiles 8, 9) of dC = dZ2 . W2^T and their parameter sums --------
+// A sixth of dx_kernel's work per tile, bound by reading dZ2 (16 KB per agent) once more. Every wave is on its own: wave
+// w = (rh, ft, par) takes row half rh of feature tile 8 + ft of every second tile (parity par) of the workgroup and reads its
+// 32 dZ2 rows straight from global memory as A fragments, one tile ahead; the two parities are combined once, at the end.
+// (The action gradient of pass 7 needs the same product on dZ2': head_kernel<HEAD_CONST> takes it from registers.)
+template <int S>
+__global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
+    typedef Critic NET;
+    constexpr int KP = NET::KP;
+    __shared__ __attribute__((aligned(16))) bf16 xt[8][2][32 * 32];  // per wave, per buffer: [k column][row of its half]
+    __shared__ float comb[4][64][2 + 16];  // parity-1 waves' U0, U1, V -> their parity-0 partners
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, rh = w & 1, ftl = (w >> 1) & 1, par = w >> 2;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const float* th = p.net.th + (long)set * p.net.th_stride;
+    const f32x16 zero16 = {};
+    const int ft = 8 + ftl;
+    bf16x8 w2[8];
+    {
+        const bf16* src = p.net.W2R + ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w2[s] = *(const bf16x8*)(src + 16 * s);
+    }
+    const bf16x8 wf = layer1_wf<S, NET>(p.net, th, ft, r, h);
+    f32x16 V = zero16;
+    float U0 = 0.f, U1 = 0.f;
+    for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
+        const int k = (i >> 5) & 31;
+        xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
+    }
+    __syncthreads();
+    const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
+    bf16x8 dzn[8];
+    float an = 0.f;
+    auto fetch = [&](int k) {
+        const long ri = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh + r;
+        const bf16* src = p.dz + ri * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dzn[s] = *(const bf16x8*)(src + 16 * s);
+        an = p.x[ri];
+    };
+    if (par < ntile) fetch(par);
+    int buf = 0;
+    for (int k = par; k < ntile; k += 2, buf ^= 1) {
+        bf16x8 dzf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dzf[s] = dzn[s];
+        const bf16x8 xf = make_xf(an, 0.f, 0.f, 0.f, h);
+        if (k + 2 < ntile) fetch(k + 2);
+        if (h == 0) {  // [k][row] image of [a_hi 0 0 0 | a_lo 0 0 0] of the wave's 32 rows: the h = 0 fragment, transposed
+            xt[w][buf][r] = xf[0];
+            xt[w][buf][4 * 32 + r] = xf[4];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 xb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
+            const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
+        }
+        f32x16 dc = zero16;  // [row][feature]: feature on the lane
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dc = mfma(dzf[s], w2[s], dc);
+        const f32x16 p1 = mfma(xf, wf, zero16);
+        float u0 = 0.f, u1 = 0.f;
+        bf16x8 va[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pr = relu(p1[i]);
+            u0 += dc[i];
+            u1 = fmaf(dc[i], pr, u1);
+            va[i >> 3][i & 7] = (bf16)(pr > 0.f ? dc[i] : 0.f);
+        }
+        U0 += u0, U1 += u1;
+        V = mfma(va[0], xb[0], V);
+        V = mfma(va[1], xb[1], V);
+    }
+    const int pw = w & 3;  // (rh, ftl)
+    if (par == 1) {
+        comb[pw][lane][0] = U0, comb[pw][lane][1] = U1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) comb[pw][lane][2 + i] = V[i];
+    }
+    __syncthreads();
+    if (par == 0) {
+        U0 += comb[pw][lane][0], U1 += comb[pw][lane][1];
+        float* pu = p.partU + ((((long)blockIdx.x * 2 + rh) * 2 + h) * KP + 32 * ft + r) * 2;
+        pu[0] = U0, pu[1] = U1;
+        if (r < 16) {
+            float* pv = p.partV + (((long)blockIdx.x * 2 + rh) * KP + 32 * ft) * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pv[(long)acc_row(i, h) * 16] = V[i] + comb[pw][lane][2 + i];
         }
     }
 }
@@ -918,7 +1015,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     auto F = [&](size_t off) { return (float*)(ws + off); };
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
-    h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.dz = dz;
+    h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.dz = dz, h.dmu = dmu;
     auto head = [&](auto kern, int ni, const bf16* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {
         h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
@@ -927,7 +1024,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     DwArgs dw;
     dw.n_agents = n_agents, dw.n_sets = n_sets, dw.dz = dz;
     DxArgs dx;
-    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.dz = dz, dx.dmu = dmu;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.dz = dz;
     // 1-2: targets
     head(head_kernel<S, Actor, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
     head(head_kernel<S, Critic, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
@@ -939,20 +1036,17 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     hipLaunchKernelGGL((dw_kernel<S, Critic>), grid, block, 0, st, dw);
     dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]);
     dx.xf = xfs, dx.x = nullptr;
-    hipLaunchKernelGGL((dx_kernel<S, Critic, 0, 8, false>), grid, block, 0, st, dx);
+    hipLaunchKernelGGL((dx_kernel<S, Critic>), grid, block, 0, st, dx);
     dx.x = a;
-    hipLaunchKernelGGL((dx_kernel<S, Critic, 8, 2, false>), grid, block, 0, st, dx);
+    hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
     // 7-8: actor loss through the critic, gradient w.r.t. the action
     head(head_kernel<S, Critic, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
-    (void)hipMemsetAsync(dmu, 0, sizeof(float) * (size_t)n_agents * TILE, st);
-    dx.x = mu;
-    hipLaunchKernelGGL((dx_kernel<S, Critic, 8, 2, true>), grid, block, 0, st, dx);
     // 9-11: actor gradients
     head(head_kernel<S, Actor, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
     dw.net = net[0], dw.xf = xfs, dw.act = nullptr, dw.partG = F(pl.partG[0]);
     hipLaunchKernelGGL((dw_kernel<S, Actor>), grid, block, 0, st, dw);
     dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.x = nullptr;
-    hipLaunchKernelGGL((dx_kernel<S, Actor, 0, 8, false>), grid, block, 0, st, dx);
+    hipLaunchKernelGGL((dx_kernel<S, Actor>), grid, block, 0, st, dx);
     // 12: finalize
     FinArgs fa;
     fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
