@@ -237,8 +237,13 @@ struct HeadArgs {
 // no LDS round trip for activations -- and multiplies it into all four 32-column tiles (A = weight fragments from LDS, one
 // ds_read_b128 per MFMA). Result: lane = batch row, 64 registers = its second-layer outputs, so the output layer is a
 // per-lane dot product (+ one exchange with the partner lane) and dZ2 leaves in 16-byte row-major pieces.
+// Waves per workgroup: the modes without the 64 T1 accumulators fit 168 registers -> three waves per SIMD instead of two
+// (more issue-stall and LDS-latency cover); part / part_s are indexed [grid][8 waves] and only exist for the 8-wave modes.
+__host__ __device__ constexpr int head_waves(int mode) { return (mode == OUT_TANH || mode == OUT_TD) ? 12 : 8; }
+
 template <int S, class NET, int MODE>
-__global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
+__global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadArgs p) {
+    constexpr int NW = head_waves(MODE), NTH = 64 * NW;
     constexpr int K = NET::K, KW = NET::KW, NKS = K / 16, NFT = NET::NFT, LD = KW + 8;  // LD/2 = 4 (mod 8) dwords: conflict-free b128
     __shared__ __attribute__((aligned(16))) bf16 wimg[H2 * LD];
     __shared__ __attribute__((aligned(16))) float c3s[H2];
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     const float* th = p.net.th + (long)set * p.net.th_stride;
     {
         const bf16* src = p.net.W2T + (long)set * H2 * KW;
-        for (int i = tid; i < H2 * (KW / 8); i += NT) {
+        for (int i = tid; i < H2 * (KW / 8); i += NTH) {
             const int n = i / (KW / 8), c = i - n * (KW / 8);
             *(uint4*)(wimg + n * LD + 8 * c) = *(const uint4*)(src + (long)n * KW + 8 * c);
         }
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     const float d3 = vec[2 * H2];
     if (AG) {
         const bf16* src = p.net.W2R + ((long)set * NET::KP + H1) * H2;
-        for (int i = tid; i < 64 * (H2 / 8); i += NT) {
+        for (int i = tid; i < 64 * (H2 / 8); i += NTH) {
             const int f = i / (H2 / 8), c = i - f * (H2 / 8);
             *(uint4*)(w2a + f * LDA + 8 * c) = *(const uint4*)(src + (long)f * H2 + 8 * c);
         }
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
             ctab[tid][0] = wa, ctab[tid][1] = ba, ctab[tid][2] = ia * wa, ctab[tid][3] = 0.f;
         }
     }
-    for (int ft = w; ft < NFT; ft += 8) wfs[ft * 64 + lane] = layer1_wf<S, NET>(p.net, th, ft, r, h);
+    for (int ft = w; ft < NFT; ft += NW) wfs[ft * 64 + lane] = layer1_wf<S, NET>(p.net, th, ft, r, h);
     bf16x8 onef;  // activation fragment of the bias step: feature K = 1, features K+1.. = 0
 #pragma unroll
     for (int j = 0; j < 8; ++j) onef[j] = (bf16)((j == 0 && h == 0) ? 1.f : 0.f);
@@ -301,12 +306,12 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     };
     if (q < ntile) fetch_in(q);
     const bf16* wrow = wimg + r * LD + 8 * h;  // + 32 nt LD + 16 ks
-    for (int k = q; k < ntile; k += 4) {
+    for (int k = q; k < ntile; k += NW / 2) {
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
         const bf16x8 xs = nx, xa = make_xf(na, 0.f, 0.f, 0.f, h);
         const float ty = ny, tw = nw, ta = na;
-        if (k + 4 < ntile) fetch_in(k + 4);
+        if (k + NW / 2 < ntile) fetch_in(k + NW / 2);
         f32x16 acc[4] = {zero16, zero16, zero16, zero16};
         // relu + bf16 of a first-layer tile [feature][row] (row on the lane): 4 groups of 4 consecutive features
         auto pack = [&](const f32x16& p1, unsigned (&pk)[4][2]) {
@@ -1016,22 +1021,22 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.dz = dz, h.dmu = dmu;
-    auto head = [&](auto kern, int ni, const bf16* x, const float* act, const float* rr, const float* yin, float* out, float* part,
-                    float* part_s) {
+    auto head = [&](auto kern, int mode, int ni, const bf16* x, const float* act, const float* rr, const float* yin, float* out,
+                    float* part, float* part_s) {
         h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
-        hipLaunchKernelGGL(kern, grid, block, 0, st, h);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * head_waves(mode)), 0, st, h);
     };
     DwArgs dw;
     dw.n_agents = n_agents, dw.n_sets = n_sets, dw.dz = dz;
     DxArgs dx;
     dx.n_agents = n_agents, dx.n_sets = n_sets, dx.dz = dz;
     // 1-2: targets
-    head(head_kernel<S, Actor, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
-    head(head_kernel<S, Critic, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+    head(head_kernel<S, Actor, OUT_TANH>, OUT_TANH, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+    head(head_kernel<S, Critic, OUT_TD>, OUT_TD, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
     // 3: mu (independent of the critic passes)
-    head(head_kernel<S, Actor, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+    head(head_kernel<S, Actor, OUT_TANH>, OUT_TANH, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
     // 4-6: critic loss and gradients
-    head(head_kernel<S, Critic, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    head(head_kernel<S, Critic, HEAD_CRITIC>, HEAD_CRITIC, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
     dw.net = net[1], dw.xf = xfs, dw.act = a, dw.partG = F(pl.partG[1]);
     hipLaunchKernelGGL((dw_kernel<S, Critic>), grid, block, 0, st, dw);
     dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]);
@@ -1040,9 +1045,9 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     dx.x = a;
     hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
     // 7-8: actor loss through the critic, gradient w.r.t. the action
-    head(head_kernel<S, Critic, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
+    head(head_kernel<S, Critic, HEAD_CONST>, HEAD_CONST, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
     // 9-11: actor gradients
-    head(head_kernel<S, Actor, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
+    head(head_kernel<S, Actor, HEAD_ACTOR>, HEAD_ACTOR, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
     dw.net = net[0], dw.xf = xfs, dw.act = nullptr, dw.partG = F(pl.partG[0]);
     hipLaunchKernelGGL((dw_kernel<S, Actor>), grid, block, 0, st, dw);
     dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.x = nullptr;
