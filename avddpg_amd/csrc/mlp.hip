@@ -1389,6 +1389,87 @@ __global__ __launch_bounds__(NTHREADS) void mlp_rows_kernel(avd_mlp_layout L, in
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The actor forward for agents that SHARE weight sets (set_mod > 0: interfrl with shared sets, trainer.py:121-128): one
+// workgroup evaluates R agents of the same set, so the set's 143 KB of weights are read once per R rows instead of once
+// per row (20 480 agents x 143 KB = 2.9 GB of L2 reads per step as batch-1 GEMVs). Every row goes through EXACTLY
+// mlp_rows_kernel's sequence of operations (same k split, same partial-sum order, same reduction tree), so the result
+// is bit-identical to the batch-1 kernel: tests/test_gpu_trainer.py::test_shared_sets_equal_per_agent_sets_under_interfrl.
+// ------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void gemv_relu_rows(const float* x, int ldx, int K, const float* __restrict__ W,
+                                               const float* __restrict__ b, int N, float* part, float* y, int ldy) {
+    const int cols = N < NTHREADS ? N : NTHREADS;
+    const int ksplit = NTHREADS / cols;
+    for (int n0 = 0; n0 < N; n0 += cols) {
+        const int n = n0 + (threadIdx.x % cols);
+        const int kh = threadIdx.x / cols;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        if (kh < ksplit && n < N) {
+            const int kb = (K * kh) / ksplit, ke = (K * (kh + 1)) / ksplit;
+#pragma unroll 4
+            for (int k = kb; k < ke; ++k) {
+                const float w = W[(long)k * N + n];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fmaf(x[r * ldx + k], w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) part[r * NTHREADS + threadIdx.x] = acc[r];
+        __syncthreads();
+        if (threadIdx.x < cols && n < N) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float sum = b[n];
+                for (int h = 0; h < ksplit; ++h) sum += part[r * NTHREADS + h * cols + threadIdx.x];
+                y[r * ldy + n] = fmaxf(sum, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void actor_rows_shared_kernel(avd_mlp_layout L, int set_mod, int n_agents,
+                                                                      const float* __restrict__ theta,
+                                                                      const float* __restrict__ stats,
+                                                                      const float* __restrict__ state, int x_stride, float high,
+                                                                      float* __restrict__ out,
+                                                                      const int32_t* __restrict__ run_if_nonzero) {
+    if (run_if_nonzero && *run_if_nonzero == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* h1 = smem;                        // [R][H1]
+    float* h2 = h1 + R * L.H1;               // [R][H2]
+    float* part = h2 + R * L.H2;             // [R][NTHREADS]
+    float* xin = part + R * NTHREADS;        // [R][MAX_S]
+    const int set = blockIdx.x % set_mod, g = blockIdx.x / set_mod, P = n_agents / set_mod;
+    const float* th = theta + (long)set * L.theta_size;
+    const float* st = stats + (long)set * L.stats_size;
+    // row r = agent (R g + r) * set_mod + set; rows past the last platoon repeat the last one and are not stored
+    for (int i = threadIdx.x; i < R * L.S; i += NTHREADS) {
+        const int r = i / L.S, k = i - r * L.S, pl = min(R * g + r, P - 1);
+        xin[r * gen::MAX_S + k] = state[((long)pl * set_mod + set) * x_stride + k];
+    }
+    __syncthreads();
+    gemv_relu_rows<R>(xin, gen::MAX_S, L.S, th + L.aW1, th + L.ab1, L.H1, part, h1, L.H1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) bn_apply(h1 + r * L.H1, L.H1, th + L.ag1, th + L.abe1, st + L.amm1, st + L.amv1);
+    __syncthreads();
+    gemv_relu_rows<R>(h1, L.H1, L.H1, th + L.aW2, th + L.ab2, L.H2, part, h2, L.H2);
+#pragma unroll
+    for (int r = 0; r < R; ++r) bn_apply(h2 + r * L.H2, L.H2, th + L.ag2, th + L.abe2, st + L.amm2, st + L.amv2);
+    __syncthreads();
+    for (int a = 0; a < L.A; ++a) {
+        for (int r = 0; r < R; ++r) {
+            const float z = block_dot(h2 + r * L.H2, th + L.aW3 + a, L.A, L.H2, part) + th[L.ab3 + a];
+            const int pl = R * g + r;
+            if (threadIdx.x == 0 && pl < P) out[((long)pl * set_mod + set) * L.A + a] = tanhf(z) * high;
+        }
+    }
+}
+
 #ifdef AVD_PHASE_TIMING
 }  // namespace avd
 extern "C" int avd_debug_phase_cycles(unsigned long long* h_out, int reset) {
@@ -1470,6 +1551,17 @@ static int launch_rows(const avd_mlp_layout* lay, int mode, int n_agents, int se
     AVD_REQUIRE(n_agents > 0 && set_mod >= 0 && x_stride >= lay->S, "%s: n_agents=%d set_mod=%d x_stride=%d", who,
                 n_agents, set_mod, x_stride);
     AVD_REQUIRE(theta && stats && state && out && (mode == 0 || action), "%s: null pointer", who);
+    constexpr int R = 8;  // shared sets: R agents of a set per workgroup (weights read once per R rows, same bits per row)
+    if (mode == 0 && set_mod > 0 && n_agents % set_mod == 0 && n_agents / set_mod >= R) {
+        const size_t ldr = sizeof(float) * (size_t)R * (lay->H1 + lay->H2 + NTHREADS + gen::MAX_S);
+        if (ldr <= 64 * 1024) {
+            const int P = n_agents / set_mod;
+            hipLaunchKernelGGL(actor_rows_shared_kernel<R>, dim3((unsigned)((P + R - 1) / R) * set_mod), dim3(NTHREADS), ldr,
+                               (hipStream_t)stream, *lay, set_mod, n_agents, theta, stats, state, x_stride, high, out,
+                               run_if_nonzero);
+            return check_launch(who);
+        }
+    }
     const size_t lds = sizeof(float) * (size_t)(lay->H1 + lay->Ha + lay->H2 + NTHREADS + gen::MAX_S + gen::MAX_A);
     if (lds > 160 * 1024) {
         set_error("%s: hidden sizes need %zu B of LDS (> 160 KiB)", who, lds);

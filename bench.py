@@ -229,7 +229,7 @@ def main():
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x4 persistent kernels + finalize)" if fset else
+        roofs.append({"kernel": ("avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
                                  "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)"), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})

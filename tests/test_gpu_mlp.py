@@ -406,3 +406,30 @@ def test_full_size_fused_update_is_bitwise_the_two_kernel_update_20480_agents():
             assert torch.equal(x, y), step
         assert torch.equal(nxt_act, grp_b.actor(nxt, 0))
     assert int(grp_a.step[0]) == int(grp_b.step[-1]) == 2 and torch.isfinite(grp_a.theta).all()
+
+
+@pytest.mark.parametrize("S,P,M", [(4, 8, 1), (4, 13, 3), (3, 37, 5), (4, 4096, 5)])
+def test_shared_set_actor_rows_are_bitwise_the_batch1_kernel(S, P, M):
+    """avd_actor_forward_f32 with shared weight sets (set_mod = M) evaluates 8 agents of a set per workgroup; every row goes
+    through the batch-1 kernel's exact operation sequence, so the actions are the same BITS as one workgroup per agent on
+    replicated weights (the reference's P copies of vehicle m's actor, workers/trainer.py:121-128, 287-289). P = 13 / 37
+    leave a ragged last group; rows of 4 floats with S = 3 exercise the stride."""
+    need_gpu()
+    conf, shared = _perturbed_group(M, S=S, seed=131)
+    rs = np.random.RandomState(132)
+    n = P * M
+    x = t(rs.normal(0, 1.5, size=(n, 4)).astype(np.float32))
+    got = shared.actor(x, set_mod=M, x_stride=4)
+    # the same weights, one copy per agent (agent v = p*M + m holds set m), through the one-agent-per-workgroup kernel
+    per = vec.AgentGroup(n, S, 1, conf)
+    per.theta.copy_(shared.theta.repeat(P, 1))
+    per.stats.copy_(shared.stats.repeat(P, 1))
+    ref = per.actor(x, set_mod=0, x_stride=4)
+    assert torch.equal(got, ref) and got.abs().max() > 0.05
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    keep = torch.full_like(got, 7.0)
+    shared.actor(x, set_mod=M, x_stride=4, out=keep, run_if_nonzero=flag)
+    assert (keep == 7.0).all()  # flag 0: the conditional launch leaves `out` alone
+    flag.fill_(1)
+    shared.actor(x, set_mod=M, x_stride=4, out=keep, run_if_nonzero=flag)
+    assert torch.equal(keep, ref)
