@@ -103,7 +103,7 @@ struct NetP {
     int oW1, ob1;     // first (state) layer weights [S][H1] / bias, offsets into th
     int oWa, oba;     // critic action layer [1][HA] / bias (critic only)
     int oga, omva;    // critic action-branch BN gamma (th) / moving variance (st): dx_kernel's action-gradient mode
-    const bf16* W2T;  // [sets][H2][KW]  bf16(inv1[f] * W2[f][n]) transposed, feature K = b2' (folded bias): head_kernel's LDS image
+    const bf16* W2T;  // [sets][H2][KW]  bf16(inv1[f] * W2[f][n]) transposed, features K, K + 1 = b2' (folded bias) as a bf16 pair: head_kernel's LDS image
     const bf16* W2R;  // [sets][KP][H2]  bf16(W2[f][n]), rows >= K zero: dx_kernel's resident operand (online nets only)
     const float* vec; // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3
 };
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             w = th[oW2 + (long)f * H2 + n];
             shw = sh * w;
         }
-        if (f < KW && f != K) a.W2T[net][((long)set * H2 + n) * KW + f] = (bf16)(inv * w);  // (feature K: the folded bias, below)
+        if (f < KW && f != K && f != K + 1) a.W2T[net][((long)set * H2 + n) * KW + f] = (bf16)(inv * w);  // (K, K + 1: the bias, below)
         if (!target && f < KP) a.W2R[net][((long)set * KP + f) * H2 + n] = (bf16)w;
     }
     red[f] = shw;
@@ -190,7 +190,11 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
     if (f == 0) {
         vec[n] = th[ob2 + n] + red[0];
-        a.W2T[net][((long)set * H2 + n) * KW + K] = (bf16)vec[n];
+        // the folded bias b2' rides in the weight image as features K and K + 1 = its bf16 pair (hi, lo), met by two
+        // constant-one activations: 2^-17 relative (one bf16 alone would put 2^-9 of the bias into every pre-activation)
+        const bf16 bh = (bf16)vec[n];
+        a.W2T[net][((long)set * H2 + n) * KW + K] = bh;
+        a.W2T[net][((long)set * H2 + n) * KW + K + 1] = (bf16)(vec[n] - (float)bh);
         const float inv2 = (1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n];
         vec[H2 + n] = inv2 * th[oW3 + n];
     }
@@ -280,9 +284,9 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         }
     }
     for (int ft = w; ft < NFT; ft += NW) wfs[ft * 64 + lane] = layer1_wf<S, NET>(p.net, th, ft, r, h);
-    bf16x8 onef;  // activation fragment of the bias step: feature K = 1, features K+1.. = 0
+    bf16x8 onef;  // activation fragment of the bias step: features K, K + 1 = 1 (the bias's bf16 pair), K + 2.. = 0
 #pragma unroll
-    for (int j = 0; j < 8; ++j) onef[j] = (bf16)((j == 0 && h == 0) ? 1.f : 0.f);
+    for (int j = 0; j < 8; ++j) onef[j] = (bf16)((j < 2 && h == 0) ? 1.f : 0.f);
     const f32x16 zero16 = {};
     float T1[4][16], Dacc = 0.f, Lacc = 0.f;
 #pragma unroll

@@ -54,11 +54,14 @@ def test_fused_set_learner_matches_oracle_on_concatenated_batch(S, P, M):
         assert abs(lo[1] - aux["actor_loss"]) <= 1e-2 * max(1e-2, abs(aux["actor_loss"]))
 
 
-def test_fused_set_learner_equals_per_agent_kernel_plus_federated_mean_and_layerwise_learner():
+@pytest.mark.parametrize("P,M", [(8, 3), (1, 1), (70, 5)])
+def test_fused_set_learner_equals_per_agent_kernel_plus_federated_mean_and_layerwise_learner(P, M):
     """Same quantity three ways on the GPU: avd_learn_f32 per agent (exact f32 MFMA) + fed_mean over the platoons; the
-    layer-wise bf16 GEMM chain on the set-major batch (wide.hip); the fused set learner on the agent-major batch."""
+    layer-wise bf16 GEMM chain on the set-major batch (wide.hip); the fused set learner on the agent-major batch. On weights
+    with non-trivial BatchNorm / bias terms the fused learner must be as close to the exact result as the layer-wise one
+    (a folded bias carried as ONE bf16 feature was not: 2.5x ... 19x the error -- it rides as a bf16 pair now)."""
     need_gpu()
-    P, M, B, S = 8, 3, 64, 4
+    B, S = 64, 4
     conf, grp = _perturbed_group(M, S=S, seed=71)
     rs = np.random.RandomState(72)
     n = P * M
@@ -71,8 +74,9 @@ def test_fused_set_learner_equals_per_agent_kernel_plus_federated_mean_and_layer
     lay = grp.lay
     for name, lo, hi in (("actor", 0, lay.actor_size), ("critic", lay.actor_size, lay.theta_size)):
         scale = np.abs(avg[:, lo:hi]).max()
-        assert np.abs(avg[:, lo:hi] - fused[:, lo:hi]).max() <= 2e-2 * scale, name
-        assert np.abs(wide[:, lo:hi] - fused[:, lo:hi]).max() <= 2e-2 * scale, name
+        ef, ew = np.abs(avg[:, lo:hi] - fused[:, lo:hi]).max() / scale, np.abs(avg[:, lo:hi] - wide[:, lo:hi]).max() / scale
+        assert ef <= 2e-2 and np.abs(wide[:, lo:hi] - fused[:, lo:hi]).max() <= 2e-2 * scale, name
+        assert ef <= 2.0 * ew + 5e-4, (name, ef, ew)  # measured: 0.9 ... 1.7 x the layer-wise learner's error
     # padding floats of the slab stay zero (what Adam relies on)
     assert fused[:, lay.actor_size - 3:lay.actor_size].max() == 0.0 or lay.actor_size % 4 == 0
 
