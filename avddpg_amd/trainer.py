@@ -122,6 +122,9 @@ class VecTrainer:
             raise ValueError(f"shared_engine={shared_engine!r}")
         if self.shared_engine in ("batched", "fused") and not self.shared:
             raise ValueError("the batched learners need shared weight sets (interfrl + gradients, every step federated)")
+        if self.shared_engine == "fused" and (lay.H1, lay.H2, lay.Ha, lay.A, lay.B) != (256, 128, 48, 1, 64):
+            raise ValueError("shared_engine='fused' (csrc/fset.hip) serves the reference widths 256/128/48, A = 1, batch 64 only; "
+                             f"got {lay.H1}/{lay.H2}/{lay.Ha}, A = {lay.A}, batch {lay.B}: use shared_engine='batched'")
         self.actor_out = torch.zeros(n_agents, self.A, **f32)
         self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)

@@ -118,7 +118,13 @@ def test_fused_set_learner_weighted_mean_matches_weighted_fed_mean():
 
 
 def test_fused_set_learner_rejects_other_widths():
+    from avddpg_amd import trainer
+
     need_gpu()
+    with pytest.raises(ValueError, match="reference widths"):
+        trainer.VecTrainer(config.Config(num_platoons=2, pl_size=2, fed_method="interfrl", weighted_average_enabled=False,
+                                         actor_layer1_size=512, actor_layer2_size=256, critic_layer1_size=512,
+                                         critic_layer2_size=256), rng="device", shared_engine="fused")
     conf = config.Config(actor_layer1_size=512, actor_layer2_size=256, critic_layer1_size=512, critic_layer2_size=256)
     grp = vec.AgentGroup(1, 4, 1, conf)
     z = torch.zeros(1, 64, 4, device="cuda")
