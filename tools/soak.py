@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Diagnostic: long runs (device RNG, auto-reset) of the fused nofrl path and the batched interfrl learner at 256x5
-platoons; prints weight magnitude / finiteness every 300 steps."""
+platoons (layer-wise, fused and per-agent engines); prints weight magnitude / finiteness every 300 steps."""
 import os
 import sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avddpg_amd import config, trainer
 for kw, fused, eng, steps in ((dict(), True, None, 1500),
                              (dict(fed_method="interfrl", weighted_average_enabled=False), False, "batched", 600),
+                             (dict(fed_method="interfrl", weighted_average_enabled=False), False, "fused", 3000),
                              (dict(fed_method="interfrl", weighted_average_enabled=False), False, "per_agent", 600)):
     conf = config.Config(num_platoons=256, pl_size=5, buffer_size=2000, **kw)
     vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, fused_update=fused, shared_engine=eng)
