@@ -331,11 +331,7 @@ __device__ __forceinline__ void dx_load(DxOps<KIN, N>& o, const float* __restric
     const int lane = tid_here() & 63, lr = lane & 15, lg = lane >> 4;
     const unsigned wrow = lr * N + 4 * lg, c = cl + lr;
 #pragma unroll
-#ifdef AVD_EXP_NODX
-    for (int q = 0; q < N / 16; ++q) o.wc[q] = (f32x4){0.001f * q, 0.002f, 0.003f, 0.004f};  // traffic experiment: no dX operand loads
-#else
     for (int q = 0; q < N / 16; ++q) o.wc[q] = *(const f32x4*)((W2row + 16 * q) + wrow);
-#endif
     featw_load<KIN, 1>(o.fw, s, c);
     o.gam = (s.th + s.og)[c], o.mean = (s.st + s.omm)[c], o.var = (s.st + s.omv)[c];
 }
