@@ -10,6 +10,7 @@ AVD_LEARN_KERNEL=fast python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_defa
 python bench.py --no-fused --no-cpu-baseline > $OUT/${TAG}_bench_unfused.json 2>/dev/null
 python bench.py --mode interfrl --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
 python bench.py --mode interfrl --engine batched --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_batched.json 2>/dev/null
+python bench.py --mode interfrl --engine fused --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_fused.json 2>/dev/null
 python bench.py --mode interfrl --hidden 1024 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
 python bench.py --pl-size 10 --buffer-size 50000 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_config3_4096x10.json 2>/dev/null
 python bench.py --framework centralized --no-cpu-baseline > $OUT/${TAG}_bench_centralized_4096x5.json 2>/dev/null
