@@ -213,3 +213,20 @@ def test_trainer_fused_engine_weighted_federation_runs_model_a():
     assert np.allclose(w, ref, rtol=1e-6)
     assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
     assert not torch.equal(vt.agents.theta, th0)
+
+
+def test_mfma_layout_probe_passes_on_this_gpu():
+    """The three hardware layouts csrc/fset.hip is built on -- v_mfma_f32_32x32x16_bf16 lane maps, an accumulator tile as the
+    next MFMA's A operand (permuted k order), ds_read_b64_tr_b16 as the B operand of that product -- checked with exact
+    small-integer data by tools/probes/mfma_layout.hip on the GPU the tests run on."""
+    import os
+    import subprocess
+
+    need_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, exe = os.path.join(root, "tools", "probes", "mfma_layout.hip"), os.path.join(root, "tools", "probes", "mfma_layout")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value", src, "-o", exe], check=True,
+                       capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.count("PASS") == 3 and "FAIL" not in out.stdout, out.stdout + out.stderr
