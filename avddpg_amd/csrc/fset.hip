@@ -64,6 +64,19 @@ __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >
 // canonicalize + max (it must quiet signalling NaNs) -- two VALU instructions per element in loops whose VALU count bounds
 // them. (Inline assembly is not an option: hipcc does not pad the MFMA -> VALU read hazard for an opaque instruction.)
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+// relu + bf16 of a PAIR in two instructions: v_cvt_pk_bf16_f32, then v_pk_max_i16 against 0 -- a negative float is a negative
+// int16 in its upper 16 bits, so the signed 16-bit max IS relu on the packed pair (-0.0 -> +0) -- instead of two v_max_f32 and
+// the conversion
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_bf16x2(float a, float b) {
+    const f32x2 f = {a, b};
+    s16x2 v = __builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2));
+    const s16x2 z = {0, 0};
+    v = __builtin_elementwise_max(v, z);
+    return __builtin_bit_cast(unsigned, v);
+}
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -321,11 +334,8 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         auto pack = [&](const f32x16& p1, unsigned (&pk)[4][2]) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (bf16)relu(p1[4 * g + j]);
-                const uint2 u = __builtin_bit_cast(uint2, v);
-                pk[g][0] = u.x, pk[g][1] = u.y;
+                pk[g][0] = relu_bf16x2(p1[4 * g], p1[4 * g + 1]);
+                pk[g][1] = relu_bf16x2(p1[4 * g + 2], p1[4 * g + 3]);
             }
         };
         // Software pipeline over the feature tiles: [first-layer MFMA of tile ft+1] [8 second-layer MFMAs of tile ft]
@@ -589,10 +599,10 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
                 const f32x16 p1 = mfma(xf, wf[i], zero16);  // [row][feature]: feature on the lane
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8 xo;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xo[j] = (bf16)relu(p1[8 * s + j]);
-                    G[i] = mfma(xo, bfr[rh][s], G[i]);
+                    uint4 xu;
+                    xu.x = relu_bf16x2(p1[8 * s], p1[8 * s + 1]), xu.y = relu_bf16x2(p1[8 * s + 2], p1[8 * s + 3]);
+                    xu.z = relu_bf16x2(p1[8 * s + 4], p1[8 * s + 5]), xu.w = relu_bf16x2(p1[8 * s + 6], p1[8 * s + 7]);
+                    G[i] = mfma(__builtin_bit_cast(bf16x8, xu), bfr[rh][s], G[i]);
                 }
             }
         }
