@@ -947,14 +947,18 @@ struct Plan {
     int grid, J;
     size_t W2T[4], W2R[2], vec[4], a2, y, mu, dmu, dz, xfs, xfs2, partH[2], partHs[3], partU[2], partV[2], partG[2], total;
 };
+// CUs of the CURRENT device (cached per device ordinal): the plan -- workgroups per set, workspace layout, the grouping of the
+// partial sums and therefore the bits of the result -- is a function of (CU count, n_sets, n_agents); results are
+// deterministic per device model, not across parts with different CU counts.
 static int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < 64 && cache[dev]) return cache[dev];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    const int n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (dev < 64) cache[dev] = n;
     return n;
 }
 static Plan make_plan(int n_agents, int n_sets) {
@@ -1102,7 +1106,8 @@ extern "C" int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents,
     const fset::Plan pl = fset::make_plan(n_agents, n_sets);
     AVD_REQUIRE(workspace_bytes >= pl.total, "avd_learn_set_fused_bf16: workspace %zu B < %zu B", workspace_bytes, pl.total);
     // (padding floats of the slab are never written by finalize: keep them zero like every other gradient producer)
-    (void)hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream);
+    if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream) != hipSuccess)
+        return check_launch("avd_learn_set_fused_bf16: hipMemsetAsync(grads)");
     if (lay->S == 4)
         return fset::run<4>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
                             losses, (unsigned char*)workspace, pl, (hipStream_t)stream);

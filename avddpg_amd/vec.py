@@ -326,6 +326,7 @@ class AgentGroup:
         agent_weight [n_agents] (optional): w_p * P / sum(w) per agent = the weighted federated mean.
         Returns the mean gradient per set [n_sets, theta_size]."""
         import ctypes
+        self._check_agent_major(s, a, r, s2, n_agents, agent_weight)
         if grads is None:
             grads = torch.empty(self.n_sets, self.lay.theta_size, dtype=torch.float32, device=self.device)
         need = ctypes.c_size_t(0)
@@ -337,6 +338,23 @@ class AgentGroup:
              ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma,
              self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
+
+    def _check_agent_major(self, s, a, r, s2, n_agents, agent_weight):
+        """The set learners of csrc/fset.hip / fsplit.hip take raw pointers to tightly packed AGENT-major f32 batches
+        [n_agents, B, S]: a set-major or strided view (what learn_shared wants) would silently give wrong gradients."""
+        lay = self.lay
+        want = {"s": (n_agents, lay.B, lay.S), "s2": (n_agents, lay.B, lay.S), "r": (n_agents, lay.B)}
+        for name, x in (("s", s), ("s2", s2), ("r", r)):
+            if tuple(x.shape) != want[name] or x.dtype != torch.float32 or not x.is_contiguous():
+                raise _hip.AvdError(f"set learner: {name} must be contiguous float32 {want[name]} (agent-major), got "
+                                    f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
+        if a.numel() != n_agents * lay.B * lay.A or a.dtype != torch.float32 or not a.is_contiguous() or a.shape[0] != n_agents:
+            raise _hip.AvdError(f"set learner: a must be contiguous float32 [{n_agents}, {lay.B}(, {lay.A})], got {tuple(a.shape)} {a.dtype}")
+        if n_agents <= 0 or n_agents % self.n_sets:
+            raise _hip.AvdError(f"set learner: n_agents={n_agents} is not a multiple of n_sets={self.n_sets}")
+        if agent_weight is not None and (agent_weight.numel() != n_agents or agent_weight.dtype != torch.float32
+                                         or not agent_weight.is_contiguous()):
+            raise _hip.AvdError(f"set learner: agent_weight must be contiguous float32 [{n_agents}]")
 
     def actor_shared(self, states_set_major, n_agents, out=None):
         """actor(state) for agents sharing this group's weight sets as one bf16 GEMM chain per set (csrc/wide.hip):

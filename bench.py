@@ -9,8 +9,16 @@ independent actor/critic/target/Adam/replay set per (platoon, vehicle) = 20480 a
 steady state (capacity 100000 rows per agent, full).  `--mode interfrl` runs configs[3]'s federated variant
 (one weight set per vehicle index, gradients averaged over platoons and all-reduced across ranks with RCCL).
 
-Launch: python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run, one rank per GPU)
-Rank 0 prints ONE JSON line.
+Launch: python bench.py --gpus N --steps K --warmup W. N > 1: one rank per GPU, either under torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when WORLD_SIZE is not set, started BY this script as N child
+processes before anything touches the GPU (the parent only waits and never imports torch). Rank 0 prints ONE JSON line.
+
+Without --mode the line carries BOTH workloads of the 4096 x 5 shape, measured one after the other in the same run:
+the primary one (PRIMARY_MODE) as `value`, the other under `also_measured`:
+  * nofrl    -- the reference's default `fed_method` (src/config.py:25): 20480 independent agents, HBM-bound, no
+                data-path collective (replicas only across GPUs);
+  * interfrl -- BASELINE configs[3]'s per-GPU shape (workers/trainer.py:400-431): gradients averaged over the platoons
+                of ALL ranks through one RCCL all-reduce per step (`rccl_ranks` = N).
 """
 import argparse
 import json
@@ -37,10 +45,14 @@ def parse():
     ap.add_argument("--platoons", type=int, default=4096, help="platoons per GPU")
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
-    ap.add_argument("--mode", choices=["nofrl", "interfrl"], default="nofrl")
-    ap.add_argument("--engine", choices=["per_agent", "batched", "fused"], default=None,
+    ap.add_argument("--mode", choices=["nofrl", "interfrl"], default=None,
+                    help="measure this workload only (default: both, PRIMARY_MODE as `value`, the other under `also_measured`)")
+    ap.add_argument("--no-secondary", action="store_true", help="default run: skip the non-primary workload")
+    ap.add_argument("--engine", choices=["per_agent", "batched", "fused", "fused3"], default=None,
                     help="interfrl: per_agent = f32 LDS-resident learn kernel per agent + federated sum; batched = one "
-                         "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist)")
+                         "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist); "
+                         "fused = persistent set learner, bf16 operands (fset.hip); fused3 = the same with every operand an exact "
+                         "bf16 hi+lo pair, f32-class results (fsplit.hip)")
     ap.add_argument("--hidden", type=int, default=None,
                     help="actor/critic layer1 = layer2 size (BASELINE config 5: 1024; needs --mode interfrl)")
     ap.add_argument("--framework", choices=["decentralized", "centralized"], default="decentralized",
@@ -53,6 +65,9 @@ def parse():
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test: every rank uses GPU 0 (a 1-GPU box cannot host one rank per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
+    ap.add_argument("--master-port", type=int, default=0, help="self-spawned ranks: rendezvous port (0 = pick a free one)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -90,64 +105,106 @@ def _cpu_worker(seconds, pl_size, q):
     q.put((r["value"], r["updates_per_s"]))
 
 
-def cpu_baseline_all_cores(seconds, pl_size):
+def cpu_baseline_all_cores(seconds, pl_size, max_workers=None):
     """platoons are independent, so the host's whole-socket figure is N independent single-thread copies of
-    the reference-shaped loop, N = the cores this process may run on. Reported beside the 1-thread figure, never as it."""
+    the reference-shaped loop, N = the cores this process may run on. Reported beside the 1-thread figure, never as it.
+    Opt-in (--cpu-all-cores). One overall deadline; stragglers are terminated together and the sum over the workers that
+    did report is returned with their count."""
     import multiprocessing as mp
+    import queue as _queue
 
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if max_workers:
+        n = min(n, max_workers)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_cpu_worker, args=(seconds, pl_size, q)) for _ in range(n)]
     for p in procs:
         p.start()
+    res, deadline = [], time.monotonic() + seconds * 3 + 90
     try:
-        res = [q.get(timeout=seconds * 3 + 90) for _ in procs]
+        while len(res) < n and time.monotonic() < deadline:
+            try:
+                res.append(q.get(timeout=1.0))
+            except _queue.Empty:
+                if not any(p.is_alive() for p in procs) and q.empty():
+                    break
     finally:
         for p in procs:
-            p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
-    return {"value": sum(r[0] for r in res), "unit": "env-steps/s", "updates_per_s": sum(r[1] for r in res), "cores": n,
-            "sample": f"{n} independent single-thread processes of the same loop, {seconds:.0f} s each, throughputs summed"}
+        for p in procs:
+            p.join(timeout=2)
+    return {"value": sum(r[0] for r in res), "unit": "env-steps/s", "updates_per_s": sum(r[1] for r in res), "cores": len(res),
+            "sample": f"{len(res)} of {n} independent single-thread processes of the same loop reported, {seconds:.0f} s each, "
+                      "throughputs summed"}
 
 
-def main():
-    args = parse()
+# The workload whose throughput is `value` when no --mode is given; the other one is measured in the same run and
+# reported under `also_measured`. The same at every N, so that value(N) / value(1) is a scaling figure.
+PRIMARY_MODE = "nofrl"
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one, which has not
+    touched the GPU (no torch import, no HIP call) and only waits. Each child is this script with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, i.e. exactly what torch.distributed.run would start. Rank 0's stdout is ours."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:  # one rank failed: the others would wait in a collective forever
+                    rc = rc or code
+                    for o in pending:
+                        o.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def run_workload(args, mode, engine, rank, world, group):
+    """Build the trainer for one workload, time args.steps steps of it, return the fields of the JSON line."""
     import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    dev = 0 if args.single_device else local_rank
-    torch.cuda.set_device(dev)
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(args.backend)
-        group = dist.group.WORLD
 
     from avddpg_amd import config, trainer
 
     P, L = args.platoons, args.pl_size
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
-                         fed_method="interfrl" if args.mode == "interfrl" else "normal",
+                         fed_method="interfrl" if mode == "interfrl" else "normal",
                          weighted_average_enabled=False, random_seed=1, framework=args.framework)  # random_seed: initial weights, the same on every rank
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
-    vt = trainer.VecTrainer(conf, rng="device", group=group if args.mode == "interfrl" else None, auto_reset=True,
+    vt = trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
                             seed=1 + rank, pipeline_chunks=args.chunks,
-                            fused_update=(args.mode == "nofrl" and not args.no_fused),
-                            shared_engine=args.engine if args.mode == "interfrl" else None)
-    batched = vt.shared and vt.shared_engine in ("batched", "fused")
-    fset = vt.shared and vt.shared_engine == "fused"
+                            fused_update=(mode == "nofrl" and not args.no_fused),
+                            shared_engine=engine if mode == "interfrl" else None)
+    batched = vt.shared and vt.shared_engine in ("batched", "fused", "fused3")
+    fset = vt.shared and vt.shared_engine in ("fused", "fused3")
+    split3 = vt.shared and vt.shared_engine == "fused3"
     # synthetic steady state: replay rings full of random-init-platoon-like rows
     ring = vt.replay.ring
     chunk = max(1, (1 << 28) // (ring.shape[1] * ring.shape[2]))
@@ -229,7 +286,9 @@ def main():
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
+        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: persistent head / dw / dx kernels, every GEMM operand "
+                                 "an exact bf16 hi+lo pair: 2-3 MFMAs per algorithmic product)" if split3 else
+                                 "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
                                  "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)"), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})
@@ -238,13 +297,13 @@ def main():
         upd_s = stage_ms["update"] / 1e3
         roofs.append({"kernel": lk, "bound": "mfma", "achieved": flop_per_sample * 64 * n_agents / learn_s / 1e12,
                       "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "_t": learn_s})
-        if args.mode == "nofrl":
+        if mode == "nofrl":
             roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
-    if os.path.exists(pmc_path) and P == 4096 and L == 5 and args.mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
+    if os.path.exists(pmc_path) and P == 4096 and L == 5 and mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
         pmc = json.load(open(pmc_path))["kernels"]
         want = {fused_name: (lk,) if lk == "learn_kernel_l" else (lk, "adam_polyak_ranges"), lk: (lk,),
                 "adam_polyak_kernel": ("adam_polyak_kernel",)}
@@ -263,51 +322,102 @@ def main():
         for r in roofs:
             r.pop("_t", None)
     roof_learn, roof_upd = roofs[0], (roofs[1] if len(roofs) > 1 else None)
+    rccl = mode == "interfrl" and world > 1
+
+    out = {
+        "value": env_steps_per_s,
+        "unit": "env-steps/s",
+        "updates_per_s": updates_per_s,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "dtype": ("f32-class: every GEMM operand an exact bf16 hi+lo pair (bf16x3 split, 2^-17 per operand), f32 accumulation, "
+                  "parameters and optimiser" if split3 else
+                  "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32"),
+        "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
+                               + ("centralized " if args.framework == "centralized" else "")
+                               + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
+                                  if mode == "nofrl" else
+                                  "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
+                                  + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else "")))
+                               + f", B=64, replay capacity {args.buffer_size} (full), 1 update per env step",
+                   "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": mode,
+                   "parallelism": f"platoon shards x{world}" + (f" + one {args.backend} all-reduce(sum) of the [M, theta] gradient slab per step"
+                                                                if rccl else " (no data-path collective)")},
+        "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
+        "stages_ms": stage_ms,
+        "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
+                      "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
+                      "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
+                     if (fused and getattr(vt, "_act_ready", False)) else
+                     f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
+                     (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
+                      "summed kernel durations and overlap") if (mode == "nofrl" and args.chunks > 1) else
+                     ("split-operand fused shared-set learner (avd_learn_set_split_bf16x3) + Adam/Polyak on the sets" if split3 else
+                      "fused shared-set learner (avd_learn_set_fused_bf16: second-layer weights resident in registers, first layers on "
+                      "the matrix cores, per-workgroup gradient partials) + Adam/Polyak on the sets" if fset else
+                      "batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
+        "kernels": [r for r in (roof_learn, roof_upd) if r],
+    }
+    if rccl:
+        out["rccl_ranks"] = world if args.backend == "nccl" else 0
+        out["collective_backend"] = args.backend
+    del vt
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # this process never touches the GPU
+    if os.environ.get("AVD_BENCH_SPAWN_PROBE"):  # launcher plumbing check (tests/test_dist_cpu.py): no GPU, no torch
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        sys.exit(0 if os.environ.get("AVD_BENCH_SPAWN_PROBE") != "fail1" or os.environ.get("RANK") != "1" else 3)
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
+        group = dist.group.WORLD
+
+    if args.mode:
+        modes = [args.mode]
+    else:
+        modes = [PRIMARY_MODE] + ([] if args.no_secondary or args.hidden or args.framework != "decentralized" else
+                                  ["interfrl" if PRIMARY_MODE == "nofrl" else "nofrl"])
+    results = [run_workload(args, m, args.engine, rank, world, group) for m in modes]
 
     if rank == 0:
-        out = {
-            "metric": "env-steps/sec + DDPG updates/sec, 4096x5-vehicle platoons",
-            "value": env_steps_per_s,
-            "unit": "env-steps/s",
-            "updates_per_s": updates_per_s,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
-                                   + ("centralized " if args.framework == "centralized" else "")
-                                   + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
-                                      if args.mode == "nofrl" else
-                                      "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
-                                      + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else "")))
-                                   + f", B=64, replay capacity {args.buffer_size} (full), 1 update per env step",
-                       "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": args.mode,
-                       "parallelism": f"platoon shards x{world}" + (" + RCCL all-reduce" if args.mode == "interfrl" and world > 1 else " (no data-path collective)")},
-            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
-            "stages_ms": stage_ms,
-            "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
-                          "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
-                          "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
-                         if (fused and getattr(vt, "_act_ready", False)) else
-                         f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
-                         (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
-                          "summed kernel durations and overlap") if (args.mode == "nofrl" and args.chunks > 1) else
-                         ("fused shared-set learner (avd_learn_set_fused_bf16: second-layer weights resident in registers, first layers on "
-                           "the matrix cores, per-workgroup gradient partials) + Adam/Polyak on the sets" if fset else
-                          "batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
-            "kernels": [r for r in (roof_learn, roof_upd) if r],
-        }
+        first = results[0]
+        out = {"metric": "env-steps/sec + DDPG updates/sec, 4096x5-vehicle platoons", "value": first["value"],
+               "unit": first["unit"], "updates_per_s": first["updates_per_s"], "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": first["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": first["dtype"], "data": "synthetic"}
+        out.update({k: v for k, v in first.items() if k not in out})
+        if len(results) > 1:
+            out["also_measured"] = {r["config"]["mode"]: {k: r[k] for k in ("value", "unit", "updates_per_s", "ms_per_step", "dtype",
+                                                                          "config", "roofline", "stages_ms", "pipeline")
+                                                          + (("rccl_ranks", "collective_backend") if "rccl_ranks" in r else ())}
+                                    for r in results[1:]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
-            try:  # the whole host beside the reference's own 1-thread setting
-                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), L)
-            except Exception as e:  # never let the side figure break the bench line
-                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size)
+            if args.cpu_all_cores:  # the whole host beside the reference's own 1-thread setting (opt-in side figure)
+                try:
+                    out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), args.pl_size)
+                except Exception as e:  # never let the side figure break the bench line
+                    out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

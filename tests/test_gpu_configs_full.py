@@ -1,0 +1,164 @@
+"""BASELINE.json configs[2] (4096 platoons x 10 vehicles) and configs[4] (hidden = 1024, bf16, 4096 platoons) at FULL
+size through replay / learn / update / trainer, not only the env kernel: oracle spot checks on individual agents (the
+oracle finishes those in seconds) plus size-independent properties -- determinism, lane independence, fused ==
+two-kernel, mean-of-halves -- for the whole batch."""
+import numpy as np
+import pytest
+import torch
+
+from avddpg_amd import config, trainer, vec
+from oracle import mlp as omlp
+from tests.gpu_util import need_gpu
+from tests.test_gpu_mlp import GRAD_TOL, _nets, _perturbed_group, _relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _free(*objs):
+    del objs
+    torch.cuda.empty_cache()
+
+
+def test_config3_trainer_4096x10_learns_like_the_oracle_and_fused_equals_two_kernel_path():
+    """configs[2]: 40960 agents (pl_size = 10 is beyond the reference's `Platoon` length check, src/environment.py:84-85,
+    which fires after full construction; the dynamics are defined for any L). Two VecTrainers on the same Philox
+    streams, one with the fused learn+Adam+Polyak kernel, one with learn -> gradient slab -> Adam/Polyak: 70 steps =
+    5 updates of every agent. Checked: the replay gate opens at the 65th add for all 40960 agents; the two paths end in
+    bit-identical weights / targets / moments (determinism across kernels at this grid size); three agents' gradients of
+    the 70th step against the float64 oracle on the batch they actually sampled; every platoon's chain of 10 vehicles
+    fed the replay rows the env produced."""
+    need_gpu()
+    P, L, steps = 4096, 10, 70
+    mk = lambda fused: trainer.VecTrainer(config.Config(num_platoons=P, pl_size=L, buffer_size=128), rng="device", auto_reset=True,
+                                          seed=3, fused_update=fused)
+    a, b = mk(True), mk(False)
+    assert a.n_agents == b.n_agents == P * L and a.agents.n_sets == P * L and not a.shared
+    for vt in (a, b):
+        vt.reset_episode()
+    for i in range(steps - 1):
+        a.step()
+        b.step()
+    assert a.updates == b.updates == (steps - 1 - 64) * P * L
+    spots = (0, 17 * L + 9, P * L - 1)  # first / a chain tail / last agent
+    pre = {v: _nets(b.agents, v, np.float64) for v in spots}
+    pre32 = {v: _nets(b.agents, v, np.float32) for v in spots}
+    a.step()
+    b.step()
+    torch.cuda.synchronize()
+    # replay rows of the last step: [s a r s'] with s' = the env's current state, s = its previous one
+    row = b.replay.ring[:, (b.replay.buffer_counter - 1) % b.replay.cap]
+    assert torch.equal(row[:, :4], b.env.x_prev.view(P * L, 4)) and torch.equal(row[:, 6:10], b.env.x.view(P * L, 4))
+    assert torch.equal(row[:, 4], b.actions.view(-1)) and torch.equal(row[:, 5], b.env.reward.view(-1))
+    for v in spots:
+        batch = (b.replay.s[v].cpu().numpy(), b.replay.a[v].cpu().numpy(), b.replay.r[v].cpu().numpy()[:, None],
+                 b.replay.s2[v].cpu().numpy())
+        cg, ag, _ = omlp.learn(batch, *pre[v])
+        cg32, ag32, _ = omlp.learn(tuple(x.astype(np.float32) for x in batch), *pre32[v])
+        gcg, gag = b.agents.grads_as_lists(b.grads[v])
+        for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref)), v
+    for name in ("theta", "theta_t", "stats_t", "m", "v"):
+        assert torch.equal(getattr(a.agents, name), getattr(b.agents, name)), name
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.replay.ring, b.replay.ring)
+    assert torch.isfinite(a.agents.theta).all() and int(a.agents.step.min()) == int(a.agents.step.max()) == steps - 64
+    # the agents did diverge from each other (independent replay streams), i.e. 40960 different updates were made
+    assert not torch.equal(a.agents.theta[0], a.agents.theta[1])
+    _free(a, b)
+
+
+def test_config3_learn_kernels_lane_independent_at_40960_agents():
+    """Lane independence + determinism of Trainer.learn at configs[2]'s grid (40960 workgroups): a duplicated agent gives
+    the same bits wherever it sits; two launches agree bit for bit."""
+    need_gpu()
+    n = 4096 * 10
+    grp = vec.AgentGroup(n, 4, 1, config.Config(), seed=12)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    grp.theta.add_(torch.randn(grp.theta.shape, device="cuda", generator=g) * 0.01 * (grp.theta != 0))
+    grp.theta_t.copy_(grp.theta)
+    s = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+    a = torch.rand(n, 64, 1, device="cuda", generator=g) * 5 - 2.5
+    r = -torch.rand(n, 64, device="cuda", generator=g)
+    s2 = torch.randn(n, 64, 4, device="cuda", generator=g) * 1.5
+    for dst in (6, 20481, n - 1):
+        for x in (grp.theta, grp.theta_t, grp.stats, grp.stats_t, s, a, r, s2):
+            x[dst].copy_(x[5])
+    g1 = grp.learn(s, a, r, s2, 0)
+    g2 = grp.learn(s, a, r, s2, 0)
+    assert torch.equal(g1, g2) and torch.isfinite(g1).all()
+    for dst in (6, 20481, n - 1):
+        assert torch.equal(g1[dst], g1[5])
+    assert not torch.equal(g1[5], g1[7])
+    _free(grp, g1, g2)
+
+
+def _wide_group(M, seed):
+    return _perturbed_group(M, S=4, seed=seed, actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024,
+                            critic_layer2_size=1024)
+
+
+def test_config5_hidden1024_against_the_oracle_on_4096_rows_per_set():
+    """configs[4]'s widths with 64 platoons per set = 4096 rows per weight set (20480 rows in all): every gradient
+    tensor against the float64 oracle on the set's concatenated batch. bf16 GEMM operands behind 1024-long reductions:
+    6 % of each tensor's max (8 % allowed at 512 rows in tests/test_gpu_wide.py; more rows average the rounding)."""
+    need_gpu()
+    P, M, B = 64, 5, 64
+    conf, grp = _wide_group(M, 111)
+    rs = np.random.RandomState(112)
+    rows = P * B
+    s = rs.normal(0, 1.5, size=(M, rows, 4)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(M, rows, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(M, rows))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(M, rows, 4)).astype(np.float32)
+    tt = lambda x: torch.from_numpy(x).cuda()
+    losses = torch.zeros(M, 2, device="cuda")
+    g = grp.learn_shared(tt(s), tt(a), tt(r), tt(s2), P * M, losses=losses)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in (0, M - 1):
+        cg, ag, aux = omlp.learn((s[k], a[k], r[k][:, None], s2[k]), *_nets(grp, k, np.float64))
+        gcg, gag = grp.grads_as_lists(g[k])
+        for got, ref in zip(gcg + gag, cg + ag):
+            worst = max(worst, _relerr(got, ref))
+        assert abs(float(losses[k, 0]) - aux["critic_loss"]) <= 1e-2 * abs(aux["critic_loss"])
+    assert worst <= 6e-2, worst
+    _free(grp, g)
+
+
+def test_config5_hidden1024_full_size_mean_of_halves_and_determinism_of_the_step():
+    """configs[4] at 4096 platoons x 5 sets x 64 rows, hidden 1024 (25.6 GB of workspace): the mean gradient over all
+    platoons equals the average of the mean gradients over the two halves of the platoons (rows are independent:
+    inference-mode BN), 1e-3 of each slab's max (same operand rounding, split-K summation order differs); and a
+    VecTrainer of that shape takes federated steps with finite results."""
+    need_gpu()
+    P, M, B, S = 4096, 5, 64, 4
+    conf, grp = _wide_group(M, 121)
+    g = torch.Generator(device="cuda").manual_seed(122)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    s, a = 1.5 * rn(M, P * B, S), 2.5 * (2 * torch.rand(M, P * B, 1, device="cuda", generator=g) - 1)
+    r, s2 = -rn(M, P * B).abs() * 0.3, 1.5 * rn(M, P * B, S)
+    full = grp.learn_shared(s, a, r, s2, P * M).clone()
+    h = P * B // 2
+    halves = []
+    for lo in (0, h):
+        sl = lambda x: x[:, lo:lo + h].contiguous()
+        halves.append(grp.learn_shared(sl(s), sl(a), sl(r), sl(s2), P * M // 2).clone())
+    avg = 0.5 * (halves[0] + halves[1])
+    assert torch.isfinite(full).all() and full.abs().max() > 0
+    lay = grp.lay
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        d = (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item()
+        assert d <= 1e-3 * full[:, lo:hi].abs().max().item(), (lo, d)
+    assert not torch.allclose(halves[0], halves[1])
+    _free(grp, full, halves, s, a, r, s2)
+    c = config.Config(num_platoons=P, pl_size=M, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False,
+                      actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024, critic_layer2_size=1024)
+    vt = trainer.VecTrainer(c, rng="device", auto_reset=True)
+    assert vt.shared and vt.shared_engine == "batched"
+    th0 = vt.agents.theta.clone()
+    vt.reset_episode()
+    for _ in range(67):
+        vt.step()
+    torch.cuda.synchronize()
+    assert vt.updates == 3 * P * M and torch.isfinite(vt.agents.theta).all() and not torch.equal(vt.agents.theta, th0)
+    assert (vt.set_losses[:, 0] >= 0).all() and int(vt.agents.step[0]) == 3
+    _free(vt)

@@ -78,3 +78,33 @@ def test_two_rank_interfrl_weight_sets_stay_identical(shared):
         ref = th_a[0, m]
         assert all(np.array_equal(ref, th_a[p, m]) for p in range(th_a.shape[0]))
         assert all(np.array_equal(ref, th_b[p, m]) for p in range(th_b.shape[0]))
+
+
+def test_bench_gpus2_self_spawned_ranks_run_both_workloads_and_print_one_line():
+    """`python bench.py --gpus 2` with no launcher: the script starts its two ranks itself (children, before any GPU call),
+    runs nofrl (replicas) and interfrl (one all-reduce of the gradient slab per step) and rank 0 prints ONE JSON line.
+    On a 1-GPU box: --single-device + gloo (RCCL refuses two ranks per device); on an N-GPU node the same command
+    without those two flags runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--platoons", "96",
+           "--buffer-size", "512", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
+    modes = {out["config"]["mode"]: out} | out["also_measured"]
+    assert set(modes) == {"nofrl", "interfrl"}
+    for m, r in modes.items():
+        assert r["value"] > 0 and abs(r["value"] - 2 * 96 * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
+        assert r["roofline"]["bound"] in ("hbm", "mfma") and r["roofline"]["achieved"] > 0
+    assert modes["interfrl"]["collective_backend"] == "gloo" and "all-reduce" in modes["interfrl"]["config"]["parallelism"]
+    assert "no data-path collective" in modes["nofrl"]["config"]["parallelism"]
