@@ -33,54 +33,10 @@
 // GEMM operands are bf16 (8 significant bits), accumulation / parameters / gradients f32: the same numerics class as
 // avd_learn_shared_bf16 (wide.hip), against which, against the exact f32 per-agent kernel + federated mean and against the
 // float64 oracle it is tested (tests/test_gpu_fset.py).
-#include "common.h"
+#include "fset_common.h"
 
 namespace avd {
 namespace fset {
-
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr float BN_EPS = 1e-3f;  // tf.keras BatchNormalization default epsilon (agent/model.py:28)
-constexpr int TILE = 64, H1 = 256, H2 = 128, HA = 48, NT = 512, VEC = 264;
-
-// K features enter the second layer; KP = K rounded up to feature tiles of 32 (dx operands); KW = K + 16: the head's weight
-// image with the folded bias as feature K; NFT first-layer tiles; dw also accumulates a constant-one feature K (its G row is
-// the column sum of dZ2 = the gradient of b2): NGT tiles, KG rows.
-struct Actor {
-    static constexpr int K = 256, KP = 256, KW = 272, NFT = 8, NGT = 9, KG = 288;
-    static constexpr bool critic = false;
-};
-struct Critic {
-    static constexpr int K = 304, KP = 320, KW = 320, NFT = 10, NGT = 10, KG = 320;  // 256 state + 48 action features
-    static constexpr bool critic = true;
-};
-
-// row (M index) of accumulator register i of a 32x32 MFMA result in lane half h; the column is lane & 31
-__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-
-// relu: ONE v_max_f32 when the file is compiled with -fno-honor-nans (Makefile); otherwise fmaxf is lowered to
-// canonicalize + max (it must quiet signalling NaNs) -- two VALU instructions per element in loops whose VALU count bounds
-// them. (Inline assembly is not an option: hipcc does not pad the MFMA -> VALU read hazard for an opaque instruction.)
-__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
-// relu + bf16 of a PAIR in two instructions: v_cvt_pk_bf16_f32, then v_pk_max_i16 against 0 -- a negative float is a negative
-// int16 in its upper 16 bits, so the signed 16-bit max IS relu on the packed pair (-0.0 -> +0) -- instead of two v_max_f32 and
-// the conversion
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned relu_bf16x2(float a, float b) {
-    const f32x2 f = {a, b};
-    s16x2 v = __builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2));
-    const s16x2 z = {0, 0};
-    v = __builtin_elementwise_max(v, z);
-    return __builtin_bit_cast(unsigned, v);
-}
-
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
 
 // ---- first layer on the matrix cores -------------------------------------------------------------------------------
 // z1[row][f] = sum_k x[row][k] W1[k][f] + b1[f] as ONE 32x32x16 bf16 MFMA with both operands split into bf16 pairs:
@@ -149,12 +105,18 @@ __device__ __forceinline__ void load_x(const float* xa, int row, float (&x)[4]) 
 
 // The first-layer input fragments of every batch row, built ONCE per learn call (every pass of the chain and each of the 8
 // waves of a workgroup would otherwise redo the split): out[row][h] = make_xf(x[row], h), 32 bytes per row.
+// `extra` (a or r, one float per row; lane half 0 checks it) and x are also tested for non-finite values: this file is built
+// with -fno-honor-nans and relu() turns a NaN into 0, so a non-finite input would otherwise vanish instead of propagating
+// like it does in the f32 engines: *bad is set and finalize writes NaN gradients.
 template <int S>
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, long rows, bf16* out) {
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float* extra, long rows, bf16* out, int* bad) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * rows) return;
     float v[4];
     load_x<S>(x, (int)(i >> 1), v);
+    bool nf = not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
+    if (!(i & 1)) nf = nf || not_finite(extra[i >> 1]);
+    if (nf) atomicOr(bad, 1);
     *(bf16x8*)(out + 8 * i) = make_xf(v[0], v[1], v[2], v[3], (int)(i & 1));
 }
 
@@ -165,6 +127,7 @@ struct PrepArgs {
     bf16* W2T[4];  // net 0 actor, 1 critic, 2 target actor, 3 target critic
     bf16* W2R[4];  // online nets only
     float* vec[4];
+    int* bad;      // set when a weight / BN statistic is not finite
 };
 __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     __shared__ float red[320];
@@ -187,6 +150,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             const float sh = th[obe + ff] - st[omm + ff] * inv;
             w = th[oW2 + (long)f * H2 + n];
             shw = sh * w;
+            if (not_finite(w) || not_finite(inv) || not_finite(sh)) atomicOr(a.bad, 1);
         }
         if (f < KW && f != K && f != K + 1) a.W2T[net][((long)set * H2 + n) * KW + f] = (bf16)(inv * w);  // (K, K + 1: the bias, below)
         if (!target && f < KP) a.W2R[net][((long)set * KP + f) * H2 + n] = (bf16)w;
@@ -203,6 +167,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
     if (f == 0) {
         vec[n] = th[ob2 + n] + red[0];
+        if (not_finite(vec[n]) || not_finite(th[oW3 + n]) || not_finite(th[ob3])) atomicOr(a.bad, 1);
         // the folded bias b2' rides in the weight image as features K and K + 1 = its bf16 pair (hi, lo), met by two
         // constant-one activations: 2^-17 relative (one bf16 alone would put 2^-9 of the bias into every pre-activation)
         const bf16 bh = (bf16)vec[n];
@@ -830,20 +795,6 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 }
 
 // ---- finalize: sum the workgroups' partials of a set (fixed order), apply the BN folds, write the gradient slab -------
-struct FinArgs {
-    avd_mlp_layout L;
-    int n_sets, J, S;  // J = workgroups per set; workgroup j of set m has block index j * n_sets + m
-    const float *theta, *stats;
-    const float* partH[2];   // [0] actor (pass 9), [1] critic (pass 4)
-    const float* partHs[2];
-    const float* partLa;     // pass 7's part_s (actor loss sums)
-    const float* partU[2];
-    const float* partV[2];
-    const float* partG[2];
-    float* grads;   // [n_sets][theta_size]
-    float* losses;  // [n_sets][2] or NULL
-    float inv_n;
-};
 // One item per 32 lanes: output column n (items 0..127: output layer, BN2, b2) or first-layer feature f (items 128..):
 // lane jl sums the partials of workgroups jl, jl + 32, .. of the set, then a fixed shuffle tree combines the 32 lanes.
 __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
@@ -876,7 +827,9 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
             S2 += a.partG[net][(wg * KG + K) * H2 + n];  // dw_kernel's constant-one feature: sum over rows of dZ2 = db2
         }
         T1 = allsum(T1), S2 = allsum(S2), D = allsum(D);
+        if (a.c3[net]) S2 *= a.c3[net][(long)set * VEC + H2 + n];  // fsplit: the column factor c3[n] of dZ2 is applied here
         if (critic && n == 0) Lc = allsum(Lc), La = allsum(La);
+        if (a.bad && *a.bad) T1 = S2 = D = Lc = La = __uint_as_float(0x7fc00000u);  // non-finite input: NaN out, like the f32 engines
         if (jl == 0) {
             const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
             const float sh2 = th[obe2 + n] - mm2 * inv2, w3 = th[oW3 + n];
@@ -896,12 +849,12 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
     for (int k = 0; k < 9; ++k) V[k] = 0.f;
     for (int j = jl; j < a.J; j += 32) {
         const long wg = (long)j * a.n_sets + set;
-        for (int rh = 0; rh < 2; ++rh) {
+        for (int rh = 0; rh < a.nrh; ++rh) {
             for (int h = 0; h < 2; ++h) {
-                const float* pu = a.partU[net] + ((((wg * 2 + rh) * 2 + h) * KP) + f) * 2;
+                const float* pu = a.partU[net] + ((((wg * a.nrh + rh) * 2 + h) * KP) + f) * 2;
                 U0 += pu[0], U1 += pu[1];
             }
-            const float* pv = a.partV[net] + ((wg * 2 + rh) * KP + f) * 16;
+            const float* pv = a.partV[net] + ((wg * a.nrh + rh) * KP + f) * 16;
 #pragma unroll
             for (int k = 0; k < 9; ++k) V[k] += pv[k];
         }
@@ -909,6 +862,7 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
     U0 = allsum(U0), U1 = allsum(U1);
 #pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = allsum(V[k]);
+    if (a.bad && *a.bad) U0 = U1 = V[0] = V[4] = V[8] = __uint_as_float(0x7fc00000u);
     if (jl == 0) {
         int og, obe, omm, omv, oW, ob, ff = f, ld = H1, sin = a.S;
         if (!critic) og = L.ag1, obe = L.abe1, omm = L.amm1, omv = L.amv1, oW = L.aW1, ob = L.ab1;
@@ -938,19 +892,26 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     const float inv1 = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff], sh1 = th[obe + ff] - st[omm + ff] * inv1;
     float G = 0.f;
     for (int j = 0; j < a.J; ++j) G += a.partG[net][(((long)j * a.n_sets + set) * KG + f) * H2 + n];
+    if (a.c3[net]) G *= a.c3[net][(long)set * VEC + H2 + n];
+    if (a.bad && *a.bad) G = __uint_as_float(0x7fc00000u);
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
     g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
+}
+
+void launch_finalize(const FinArgs& fa, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, 2, (H2 + Critic::K + 15) / 16), dim3(512), 0, st, fa);
+    hipLaunchKernelGGL(finalize_w2_kernel, dim3(Critic::K, fa.n_sets, 2), dim3(H2), 0, st, fa);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Plan {
     int grid, J;
-    size_t W2T[4], W2R[2], vec[4], a2, y, mu, dmu, dz, xfs, xfs2, partH[2], partHs[3], partU[2], partV[2], partG[2], total;
+    size_t W2T[4], W2R[2], vec[4], a2, y, mu, dmu, dz, xfs, xfs2, partH[2], partHs[3], partU[2], partV[2], partG[2], bad, total;
 };
 // CUs of the CURRENT device (cached per device ordinal): the plan -- workgroups per set, workspace layout, the grouping of the
 // partial sums and therefore the bits of the result -- is a function of (CU count, n_sets, n_agents); results are
 // deterministic per device model, not across parts with different CU counts.
-static int cu_count() {
+int cu_count() {
     static int cache[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
@@ -992,6 +953,7 @@ static Plan make_plan(int n_agents, int n_sets) {
         pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
     }
     for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 8 * 2);
+    pl.bad = take(sizeof(int));
     pl.total = o;
     return pl;
 }
@@ -1026,11 +988,14 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         n.oWa = critic ? L.cWa : 0, n.oba = critic ? L.cba : 0, n.oga = critic ? L.cga : 0, n.omva = critic ? L.cmva : 0;
         n.W2T = pa.W2T[i], n.W2R = pa.W2R[i], n.vec = pa.vec[i];
     }
+    pa.bad = (int*)(ws + pl.bad);
+    (void)hipMemsetAsync(ws + pl.bad, 0, sizeof(int), st);
     hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
     const long nrows = (long)n_agents * TILE;
     bf16 *xfs = (bf16*)(ws + pl.xfs), *xfs2 = (bf16*)(ws + pl.xfs2);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, nrows, xfs);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, nrows, xfs2);
+    int* bad = (int*)(ws + pl.bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, nrows, xfs, bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, nrows, xfs2, bad);
     const int P = n_agents / n_sets;
     const float inv_n = 1.0f / ((float)P * TILE);
     float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
@@ -1077,8 +1042,8 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     for (int i = 0; i < 2; ++i)
         fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]);
-    hipLaunchKernelGGL(finalize_small_kernel, dim3(n_sets, 2, (H2 + Critic::K + 15) / 16), dim3(512), 0, st, fa);
-    hipLaunchKernelGGL(finalize_w2_kernel, dim3(Critic::K, n_sets, 2), dim3(H2), 0, st, fa);
+    fa.nrh = 2, fa.c3[0] = fa.c3[1] = nullptr, fa.bad = (const int*)(ws + pl.bad);
+    launch_finalize(fa, st);
     return check_launch("avd_learn_set_fused_bf16");
 }
 

@@ -1,0 +1,1117 @@
+// Split-operand fused shared-weight-set learner ("fsplit"): the same quantity as fset.hip -- Trainer.learn
+// (workers/trainer.py:472-508) + the federated mean over the platoons (src/server/federated.py:47-63, 99-118;
+// workers/trainer.py:400-431) for agents that SHARE their networks (interfrl, every step federated: trainer.py:121-128) at the
+// reference widths 256 / 128 / 48 (src/config.py:112-117) -- but with f32-class results: the reference computes in float32
+// (agent/model.py:26-36, 63-83) and single-rounded bf16 operands miss it by 1.7e-2 on the actor gradients (fset.hip).
+//
+// Every matrix product runs on v_mfma_f32_32x32x16_bf16 with BOTH operands carried as exact bf16 pairs x = hi + lo
+// (hi = bf16(x), lo = bf16(x - hi): 2^-17 relative per operand), accumulated in f32:
+//     A . B  ~=  A_hi . B_hi + A_lo . B_hi + A_hi . B_lo          (the dropped lo . lo term is 2^-18 of the product)
+// Three structural facts keep this from costing 3x fset.hip:
+//   * the output layers are one unit wide, so the second-layer gradient is rank one times a mask:
+//         dZ2[row][n] = g3[row] * c3[n] * [z2[row][n] > 0]
+//     The mask (with the sign of g3) is EXACT in bf16: it is what the heads write (as bf16 +-1 / 0, "sm"), c3[n] is folded
+//     into the other operand (dx: W2c[f][n] = c3[n] W2[f][n], split once per call) or applied at the end (dw: finalize), and
+//     |g3[row]| is folded into the first-layer input (dw: relu(W1 (|g| x) + |g| b1) = |g| P1, one MFMA with split operands
+//     like every first layer here) or multiplied onto the f32 result (dx). dw and dx then need TWO MFMAs per product, and the
+//     heads split nothing on their way out.
+//   * second-layer weights are split once per call (prep) and stay in LDS (heads: hi + lo images, 135 / 160 KB, stored in the
+//     k order in which a first-layer accumulator tile IS the next MFMA's B operand: no cross-lane exchange of activations)
+//     or in registers (dx); only the activations are split on the fly (4 VALU per element, in the shadow of the MFMAs).
+//   * the action gradient of the actor loss needs no dZ2 at all: dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row] with
+//     M = W2T[:, action features] . (mask_a * wa), a second product over the action k-steps with the weight fragments the
+//     forward pass has just read.
+// Kernel chain, workspace, partial-sum layouts and the deterministic two-stage reduction are fset.hip's (finalize_* are
+// shared, fset_common.h). Tested against the float64 oracle at the f32 kernels' tolerance (1e-4 of each tensor's max,
+// tests/test_gpu_fsplit.py) -- not the 2 % the bf16 learners are allowed.
+#include "fset_common.h"
+
+namespace avd {
+namespace fsplit {
+using namespace fset;
+
+struct ActorS {
+    static constexpr int K = 256, KP = 256, NFT = 8, NKS = 16, LD = 264, NGT = 9, KG = 288;
+    static constexpr bool critic = false;
+};
+struct CriticS {
+    static constexpr int K = 304, KP = 320, NFT = 10, NKS = 19, LD = 312, NGT = 10, KG = 320;  // 256 state + 48 action features
+    static constexpr bool critic = true;
+};
+constexpr int NGT_MAX = 10;
+
+// ---- exact bf16 pairs -------------------------------------------------------------------------------------------------
+// (a, b) -> packed hi pair and packed lo pair: 2 x (float(hi) by shift / mask, subtract) + 2 conversions
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 f = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+    const f32x2 l = {a - ha, b - hb};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+}
+__device__ __forceinline__ void split1(float x, bf16& hi, bf16& lo) {
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+__device__ __forceinline__ bf16x8 frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+    uint4 o;
+    o.x = a, o.y = b, o.z = c, o.w = d;
+    return __builtin_bit_cast(bf16x8, o);
+}
+
+// fp16 pairs (heads): 11 + 11 significant bits, |x - hi - lo| <= 2^-24 |x| -- an f32 value almost exactly. The heads need
+// it: the hi + lo residual of a WEIGHT is the same for every batch row, so it biases q and y instead of averaging out, and
+// the TD error q - y amplifies the bias by |q| / |q - y| (measured with bf16 pairs: 1e-3 of a gradient tensor's max at 51
+// platoons, same for the mean of 51 single-platoon calls). fp16 has a 5-bit exponent, so the static operands are scaled by
+// powers of two (exact) into its upper range and the scales are folded into f32 constants downstream: second-layer weights
+// by SW (per set and net, max |W| SW in [2^12, 2^13)), first-layer weights and biases by S1 (activations then sit 2^6 higher,
+// their lo parts stay normal numbers); overflow of an activation (P1 >= 1023) becomes inf and then NaN -- loud.
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float S1 = 64.f;
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 f = {a, b};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 l = {a - (float)h[0], b - (float)h[1]};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2));
+}
+__device__ __forceinline__ void split1h(float x, f16& hi, f16& lo) {
+    hi = (f16)x;
+    lo = (f16)(x - (float)hi);
+}
+__device__ __forceinline__ f16x8 fragh(unsigned a, unsigned b, unsigned c, unsigned d) {
+    uint4 o;
+    o.x = a, o.y = b, o.z = c, o.w = d;
+    return __builtin_bit_cast(f16x8, o);
+}
+__device__ __forceinline__ f32x16 mfmah(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// the first-layer fragments of the heads, fp16 (same slot layout as make_xq / make_wf below; sc scales weights and bias)
+__device__ __forceinline__ f16x8 make_xh(float x0, float x1, float x2, float x3, int h) {
+    f16 a0, a1, a2, a3, l0, l1, l2, l3;
+    split1h(x0, a0, l0), split1h(x1, a1, l1), split1h(x2, a2, l2), split1h(x3, a3, l3);
+    const f16 one = (f16)1.f, zero = (f16)0.f;
+    f16x8 v;
+    v[0] = a0, v[1] = a1, v[2] = a2, v[3] = a3;
+    v[4] = h ? one : l0, v[5] = h ? one : l1, v[6] = h ? zero : l2, v[7] = h ? zero : l3;
+    return v;
+}
+__device__ __forceinline__ f16x8 make_wh(float w0, float w1, float w2, float w3, float b, float sc, int h) {
+    f16 a0, a1, a2, a3, l0, l1, l2, l3, bh, bl;
+    split1h(sc * w0, a0, l0), split1h(sc * w1, a1, l1), split1h(sc * w2, a2, l2), split1h(sc * w3, a3, l3), split1h(sc * b, bh, bl);
+    const f16 zero = (f16)0.f;
+    f16x8 v;
+    v[0] = h ? l0 : a0, v[1] = h ? l1 : a1, v[2] = h ? l2 : a2, v[3] = h ? l3 : a3;
+    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? zero : a2, v[7] = h ? zero : a3;
+    return v;
+}
+
+// ---- first layer on the matrix cores (see fset.hip) ---------------------------------------------------------------------
+//   k slot      0..3        4..7        8..11       12       13       14      15
+//   input  x:   (gx)_hi     (gx)_lo     (gx)_hi     g_hi     g_hi     g_lo    0       (g = 1: plain forward pass)
+//   weight w:   w_hi        w_hi        w_lo        b_hi     b_lo     b_hi    0
+// = g (x . w + b) to 2^-16: the row factor g = |g3[row]| rides in the input fragment (dw_kernel).
+__device__ __forceinline__ bf16x8 make_xq(float x0, float x1, float x2, float x3, float g, int h) {
+    bf16 a0, a1, a2, a3, l0, l1, l2, l3, gh, gl;
+    split1(x0, a0, l0), split1(x1, a1, l1), split1(x2, a2, l2), split1(x3, a3, l3), split1(g, gh, gl);
+    const bf16 zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = a0, v[1] = a1, v[2] = a2, v[3] = a3;
+    v[4] = h ? gh : l0, v[5] = h ? gh : l1, v[6] = h ? gl : l2, v[7] = h ? zero : l3;
+    return v;
+}
+__device__ __forceinline__ bf16x8 make_wf(float w0, float w1, float w2, float w3, float b, int h) {
+    bf16 a0, a1, a2, a3, l0, l1, l2, l3, bh, bl;
+    split1(w0, a0, l0), split1(w1, a1, l1), split1(w2, a2, l2), split1(w3, a3, l3), split1(b, bh, bl);
+    const bf16 zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = h ? l0 : a0, v[1] = h ? l1 : a1, v[2] = h ? l2 : a2, v[3] = h ? l3 : a3;
+    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? bh : a2, v[7] = h ? zero : a3;
+    return v;
+}
+
+template <int S>
+__device__ __forceinline__ void load_x(const float* xa, long row, float (&x)[4]) {
+    if (S == 4) {
+        const float4 v = *(const float4*)(xa + 4 * row);
+        x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = k < S ? xa[S * row + k] : 0.f;
+    }
+}
+
+// position of feature f in the heads' weight image: inside each tile of 32, bits 2 and 3 of the index trade places. Element
+// jj of lane half h of k-step s of a first-layer accumulator tile [feature][row] is feature 16 s + 8 (jj >> 2) + 4 h + (jj & 3)
+// (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"); stored at 16 s + 8 h + jj the weights of those 8
+// features are ONE 16-byte LDS read of the A operand's lane (n, h).
+__host__ __device__ constexpr int wpos(int f) { return (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1); }
+
+// one network's operands (device pointers into the caller's slabs and the workspace)
+struct NetP {
+    const float* th;   // theta or theta_t (+ actor_size for a critic); set stride th_stride
+    long th_stride;
+    const f16* Whi;    // [sets][H2][K]   fp16 hi of SW * inv1[f] * W2[f][n] at [n][wpos(f)]: the heads' LDS image
+    const f16* Wlo;    //                 its lo
+    const bf16* Wchi;  // [sets][KP][H2]  hi of c3[n] * W2[f][n], rows >= K zero: dx_kernel's resident operand (online nets)
+    const bf16* Wclo;
+    const bf16x8* wf1; // [sets][NGT_MAX][64] first-layer weight fragments per feature tile and lane (feature K: the constant one)
+    const f16x8* wf1h; // the same as fp16 pairs scaled by S1: the heads' first layers
+    const float* vec;  // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3, SW
+    const unsigned* wap;  // [sets][2 hi/lo][2 h][3 k-steps][4] packed fp16 pairs of S1 * wa, the critic's action-layer weights (HEAD_CONST)
+};
+
+// ---- pack: split first-layer input fragments of every batch row, once per learn call (+ the finiteness test) ----------
+// outh: fp16 pairs (heads); outb: bf16 pairs (dx_kernel) or NULL
+template <int S>
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float* extra, long rows, f16x8* outh, bf16x8* outb, int* bad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * rows) return;
+    float v[4];
+    load_x<S>(x, i >> 1, v);
+    bool nf = not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
+    if (!(i & 1)) nf = nf || not_finite(extra[i >> 1]);
+    if (nf) atomicOr(bad, 1);
+    outh[i] = make_xh(v[0], v[1], v[2], v[3], (int)(i & 1));
+    if (outb) outb[i] = make_xq(v[0], v[1], v[2], v[3], 1.f, (int)(i & 1));
+}
+
+// ---- operand preparation ---------------------------------------------------------------------------------------------
+struct PrepArgs {
+    avd_mlp_layout L;
+    int S;
+    const float *theta, *stats, *theta_t, *stats_t;
+    f16 *Whi[4], *Wlo[4];  // net 0 actor, 1 critic, 2 target actor, 3 target critic
+    bf16 *Wchi[4], *Wclo[4];  // online nets only
+    bf16x8* wf1[4];
+    f16x8* wf1h[4];
+    float* vec[4];
+    unsigned* wap;
+    int* bad;
+};
+// SW per (net, set): the power of two that puts max |inv1[f] W2[f][n]| into [2^12, 2^13) -> vec[2 H2 + 1]
+__global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
+    __shared__ float red[256];
+    const int net = blockIdx.x, set = blockIdx.y, tid = threadIdx.x;
+    const bool critic = net & 1, target = net >= 2;
+    const avd_mlp_layout& L = a.L;
+    const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
+    const int K = critic ? CriticS::K : ActorS::K, oW2 = critic ? L.cW2 : L.aW2;
+    float m = 0.f;
+    for (int f = tid; f < K; f += 256) {
+        int og, omv, ff = f;
+        if (!critic) og = L.ag1, omv = L.amv1;
+        else if (f < H1) og = L.cgs, omv = L.cmvs;
+        else og = L.cga, omv = L.cmva, ff = f - H1;
+        const float inv = fabsf((1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff]);
+        float wm = 0.f;
+        for (int n = 0; n < H2; ++n) wm = fmaxf(wm, fabsf(th[oW2 + (long)f * H2 + n]));
+        m = fmaxf(m, inv * wm);
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int e = 0;
+        const float mx = red[0];
+        if (mx > 0.f && !not_finite(mx)) (void)frexpf(mx, &e);  // mx = fr * 2^e, fr in [0.5, 1)
+        int k = 13 - e;  // mx * 2^k in [2^12, 2^13)
+        k = k < -14 ? -14 : (k > 30 ? 30 : k);
+        a.vec[net][(long)set * VEC + 2 * H2 + 1] = ldexpf(1.f, k);
+    }
+}
+// one block per (output column n, net, set), one thread per feature f
+__global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
+    __shared__ float red[320];
+    const int n = blockIdx.x, net = blockIdx.y, set = blockIdx.z, f = threadIdx.x;
+    const bool critic = net & 1, target = net >= 2;
+    const avd_mlp_layout& L = a.L;
+    const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
+    const int K = critic ? CriticS::K : ActorS::K, KP = critic ? CriticS::KP : ActorS::KP;
+    const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2, oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
+    const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
+    const float inv2n = (1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n], c3n = inv2n * th[oW3 + n];
+    float shw = 0.f;
+    if (f < KP) {
+        float w = 0.f, inv = 0.f;
+        if (f < K) {
+            int og, obe, omm, omv, ff = f;
+            if (!critic) og = L.ag1, obe = L.abe1, omm = L.amm1, omv = L.amv1;
+            else if (f < H1) og = L.cgs, obe = L.cbes, omm = L.cmms, omv = L.cmvs;
+            else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, ff = f - H1;
+            inv = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff];
+            const float sh = th[obe + ff] - st[omm + ff] * inv;
+            w = th[oW2 + (long)f * H2 + n];
+            shw = sh * w;
+            if (not_finite(w) || not_finite(inv) || not_finite(sh)) atomicOr(a.bad, 1);
+            f16 hi, lo;
+            split1h(a.vec[net][(long)set * VEC + 2 * H2 + 1] * (inv * w), hi, lo);
+            const long at = ((long)set * H2 + n) * K + wpos(f);
+            a.Whi[net][at] = hi, a.Wlo[net][at] = lo;
+        }
+        if (!target) {
+            bf16 hi, lo;
+            split1(c3n * w, hi, lo);
+            const long at = ((long)set * KP + f) * H2 + n;
+            a.Wchi[net][at] = hi, a.Wclo[net][at] = lo;
+        }
+    }
+    red[f] = shw;
+    __syncthreads();
+    if (f < 64) red[f] += red[f + 256];  // 320 = 256 + 64
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (f < o) red[f] += red[f + o];
+        __syncthreads();
+    }
+    float* vec = a.vec[net] + (long)set * VEC;
+    if (f == 0) {
+        vec[n] = th[ob2 + n] + red[0];
+        vec[H2 + n] = c3n;
+        if (not_finite(vec[n]) || not_finite(c3n) || not_finite(th[ob3])) atomicOr(a.bad, 1);
+    }
+    if (n == 0) {  // d3 = b3 + sum_n sh2[n] w3[n]
+        __syncthreads();
+        float v = 0.f;
+        if (f < H2) {
+            const float inv2 = (1.0f / sqrtf(st[omv2 + f] + BN_EPS)) * th[og2 + f];
+            v = (th[obe2 + f] - st[omm2 + f] * inv2) * th[oW3 + f];
+        }
+        red[f] = v;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) {
+            if (f < o) red[f] += red[f + o];
+            __syncthreads();
+        }
+        if (f == 0) vec[2 * H2] = th[ob3] + red[0];
+    }
+}
+// first-layer weight fragments: one block per (feature tile, net, set), one thread per lane of the fragment; tiles >= 8 of a
+// critic are its action layer; feature K of every net is the constant one relu(0 x + 1) (dw_kernel: its row of G is db2)
+__global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
+    const int ft = blockIdx.x, net = blockIdx.y, set = blockIdx.z, lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const bool critic = net & 1, target = net >= 2;
+    const avd_mlp_layout& L = a.L;
+    const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const int K = critic ? CriticS::K : ActorS::K;
+    const int f = 32 * ft + r;
+    float w[4] = {0.f, 0.f, 0.f, 0.f}, b = 0.f;
+    if (f == K) {
+        b = 1.f;
+    } else if (f < K) {
+        if (critic && ft >= 8) {
+            w[0] = th[L.cWa + (f - H1)], b = th[L.cba + (f - H1)];
+        } else {
+            const float* W = th + (critic ? L.cWs : L.aW1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = k < a.S ? W[k * H1 + f] : 0.f;
+            b = th[(critic ? L.cbs : L.ab1) + f];
+        }
+        if (not_finite(w[0]) || not_finite(w[1]) || not_finite(w[2]) || not_finite(w[3]) || not_finite(b)) atomicOr(a.bad, 1);
+    }
+    a.wf1[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wf(w[0], w[1], w[2], w[3], b, h);
+    a.wf1h[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wh(w[0], w[1], w[2], w[3], b, S1, h);
+    if (net == 1 && ft == 0 && lane < 48) {
+        // HEAD_CONST's B operand of M = W2T[:, action] . (mask_a * wa): element jj of lane half hh of action k-step ks is action
+        // feature fa = 16 ks + 8 (jj >> 2) + 4 hh + (jj & 3); entry [hl][hh][ks][m] packs elements jj = 2 m, 2 m + 1
+        const int hl = lane / 24, hh = (lane / 12) & 1, ks = (lane / 4) % 3, m = lane & 3;
+        unsigned v = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int jj = 2 * m + e, fa = 16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+            f16 hi, lo;
+            split1h(S1 * th[L.cWa + fa], hi, lo);
+            v |= (unsigned)__builtin_bit_cast(unsigned short, hl ? lo : hi) << (16 * e);
+        }
+        a.wap[(long)set * 48 + lane] = v;
+    }
+}
+
+// ---- head: first layer -> second-layer GEMM (three MFMAs per product) -> output layer [-> its backward] -------------------
+enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4 };
+struct HeadArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const f16x8* xf;   // [n_agents][64][2] packed first-layer input fragments of the states, fp16 pairs (pack_x_kernel)
+    const float* act;  // [n_agents][64] the critic's action input (a, a' or mu)
+    const float* r;    // OUT_TD: rewards [n_agents][64]
+    const float* yin;  // HEAD_CRITIC: TD targets; HEAD_ACTOR: dmu
+    const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
+    float* out;        // OUT_*: per-row result
+    bf16* sm;          // HEAD_CRITIC / HEAD_ACTOR: sign(g3) * [z2 > 0] as bf16 +-1 / 0, [n_agents][64][128]
+    float* g3;         // HEAD_CRITIC / HEAD_ACTOR: the row factor of dZ2 [n_agents][64]
+    float* dmu;        // HEAD_CONST: dLa/dmu per row [n_agents][64]
+    float* part;       // HEAD_CRITIC / HEAD_ACTOR: [grid][8 waves][128] sums T1 = sum_rows g3 * p2 per output column
+    float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
+    float gamma, high, inv_n;
+};
+
+// Workgroup = 8 waves bound to one weight set; LDS holds the fp16 hi and lo images of its BN-folded, scaled second-layer
+// weights for the workgroup's whole life. Wave w owns rows [32 (w & 1), +32) of every 4th tile. Per feature tile: the first layer of ITS rows
+// on the matrix cores (lane = batch row, registers = features), relu, hi / lo split of the 16 values (VALU), and per k-step
+// and 32-column tile three MFMAs (A = weight fragments from LDS, B = the split activations as they stand in the registers).
+template <int S, class NET, int MODE>
+__global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
+    constexpr int K = NET::K, NKS = NET::NKS, NFT = NET::NFT, LD = NET::LD;  // LD/2 = 4 (mod 8) dwords: conflict-free b128
+    constexpr bool AG = (MODE == HEAD_CONST), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR);
+    __shared__ __attribute__((aligned(16))) f16 wimg[2][H2 * LD];
+    __shared__ __attribute__((aligned(16))) float b2s[H2];
+    __shared__ __attribute__((aligned(16))) float c3s[H2];
+    __shared__ __attribute__((aligned(16))) unsigned waps[AG ? 48 : 4];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, q = w >> 1, rh = w & 1;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    for (int i = tid; i < 2 * H2 * (K / 8); i += 512) {
+        const int hl = i / (H2 * (K / 8)), rem = i - hl * (H2 * (K / 8)), n = rem / (K / 8), c = rem - n * (K / 8);
+        const f16* src = (hl ? p.net.Wlo : p.net.Whi) + ((long)set * H2 + n) * K + 8 * c;
+        *(uint4*)(&wimg[hl][n * LD + 8 * c]) = *(const uint4*)src;
+    }
+    const float* vec = p.net.vec + (long)set * VEC;
+    // acc = SW S1 z2: the scales of the fp16 operands are folded into the f32 tables (bias in, output weights out)
+    const float SW = vec[2 * H2 + 1], sc = SW * S1, isc = 1.f / sc;
+    if (tid < H2) b2s[tid] = vec[tid] * sc, c3s[tid] = vec[H2 + tid] * isc;
+    if (AG && tid < 48) waps[tid] = p.net.wap[(long)set * 48 + tid];
+    const float d3 = vec[2 * H2];
+    const f16x8* wf1 = p.net.wf1h + (long)set * NGT_MAX * 64 + lane;  // + 64 ft
+    const f32x16 zero16 = {};
+    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f;
+#pragma unroll
+    for (int t = 0; t < (BWD ? 4 : 1); ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T1[t][i] = 0.f;
+    __syncthreads();
+
+    const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;  // tiles of this workgroup: j0, j0 + J, ..
+    const int row = 32 * rh + r;
+    f16x8 nx = {};
+    float na = 0.f, ny = 0.f, nw = 1.f;
+    auto fetch_in = [&](int k) {  // one unit (32 rows of a tile) ahead
+        const int agent = (j0 + k * J) * p.n_sets + set;
+        const long ri = (long)agent * TILE + row;
+        nx = p.xf[2 * ri + h];
+        if (NET::critic) na = p.act[ri];
+        if (MODE == OUT_TD) ny = p.r[ri];
+        if (BWD) ny = p.yin[ri];
+        if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
+    };
+    if (q < ntile) fetch_in(q);
+    const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
+    const f16* wlo0 = &wimg[1][r * LD + 8 * h];
+    for (int k = q; k < ntile; k += 4) {
+        const int agent = (j0 + k * J) * p.n_sets + set;
+        const long ri = (long)agent * TILE + row;
+        const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h);
+        const float ty = ny, tw = nw;
+        if (k + 4 < ntile) fetch_in(k + 4);
+        f32x16 acc[4], M[AG ? 4 : 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *(const float4*)(b2s + 32 * t + 8 * g + 4 * h);
+                acc[t][4 * g] = b.x, acc[t][4 * g + 1] = b.y, acc[t][4 * g + 2] = b.z, acc[t][4 * g + 3] = b.w;
+            }
+#pragma unroll
+        for (int t = 0; t < (AG ? 4 : 1); ++t) M[t] = zero16;
+        // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
+        unsigned ph[8], pl[8];
+        auto split16 = [&](const f32x16& p1) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), ph[m], pl[m]);
+        };
+        split16(mfmah(wf1[0], xs, zero16));
+        f16x8 wfn = wf1[64];
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            f32x16 p1n = zero16;
+            if (ft + 1 < NFT) {
+                p1n = mfmah(wfn, (NET::critic && ft + 1 >= 8) ? xa : xs, zero16);
+                if (ft + 2 < NFT) wfn = wf1[64 * (ft + 2)];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ks = 2 * ft + s;
+                if (ks >= NKS) continue;  // (the critic's last tile holds only 16 features)
+                const f16x8 bhi = fragh(ph[4 * s], ph[4 * s + 1], ph[4 * s + 2], ph[4 * s + 3]);
+                const f16x8 blo = fragh(pl[4 * s], pl[4 * s + 1], pl[4 * s + 2], pl[4 * s + 3]);
+                f16x8 mhi = {}, mlo = {};
+                if (AG && ft >= 8) {
+                    // action features: B operand of M = mask_a * wa (hi, lo), from the packed constants and the relu'd hi
+                    // pairs (a half is non-zero exactly where the activation is positive)
+                    const int kk = ks - 16;
+                    const uint4 ch = *(const uint4*)(waps + (0 * 2 + h) * 12 + 4 * kk), cl = *(const uint4*)(waps + (1 * 2 + h) * 12 + 4 * kk);
+                    const unsigned chv[4] = {ch.x, ch.y, ch.z, ch.w}, clv[4] = {cl.x, cl.y, cl.z, cl.w};
+                    unsigned mh[4], ml[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                        const u16x2 v = __builtin_bit_cast(u16x2, ph[4 * s + m]), one = {1, 1}, z2 = {0, 0};
+                        const unsigned mask = __builtin_bit_cast(unsigned, (u16x2)(z2 - __builtin_elementwise_min(v, one)));
+                        mh[m] = chv[m] & mask, ml[m] = clv[m] & mask;
+                    }
+                    mhi = fragh(mh[0], mh[1], mh[2], mh[3]), mlo = fragh(ml[0], ml[1], ml[2], ml[3]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f16x8 whi = *(const f16x8*)(whi0 + 32 * t * LD + 16 * ks);
+                    const f16x8 wlo = *(const f16x8*)(wlo0 + 32 * t * LD + 16 * ks);
+                    acc[t] = mfmah(whi, bhi, acc[t]);
+                    acc[t] = mfmah(wlo, bhi, acc[t]);
+                    acc[t] = mfmah(whi, blo, acc[t]);
+                    if (AG && ft >= 8) {
+                        M[t] = mfmah(whi, mhi, M[t]);
+                        M[t] = mfmah(wlo, mhi, M[t]);
+                        M[t] = mfmah(whi, mlo, M[t]);
+                    }
+                }
+            }
+            if (ft + 1 < NFT) split16(p1n);
+            // (tiles stay in program order: hoisting every tile's first-layer MFMA and weight reads costs hundreds of registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float zp = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[t][4 * g + j] = relu(acc[t][4 * g + j]);
+                    zp = fmaf(acc[t][4 * g + j], cc[j], zp);
+                }
+            }
+        zp += __shfl_xor(zp, 32);
+        const float z = d3 + zp;
+        if (MODE == OUT_TANH) {
+            const float o = tanhf(z) * p.high;
+            if (h == 0) p.out[ri] = o;
+        } else if (MODE == OUT_TD) {
+            if (h == 0) p.out[ri] = ty + p.gamma * z;
+        } else {
+            float g3, loss;
+            if (MODE == HEAD_CRITIC) {
+                const float diff = z - ty;
+                g3 = 2.f * diff * p.inv_n * tw, loss = diff * diff;
+            } else if (MODE == HEAD_CONST) {
+                g3 = -p.inv_n * tw, loss = z;
+            } else {
+                const float t = tanhf(z);
+                g3 = ty * p.high * (1.f - t * t), loss = 0.f;
+            }
+            if (AG) {
+                // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
+                // (the accumulators hold SW S1 M -- SW from the weights, S1 from the scaled wa -- and c3s carries 1 / (SW S1))
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                        const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sum += acc[t][4 * g + j] > 0.f ? cc[j] * M[t][4 * g + j] : 0.f;
+                    }
+                sum += __shfl_xor(sum, 32);
+                if (h == 0) p.dmu[ri] = g3 * sum;
+            } else {
+                if (h == 0) p.g3[ri] = g3;
+                const float g3i = g3 * isc;  // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc)
+                const unsigned s16 = g3 < 0.f ? 0xbf80u : 0x3f80u;  // bf16 -1 / +1
+                bf16* dst = p.sm + ri * H2 + 8 * h;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int i = 4 * g + 2 * e;
+                            T1[t][i] = fmaf(g3i, acc[t][i], T1[t][i]);
+                            T1[t][i + 1] = fmaf(g3i, acc[t][i + 1], T1[t][i + 1]);
+                            pk[g][e] = (acc[t][i] > 0.f ? s16 : 0u) | (acc[t][i + 1] > 0.f ? s16 << 16 : 0u);
+                        }
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                        uint4 o;
+                        o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                        *(uint4*)(dst + 32 * t + 16 * gg) = o;
+                    }
+                }
+            }
+            if (h == 0) Dacc += g3, Lacc += loss;
+        }
+    }
+    if (MODE >= HEAD_CRITIC) {
+        // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
+        if (BWD) {
+            float* pt = p.part + ((long)blockIdx.x * 8 + w) * H2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = T1[t][i];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+                    if (r == 0) pt[32 * t + acc_row(i, h)] = v;
+                }
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            Dacc += __shfl_xor(Dacc, o);
+            Lacc += __shfl_xor(Lacc, o);
+        }
+        if (lane == 0) {
+            p.part_s[((long)blockIdx.x * 8 + w) * 2] = Dacc;
+            p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc;
+        }
+    }
+}
+
+// ---- dw: G[f][n] += sum_rows (|g3| P1)[row][f] * sm[row][n] over all tiles of the workgroup -------------------------------
+struct DwArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const float* x;    // states [n_agents][64][S]
+    const float* act;  // the critic's action input [n_agents][64]
+    const float* g3;   // [n_agents][64]
+    const bf16* sm;    // [n_agents][64][128]
+    float* partG;      // [grid][KG][128] (row K: the constant-one feature = sum over rows of g3 * mask -> db2 / c3)
+};
+// Wave w = (cp, slot): column tiles 2 cp, 2 cp + 1 of feature tiles fg, fg + 4, fg + 8 with fg = slot (cp = 0) or 3 - slot
+// (cp = 1) -- the two waves of a SIMD (w, w + 4) then carry 5 feature tiles between them whatever NGT is. A first-layer tile
+// is evaluated with the batch rows as the M index and the row factor |g3| in its input fragment (result: feature on the lane,
+// rows in the registers = the A operand of G = Q^T . sm in permuted k order), relu'd and split once and used against both
+// column tiles; the sm tile goes through LDS (row stride 320 B: conflict-free ds_read_b64_tr_b16). One barrier per tile.
+template <int S, class NET>
+__global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
+    constexpr int KG = NET::KG, NGT = NET::NGT, LDZ = 160;
+    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, cp = w >> 2, slot = w & 3;
+    const int fg = cp ? 3 - slot : slot;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const bf16x8* wf1 = p.net.wf1 + (long)set * NGT_MAX * 64 + lane;
+    const bool third = fg + 8 < NGT;
+    bf16x8 wf[3];
+    f32x16 G[3][2];
+    const f32x16 zero16 = {};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        wf[i] = (i < 2 || third) ? wf1[64 * (fg + 4 * i)] : bf16x8{};
+        G[i][0] = zero16, G[i][1] = zero16;
+    }
+    const bool act_tile = NET::critic && third;  // tile fg + 8 of a critic takes the action as its input
+
+    const int srow = tid >> 3, sch = tid & 7;  // staging: 64 rows x 8 chunks of 32 bytes
+    uint4 d0 = {}, d1 = {};
+    auto fetch = [&](int agent) {
+        const uint4* src = (const uint4*)(p.sm + ((long)agent * TILE + srow) * H2 + 16 * sch);
+        d0 = src[0], d1 = src[1];
+    };
+    auto stage = [&](int buf) {
+        uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
+        dst[0] = d0, dst[1] = d1;
+    };
+    float nx[2][4], ng[2] = {0.f, 0.f}, na[2] = {0.f, 0.f};  // the next tile's inputs, requested a tile ahead like its sm
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nx[e][k] = 0.f;
+    auto fetch_x = [&](int agent) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long ri = (long)agent * TILE + 32 * e + r;
+            load_x<S>(p.x, ri, nx[e]);
+            ng[e] = p.g3[ri];
+            if (act_tile) na[e] = p.act[ri];
+        }
+    };
+    if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0);
+    __syncthreads();
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    int buf = 0;
+    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
+        const bool more = pi + J < P;
+        bf16x8 xq[2], xaq[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float g = fabsf(ng[e]);
+            xq[e] = make_xq(g * nx[e][0], g * nx[e][1], g * nx[e][2], g * nx[e][3], g, h);
+            xaq[e] = make_xq(g * na[e], 0.f, 0.f, 0.f, g, h);
+        }
+        if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
+        bf16x8 bfr[2][2][2];  // [column tile][row half][k-step]
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int R0 = 32 * e + 16 * s + 8 * hf + 4 * (g4 >> 1);
+                        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * (2 * cp + c) + 16 * (g4 & 1) + 4 * pp));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bfr[c][e][s][4 * hf + j] = t[j];
+                    }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i == 2 && !third) continue;
+            const bool at = act_tile && i == 2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x16 p1 = mfma(at ? xaq[e] : xq[e], wf[i], zero16);  // [row][feature]: feature on the lane
+                unsigned qh[8], ql[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) split2(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 ahi = frag(qh[4 * s], qh[4 * s + 1], qh[4 * s + 2], qh[4 * s + 3]);
+                    const bf16x8 alo = frag(ql[4 * s], ql[4 * s + 1], ql[4 * s + 2], ql[4 * s + 3]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        G[i][c] = mfma(ahi, bfr[c][e][s], G[i][c]);
+                        G[i][c] = mfma(alo, bfr[c][e][s], G[i][c]);
+                    }
+                }
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i == 2 && !third) continue;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* dst = p.partG + ((long)blockIdx.x * KG + 32 * (fg + 4 * i)) * H2 + 32 * (2 * cp + c) + r;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G[i][c][k];
+        }
+    }
+}
+
+// ---- dx: dC = |g3| (sm . W2c^T), BN/ReLU backward of the first layer and its parameter sums -----------------------------------
+struct DxArgs {
+    NetP net;
+    int n_agents, n_sets;
+    const bf16* xf;    // dx_kernel: packed state fragments, bf16 pairs (pack_x_kernel): the [k][row] image of V's B operand
+    const f16x8* xfh;  // dx_kernel: the same as fp16 pairs: the first layer, whose SIGN is the relu mask -- with bf16 pairs (2^-16)
+                       // about 1e-5 of the pre-activations land on the wrong side of zero, and one flipped row moves an entry of
+                       // dW1 / db1 by ~1e-3 of the tensor's max (measured); fp16 pairs put z1 at the f32 level
+    const float* act;  // dxa_kernel: the per-row action input [n_agents][64]
+    const float* g3;
+    const bf16* sm;
+    float* partU;      // [grid][2 h][KP][2]   sum dC, sum dC * p1 per feature
+    float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
+};
+// Wave w = state feature tile w (8 tiles), both row halves. Resident: hi and lo of the tile's rows of W2c as B fragments
+// (reduction over the 128 columns; A = the sm rows, exact). dC comes out [row][feature] (feature on the lane) like the
+// recomputed first layer: the per-feature sums over rows are per-lane sums over the registers, and the masked gradient tile,
+// split, is the A operand of V = (dC * mask)^T . [x_hi | x_lo | 1] -> dW1, db1 (k order permuted as in dw_kernel; the [k][row]
+// image of the inputs is staged once per tile by waves 0 and 1).
+template <int S, class NET>
+__global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
+    constexpr int KP = NET::KP, LDZ = 136;  // 272-byte rows: conflict-free b128 row reads
+    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];
+    __shared__ __attribute__((aligned(16))) bf16 xt[2][2][32 * 32];  // per buffer, per row half: [k column][row]
+    __shared__ __attribute__((aligned(16))) float g3s[2][TILE];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, ft = w;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const f32x16 zero16 = {};
+    bf16x8 wch[8], wcl[8];
+    {
+        const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wch[s] = *(const bf16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const bf16x8*)(p.net.Wclo + at + 16 * s);
+    }
+    const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1: p1 = S1 z1, U1 rescaled at the end)
+    f32x16 V = zero16;
+    float U0 = 0.f, U1 = 0.f;
+    for (int i = tid; i < 2 * 2 * 32 * 32; i += NT) {  // columns 9.. stay zero, column 8 is the ones column (bias)
+        const int k = (i >> 5) & 31;
+        (&xt[0][0][0])[i] = (bf16)(k == 8 ? 1.f : 0.f);
+    }
+    const int srow = tid >> 3, sch = tid & 7;
+    uint4 d0 = {}, d1 = {};
+    float gn = 0.f;
+    auto fetch = [&](int agent) {
+        const uint4* src = (const uint4*)(p.sm + ((long)agent * TILE + srow) * H2 + 16 * sch);
+        d0 = src[0], d1 = src[1];
+        if (tid < TILE) gn = p.g3[(long)agent * TILE + tid];
+    };
+    auto stage = [&](int buf) {
+        uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
+        dst[0] = d0, dst[1] = d1;
+        if (tid < TILE) g3s[buf][tid] = fabsf(gn);
+    };
+    f16x8 xfn[2] = {};  // the rows' input fragments [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1), both row halves
+    bf16x8 xbn = {};    // waves 0, 1, lane half 0: the bf16 fragment [x_hi | x_lo] of row r of row half w
+    auto fetch_x = [&](int agent) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) xfn[e] = p.xfh[((long)agent * TILE + 32 * e + r) * 2 + h];
+        if (w < 2 && h == 0) xbn = ((const bf16x8*)p.xf)[((long)agent * TILE + 32 * w + r) * 2];
+    };
+    auto stage_x = [&](int buf) {  // [k][row] image of [x_hi | x_lo]: the h = 0 fragments, transposed (waves 0, 1: one row half each)
+        if (w < 2 && h == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xt[buf][w][k * 32 + r] = xbn[k];
+        }
+    };
+    __syncthreads();  // the zero / ones fill above before the first stage_x
+    if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0), stage_x(0);
+    __syncthreads();
+    int buf = 0;
+    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
+        const bool more = pi + J < P;
+        const f16x8 xf[2] = {xfn[0], xfn[1]};
+        if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            bf16x8 smf[8];
+            const bf16* arow = smimg[buf] + (32 * e + r) * LDZ + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) smf[s] = *(const bf16x8*)(arow + 16 * s);
+            bf16x8 xb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x4 lo = *(const bf16x4*)(&xt[buf][e][r * 32 + 16 * s + 4 * h]);
+                const bf16x4 hi = *(const bf16x4*)(&xt[buf][e][r * 32 + 16 * s + 8 + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
+            }
+            f32x16 dc = zero16;  // [row][feature]: feature on the lane
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dc = mfma(smf[s], wch[s], dc), dc = mfma(smf[s], wcl[s], dc);
+            const f32x16 p1 = mfmah(xf[e], wf, zero16);
+            float u0 = 0.f, u1 = 0.f;
+            unsigned vh[8], vl[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 gq = *(const float4*)(&g3s[buf][32 * e + 8 * g + 4 * h]);
+                const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+                float dm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * g + j;
+                    const float pr = relu(p1[k]), d = dc[k] * gg[j];
+                    u0 += d;
+                    u1 = fmaf(d, pr, u1);
+                    dm[j] = pr > 0.f ? d : 0.f;
+                }
+                split2(dm[0], dm[1], vh[2 * g], vl[2 * g]);
+                split2(dm[2], dm[3], vh[2 * g + 1], vl[2 * g + 1]);
+            }
+            U0 += u0, U1 += u1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                V = mfma(frag(vh[4 * s], vh[4 * s + 1], vh[4 * s + 2], vh[4 * s + 3]), xb[s], V);
+                V = mfma(frag(vl[4 * s], vl[4 * s + 1], vl[4 * s + 2], vl[4 * s + 3]), xb[s], V);
+            }
+        }
+        if (more) stage(buf ^ 1), stage_x(buf ^ 1);
+        __syncthreads();
+    }
+    float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
+    pu[0] = U0, pu[1] = U1 * (1.f / S1);
+    if (r < 16) {
+        float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft) * 16 + r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[k];
+    }
+}
+
+// ---- dxa: the critic's ACTION feature tiles (48 features = tiles 8, 9) of dC and their parameter sums ----------------------
+// A quarter of dx_kernel's work per tile. Every wave is on its own: wave w = (rh, ft, par) takes row half rh of feature tile
+// 8 + ft of every second tile (parity par) of the workgroup and reads its 32 sm rows straight from global memory as A
+// fragments, one tile ahead; the two parities and the two row halves are combined once, at the end.
+template <int S>
+__global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
+    typedef CriticS NET;
+    constexpr int KP = NET::KP;
+    __shared__ __attribute__((aligned(16))) bf16 xt[8][2][32 * 32];  // per wave, per buffer: [k column][row of its half]
+    __shared__ float comb[8][64][2 + 16];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, rh = w & 1, ftl = (w >> 1) & 1, par = w >> 2;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    const f32x16 zero16 = {};
+    const int ft = 8 + ftl;
+    bf16x8 wch[8], wcl[8];
+    {
+        const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wch[s] = *(const bf16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const bf16x8*)(p.net.Wclo + at + 16 * s);
+    }
+    const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1, like dx_kernel's)
+    f32x16 V = zero16;
+    float U0 = 0.f, U1 = 0.f;
+    for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
+        const int k = (i >> 5) & 31;
+        xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
+    }
+    __syncthreads();
+    const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
+    bf16x8 smn[8];
+    float an = 0.f, gn[16];
+    auto fetch = [&](int k) {
+        const long r0 = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh, ri = r0 + r;
+        const bf16* src = p.sm + ri * H2 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) smn[s] = *(const bf16x8*)(src + 16 * s);
+        an = p.act[ri];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(p.g3 + r0 + 8 * g + 4 * h);
+            gn[4 * g] = v.x, gn[4 * g + 1] = v.y, gn[4 * g + 2] = v.z, gn[4 * g + 3] = v.w;
+        }
+    };
+    if (par < ntile) fetch(par);
+    int buf = 0;
+    for (int k = par; k < ntile; k += 2, buf ^= 1) {
+        bf16x8 smf[8];
+        float gg[16];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) smf[s] = smn[s];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gg[i] = fabsf(gn[i]);
+        const f16x8 xf = make_xh(an, 0.f, 0.f, 0.f, h);
+        bf16 abh, abl;
+        split1(an, abh, abl);
+        if (k + 2 < ntile) fetch(k + 2);
+        if (h == 0) {  // [k][row] image of [a_hi 0 0 0 | a_lo 0 0 0] (bf16 pair) of the wave's 32 rows
+            xt[w][buf][r] = abh;
+            xt[w][buf][4 * 32 + r] = abl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 xb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
+            const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
+        }
+        f32x16 dc = zero16;  // [row][feature]: feature on the lane
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dc = mfma(smf[s], wch[s], dc), dc = mfma(smf[s], wcl[s], dc);
+        const f32x16 p1 = mfmah(xf, wf, zero16);
+        float u0 = 0.f, u1 = 0.f;
+        unsigned vh[8], vl[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            float dm[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * m + e;
+                const float pr = relu(p1[i]), d = dc[i] * gg[i];
+                u0 += d;
+                u1 = fmaf(d, pr, u1);
+                dm[e] = pr > 0.f ? d : 0.f;
+            }
+            split2(dm[0], dm[1], vh[m], vl[m]);
+        }
+        U0 += u0, U1 += u1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            V = mfma(frag(vh[4 * s], vh[4 * s + 1], vh[4 * s + 2], vh[4 * s + 3]), xb[s], V);
+            V = mfma(frag(vl[4 * s], vl[4 * s + 1], vl[4 * s + 2], vl[4 * s + 3]), xb[s], V);
+        }
+    }
+    // combine the four (rh, par) waves of a feature tile in a fixed order: wave (rh 0, par 0) of the tile writes
+    U1 *= 1.f / S1;
+    comb[w][lane][0] = U0, comb[w][lane][1] = U1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) comb[w][lane][2 + i] = V[i];
+    __syncthreads();
+    if (rh == 0 && par == 0) {
+        const int o1 = w + 1, o2 = w + 4, o3 = w + 5;  // (rh 1, par 0), (rh 0, par 1), (rh 1, par 1)
+        U0 = ((U0 + comb[o1][lane][0]) + comb[o2][lane][0]) + comb[o3][lane][0];
+        U1 = ((U1 + comb[o1][lane][1]) + comb[o2][lane][1]) + comb[o3][lane][1];
+        float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
+        pu[0] = U0, pu[1] = U1;
+        if (r < 16) {
+            float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft) * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                pv[(long)acc_row(i, h) * 16] = ((V[i] + comb[o1][lane][2 + i]) + comb[o2][lane][2 + i]) + comb[o3][lane][2 + i];
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+struct Plan {
+    int grid, J;
+    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1[4], wf1h[4], vec[4], wap, xfb, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partU[2],
+        partV[2], partG[2], bad, total;
+};
+static Plan make_plan(int n_agents, int n_sets) {
+    Plan pl;
+    const int P = n_agents / n_sets;
+    int J = cu_count() / n_sets;  // one 512-thread workgroup per CU, every workgroup bound to one set
+    if (const char* e = getenv("AVD_FSPLIT_J")) J = atoi(e);  // diagnostics
+    if (J < 1) J = 1;
+    if (J > P) J = P;
+    pl.J = J, pl.grid = J * n_sets;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    for (int i = 0; i < 4; ++i) {
+        const int K = (i & 1) ? CriticS::K : ActorS::K, KP = (i & 1) ? CriticS::KP : ActorS::KP;
+        pl.Whi[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K), pl.Wlo[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K);
+        pl.vec[i] = take(sizeof(float) * (size_t)n_sets * VEC);
+        pl.wf1[i] = take(16 * (size_t)n_sets * NGT_MAX * 64), pl.wf1h[i] = take(16 * (size_t)n_sets * NGT_MAX * 64);
+        if (i < 2) pl.Wchi[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2), pl.Wclo[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2);
+    }
+    pl.wap = take(4 * (size_t)n_sets * 48);
+    const size_t rows = (size_t)n_agents * TILE;
+    pl.a2 = take(4 * rows), pl.y = take(4 * rows), pl.mu = take(4 * rows), pl.dmu = take(4 * rows), pl.g3 = take(4 * rows);
+    pl.sm = take(sizeof(bf16) * rows * H2);
+    pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows), pl.xfb = take(32 * rows);
+    for (int i = 0; i < 2; ++i) {
+        const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
+        pl.partH[i] = take(4 * (size_t)pl.grid * 8 * H2);
+        pl.partU[i] = take(4 * (size_t)pl.grid * 2 * KP * 2);
+        pl.partV[i] = take(4 * (size_t)pl.grid * KP * 16);
+        pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
+    }
+    for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 8 * 2);
+    pl.bad = take(sizeof(int));
+    pl.total = o;
+    return pl;
+}
+static int check_shape(const avd_mlp_layout* L, int n_agents, int n_sets, const char* who) {
+    AVD_REQUIRE(L, "%s: null layout", who);
+    if (L->H1 != H1 || L->H2 != H2 || L->Ha != HA || L->A != 1 || (L->S != 3 && L->S != 4) || L->B != TILE) {
+        set_error("%s: serves the reference widths only (layer1 256, layer2 128, action layer 48, A = 1, S in {3, 4}, B = 64); "
+                  "got H1=%d H2=%d Ha=%d A=%d S=%d B=%d (avd_learn_shared_bf16 takes other widths)",
+                  who, L->H1, L->H2, L->Ha, L->A, L->S, L->B);
+        return AVD_E_UNSUPPORTED;
+    }
+    AVD_REQUIRE(n_sets > 0 && n_sets <= 64 && n_agents > 0 && n_agents % n_sets == 0, "%s: n_agents=%d n_sets=%d", who, n_agents,
+                n_sets);
+    return AVD_OK;
+}
+
+template <int S>
+static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* theta, const float* stats, const float* theta_t,
+               const float* stats_t, const float* s, const float* a, const float* r, const float* s2, const float* aw, float gamma,
+               float high, float* grads, float* losses, unsigned char* ws, const Plan& pl, hipStream_t st) {
+    PrepArgs pa;
+    pa.L = L, pa.S = S, pa.theta = theta, pa.stats = stats, pa.theta_t = theta_t, pa.stats_t = stats_t;
+    pa.wap = (unsigned*)(ws + pl.wap), pa.bad = (int*)(ws + pl.bad);
+    NetP net[4];
+    for (int i = 0; i < 4; ++i) {
+        const bool critic = i & 1, target = i >= 2;
+        pa.Whi[i] = (f16*)(ws + pl.Whi[i]), pa.Wlo[i] = (f16*)(ws + pl.Wlo[i]), pa.vec[i] = (float*)(ws + pl.vec[i]);
+        pa.wf1[i] = (bf16x8*)(ws + pl.wf1[i]), pa.wf1h[i] = (f16x8*)(ws + pl.wf1h[i]);
+        pa.Wchi[i] = i < 2 ? (bf16*)(ws + pl.Wchi[i]) : nullptr, pa.Wclo[i] = i < 2 ? (bf16*)(ws + pl.Wclo[i]) : nullptr;
+        NetP& n = net[i];
+        n.th = (target ? theta_t : theta) + (critic ? L.actor_size : 0), n.th_stride = L.theta_size;
+        n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1 = pa.wf1[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
+        n.wap = pa.wap;
+    }
+    if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int), st) != hipSuccess) return check_launch("avd_learn_set_split_bf16x3: memset");
+    hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
+    hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
+    const long nrows = (long)n_agents * TILE;
+    f16x8 *xfs = (f16x8*)(ws + pl.xfs), *xfs2 = (f16x8*)(ws + pl.xfs2);
+    bf16x8* xfb = (bf16x8*)(ws + pl.xfb);
+    int* bad = (int*)(ws + pl.bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, nrows, xfs, xfb, bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, nrows, xfs2, (bf16x8*)nullptr, bad);
+    const int P = n_agents / n_sets;
+    const float inv_n = 1.0f / ((float)P * TILE);
+    float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
+    float* g3 = (float*)(ws + pl.g3);
+    bf16* sm = (bf16*)(ws + pl.sm);
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    const dim3 grid(pl.grid), block(NT);
+    HeadArgs h;
+    h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
+    auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
+                    float* part_s) {
+        h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
+        hipLaunchKernelGGL(kern, grid, block, 0, st, h);
+    };
+    DwArgs dw;
+    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s;
+    DxArgs dx;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xf = (const bf16*)xfb, dx.xfh = xfs;
+    // 1-2: targets
+    head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+    head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+    // 3: mu (independent of the critic passes)
+    head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+    // 4-6: critic loss and gradients
+    head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]);
+    hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
+    dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
+    hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
+    hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
+    // 7-8: actor loss through the critic, gradient w.r.t. the action
+    head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
+    // 9-11: actor gradients
+    head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
+    dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]);
+    hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
+    dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr;
+    hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
+    // 12: finalize (shared with fset.hip)
+    FinArgs fa;
+    fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.nrh = 1, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
+    fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]), fa.bad = bad;
+    for (int i = 0; i < 2; ++i)
+        fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
+        fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
+    launch_finalize(fa, st);
+    return check_launch("avd_learn_set_split_bf16x3");
+}
+
+}  // namespace fsplit
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes) {
+    int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_workspace");
+    if (rc) return rc;
+    AVD_REQUIRE(bytes, "avd_learn_set_split_workspace: null pointer");
+    *bytes = fsplit::make_plan(n_agents, n_sets).total;
+    return AVD_OK;
+}
+
+extern "C" int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                                          const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                                          const float* s2, const float* agent_weight, float gamma, float high, float* grads,
+                                          float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_bf16x3");
+    if (rc) return rc;
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads && workspace,
+                "avd_learn_set_split_bf16x3: null pointer");
+    const fsplit::Plan pl = fsplit::make_plan(n_agents, n_sets);
+    AVD_REQUIRE(workspace_bytes >= pl.total, "avd_learn_set_split_bf16x3: workspace %zu B < %zu B", workspace_bytes, pl.total);
+    // (padding floats of the slab are never written by finalize: keep them zero like every other gradient producer)
+    if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream) != hipSuccess)
+        return check_launch("avd_learn_set_split_bf16x3: hipMemsetAsync(grads)");
+    if (lay->S == 4)
+        return fsplit::run<4>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
+                              losses, (unsigned char*)workspace, pl, (hipStream_t)stream);
+    return fsplit::run<3>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads, losses,
+                          (unsigned char*)workspace, pl, (hipStream_t)stream);
+}

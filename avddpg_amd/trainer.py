@@ -113,22 +113,23 @@ class VecTrainer:
         # Shared weight sets: "per_agent" = the f32 LDS-resident kernel per agent + fed_sum (exact f32, widths up to
         # 256); "batched" = one learn over each set's P x 64 rows as bf16 MFMA GEMMs (csrc/wide.hip; any width multiple
         # of 64, e.g. BASELINE config 5's 1024); "fused" = the same quantity at the reference widths as persistent
-        # register-resident-weight kernels (csrc/fset.hip; bf16 operands, deterministic, agent-major batches).
+        # register-resident-weight kernels (csrc/fset.hip; bf16 operands, deterministic, agent-major batches); "fused3" =
+        # that design with every GEMM operand an exact bf16 hi + lo pair (csrc/fsplit.hip): f32-class results.
         # Default: per_agent where it exists.
         lay = self.agents.lay
         fits = lay.H2 <= 256
         self.shared_engine = shared_engine or ("batched" if (self.shared and not fits) else "per_agent")
-        if self.shared_engine not in ("per_agent", "batched", "fused"):
+        if self.shared_engine not in ("per_agent", "batched", "fused", "fused3"):
             raise ValueError(f"shared_engine={shared_engine!r}")
-        if self.shared_engine in ("batched", "fused") and not self.shared:
+        if self.shared_engine in ("batched", "fused", "fused3") and not self.shared:
             raise ValueError("the batched learners need shared weight sets (interfrl + gradients, every step federated)")
-        if self.shared_engine == "fused" and (lay.H1, lay.H2, lay.Ha, lay.A, lay.B) != (256, 128, 48, 1, 64):
-            raise ValueError("shared_engine='fused' (csrc/fset.hip) serves the reference widths 256/128/48, A = 1, batch 64 only; "
+        if self.shared_engine in ("fused", "fused3") and (lay.H1, lay.H2, lay.Ha, lay.A, lay.B) != (256, 128, 48, 1, 64):
+            raise ValueError("shared_engine='fused' / 'fused3' (csrc/fset.hip, fsplit.hip) serve the reference widths 256/128/48, A = 1, batch 64 only; "
                              f"got {lay.H1}/{lay.H2}/{lay.Ha}, A = {lay.A}, batch {lay.B}: use shared_engine='batched'")
         self.actor_out = torch.zeros(n_agents, self.A, **f32)
         self.actions = torch.zeros(self.P, self.M, self.A, **f32)  # self.actions[p][m] (trainer.py:179)
         self.leader_exog = torch.zeros(self.P, **f32)
-        batched = self.shared and self.shared_engine in ("batched", "fused")  # no per-agent gradient slab (188 GB at hidden 1024)
+        batched = self.shared and self.shared_engine in ("batched", "fused", "fused3")  # no per-agent gradient slab (188 GB at hidden 1024)
         self.grads = None if batched else torch.zeros(n_agents, self.agents.lay.theta_size, **f32)
         self.losses = torch.zeros(n_agents, 2, **f32)
         self.ep_reward = torch.zeros(self.P, self.M, **f32)  # float32 accumulators (trainer.py:249, 321)
@@ -266,7 +267,7 @@ class VecTrainer:
             self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,
                                     timers=self.timers)
             return
-        if self.shared and self.shared_engine in ("batched", "fused"):
+        if self.shared and self.shared_engine in ("batched", "fused", "fused3"):
             weights = None
             if is_weighted_fed_enabled(conf, ep):
                 if self.fed_weights is None or self.fed_weights[0] != ep:
@@ -290,9 +291,10 @@ class VecTrainer:
         rw = wsum = None
         if weights is not None:  # [P, M] -> factors w_p * P / sum_p w_p (federated.py:99-118)
             wsum = weights.sum(dim=0)  # [M]
-        if self.shared_engine == "fused":  # agent-major batches as sampled, one factor per agent
+        if self.shared_engine in ("fused", "fused3"):  # agent-major batches as sampled, one factor per agent
             aw = None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous()
-            self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw)
+            self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw,
+                                        split=self.shared_engine == "fused3")
         else:
             if weights is not None:  # per-row factors, set-major
                 rw = (weights * (float(P) / wsum)).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()

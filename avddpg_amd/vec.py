@@ -319,25 +319,34 @@ class AgentGroup:
              self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
-    def learn_set_fused(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None):
+    def learn_set_fused(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None, split=False):
         """Trainer.learn + federated mean for agents that SHARE this group's ``n_sets`` weight sets, at the reference
-        widths, as persistent register-resident-weight kernels (csrc/fset.hip). Batches are AGENT-MAJOR as sampled
-        (agent v = p*n_sets + m uses set m): s, s2 [n_agents, B, S], a [n_agents, B(, 1)], r [n_agents, B].
+        widths, as persistent resident-weight kernels. Batches are AGENT-MAJOR as sampled (agent v = p*n_sets + m uses set
+        m): s, s2 [n_agents, B, S], a [n_agents, B(, 1)], r [n_agents, B].
         agent_weight [n_agents] (optional): w_p * P / sum(w) per agent = the weighted federated mean.
+        split=False: bf16 GEMM operands (csrc/fset.hip, avd_learn_set_fused_bf16);
+        split=True: every operand an exact bf16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_bf16x3).
         Returns the mean gradient per set [n_sets, theta_size]."""
         import ctypes
         self._check_agent_major(s, a, r, s2, n_agents, agent_weight)
         if grads is None:
             grads = torch.empty(self.n_sets, self.lay.theta_size, dtype=torch.float32, device=self.device)
+        wsf, fn, attr = (("avd_learn_set_split_workspace", "avd_learn_set_split_bf16x3", "_fsplit_ws") if split else
+                         ("avd_learn_set_fused_workspace", "avd_learn_set_fused_bf16", "_fset_ws"))
         need = ctypes.c_size_t(0)
-        call("avd_learn_set_fused_workspace", self._layp, n_agents, self.n_sets, ctypes.byref(need))
-        ws = getattr(self, "_fset_ws", None)
+        call(wsf, self._layp, n_agents, self.n_sets, ctypes.byref(need))
+        ws = getattr(self, attr, None)
         if ws is None or ws.numel() < need.value:
-            ws = self._fset_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-        call("avd_learn_set_fused_bf16", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
-             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma,
-             self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
+            ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            setattr(self, attr, ws)
+        call(fn, self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(self.theta_t), ptr(self.stats_t),
+             ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma, self.high, ptr(grads), ptr(losses),
+             ptr(ws), ws.numel(), stream_handle())
         return grads
+
+    def learn_set_split(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None):
+        """learn_set_fused with f32-class results (split operands, csrc/fsplit.hip)."""
+        return self.learn_set_fused(s, a, r, s2, n_agents, grads=grads, losses=losses, agent_weight=agent_weight, split=True)
 
     def _check_agent_major(self, s, a, r, s2, n_agents, agent_weight):
         """The set learners of csrc/fset.hip / fsplit.hip take raw pointers to tightly packed AGENT-major f32 batches

@@ -269,6 +269,20 @@ int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets
                              const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* avd_learn_set_fused_bf16 with f32-class results (csrc/fsplit.hip): same arguments, same workspace protocol, same
+ * deterministic reduction, but every matrix-product operand is carried as an exact bf16 pair hi + lo (2^-17 relative) and
+ * each product runs as A_hi B_hi + A_lo B_hi + A_hi B_lo on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- two MFMAs where
+ * one operand is the exact relu mask: dZ2 = g3[row] c3[n] [z2 > 0] is rank one times a mask (the output layers are one unit
+ * wide). The reference computes Trainer.learn in float32 (agent/model.py:26-36, 63-83; workers/trainer.py:472-508): this
+ * entry point matches the f32 kernels' tolerance against the float64 oracle (1e-4 of each tensor's max), which the
+ * single-rounded bf16 operands of avd_learn_set_fused_bf16 miss by two orders of magnitude on the actor gradients.
+ * A non-finite input (weights, BN statistics, s, a, r, s2) gives an all-NaN gradient slab, as it would through f32 kernels. */
+int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
+int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                               const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                               const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* actor(state) (agent/model.py:26-36, workers/trainer.py:286-289) for agents that share n_sets weight sets, as the same
  * bf16 GEMM chain: state [n_sets][rows][S] SET-MAJOR (rows = n_agents / n_sets, tightly packed S floats per row),
  * out [n_sets][rows] = tanh(.) * high. */

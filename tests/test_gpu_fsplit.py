@@ -1,0 +1,212 @@
+"""GPU parity of the split-operand fused set learner (csrc/fsplit.hip, avd_learn_set_split_bf16x3): Trainer.learn
+(workers/trainer.py:472-508) + federated mean (src/server/federated.py:47-63, 99-118) for agents that share their networks,
+with every GEMM operand an exact bf16 hi + lo pair. The bar is the F32 kernels' bar, not a bf16 one: GRAD_TOL = 1e-4 of each
+tensor's max against the float64 oracle (tests/test_gpu_mlp.py), the same against the exact-f32 per-agent kernel + fed_mean,
+bit-identical reruns, and at full size (4096 x 5) through the f32 engine and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from avddpg_amd import config, vec
+from oracle import mlp as omlp
+from tests.gpu_util import need_gpu, t
+from tests.test_gpu_fset import NAMES, _batch
+from tests.test_gpu_mlp import GRAD_TOL, _nets, _perturbed_group, _relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
+def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
+    """The mean over a set's P agents of their 64-row batch gradients == the gradient of the P*64-row batch (inference-mode
+    BN: rows are independent). Every gradient tensor within max(1e-4, 4 x the float32 oracle's own error) of the float64
+    oracle -- the assertion of the exact-f32 learn kernels (tests/test_gpu_mlp.py::test_learn_gradients_match_oracle)."""
+    need_gpu()
+    B = 64
+    conf, grp = _perturbed_group(M, S=S, seed=61)
+    rs = np.random.RandomState(62)
+    n = P * M  # agent v = p*M + m uses set m
+    s, a, r, s2 = _batch(rs, n, S)
+    losses = torch.zeros(M, 2, device="cuda")
+    g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n, losses=losses)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g).all()
+    errs = {}
+    for k in range(M):
+        sel = np.arange(P) * M + k
+        cat = lambda x: x[sel].reshape(P * B, *x.shape[2:])
+        batch = (cat(s), cat(a), cat(r)[:, None], cat(s2))
+        cg, ag, aux = omlp.learn(batch, *_nets(grp, k, np.float64))
+        cg32, ag32, _ = omlp.learn(batch, *_nets(grp, k, np.float32))
+        gcg, gag = grp.grads_as_lists(g[k])
+        for name, got, ref, r32 in zip(NAMES, gcg + gag, cg + ag, cg32 + ag32):
+            e = _relerr(got, ref)
+            if e > max(GRAD_TOL, 4 * _relerr(r32, ref)):
+                errs[(k, name)] = (e, _relerr(r32, ref))
+        lo = losses[k].cpu().numpy()
+        assert abs(lo[0] - aux["critic_loss"]) <= 1e-4 * abs(aux["critic_loss"])
+        assert abs(lo[1] - aux["actor_loss"]) <= 1e-4 * max(1e-2, abs(aux["actor_loss"]))
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("P,M", [(8, 3), (1, 1), (70, 5)])
+def test_split_set_learner_equals_per_agent_f32_kernel_plus_federated_mean(P, M):
+    """avd_learn_f32 per agent (exact f32 MFMA) + fed_mean over the platoons vs the split learner on the same agent-major
+    batch: 1e-4 of each block's max (the bf16 learner of fset.hip: 1.7e-2 on the actor block)."""
+    need_gpu()
+    B, S = 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=71)
+    rs = np.random.RandomState(72)
+    n = P * M
+    s, a, r, s2 = _batch(rs, n, S)
+    per_agent = grp.learn(t(s), t(a), t(r), t(s2), M)
+    avg = vec.fed_mean(per_agent, P, M, method=conf.interfrl).cpu().numpy()  # [M, theta]
+    split = grp.learn_set_split(t(s), t(a), t(r), t(s2), n).cpu().numpy()
+    bf16 = grp.learn_set_fused(t(s), t(a), t(r), t(s2), n).cpu().numpy()
+    lay = grp.lay
+    for name, lo, hi in (("actor", 0, lay.actor_size), ("critic", lay.actor_size, lay.theta_size)):
+        scale = np.abs(avg[:, lo:hi]).max()
+        es, eb = np.abs(avg[:, lo:hi] - split[:, lo:hi]).max() / scale, np.abs(avg[:, lo:hi] - bf16[:, lo:hi]).max() / scale
+        assert es <= GRAD_TOL, (name, es, eb)
+        assert es < 0.05 * eb or eb < 1e-4, (name, es, eb)  # two orders of magnitude closer than single-rounded operands
+    # padding floats of the slab stay zero (what Adam relies on)
+    assert split[:, lay.actor_size - 3:lay.actor_size].max() == 0.0 or lay.actor_size % 4 == 0
+
+
+def test_split_set_learner_is_deterministic():
+    need_gpu()
+    P, M, S = 40, 5, 4
+    conf, grp = _perturbed_group(M, S=S, seed=75)
+    s, a, r, s2 = (t(x) for x in _batch(np.random.RandomState(76), P * M, S))
+    g1 = grp.learn_set_split(s, a, r, s2, P * M).clone()
+    g2 = grp.learn_set_split(s, a, r, s2, P * M).clone()
+    assert torch.equal(g1, g2)
+
+
+def test_split_set_learner_weighted_mean_matches_weighted_fed_mean():
+    """Server.get_weighted_avg_params (src/server/federated.py:99-118) through per-agent factors w_p * P / sum(w)."""
+    need_gpu()
+    P, M, B, S = 6, 2, 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=101)
+    rs = np.random.RandomState(102)
+    n = P * M
+    s, a, r, s2 = _batch(rs, n, S)
+    for p in range(P):  # make the platoons' gradients differ, else any weighting gives the same mean
+        r[p * M:(p + 1) * M] *= 1.0 + 4.0 * p
+        s[p * M:(p + 1) * M] += 0.5 * p
+    w = np.linspace(0.2, 3.0, P)[:, None].repeat(M, axis=1).astype(np.float32) * rs.uniform(0.8, 1.2, size=(P, M)).astype(np.float32)
+    per_agent = grp.learn(t(s), t(a), t(r), t(s2), M)
+    avg = vec.fed_mean(per_agent, P, M, weights=t(w), method=conf.interfrl).cpu().numpy()
+    aw = (w * (P / w.sum(axis=0))).reshape(-1).astype(np.float32)  # agent-major [P*M]
+    g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n, agent_weight=t(aw)).cpu().numpy()
+    unweighted = grp.learn_set_split(t(s), t(a), t(r), t(s2), n).cpu().numpy()
+    lay = grp.lay
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        scale = np.abs(avg[:, lo:hi]).max()
+        assert np.abs(avg[:, lo:hi] - g[:, lo:hi]).max() <= GRAD_TOL * scale
+        assert np.abs(avg[:, lo:hi] - unweighted[:, lo:hi]).max() > 5e-2 * scale  # the weights matter in this case
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("where", ["theta", "stats_t", "s", "a", "r"])
+def test_set_learners_turn_a_non_finite_input_into_nan_gradients(split, where):
+    """both set learners are built with -fno-honor-nans and their relu() turns a NaN into 0, so a diverged weight
+    or a poisoned replay row would vanish instead of propagating as it does through the f32 engines. The inputs are tested
+    for finiteness on the way in (bit tests) and finalize writes NaN into the whole slab."""
+    need_gpu()
+    P, M, S = 5, 2, 4
+    conf, grp = _perturbed_group(M, S=S, seed=81)
+    s, a, r, s2 = (t(x) for x in _batch(np.random.RandomState(82), P * M, S))
+    fn = grp.learn_set_split if split else grp.learn_set_fused
+    assert torch.isfinite(fn(s, a, r, s2, P * M)).all()
+    bad = float("nan") if where != "r" else float("inf")
+    if where == "theta":
+        grp.theta[1, grp.lay.cW2 + grp.lay.actor_size + 777] = bad
+    elif where == "stats_t":
+        grp.stats_t[0, grp.lay.amv1 + 3] = bad
+    else:
+        {"s": s, "a": a, "r": r}[where].view(-1)[321] = bad
+    g = fn(s, a, r, s2, P * M)
+    lay = grp.lay
+    for lo, hi in ((lay.aW2, lay.aW2 + 256 * 128), (lay.actor_size + lay.cW2, lay.actor_size + lay.cW2 + 304 * 128)):
+        assert torch.isnan(g[:, lo:hi]).all()
+
+
+def test_full_size_split_learner_against_the_f32_engine_and_the_mean_of_its_halves():
+    """BASELINE configs[3]'s per-GPU shape (4096 platoons x 5 vehicle indices, 64-row batches): against the exact-f32
+    per-agent learn kernel + federated mean at this size (1e-4 of each block's max), and the size-independent property that
+    the mean over all platoons is the average of the means over its two halves (same operand values on both sides, only
+    the f32 summation grouping differs: 2e-5)."""
+    need_gpu()
+    P, M, B, S = 4096, 5, 64, 4
+    conf, grp = _perturbed_group(M, S=S, seed=91)
+    gen = torch.Generator(device="cuda").manual_seed(92)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=gen)
+    n = P * M
+    s, a, r, s2 = 1.5 * rn(n, B, S), 2.5 * (2 * torch.rand(n, B, 1, device="cuda", generator=gen) - 1), -rn(n, B).abs() * 0.3, 1.5 * rn(n, B, S)
+    full = grp.learn_set_split(s, a, r, s2, n).clone()
+    again = grp.learn_set_split(s, a, r, s2, n)
+    assert torch.equal(full, again) and torch.isfinite(full).all() and full.abs().max() > 0
+    h = n // 2
+    halves = []
+    for lo in (0, h):
+        sl = lambda x: x[lo:lo + h].contiguous()
+        halves.append(grp.learn_set_split(sl(s), sl(a), sl(r), sl(s2), h).clone())
+    avg = 0.5 * (halves[0] + halves[1])
+    exact = vec.fed_mean(grp.learn(s, a, r, s2, M), P, M, method=conf.interfrl)
+    lay = grp.lay
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        scale = exact[:, lo:hi].abs().max().item()
+        assert (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item() <= 2e-5 * scale, lo
+        assert (full[:, lo:hi] - exact[:, lo:hi]).abs().max().item() <= GRAD_TOL * scale, lo
+    assert not torch.allclose(halves[0], halves[1])  # the halves are different batches
+
+
+def test_trainer_split_engine_tracks_per_agent_engine_under_interfrl():
+    """VecTrainer with shared weight sets: the split learner against the exact f32 per-agent kernel + fed_sum on the same
+    host RNG stream (parity mode). Identical before the first update; afterwards the gradients differ at the 1e-5 level and
+    Adam normalises every step to |dw| <= lr, so what remains is bounded by the f32 kernels' own run-to-run class: actions
+    within 2e-4 of the action range (the bf16 engine needs 5e-3 here, tests/test_gpu_fset.py)."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    P, L, steps = 6, 3, 72
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+    runs = []
+    for engine in ("per_agent", "fused3"):
+        np.random.seed(11)
+        vt = trainer.VecTrainer(conf, rng="host", shared_sets=True, shared_engine=engine)
+        vt.reset_episode()
+        traj = []
+        for i in range(steps):
+            vt.step(0, i)
+            traj.append((vt.actions.cpu().numpy().copy(), vt.env.x.cpu().numpy().copy()))
+        runs.append((vt, traj))
+    (a, ta), (b, tb) = runs
+    assert b.grads is None and b.shared_engine == "fused3" and a.updates == b.updates == (steps - 64) * P * L
+    for i in range(steps):
+        tol = 0.0 if i < 65 else 2e-4
+        assert np.abs(ta[i][0] - tb[i][0]).max() <= tol * 2.5, i
+        assert np.abs(ta[i][1] - tb[i][1]).max() <= tol * max(1.0, np.abs(ta[i][1]).max()), i
+    n_upd = steps - 64
+    for lr, lo, hi in ((conf.actor_lr, 0, a.agents.lay.actor_size), (conf.critic_lr, a.agents.lay.actor_size, a.agents.lay.theta_size)):
+        d = (a.agents.theta[:, lo:hi] - b.agents.theta[:, lo:hi]).abs()
+        assert d.max().item() <= 2 * lr * n_upd and d.mean().item() <= 0.02 * lr * n_upd
+    assert torch.isfinite(b.agents.theta).all() and int(b.agents.step[0]) == n_upd
+
+
+def test_trainer_split_engine_weighted_federation_runs_model_a():
+    """Weighted interfrl (workers/trainer.py:385-398) + Model A (S = 3) through the split engine."""
+    from avddpg_amd import trainer
+
+    need_gpu()
+    conf = config.Config(num_platoons=4, pl_size=2, buffer_size=128, fed_method="interfrl", weighted_average_enabled=True,
+                         weighted_window=2, episode_sim_time=3.0, model="ModelA")  # 30-step episodes
+    np.random.seed(2)
+    vt = trainer.VecTrainer(conf, rng="host", shared_engine="fused3")
+    assert vt.shared and vt.shared_engine == "fused3" and vt.agents.lay.S == 3
+    th0 = vt.agents.theta.clone()
+    vt.run(number_of_episodes=4)
+    assert vt.fed_weights is not None and vt.fed_weights[0] == 3
+    assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
+    assert not torch.equal(vt.agents.theta, th0)
