@@ -142,7 +142,11 @@ def cpu_baseline_all_cores(seconds, pl_size, max_workers=None):
 
 # The workload whose throughput is `value` when no --mode is given; the other one is measured in the same run and
 # reported under `also_measured`. The same at every N, so that value(N) / value(1) is a scaling figure.
-PRIMARY_MODE = "nofrl"
+# interfrl = the north star's multi-GPU workload (federated platoons, one RCCL all-reduce of the actor/critic gradients per
+# step; BASELINE configs[3] per GPU, configs[1]'s 4096 x 5 shape), run with the f32-class split-operand set learner
+# (csrc/fsplit.hip, 1e-4 of max against the float64 oracle like the f32 kernels). nofrl = the reference's default
+# `fed_method` (one independent weight / Adam set per agent): HBM-bound at 2.47 MB per agent-update, the r01/r02 headline.
+PRIMARY_MODE = "interfrl"
 
 
 def spawn_ranks(args):
@@ -286,8 +290,9 @@ def run_workload(args, mode, engine, rank, world, group):
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: persistent head / dw / dx kernels, every GEMM operand "
-                                 "an exact bf16 hi+lo pair: 2-3 MFMAs per algorithmic product)" if split3 else
+        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x6, dw x2, dx x2, dxa persistent kernels + scale, prep, "
+                                 "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
+                                 "matrix work is ~2.6x the algorithmic FLOPs priced here)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
                                  "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)"), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
@@ -329,8 +334,9 @@ def run_workload(args, mode, engine, rank, world, group):
         "unit": "env-steps/s",
         "updates_per_s": updates_per_s,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "dtype": ("f32-class: every GEMM operand an exact bf16 hi+lo pair (bf16x3 split, 2^-17 per operand), f32 accumulation, "
-                  "parameters and optimiser" if split3 else
+        "dtype": ("f32-class: every matrix-product operand an exact 16-bit pair hi+lo (fp16 pairs, 2^-24, in the forward passes and "
+                  "every relu mask; bf16 pairs, 2^-18, times exact masks in the weight/input-gradient products), A_hi B_hi + A_lo B_hi + "
+                  "A_hi B_lo on the matrix cores, f32 accumulation, parameters, gradients and optimiser" if split3 else
                   "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32"),
         "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
                                + ("centralized " if args.framework == "centralized" else "")
@@ -397,7 +403,9 @@ def main():
     else:
         modes = [PRIMARY_MODE] + ([] if args.no_secondary or args.hidden or args.framework != "decentralized" else
                                   ["interfrl" if PRIMARY_MODE == "nofrl" else "nofrl"])
-    results = [run_workload(args, m, args.engine, rank, world, group) for m in modes]
+    # interfrl without --engine: the f32-class fused set learner where it exists (reference widths, decentralized)
+    engine = args.engine or ("fused3" if (not args.hidden and args.framework == "decentralized") else None)
+    results = [run_workload(args, m, engine, rank, world, group) for m in modes]
 
     if rank == 0:
         first = results[0]

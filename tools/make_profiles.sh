@@ -9,7 +9,7 @@ cd $R
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 AVD_LEARN_KERNEL=fast python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_default_learn_kernel_t.json 2>/dev/null
 python bench.py --no-fused --no-cpu-baseline > $OUT/${TAG}_bench_unfused.json 2>/dev/null
-python bench.py --mode interfrl --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
+python bench.py --mode interfrl --engine per_agent --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
 python bench.py --mode interfrl --engine batched --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_batched.json 2>/dev/null
 python bench.py --mode interfrl --engine fused --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_fused.json 2>/dev/null
 python tools/time_fset.py > $OUT/${TAG}_fset_vs_other_learners.txt 2>/dev/null
@@ -28,7 +28,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fused -o run -- $B > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_unfused -o run -- $B --no-fused > $OUT/${TAG}_bench_under_rocprof_unfused.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_interfrl_per_agent -o run -- $B --mode interfrl > $OUT/${TAG}_bench_under_rocprof_interfrl_per_agent.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_interfrl_per_agent -o run -- $B --mode interfrl --engine per_agent > $OUT/${TAG}_bench_under_rocprof_interfrl_per_agent.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_interfrl_fused -o run -- $B --mode interfrl --engine fused > $OUT/${TAG}_bench_under_rocprof_interfrl_fused.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fused_$c -o run -- $B --steps 3 > /dev/null 2>&1
