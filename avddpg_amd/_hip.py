@@ -59,6 +59,10 @@ _PROTOS = {
     "avd_policy_f32": [_i, _P, _P, _f, _f, _P, _P],
     "avd_normal_f32": [_i, _P, _f, _u64, _u64, _P],
     "avd_uniform_f32": [_i, _P, _f, _u64, _u64, _P],
+    "avd_step_fused_f32": [_P, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _f, _f, _f, _i, _u64, _u64,
+                           _u64, _P, _i, _i64, _P, _P],
+    "avd_replay_sample_f32": [_i, _i, _i, _i, _i, _P, _i, _u64, _u64, _P, _P, _P, _P, _P, _P],
+    "avd_actor_forward_set_f32": [_LP, _i, _i, _P, _P, _P, _i, _f, _P, _P, _P],
     "avd_replay_add_f32": [_i, _i, _i, _i, _P, _i64, _P, _P, _i, _P, _P, _P],
     "avd_replay_indices": [_i, _i, _i, _u64, _u64, _P, _P],
     "avd_replay_gather_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P],

@@ -167,6 +167,116 @@ __global__ __launch_bounds__(ENV_THREADS) void env_reset_kernel(const avd_env_co
     }
 }
 
+// ---- one launch per training step: OU noise -> policy clip -> leader exog -> platoon step -> replay add (+ reward sums) -----
+// workers/trainer.py:282-322 for every platoon at once (device-RNG mode, decentralized agents): what ou_step_kernel,
+// policy_kernel, normal_kernel / uniform_kernel, env_step_kernel, replay_add_kernel and the episodic-reward update do as
+// seven launches, with the same Philox draws (stream, call counter, index) and the same unfused float arithmetic -- the
+// results are bit-identical to the separate kernels (tests/test_gpu_trainer.py). Whole platoons sit inside ONE wavefront
+// (64 / L platoons per wave, the remaining lanes idle), so the predecessor chain is a lane shift and the per-platoon
+// any-terminal / reward reductions are wavefront operations (ballot, shuffles in vehicle order), not LDS loops.
+struct StepArgs {
+    const avd_env_consts* cst;
+    int P, L, S;
+    const float4* x_in;
+    float4* x_out;
+    float *prev_a, *cum_accel, *reward;
+    uint8_t *term, *done;
+    int32_t *any_done, *any_done_other;  // this step's flag (zero on entry); the other step parity's flag, zeroed here
+    const float* actor_out;              // [P*L] tanh(.) * high
+    float *ou_state, *action, *leader_exog;
+    float theta, mean, dt, scale, lo, hi, exog_scale;
+    int exog_uniform;
+    uint64_t seed, ou_counter, exog_counter;
+    float* ring;  // [P*L][cap][2S+2] or NULL (no replay add)
+    int cap, slot;
+    float* ep_reward;  // [P*L] += reward, or NULL
+};
+
+__global__ __launch_bounds__(ENV_THREADS) void step_fused_kernel(const StepArgs a) {
+#pragma clang fp contract(off)
+    __shared__ float sA[AVD_MAX_L][16], sB[AVD_MAX_L][4], sC[AVD_MAX_L][4];
+    const avd_env_consts* cst = a.cst;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, L = a.L;
+    for (int i = tid; i < L * 16; i += ENV_THREADS) sA[i >> 4][i & 15] = cst->A[i >> 4][i & 15];
+    for (int i = tid; i < L * 4; i += ENV_THREADS) sB[i >> 2][i & 3] = cst->B[i >> 2][i & 3], sC[i >> 2][i & 3] = cst->C[i >> 2][i & 3];
+    if (blockIdx.x == 0 && tid == 0 && a.any_done_other) *a.any_done_other = 0;
+    const int pw = 64 / L;                      // whole platoons per wave
+    const int lp = lane / L, i = lane - lp * L;  // platoon of the wave, vehicle
+    const int p = (blockIdx.x * (ENV_THREADS / 64) + wv) * pw + lp;
+    const bool active = (lp < pw) && (p < a.P);
+    const long v = (long)p * L + i;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pa = 0.f, uu = 0.f, exog_own = 0.f;
+    if (active) {
+        xv = a.x_in[v];
+        pa = a.prev_a[v];
+        // OUActionNoise.__call__ (src/noise.py:15-19) and policy (agent/ddpgagent.py:22-27)
+        const u32x4 rn = philox_at(a.seed, a.ou_counter, (uint32_t)v, STREAM_OU);
+        const float nrm = box_muller(rn.x, rn.y, nullptr);
+        const float st = a.ou_state[v];
+        const float noise = (st + (a.theta * (a.mean - st)) * a.dt) + a.scale * nrm;
+        a.ou_state[v] = noise;
+        uu = fminf(fmaxf(a.actor_out[v] + noise, a.lo), a.hi);
+        a.action[v] = uu;
+        if (i == 0) {  // leader exog, redrawn every step (workers/trainer.py:291-295; util.get_random_val)
+            const u32x4 re = philox_at(a.seed, a.exog_counter, (uint32_t)p, STREAM_NORMAL);
+            exog_own = (a.exog_uniform ? uniform_pm1(re.x) : box_muller(re.x, re.y, nullptr)) * a.exog_scale;
+            a.leader_exog[p] = exog_own;
+        }
+    }
+    __syncthreads();
+    const float* Ai = sA[i];
+    const float* Bi = sB[i];
+    const float* Ci = sC[i];
+    float ax[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ax[r] = ((Ai[r * 4 + 0] * xv.x + Ai[r * 4 + 1] * xv.y) + Ai[r * 4 + 2] * xv.z) + Ai[r * 4 + 3] * xv.w;
+    // what the follower behind needs: Model B the action, Model A the post-step accel -- one lane up
+    const float chain = cst->model_a ? (ax[2] + Bi[2] * uu) : uu;
+    const float from_pred = __shfl_up(chain, 1);
+    const float exog = (i == 0) ? exog_own : from_pred;
+    const float norm_ep = fabsf(xv.x) / cst->max_ep;
+    const float norm_ev = fabsf(xv.y) / cst->max_ev;
+    const float norm_u = fabsf(uu) / cst->abs_action_high;
+    const float n_jerk = fabsf(xv.z - pa) / cst->two_max_a;
+    const bool is_term = active && ((fabsf(xv.x) > cst->max_ep) || (fabsf(xv.y) > cst->max_ev)) && (cst->can_terminate != 0);
+    float rew = (((cst->ca * norm_ep + cst->cb * norm_ev) + cst->cc * norm_u) + cst->cd * n_jerk) * cst->re_scalar;
+    if (is_term) rew = cst->terminal_reward * cst->re_scalar;
+    const float negr = -rew;
+    const unsigned long long tmask = __ballot(is_term);
+    if (active) {
+        float4 xn;
+        xn.x = (ax[0] + Bi[0] * uu) + Ci[0] * exog;
+        xn.y = (ax[1] + Bi[1] * uu) + Ci[1] * exog;
+        xn.z = (ax[2] + Bi[2] * uu) + Ci[2] * exog;
+        xn.w = (ax[3] + Bi[3] * uu) + Ci[3] * exog;
+        a.x_out[v] = xn;
+        a.prev_a[v] = xv.z;
+        if (a.cum_accel) a.cum_accel[v] = a.cum_accel[v] + xv.z;
+        a.reward[v] = negr;
+        if (a.term) a.term[v] = is_term ? 1 : 0;
+        if (a.ep_reward) a.ep_reward[v] = a.ep_reward[v] + negr;  // float32 counters (workers/trainer.py:249, 321)
+        if (i == 0) a.done[p] = (uint8_t)(((tmask >> (lp * L)) & ((1ull << L) - 1ull)) != 0ull);
+        if (a.ring) {  // ReplayBuffer.add (src/replaybuffer.py:36-47): row [s a r s'] at slot counter % capacity
+            const int S = a.S, row = 2 * S + 2;
+            float* dst = a.ring + ((long)v * a.cap + a.slot) * row;
+            const float xo[4] = {xv.x, xv.y, xv.z, xv.w}, xw[4] = {xn.x, xn.y, xn.z, xn.w};
+            if (S == 4) {  // 40-byte rows, 8-byte aligned
+                ((float2*)dst)[0] = make_float2(xo[0], xo[1]);
+                ((float2*)dst)[1] = make_float2(xo[2], xo[3]);
+                ((float2*)dst)[2] = make_float2(uu, negr);
+                ((float2*)dst)[3] = make_float2(xw[0], xw[1]);
+                ((float2*)dst)[4] = make_float2(xw[2], xw[3]);
+            } else {
+                for (int k = 0; k < S; ++k) dst[k] = xo[k], dst[S + 2 + k] = xw[k];
+                dst[S] = uu, dst[S + 1] = negr;
+            }
+        }
+    }
+    // any-terminal flag (trainer.py:268): one plain store per workgroup at most, every writer stores the same value
+    if (a.any_done && __syncthreads_or(tmask != 0ull) && tid == 0) *a.any_done = 1;
+}
+
 __global__ void ou_step_kernel(int n, float* __restrict__ st, const float* __restrict__ normals, float theta,
                                float mean, float dt, float scale, uint64_t seed, uint64_t counter) {
 #pragma clang fp contract(off)
@@ -267,4 +377,28 @@ extern "C" int avd_uniform_f32(int n, float* out, float half_width, uint64_t see
     hipLaunchKernelGGL(uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, out, half_width, seed,
                        counter);
     return check_launch("avd_uniform_f32");
+}
+
+extern "C" int avd_step_fused_f32(const avd_env_consts* d_consts, int P, int L, int S, const float* x_in, float* x_out,
+                                  float* prev_a, float* cum_accel, float* reward, uint8_t* term, uint8_t* done,
+                                  int32_t* any_done, int32_t* any_done_other, const float* actor_out, float* ou_state,
+                                  float* action, float* leader_exog, float ou_theta, float ou_mean, float ou_dt, float ou_std_dev,
+                                  float action_low, float action_high, float exog_scale, int exog_uniform, uint64_t seed,
+                                  uint64_t ou_counter, uint64_t exog_counter, float* ring, int cap, int64_t replay_counter,
+                                  float* ep_reward, void* stream) {
+    AVD_REQUIRE(P > 0 && L > 0 && L <= AVD_MAX_L && (S == 3 || S == 4), "avd_step_fused_f32: P=%d L=%d S=%d", P, L, S);
+    AVD_REQUIRE(d_consts && x_in && x_out && prev_a && reward && done && actor_out && ou_state && action && leader_exog,
+                "avd_step_fused_f32: null pointer");
+    AVD_REQUIRE(!ring || (cap > 0 && replay_counter >= 0), "avd_step_fused_f32: cap=%d counter=%ld", cap, (long)replay_counter);
+    StepArgs a;
+    a.cst = d_consts, a.P = P, a.L = L, a.S = S, a.x_in = (const float4*)x_in, a.x_out = (float4*)x_out, a.prev_a = prev_a;
+    a.cum_accel = cum_accel, a.reward = reward, a.term = term, a.done = done, a.any_done = any_done, a.any_done_other = any_done_other;
+    a.actor_out = actor_out, a.ou_state = ou_state, a.action = action, a.leader_exog = leader_exog;
+    a.theta = ou_theta, a.mean = ou_mean, a.dt = ou_dt, a.scale = ou_std_dev * (float)sqrt((double)ou_dt);  // as avd_ou_step_f32
+    a.lo = action_low, a.hi = action_high, a.exog_scale = exog_scale, a.exog_uniform = exog_uniform;
+    a.seed = seed, a.ou_counter = ou_counter, a.exog_counter = exog_counter;
+    a.ring = ring, a.cap = cap, a.slot = ring ? (int)(replay_counter % cap) : 0, a.ep_reward = ep_reward;
+    const int per_block = (ENV_THREADS / 64) * (64 / L);
+    hipLaunchKernelGGL(step_fused_kernel, dim3((P + per_block - 1) / per_block), dim3(ENV_THREADS), 0, (hipStream_t)stream, a);
+    return check_launch("avd_step_fused_f32");
 }

@@ -62,9 +62,69 @@ __global__ void replay_gather_kernel(int n_agents, int cap, int S, int A, int B,
         s2[ab * S + (j - S - A - 1)] = val;
 }
 
+// ReplayBuffer.sample (src/replaybuffer.py:49-63) in one launch: a thread draws FOUR batch indices of an agent with one Philox
+// call -- the draws of replay_indices_kernel, bit for bit -- and moves their rows whole (8-byte pieces of the 40-byte rows,
+// 16-byte pieces out), instead of one thread per float behind a separate index kernel.
+template <int S>
+__global__ __launch_bounds__(256) void replay_sample_kernel(int n_agents, int cap, int B, const float* __restrict__ ring,
+                                                            uint32_t range, uint64_t seed, uint64_t counter,
+                                                            int32_t* __restrict__ idx, float* __restrict__ s,
+                                                            float* __restrict__ a, float* __restrict__ r,
+                                                            float* __restrict__ s2) {
+    constexpr int row = 2 * S + 2;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_agents * B, base = t * 4;
+    if (base >= total) return;
+    const u32x4 rr = philox_at(seed, counter, (uint32_t)t, STREAM_REPLAY);
+    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+    const int ag = (int)(base / B);  // B is a multiple of 4: the four rows belong to one agent
+    int ix[4];
+    float v[4][row];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ix[k] = (int32_t)(((uint64_t)w[k] * range) >> 32);
+        const float2* src = (const float2*)(ring + ((long)ag * cap + ix[k]) * row);
+#pragma unroll
+        for (int j = 0; j < row / 2; ++j) {
+            const float2 q = src[j];
+            v[k][2 * j] = q.x, v[k][2 * j + 1] = q.y;
+        }
+    }
+    *(int4*)(idx + base) = make_int4(ix[0], ix[1], ix[2], ix[3]);
+    *(float4*)(a + base) = make_float4(v[0][S], v[1][S], v[2][S], v[3][S]);
+    *(float4*)(r + base) = make_float4(v[0][S + 1], v[1][S + 1], v[2][S + 1], v[3][S + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (S == 4) {
+            *(float4*)(s + (base + k) * 4) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+            *(float4*)(s2 + (base + k) * 4) = make_float4(v[k][6], v[k][7], v[k][8], v[k][9]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < S; ++j) s[(base + k) * S + j] = v[k][j], s2[(base + k) * S + j] = v[k][S + 2 + j];
+        }
+    }
+}
+
 }  // namespace avd
 
 using namespace avd;
+
+extern "C" int avd_replay_sample_f32(int n_agents, int cap, int S, int A, int B, const float* ring, int range, uint64_t seed,
+                                     uint64_t counter, int32_t* idx, float* s, float* a, float* r, float* s2, void* stream) {
+    AVD_REQUIRE(n_agents > 0 && cap > 0 && (S == 3 || S == 4) && A == 1 && B > 0 && B % 4 == 0 && range > 0 && range <= cap,
+                "avd_replay_sample_f32: n=%d cap=%d S=%d A=%d B=%d range=%d (S in {3, 4}, A = 1, B a multiple of 4)", n_agents, cap, S,
+                A, B, range);
+    AVD_REQUIRE(ring && idx && s && a && r && s2, "avd_replay_sample_f32: null pointer");
+    const long calls = (long)n_agents * B / 4;
+    const dim3 grid((unsigned)((calls + 255) / 256));
+    if (S == 4)
+        hipLaunchKernelGGL(replay_sample_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, n_agents, cap, B, ring, (uint32_t)range,
+                           seed, counter, idx, s, a, r, s2);
+    else
+        hipLaunchKernelGGL(replay_sample_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, n_agents, cap, B, ring, (uint32_t)range,
+                           seed, counter, idx, s, a, r, s2);
+    return check_launch("avd_replay_sample_f32");
+}
 
 extern "C" int avd_replay_add_f32(int n_agents, int cap, int S, int A, float* ring, int64_t counter,
                                   const float* s_prev, const float* s_next, int x_stride, const float* action,

@@ -64,7 +64,7 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
-                 pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None):
+                 pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None, fused_step=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'.
@@ -147,6 +147,20 @@ class VecTrainer:
             raise ValueError("auto_reset (device-side episode bookkeeping) cannot be combined with a federated method and "
                              "weighted_average_enabled: the weights need the per-episode reward lists; run the episode "
                              "loop (VecTrainer.run) or set weighted_average_enabled=False")
+        # fused_step: OU noise, policy clip, leader exog, platoon step, replay add and the reward counters in ONE launch
+        # (avd_step_fused_f32; bit-identical to the separate kernels). Device-RNG mode, decentralized agents. Default: on
+        # where it applies.
+        can_fuse_step = rng == "device" and not self.centralized and self.A == 1 and self.S in (3, 4)
+        self.fused_step = can_fuse_step if fused_step is None else bool(fused_step)
+        if self.fused_step and not can_fuse_step:
+            raise ValueError("fused_step needs rng='device' and the decentralized framework")
+        # shared sets at the reference widths with a set learner: act on the f32 matrix cores (csrc/act.hip) instead of the
+        # batch-1 rows kernel (same values up to the f32 summation order; the rows kernel stays wherever bit-equality with
+        # the per-agent weight-set regime is asserted, i.e. the per_agent engine)
+        self.act_mfma = (self.shared and self.shared_engine in ("fused", "fused3")
+                         and (lay.H1, lay.H2, lay.A) == (256, 128, 1) and lay.S in (3, 4))
+        self._step_parity = 0
+        self._added = False
         self.fused_update = bool(fused_update)  # nofrl (any framework / widths the learn kernels serve): avd_learn_update_f32
         # fused_update also has the learn kernel evaluate the UPDATED actor on the state the next step acts from
         # (workers/trainer.py:287-289): self.actor_out then already holds the next step's actor outputs unless the states
@@ -192,8 +206,13 @@ class VecTrainer:
             # terminal resets ALL platoons, :268-269 -- the flag of the previous step is still set at this point)
             self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out,
                               run_if_nonzero=self.env.any_done)
+        elif self.act_mfma:
+            self.agents.actor_set(states, P * M, x_stride=self.x_stride, out=self.actor_out.view(-1))
         else:
             self.agents.actor(states, self.set_mod, x_stride=self.x_stride, out=self.actor_out)
+        if self.fused_step:
+            self._step_fused()
+            return
         if self.rng == "host":
             # reference draw order per platoon: M OU normals, then the leader exog (trainer.py:286-295)
             normals = np.empty((P, M))
@@ -218,6 +237,26 @@ class VecTrainer:
         self.env.any_done.zero_()
         self.env.step(self.actions.view(P, self.L), self.leader_exog)
 
+    def _step_fused(self):
+        """advance_environment (workers/trainer.py:282-302) + the replay add and reward counters of train_all_models
+        (:314-321) in one launch; the host only keeps the call counters in step with the separate-kernel path."""
+        conf, env, ou, rp = self.conf, self.env, self.ou, self.replay
+        k = self._step_parity
+        self._step_parity ^= 1
+        env.any_done = env._any_flags[k:k + 1]  # this step's flag (cleared by the previous step's launch, zero at start)
+        other = env._any_flags[1 - k:2 - k]
+        env.x, env.x_prev = env.x_prev, env.x
+        call("avd_step_fused_f32", ptr(env.d_consts), self.P, self.L, self.S, ptr(env.x_prev), ptr(env.x), ptr(env.prev_a),
+             ptr(env.cum_accel), ptr(env.reward), ptr(env.term), ptr(env.done), ptr(env.any_done), ptr(other),
+             ptr(self.actor_out), ptr(ou.state), ptr(self.actions), ptr(self.leader_exog), conf.theta, 0.0, conf.ou_dt,
+             conf.std_dev, conf.action_low, conf.action_high, conf.reset_max_u, 1 if conf.rand_gen == conf.uniform else 0,
+             self.seed, ou.calls, self.exog_calls, ptr(rp.ring), rp.cap, rp.buffer_counter, ptr(self.ep_reward), stream_handle())
+        ou.calls += 1
+        self.exog_calls += 1
+        env.step_count += 1
+        rp.buffer_counter += 1
+        self._added = True
+
     def _weights_for_fed(self, ep):
         """trainer.py:385-398: w = |1 / mean(last `weighted_window` episodic rewards)| per agent."""
         w = np.empty((self.P, self.M), dtype=np.float32)
@@ -241,9 +280,12 @@ class VecTrainer:
             # centralized: the platoon reward (1/L) * sum of the vehicles' (environment.py:236, 281)
             reward = env.reward_mean.view(P, 1) if self.centralized else env.reward
             xs = self.x_stride
-            self.replay.add(env.x_prev.view(P * M, xs), self.actions.view(P * M, self.A), reward.view(-1),
-                            env.x.view(P * M, xs), xs)
-            self.ep_reward += reward
+            if self._added:  # the fused step launch has already written the row and the reward counters
+                self._added = False
+            else:
+                self.replay.add(env.x_prev.view(P * M, xs), self.actions.view(P * M, self.A), reward.view(-1),
+                                env.x.view(P * M, xs), xs)
+                self.ep_reward += reward
             if not self.replay.buffer_counter > conf.batch_size:  # strict gate: first update after the 65th add (:322)
                 return None
             return self.replay.sample()

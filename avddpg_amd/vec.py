@@ -60,7 +60,10 @@ class VecPlatoon:
         self.reward_mean = torch.zeros(P, **f32) if centralized else None
         self.term = torch.zeros(P, L, dtype=torch.uint8, device=self.device)
         self.done = torch.zeros(P, dtype=torch.uint8, device=self.device)
-        self.any_done = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # two any-terminal flag words used alternately by the fused step (avd_step_fused_f32 clears the other one); the
+        # separate-kernel path keeps using word 0 and clears it with a fill
+        self._any_flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.any_done = self._any_flags[0:1]
         self.reset_count = 0
         self.step_count = 0
         if rng == "host":
@@ -223,6 +226,13 @@ class VecReplay:
         return self.s, self.a, self.r, self.s2
 
     def sample(self, host_idx=None):
+        """ReplayBuffer.sample (src/replaybuffer.py:49-63). Device-RNG mode: index draw + row gather in ONE launch
+        (avd_replay_sample_f32: the same Philox draws as draw_indices(), bit for bit, rows moved whole)."""
+        if self.rng != "host" and host_idx is None and self.A == 1 and self.S in (3, 4) and self.B % 4 == 0:
+            call("avd_replay_sample_f32", self.n, self.cap, self.S, self.A, self.B, ptr(self.ring), self.sample_range(), self.seed,
+                 self.samples, ptr(self.idx), ptr(self.s), ptr(self.a), ptr(self.r), ptr(self.s2), stream_handle())
+            self.samples += 1
+            return self.s, self.a, self.r, self.s2
         self.draw_indices(host_idx)
         return self.gather()
 
@@ -277,6 +287,16 @@ class AgentGroup:
         else:
             call("avd_actor_forward_f32", self._layp, n_agents, set_mod, ptr(th), ptr(st), ptr(states), x_stride,
                  self.high, ptr(out), stream_handle())
+        return out
+
+    def actor_set(self, states, n_agents, x_stride=None, out=None, run_if_nonzero=None):
+        """actor(state) for n_agents agents that SHARE this group's weight sets (agent v uses set v % n_sets) on the f32
+        matrix cores (csrc/act.hip; reference widths). states [n_agents, x_stride] -> [n_agents]; same values as
+        actor(states, set_mod=n_sets) up to the f32 summation order."""
+        x_stride = states.shape[-1] if x_stride is None else x_stride
+        out = torch.empty(n_agents, dtype=torch.float32, device=self.device) if out is None else out
+        call("avd_actor_forward_set_f32", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(states), x_stride,
+             self.high, ptr(out), ptr(run_if_nonzero), stream_handle())
         return out
 
     def critic(self, states, actions, set_mod, x_stride=None, out=None, target=False):

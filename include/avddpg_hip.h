@@ -235,6 +235,36 @@ int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float*
 int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n, const float* src,
                         float* dst, void* stream);
 
+/* ---- one launch per training step (device-RNG mode, decentralized agents) ----------------------------------------
+ * advance_environment + the replay add of train_all_models (workers/trainer.py:282-322) for all P platoons:
+ *   noise  = OUActionNoise.__call__()                       src/noise.py:15-19        (= avd_ou_step_f32, Philox stream OU)
+ *   action = clip(actor_out + noise, low, high)             agent/ddpgagent.py:22-27  (= avd_policy_f32)
+ *   exog   = get_random_val(rand_gen, reset_max_u)          workers/trainer.py:291-295 (= avd_normal_f32 / avd_uniform_f32)
+ *   states, rewards, terminal = Platoon.step(action, exog)  src/environment.py:209-241 (= avd_env_step_f32)
+ *   ReplayBuffer.add((prev_state, action, reward, state))   src/replaybuffer.py:36-47  (= avd_replay_add_f32; ring may be NULL)
+ *   episodic reward counters += reward                      workers/trainer.py:321     (ep_reward may be NULL)
+ * Same draws (seed, call counters, indices) and the same unfused float32 arithmetic as the separate entry points: results are
+ * bit-identical to calling them one after the other. any_done: this step's any-terminal flag (must be 0 on entry);
+ * any_done_other (optional): a second flag word that is set to 0 (two flags used alternately need no clearing launch). */
+int avd_step_fused_f32(const avd_env_consts* d_consts, int P, int L, int S, const float* x_in, float* x_out, float* prev_a,
+                       float* cum_accel, float* reward, uint8_t* term, uint8_t* done, int32_t* any_done, int32_t* any_done_other,
+                       const float* actor_out, float* ou_state, float* action, float* leader_exog, float ou_theta, float ou_mean,
+                       float ou_dt, float ou_std_dev, float action_low, float action_high, float exog_scale, int exog_uniform,
+                       uint64_t seed, uint64_t ou_counter, uint64_t exog_counter, float* ring, int cap, int64_t replay_counter,
+                       float* ep_reward, void* stream);
+
+/* ReplayBuffer.sample (src/replaybuffer.py:49-63) in one launch: avd_replay_indices (same Philox draws, bit for bit) + 
+ * avd_replay_gather_f32, rows moved whole. range = min(buffer_counter, capacity). S in {3, 4}, A = 1, B a multiple of 4. */
+int avd_replay_sample_f32(int n_agents, int cap, int S, int A, int B, const float* ring, int range, uint64_t seed, uint64_t counter,
+                          int32_t* idx, float* s, float* a, float* r, float* s2, void* stream);
+
+/* actor(state) for agents that SHARE n_sets weight sets (agent v uses set v % n_sets), reference widths, on the f32 matrix
+ * cores (csrc/act.hip: v_mfma_f32_32x32x2_f32, exact f32 products -- agent/model.py:26-36 in the reference's arithmetic
+ * class). Same values as avd_actor_forward_f32 with set_mod = n_sets up to the f32 summation order (1e-7 relative).
+ * run_if_nonzero (optional): device flag; the launch does nothing when it reads 0. */
+int avd_actor_forward_set_f32(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                              const float* states, int x_stride, float high, float* out, const int32_t* run_if_nonzero, void* stream);
+
 /* ---- shared-weight-set learner (interfrl with every step federated; BASELINE config 5) -----------------
  * When the P platoons' vehicle-m agents share one weight set (workers/trainer.py:121-128, 400-431: identical initial
  * weights + identical averaged gradients every step), Trainer.learn (:472-508) followed by the federated mean

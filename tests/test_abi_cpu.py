@@ -156,3 +156,16 @@ def test_shared_learner_argument_validation_without_gpu():
     assert 20 * 2**30 < need.value < 40 * 2**30  # BASELINE config 5: ~26 GiB of scratch, fits 288 GB beside the replay ring
     with pytest.raises(_hip.AvdError, match="K %"):
         _hip.call("avd_gemm_bt_bf16", 128, 128, 100, None, 100, None, 100, None, 128, None)
+
+
+def test_federated_server_keeps_the_reference_class_api():
+    """src/server/federated.py:13-16, 18, 69: Server(name, debug_enabled), get_avg_params(system_params),
+    get_weighted_avg_params(system_params, weight_sums). No compute here (no GPU): signatures only."""
+    import inspect
+
+    from avddpg_amd import federated
+
+    assert list(inspect.signature(federated.Server.__init__).parameters)[:3] == ["self", "name", "debug_enabled"]
+    assert list(inspect.signature(federated.Server.get_avg_params).parameters) == ["self", "system_params"]
+    assert list(inspect.signature(federated.Server.get_weighted_avg_params).parameters) == ["self", "system_params", "weight_sums"]
+    assert "oracle" not in open(federated.__file__).read().split('"""', 2)[2]

@@ -164,7 +164,8 @@ def test_full_size_split_learner_against_the_f32_engine_and_the_mean_of_its_halv
 
 def test_trainer_split_engine_tracks_per_agent_engine_under_interfrl():
     """VecTrainer with shared weight sets: the split learner against the exact f32 per-agent kernel + fed_sum on the same
-    host RNG stream (parity mode). Identical before the first update; afterwards the gradients differ at the 1e-5 level and
+    host RNG stream (parity mode). Before the first update the two differ only by the acting kernel (f32 matrix cores for the
+    set learners, csrc/act.hip, vs the rows kernel: f32 summation order, 2e-6); afterwards the gradients differ at the 1e-5 level and
     Adam normalises every step to |dw| <= lr, so what remains is bounded by the f32 kernels' own run-to-run class: actions
     within 2e-4 of the action range (the bf16 engine needs 5e-3 here, tests/test_gpu_fset.py)."""
     from avddpg_amd import trainer
@@ -185,7 +186,7 @@ def test_trainer_split_engine_tracks_per_agent_engine_under_interfrl():
     (a, ta), (b, tb) = runs
     assert b.grads is None and b.shared_engine == "fused3" and a.updates == b.updates == (steps - 64) * P * L
     for i in range(steps):
-        tol = 0.0 if i < 65 else 2e-4
+        tol = 2e-6 if i < 65 else 2e-4
         assert np.abs(ta[i][0] - tb[i][0]).max() <= tol * 2.5, i
         assert np.abs(ta[i][1] - tb[i][1]).max() <= tol * max(1.0, np.abs(ta[i][1]).max()), i
     n_upd = steps - 64

@@ -433,3 +433,84 @@ def test_shared_set_actor_rows_are_bitwise_the_batch1_kernel(S, P, M):
     flag.fill_(1)
     shared.actor(x, set_mod=M, x_stride=4, out=keep, run_if_nonzero=flag)
     assert torch.equal(keep, ref)
+
+
+def test_federated_server_facade_matches_reference_table_and_oracle(golden_dir):
+    """avddpg_amd.federated.Server keeps src/server/federated.py's class API (Server(name, debug).get_avg_params /
+    .get_weighted_avg_params on lists of systems of members of per-layer arrays) over avd_fed_sum / avd_fed_finalize:
+    the reference's own table (src/server/test_federated.py:26-42, golden G7) and the oracle's restatement on
+    network-shaped gradient lists (24 layers of different shapes)."""
+    import json
+    import os
+
+    from avddpg_amd import federated
+
+    need_gpu()
+    server = federated.Server("fed", False)
+    tab = json.load(open(os.path.join(golden_dir, "g7_federated.json")))
+    pl, w = tab["grads_list"], tab["weights"]
+    P, M = 2, 2
+    sysu = [[[np.array(pl[p][m][i], dtype=np.float32) for i in range(3)] for p in range(P)] for m in range(M)]
+    got = server.get_avg_params(sysu)
+    assert len(got) == M and all(len(g) == 3 for g in got)
+    for m in range(M):
+        for i in range(3):
+            assert got[m][i].dtype == np.float32 and got[m][i].shape == np.shape(pl[0][m][i])
+            assert np.allclose(got[m][i], tab["interfrl_unweighted"][m][i], rtol=1e-6)
+    sysw = [[[np.float32(w[p][m]) * sysu[m][p][i] for i in range(3)] for p in range(P)] for m in range(M)]
+    ws = [sum(w[p][m] for p in range(P)) for m in range(M)]
+    gotw = server.get_weighted_avg_params(sysw, ws)
+    for m in range(M):
+        for i in range(3):
+            assert np.allclose(gotw[m][i], tab["interfrl_weighted"][m][i], rtol=1e-6)
+    # network-shaped lists: 5 platoons x 3 vehicles of critic gradients (14 tensors) from the learn kernel
+    conf, grp = _perturbed_group(3, S=4, seed=121)
+    rs = np.random.RandomState(122)
+    Pn, Mn = 5, 3
+    n = Pn * Mn
+    s = rs.normal(0, 1.5, size=(n, 64, 4)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n, 64, 1)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n, 64))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n, 64, 4)).astype(np.float32)
+    g = grp.learn(t(s), t(a), t(r), t(s2), Mn)
+    lists = [[grp.grads_as_lists(g[p * Mn + m])[0] for p in range(Pn)] for m in range(Mn)]  # [vehicle][platoon][layer]
+    got = server.get_avg_params(lists)
+    ref = ofed.get_avg_params(lists)
+    slab = vec.fed_mean(g, Pn, Mn)  # the slab path VecTrainer uses
+    for m in range(Mn):
+        for x, y, z in zip(got[m], ref[m], grp.grads_as_lists(slab[m])[0]):
+            assert x.shape == y.shape and np.allclose(x, y, rtol=1e-5, atol=1e-9) and np.array_equal(x, z)
+    wts = rs.uniform(0.5, 6.0, size=(Mn, Pn)).astype(np.float32)
+    listw = [[[wts[m, p] * layer for layer in lists[m][p]] for p in range(Pn)] for m in range(Mn)]
+    sums = [float(wts[m].sum()) for m in range(Mn)]
+    gotw, refw = server.get_weighted_avg_params(listw, sums), ofed.get_weighted_avg_params(listw, sums)
+    for m in range(Mn):
+        for x, y in zip(gotw[m], refw[m]):
+            assert np.allclose(x, y, rtol=1e-5, atol=1e-9)
+    with pytest.raises(ValueError, match="members"):
+        server.get_avg_params([lists[0], lists[1][:3]])
+
+
+@pytest.mark.parametrize("S,P,M", [(4, 100, 5), (3, 33, 2), (4, 4096, 5)])
+def test_actor_on_the_f32_matrix_cores_for_shared_sets_matches_rows_kernel_and_oracle(S, P, M):
+    """avd_actor_forward_set_f32 (csrc/act.hip: v_mfma_f32_32x32x2_f32, exact f32 products) vs the batch-1 rows kernel with
+    shared sets (same f32 values up to the summation order: 2e-6 of the action range) and vs the float64 oracle (FWD_TOL),
+    P not a multiple of the 32-row tile, and the conditional-launch flag."""
+    need_gpu()
+    conf, grp = _perturbed_group(M, S=S, seed=131)
+    rs = np.random.RandomState(132)
+    x = rs.normal(0, 1.5, size=(P * M, 4)).astype(np.float32)  # env layout: 4 floats per agent, first S are the observation
+    ref = grp.actor(t(x), set_mod=M, x_stride=4).cpu().numpy()
+    got = grp.actor_set(t(x), P * M, x_stride=4)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * 2.5 and np.abs(ref).max() > 0.05
+    for v in (0, P * M // 2 + 1, P * M - 1):
+        aw = [w.astype(np.float64) for w in grp.get_weights(v % M, "actor")]
+        want = omlp.actor_forward(aw, x[v:v + 1, :S].astype(np.float64), 2.5)[0]
+        assert abs(float(got[v]) - float(np.ravel(want)[0])) <= FWD_TOL * 2.5
+    keep = torch.full((P * M,), 7.0, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    grp.actor_set(t(x), P * M, x_stride=4, out=keep, run_if_nonzero=flag)
+    assert torch.all(keep == 7.0)
+    flag.fill_(1)
+    grp.actor_set(t(x), P * M, x_stride=4, out=keep, run_if_nonzero=flag)
+    assert torch.equal(keep, got)

@@ -535,3 +535,122 @@ def test_fused_update_next_action_epilogue_survives_episode_resets():
     # b.actor_out already holds the NEXT step's actor outputs (unless that step must recompute them after a reset)
     nxt = a.agents.actor(a.env.x.view(-1, a.x_stride), 0, x_stride=a.x_stride)
     assert bool(b.env.done.any()) or torch.equal(b.actor_out.view(-1), nxt)
+
+
+FRL_VARIANTS = {
+    # SURVEY 8 f-2, each against the oracle loop (oracle/trainer.py) on the same host RNG stream
+    "interfrl_weighted_gradients": dict(fed_method="interfrl", weighted_average_enabled=True, weighted_window=2),
+    "interfrl_weights_delay2": dict(fed_method="interfrl", weighted_average_enabled=False, aggregation_method="weights",
+                                    fed_update_delay=0.2),
+    "intrafrl_directional_gradients": dict(fed_method="intrafrl", weighted_average_enabled=False, intra_directional_averaging=True),
+    "intrafrl_weighted_weights_delay3": dict(fed_method="intrafrl", weighted_average_enabled=True, weighted_window=2,
+                                             aggregation_method="weights", fed_update_delay=0.3),
+    "interfrl_update_count2_cutoff": dict(fed_method="interfrl", weighted_average_enabled=False, fed_update_count=2,
+                                          fed_update_delay=0.2),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(FRL_VARIANTS))
+def test_frl_variants_match_the_oracle_loop(variant):
+    """Weighted FRL (workers/trainer.py:385-398: |1 / mean(last `window` episodic rewards)|, from episode >= window), weights
+    aggregation (:433-456: group [0]'s average into every model and target), intrafrl + directional (:417-418), delays and
+    update counts with the local-update-gate quirk (:345 vs :680): VecTrainer's episode loop against the oracle's
+    per-object loop, four 45-step episodes (updates from episode 1 on), identical consumption of the global RNG stream."""
+    kw = FRL_VARIANTS[variant]
+    P, L, episodes = 2, 2, 4
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=256, episode_sim_time=4.5, **kw)
+    T = conf.steps_per_episode
+    assert T == 45
+    np.random.seed(4)
+    vt0 = trainer.VecTrainer(conf, rng="host", shared_sets=False)  # only to obtain identical initial weights
+    ref = otrainer.RefTrainer(oplatoon.EnvParams(), P, L, seed=4, buffer_size=256, fed_method=conf.fed_method,
+                              aggregation_method=conf.aggregation_method, weighted_average_enabled=conf.weighted_average_enabled,
+                              weighted_window=conf.weighted_window, fed_update_count=conf.fed_update_count,
+                              fed_cutoff_episode=conf.fed_cutoff_episode, fed_update_delay_steps=conf.fed_update_delay_steps,
+                              intra_directional_averaging=conf.intra_directional_averaging, steps_per_episode=T)
+    _copy_weights_to_oracle(vt0, ref)
+    traj = []
+    for ep in range(episodes):
+        ref.reset_episode()
+        for i in range(T):
+            done = ref.step(ep, i)
+            traj.append((ep, i, ref.actions.copy(), np.array([[np.asarray(s) for s in ref.prev_states[p]] for p in range(P)]), done))
+            if done:
+                break
+        ref.update_reward_list()
+    next_draw_ref = np.random.normal(0, 1)
+    np.random.seed(4)
+    vt = trainer.VecTrainer(conf, rng="host", shared_sets=False)
+    k = 0
+    for ep in range(episodes):
+        vt.episode = ep
+        vt.reset_episode()
+        for i in range(T):
+            done = vt.step(ep, i)
+            e_, i_, act, x, d_ = traj[k]
+            k += 1
+            assert (e_, i_, d_) == (ep, i, done)
+            tol = 1e-5 if vt.updates == 0 or (ep == 1 and i <= 19) else 5e-3
+            assert np.abs(vt.actions.cpu().numpy() - act).max() <= tol * 2.5, (ep, i, np.abs(vt.actions.cpu().numpy() - act).max())
+            got = vt.env.x.cpu().numpy()
+            assert np.all(np.abs(got - x) <= tol * np.maximum(1.0, np.abs(x))), (ep, i)
+            if done:
+                break
+        vt.update_reward_list(ep)
+    assert k == len(traj) and np.random.normal(0, 1) == next_draw_ref
+    assert vt.updates == ref.updates
+    # Adam step counters: who was updated how often (directional: leaders never; update_count 2: odd episodes stand still)
+    steps = vt.agents.step.view(P, L).cpu().numpy()
+    for p in range(P):
+        for m in range(L):
+            assert steps[p, m] == ref.a_opts[p][m].t == ref.c_opts[p][m].t, (p, m, steps[p, m], ref.a_opts[p][m].t)
+    n_upd = max(1, int(steps.max()))
+    for p in range(P):
+        for m in range(L):
+            for which, refw, lr in (("actor", ref.actors[p][m], conf.actor_lr), ("critic", ref.critics[p][m], conf.critic_lr)):
+                for got, want in zip(vt.agents.get_weights(p * L + m, which), refw):
+                    d = np.abs(got - want)
+                    assert d.max() <= 2 * lr * n_upd + 1e-6 and d.mean() <= 0.05 * lr * n_upd + 1e-7, (variant, which, d.max(), d.mean())
+    if conf.weighted_average_enabled:
+        assert vt.fed_weights is not None and vt.fed_weights[0] == episodes - 1
+        w = vt.fed_weights[1].cpu().numpy()  # [P, M]
+        want = np.array(ref.fed_weights).T if conf.fed_method == "interfrl" else np.array(ref.fed_weights)
+        assert np.allclose(w, want, rtol=1e-3)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(model="ModelA", pl_size=3), dict(rand_gen="uniform", pl_size=7, num_platoons=70),
+                                dict(fed_method="interfrl", weighted_average_enabled=False)])
+def test_fused_step_launch_is_bitwise_the_seven_separate_kernels(kw):
+    """avd_step_fused_f32 (OU noise, policy clip, leader exog, platoon step, replay add, reward counters in one launch, platoons
+    inside one wavefront, shuffle / ballot reductions) against ou_step + policy + normal/uniform + env_step + replay_add
+    + the reward update as separate launches: same Philox draws, same unfused arithmetic -> identical bits in every state
+    tensor, through episode ends (20-step episodes; any-terminal resets) and the first updates. Also covers
+    avd_replay_sample_f32 against indices + gather (the fused path samples with it, the other path is forced onto the two
+    kernels)."""
+    base = dict(num_platoons=130, pl_size=5, buffer_size=96, episode_sim_time=2.0)
+    base.update(kw)
+    runs = []
+    for fused in (True, False):
+        conf = config.Config(**base)
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=9, fused_step=fused,
+                                fused_update=(conf.fed_method == "normal"))
+        assert vt.fused_step == fused
+        if not fused:  # the unfused reference path: index kernel + gather kernel
+            rp = vt.replay
+            rp.sample = lambda host_idx=None, rp=rp: (rp.draw_indices(host_idx), rp.gather())[1]
+        vt.reset_episode()
+        for _ in range(75):
+            vt.step()
+        torch.cuda.synchronize()
+        runs.append(vt)
+    a, b = runs
+    assert a.replay.buffer_counter == b.replay.buffer_counter == 75 and a.ou.calls == b.ou.calls and a.exog_calls == b.exog_calls
+    for name in ("x", "x_prev", "prev_a", "reward", "term", "done"):
+        assert torch.equal(getattr(a.env, name), getattr(b.env, name)), name
+    assert torch.equal(a.actions, b.actions) and torch.equal(a.leader_exog, b.leader_exog) and torch.equal(a.ou.state, b.ou.state)
+    assert torch.equal(a.replay.ring, b.replay.ring) and torch.equal(a.ep_reward, b.ep_reward)
+    assert torch.equal(a.replay.idx, b.replay.idx) and torch.equal(a.replay.s, b.replay.s) and torch.equal(a.replay.s2, b.replay.s2)
+    assert torch.equal(a.replay.a, b.replay.a) and torch.equal(a.replay.r, b.replay.r)
+    assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
+    assert a.episode == b.episode >= 3 and int(a.env.any_done.item()) == int(b.env.any_done.item())
+    assert a.updates == (75 - 64) * a.n_agents
