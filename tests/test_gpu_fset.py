@@ -184,7 +184,7 @@ def test_trainer_fused_engine_tracks_per_agent_engine_under_interfrl():
     (a, ta), (b, tb) = runs
     assert b.grads is None and b.shared_engine == "fused" and a.updates == b.updates == (steps - 64) * P * L
     for i in range(steps):
-        tol = 0.0 if i < 65 else 5e-3
+        tol = 2e-6 if i < 65 else 5e-3  # (before the first update only the acting kernels differ: csrc/act.hip vs the rows kernel)
         assert np.abs(ta[i][0] - tb[i][0]).max() <= tol * 2.5, i
         assert np.abs(ta[i][1] - tb[i][1]).max() <= tol * max(1.0, np.abs(ta[i][1]).max()), i
     n_upd = steps - 64
