@@ -428,6 +428,19 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
         };
         split16(mfmah(wf1[0], xs, zero16));
         f16x8 wfn = wf1[64];
+        // Weight fragments are read ONE GROUP AHEAD (group = k-step x pair of column tiles: hi and lo of two tiles, 16
+        // registers, six MFMAs): a ds_read_b128 issued right in front of the MFMA that consumes it exposes the LDS latency
+        // four times per feature tile (measured: s_waitcnt lgkmcnt behind every read burst). wg[parity][2 t][hi, lo].
+        f16x8 wg[2][2][2];
+        auto read_group = [&](int g, f16x8 (&dst)[2][2]) {  // g = 2 ks + th
+            const int ks = g >> 1, th = g & 1;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                dst[tt][0] = *(const f16x8*)(whi0 + 32 * (2 * th + tt) * LD + 16 * ks);
+                dst[tt][1] = *(const f16x8*)(wlo0 + 32 * (2 * th + tt) * LD + 16 * ks);
+            }
+        };
+        read_group(0, wg[0]);
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
             f32x16 p1n = zero16;
@@ -459,20 +472,37 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
                     mhi = fragh(mh[0], mh[1], mh[2], mh[3]), mlo = fragh(ml[0], ml[1], ml[2], ml[3]);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f16x8 whi = *(const f16x8*)(whi0 + 32 * t * LD + 16 * ks);
-                    const f16x8 wlo = *(const f16x8*)(wlo0 + 32 * t * LD + 16 * ks);
-                    acc[t] = mfmah(whi, bhi, acc[t]);
-                    acc[t] = mfmah(wlo, bhi, acc[t]);
-                    acc[t] = mfmah(whi, blo, acc[t]);
-                    if (AG && ft >= 8) {
-                        M[t] = mfmah(whi, mhi, M[t]);
-                        M[t] = mfmah(wlo, mhi, M[t]);
-                        M[t] = mfmah(whi, mlo, M[t]);
+                for (int th = 0; th < 2; ++th) {
+                    const int g = 2 * ks + th;
+                    if (g + 1 < 2 * NKS) read_group(g + 1, wg[(g + 1) & 1]);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * th + tt;
+                        const f16x8 whi = wg[g & 1][tt][0], wlo = wg[g & 1][tt][1];
+                        acc[t] = mfmah(whi, bhi, acc[t]);
+                        acc[t] = mfmah(wlo, bhi, acc[t]);
+                        acc[t] = mfmah(whi, blo, acc[t]);
+                        if (AG && ft >= 8) {
+                            M[t] = mfmah(whi, mhi, M[t]);
+                            M[t] = mfmah(wlo, mhi, M[t]);
+                            M[t] = mfmah(whi, mlo, M[t]);
+                        }
                     }
                 }
             }
             if (ft + 1 < NFT) split16(p1n);
+            // Issue order inside the tile (an MFMA holds the SIMD's issue port for 8 of its 32 cycles: the next tile's relu /
+            // split VALU goes INTO the gaps, the next group's four fragment reads in front of each group of six MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // first-layer MFMA of the next tile
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i = 0; i < ((AG && ft >= 8) ? 12 : 6); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
             // (tiles stay in program order: hoisting every tile's first-layer MFMA and weight reads costs hundreds of registers)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -587,117 +617,222 @@ struct DwArgs {
     const float* g3;   // [n_agents][64]
     const bf16* sm;    // [n_agents][64][128]
     float* partG;      // [grid][KG][128] (row K: the constant-one feature = sum over rows of g3 * mask -> db2 / c3)
+    unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
 };
-// Wave w = (cp, slot): column tiles 2 cp, 2 cp + 1 of feature tiles fg, fg + 4, fg + 8 with fg = slot (cp = 0) or 3 - slot
-// (cp = 1) -- the two waves of a SIMD (w, w + 4) then carry 5 feature tiles between them whatever NGT is. A first-layer tile
-// is evaluated with the batch rows as the M index and the row factor |g3| in its input fragment (result: feature on the lane,
-// rows in the registers = the A operand of G = Q^T . sm in permuted k order), relu'd and split once and used against both
-// column tiles; the sm tile goes through LDS (row stride 320 B: conflict-free ds_read_b64_tr_b16). One barrier per tile.
+// Wave w owns feature tile w (both row halves, all four column tiles: 64 accumulator registers). The tiles past the eight
+// state tiles (critic: the action tiles 8, 9; actor: the constant-one tile 8) are cut into eight equal pieces, one per wave
+// (critic: tile x row half x pair of column tiles; actor: row half x column tile; 32 more accumulator registers), whose
+// row-half partials meet in LDS at the end -- every wave then does the same work per tile. A first-layer tile is evaluated
+// with the batch rows as the M index and the row factor |g3| in its input fragment (result: feature on the lane, rows in the
+// registers = the A operand of G = Q^T . sm in permuted k order), relu'd and split ONCE and used against all four column
+// tiles: 64 VALU per 17 MFMAs. The sm tile goes through LDS (row stride 320 B: conflict-free ds_read_b64_tr_b16), fetched
+// TWO tiles ahead; the |g3|-scaled input fragments are built once per tile by 128 threads and shared through LDS.
 template <int S, class NET>
 __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
-    constexpr int KG = NET::KG, NGT = NET::NGT, LDZ = 160;
-    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, cp = w >> 2, slot = w & 3;
-    const int fg = cp ? 3 - slot : slot;
+    constexpr int KG = NET::KG, LDZ = 160;
+    constexpr int XC = NET::critic ? 2 : 1;  // column tiles of a wave's extra piece
+    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];  // (40 KB: reused for the extra pieces' partial sums)
+    __shared__ __attribute__((aligned(16))) bf16x8 fq[2][TILE * 2];      // scaled input fragments [row][lane half] of the states
+    __shared__ __attribute__((aligned(16))) bf16x8 fa[2][TILE * 2];      // ... of the action (critic)
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const bf16x8* wf1 = p.net.wf1 + (long)set * NGT_MAX * 64 + lane;
-    const bool third = fg + 8 < NGT;
-    bf16x8 wf[3];
-    f32x16 G[3][2];
+    // this wave's extra piece
+    const int xt = NET::critic ? 8 + (w >> 2) : 8, xrh = NET::critic ? (w >> 1) & 1 : (w >> 2) & 1, xc0 = NET::critic ? 2 * (w & 1) : (w & 3);
+    const bf16x8 wf0 = wf1[64 * w], wfx = wf1[64 * xt];
+    f32x16 G0[4], G1[XC];
     const f32x16 zero16 = {};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        wf[i] = (i < 2 || third) ? wf1[64 * (fg + 4 * i)] : bf16x8{};
-        G[i][0] = zero16, G[i][1] = zero16;
-    }
-    const bool act_tile = NET::critic && third;  // tile fg + 8 of a critic takes the action as its input
+    for (int c = 0; c < 4; ++c) G0[c] = zero16;
+#pragma unroll
+    for (int c = 0; c < XC; ++c) G1[c] = zero16;
 
-    const int srow = tid >> 3, sch = tid & 7;  // staging: 64 rows x 8 chunks of 32 bytes
-    uint4 d0 = {}, d1 = {};
-    auto fetch = [&](int agent) {
-        const uint4* src = (const uint4*)(p.sm + ((long)agent * TILE + srow) * H2 + 16 * sch);
-        d0 = src[0], d1 = src[1];
+    // Staging. sm (335 MB per pass, from HBM): 64 rows x 8 chunks of 32 bytes, one chunk per thread, TWO tiles ahead in two
+    // register sets used alternately -- one tile of lookahead (~2.5 us) does not cover the tail of the HBM latency over 512
+    // threads and a barrier: measured, a third of the kernel was the wait for it (tools/fsplit_ablate.sh). The inputs
+    // (states, g3, actions: 31 MB, L2 / Infinity-Cache resident): one tile ahead, threads 0..127 build the |g3|-scaled fragment
+    // of (row, lane half) = (tid >> 1, tid & 1) once per tile.
+    const int srow = tid >> 3, sch = tid & 7, frow = tid >> 1, fh = tid & 1;
+    uint4 a0 = {}, a1 = {}, b0 = {}, b1 = {};
+    float sx[4] = {0.f, 0.f, 0.f, 0.f}, sg = 0.f, sa = 0.f;
+    auto smsrc = [&](int pl) { return (const uint4*)(p.sm + ((long)(pl * p.n_sets + set) * TILE + srow) * H2 + 16 * sch); };
+    auto fetch_x = [&](int pl) {
+        if (pl >= P || tid >= 2 * TILE) return;
+        const long ri = (long)(pl * p.n_sets + set) * TILE + frow;
+        load_x<S>(p.x, ri, sx);
+        sg = p.g3[ri];
+        if (NET::critic) sa = p.act[ri];
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int pl, int buf, const uint4& d0, const uint4& d1) {
+        if (pl >= P) return;
         uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
         dst[0] = d0, dst[1] = d1;
-    };
-    float nx[2][4], ng[2] = {0.f, 0.f}, na[2] = {0.f, 0.f};  // the next tile's inputs, requested a tile ahead like its sm
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) nx[e][k] = 0.f;
-    auto fetch_x = [&](int agent) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const long ri = (long)agent * TILE + 32 * e + r;
-            load_x<S>(p.x, ri, nx[e]);
-            ng[e] = p.g3[ri];
-            if (act_tile) na[e] = p.act[ri];
+        if (tid < 2 * TILE) {
+            const float g = fabsf(sg);
+            fq[buf][tid] = make_xq(g * sx[0], g * sx[1], g * sx[2], g * sx[3], g, fh);
+            if (NET::critic) fa[buf][tid] = make_xq(g * sa, 0.f, 0.f, 0.f, g, fh);
         }
     };
-    if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0);
-    __syncthreads();
     const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    int buf = 0;
-    for (int pi = j0; pi < P; pi += J, buf ^= 1) {
-        const bool more = pi + J < P;
-        bf16x8 xq[2], xaq[2];
+    // Three units per tile and wave -- own tile row half 0, row half 1, the extra piece -- as a software pipeline: the relu /
+    // split VALU of unit k + 1 is issued INTO the gaps between the MFMAs of unit k (sched_group_barrier). Issued one unit after
+    // the other, the two waves of a SIMD run their VALU phases together and their MFMA phases together (same program, one
+    // barrier per tile) and neither pipe overlaps the other: measured 5400 cycles per tile and SIMD for 2750 of MFMA.
+    auto read_b = [&](int buf, int e, int s, bf16x8 (&bfr)[4]) {  // sm fragments [column tile] of row half e, k-step s
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float g = fabsf(ng[e]);
-            xq[e] = make_xq(g * nx[e][0], g * nx[e][1], g * nx[e][2], g * nx[e][3], g, h);
-            xaq[e] = make_xq(g * na[e], 0.f, 0.f, 0.f, g, h);
-        }
-        if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
-        bf16x8 bfr[2][2][2];  // [column tile][row half][k-step]
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int hf = 0; hf < 2; ++hf) {
+                const int R0 = 32 * e + 16 * s + 8 * hf + 4 * (g4 >> 1);
+                const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * c + 16 * (g4 & 1) + 4 * pp));
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+                for (int j = 0; j < 4; ++j) bfr[c][4 * hf + j] = t[j];
+            }
+    };
+    auto split16 = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8]) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+        for (int m = 0; m < 8; ++m) split2(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
+    };
+    auto compute = [&](int buf) {
+        unsigned ah[8], al[8], bh[8], bl[8];
+        // stage 0: first layer + split of row half 0 (exposed)
+        split16(mfma(fq[buf][r * 2 + h], wf0, zero16), ah, al);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage 1: MFMAs of row half 0 | first layer + split of row half 1
+        {
+            const f32x16 p1 = mfma(fq[buf][(32 + r) * 2 + h], wf0, zero16);
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const int R0 = 32 * e + 16 * s + 8 * hf + 4 * (g4 >> 1);
-                        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * (2 * cp + c) + 16 * (g4 & 1) + 4 * pp));
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 bfr[4];
+                read_b(buf, 0, s, bfr);
+                const bf16x8 hi = frag(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
+                const bf16x8 lo = frag(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) bfr[c][e][s][4 * hf + j] = t[j];
-                    }
+                for (int c = 0; c < 4; ++c) G0[c] = mfma(hi, bfr[c], G0[c]), G0[c] = mfma(lo, bfr[c], G0[c]);
+            }
+            split16(p1, bh, bl);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (i == 2 && !third) continue;
-            const bool at = act_tile && i == 2;
+            for (int s = 0; s < 2; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const f32x16 p1 = mfma(at ? xaq[e] : xq[e], wf[i], zero16);  // [row][feature]: feature on the lane
-                unsigned qh[8], ql[8];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) split2(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 ahi = frag(qh[4 * s], qh[4 * s + 1], qh[4 * s + 2], qh[4 * s + 3]);
-                    const bf16x8 alo = frag(ql[4 * s], ql[4 * s + 1], ql[4 * s + 2], ql[4 * s + 3]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        G[i][c] = mfma(ahi, bfr[c][e][s], G[i][c]);
-                        G[i][c] = mfma(alo, bfr[c][e][s], G[i][c]);
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stage(buf ^ 1);
+        // stage 2: MFMAs of row half 1 | first layer + split of the extra piece (input fragment of ITS row half)
+        {
+            const bf16x8 xin = NET::critic ? fa[buf][(32 * xrh + r) * 2 + h] : fq[buf][(32 * xrh + r) * 2 + h];
+            const f32x16 px = mfma(xin, wfx, zero16);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 bfr[4];
+                read_b(buf, 1, s, bfr);
+                const bf16x8 hi = frag(bh[4 * s], bh[4 * s + 1], bh[4 * s + 2], bh[4 * s + 3]);
+                const bf16x8 lo = frag(bl[4 * s], bl[4 * s + 1], bl[4 * s + 2], bl[4 * s + 3]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) G0[c] = mfma(hi, bfr[c], G0[c]), G0[c] = mfma(lo, bfr[c], G0[c]);
+            }
+            split16(px, ah, al);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // stage 3: MFMAs of the extra piece: column tile(s) xc0.. of row half xrh (runtime: the fragments are read at their
+        // address, not selected from registers)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 hi = frag(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
+            const bf16x8 lo = frag(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+                bf16x8 bx;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int R0 = 32 * xrh + 16 * s + 8 * hf + 4 * (g4 >> 1);
+                    const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * (xc0 + c) + 16 * (g4 & 1) + 4 * pp));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bx[4 * hf + j] = t[j];
+                }
+                G1[c] = mfma(hi, bx, G1[c]);
+                G1[c] = mfma(lo, bx, G1[c]);
+            }
+        }
+    };
+    if (j0 < P) a0 = smsrc(j0)[0], a1 = smsrc(j0)[1];
+    fetch_x(j0);
+    if (j0 + J < P) b0 = smsrc(j0 + J)[0], b1 = smsrc(j0 + J)[1];
+    stage(j0, 0, a0, a1);
+    __syncthreads();
+#ifdef AVD_STAMP
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; }
+#else
+#define STAMP(i)
+#endif
+    for (int pi = j0; pi < P; pi += 2 * J) {
+        // tile pi from buffer 0; set a takes tile pi + 2J; set b (tile pi + J) goes to buffer 1
+        fetch_x(pi + J);
+        if (pi + 2 * J < P) a0 = smsrc(pi + 2 * J)[0], a1 = smsrc(pi + 2 * J)[1];
+        STAMP(0);
+        compute(0);
+        STAMP(1);
+        stage(pi + J, 1, b0, b1);
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
+        if (pi + J < P) {
+            // tile pi + J from buffer 1; set b takes tile pi + 3J; set a (tile pi + 2J) goes to buffer 0
+            fetch_x(pi + 2 * J);
+            if (pi + 3 * J < P) b0 = smsrc(pi + 3 * J)[0], b1 = smsrc(pi + 3 * J)[1];
+            STAMP(0);
+            compute(1);
+            STAMP(1);
+            stage(pi + 2 * J, 0, a0, a1);
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+        }
     }
+#ifdef AVD_STAMP
+    if (p.stamp && blockIdx.x == 16 && lane == 0)
+        for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = tacc[i];
+#endif
+    // the extra pieces: row-half partials summed through LDS (the sm images are dead now), fixed order: row half 0 + row half 1
+    float* comb = (float*)&smimg[0][0];  // [4 pieces of row half 1][XC][16 registers][64 lanes] <= 32 KB
+    const int cidx = NET::critic ? 2 * (w >> 2) + (w & 1) : (w & 3);  // the same for a piece's two row-half waves
+    if (xrh == 1) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (i == 2 && !third) continue;
+        for (int c = 0; c < XC; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float* dst = p.partG + ((long)blockIdx.x * KG + 32 * (fg + 4 * i)) * H2 + 32 * (2 * cp + c) + r;
+            for (int k = 0; k < 16; ++k) comb[((cidx * XC + c) * 16 + k) * 64 + lane] = G1[c][k];
+    }
+    __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G[i][c][k];
+    for (int c = 0; c < 4; ++c) {
+        float* dst = p.partG + ((long)blockIdx.x * KG + 32 * w) * H2 + 32 * c + r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G0[c][k];
+    }
+    if (xrh == 0) {
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            float* dst = p.partG + ((long)blockIdx.x * KG + 32 * xt) * H2 + 32 * (xc0 + c) + r;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G1[c][k] + comb[((cidx * XC + c) * 16 + k) * 64 + lane];
         }
     }
 }
@@ -1049,9 +1184,45 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         hipLaunchKernelGGL(kern, grid, block, 0, st, h);
     };
     DwArgs dw;
-    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s;
+    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr;
+#ifdef AVD_STAMP
+    static unsigned long long* d_stamp = nullptr;
+    if (!d_stamp) (void)hipMalloc(&d_stamp, 64 * 8);
+    dw.stamp = d_stamp;
+#endif
     DxArgs dx;
     dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xf = (const bf16*)xfb, dx.xfh = xfs;
+    // diagnostics (tools/fsplit_ablate.sh): AVD_FSPLIT_ONLY = dw | dx | head runs only those kernels of the chain (results
+    // are then meaningless, the inputs of the skipped stages are whatever the workspace holds)
+    const char* only = getenv("AVD_FSPLIT_ONLY");
+    const bool do_head = !only || !strcmp(only, "head"), do_dw = !only || !strcmp(only, "dw"), do_dx = !only || !strcmp(only, "dx");
+    if (only) {
+        if (do_head) {
+            head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+            head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+            head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+            head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, a2, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
+        }
+        if (do_dw) {
+            dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]);
+            hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
+#ifdef AVD_STAMP
+            unsigned long long hst[64];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
+            static int printed = 0;
+            if (printed++ == 3)
+                for (int w_ = 0; w_ < 8; ++w_)
+                    fprintf(stderr, "dw wave %d: fetch-issue %llu compute %llu stage %llu barrier %llu cycles over all tiles\n", w_, hst[w_ * 8],
+                            hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
+#endif
+        }
+        if (do_dx) {
+            dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
+            hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
+        }
+        return check_launch("avd_learn_set_split_bf16x3 (diagnostic subset)");
+    }
     // 1-2: targets
     head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
     head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);

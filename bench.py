@@ -405,7 +405,15 @@ def main():
                                   ["interfrl" if PRIMARY_MODE == "nofrl" else "nofrl"])
     # interfrl without --engine: the f32-class fused set learner where it exists (reference widths, decentralized)
     engine = args.engine or ("fused3" if (not args.hidden and args.framework == "decentralized") else None)
-    results = [run_workload(args, m, engine, rank, world, group) for m in modes]
+    if os.environ.get("AVD_BENCH_ORDER") == "rev":  # diagnostics: measure the secondary workload first
+        modes = modes[::-1]
+    results = []
+    for m in modes:
+        results.append(run_workload(args, m, engine, rank, world, group))
+        if os.environ.get("AVD_BENCH_PAUSE"):
+            time.sleep(float(os.environ["AVD_BENCH_PAUSE"]))
+    if os.environ.get("AVD_BENCH_ORDER") == "rev":
+        results = results[::-1]
 
     if rank == 0:
         first = results[0]
