@@ -24,6 +24,8 @@
 // Kernel chain, workspace, partial-sum layouts and the deterministic two-stage reduction are fset.hip's (finalize_* are
 // shared, fset_common.h). Tested against the float64 oracle at the f32 kernels' tolerance (1e-4 of each tensor's max,
 // tests/test_gpu_fsplit.py) -- not the 2 % the bf16 learners are allowed.
+#include <type_traits>
+
 #include "fset_common.h"
 
 namespace avd {
@@ -39,6 +41,16 @@ struct CriticS {
     static constexpr bool critic = true;
 };
 constexpr int NGT_MAX = 10;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (every index a constant inside f: `if constexpr`,
+// no reliance on the unroller for register arrays)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // ---- exact bf16 pairs -------------------------------------------------------------------------------------------------
 // (a, b) -> packed hi pair and packed lo pair: 2 x (float(hi) by shift / mask, subtract) + 2 conversions
@@ -336,21 +348,23 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
 }
 
 // ---- head: first layer -> second-layer GEMM (three MFMAs per product) -> output layer [-> its backward] -------------------
-enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4 };
+enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4, HEAD_BOTH = 5 };
 struct HeadArgs {
     NetP net;
     int n_agents, n_sets;
     const f16x8* xf;   // [n_agents][64][2] packed first-layer input fragments of the states, fp16 pairs (pack_x_kernel)
     const float* act;  // [n_agents][64] the critic's action input (a, a' or mu)
+    const float* act2; // HEAD_BOTH: mu (act = a)
     const float* r;    // OUT_TD: rewards [n_agents][64]
-    const float* yin;  // HEAD_CRITIC: TD targets; HEAD_ACTOR: dmu
+    const float* yin;  // HEAD_CRITIC / HEAD_BOTH: TD targets; HEAD_ACTOR: dmu
     const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
     float* out;        // OUT_*: per-row result
-    bf16* sm;          // HEAD_CRITIC / HEAD_ACTOR: sign(g3) * [z2 > 0] as bf16 +-1 / 0, [n_agents][64][128]
-    float* g3;         // HEAD_CRITIC / HEAD_ACTOR: the row factor of dZ2 [n_agents][64]
-    float* dmu;        // HEAD_CONST: dLa/dmu per row [n_agents][64]
-    float* part;       // HEAD_CRITIC / HEAD_ACTOR: [grid][8 waves][128] sums T1 = sum_rows g3 * p2 per output column
+    bf16* sm;          // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: sign(g3) * [z2 > 0] as bf16 +-1 / 0, [n_agents][64][128]
+    float* g3;         // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: the row factor of dZ2 [n_agents][64]
+    float* dmu;        // HEAD_CONST / HEAD_BOTH: dLa/dmu per row [n_agents][64]
+    float* part;       // backward modes: [grid][8 waves][128] sums T1 = sum_rows g3 * p2 per output column
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
+    float* part_s2;    // HEAD_BOTH: the same sums of the critic(s, mu) branch (the actor loss)
     float gamma, high, inv_n;
 };
 
@@ -358,17 +372,31 @@ struct HeadArgs {
 // weights for the workgroup's whole life. Wave w owns rows [32 (w & 1), +32) of every 4th tile. Per feature tile: the first layer of ITS rows
 // on the matrix cores (lane = batch row, registers = features), relu, hi / lo split of the 16 values (VALU), and per k-step
 // and 32-column tile three MFMAs (A = weight fragments from LDS, B = the split activations as they stand in the registers).
+//
+// Modes: OUT_TANH (actor, mu or a'), OUT_TD (target critic -> y), HEAD_ACTOR (actor backward seeds), and for the critic either
+// HEAD_CRITIC + HEAD_CONST as two launches or HEAD_BOTH: critic(s, a) and critic(s, mu) see the same states through the
+// same weights, so 8 of their 10 first-layer tiles and 192 of their 228 second-layer MFMAs per 32 rows are the SAME work --
+// one pass over the state tiles, then the action tiles twice: branch A (input a: TD seed, masks, T1) from a copy of the
+// accumulators, branch B (input mu: the action gradient through M) in place.
+// HEAD_BOTH keeps the state part (64 registers), the branch-A accumulators (64), T1 (64) and M (64) alive: it runs ONE wave
+// per SIMD (4 waves, up to 512 registers each) and relies on the in-wave interleave of split VALU and MFMAs; the other modes
+// run two waves per SIMD at <= 256 registers.
+__host__ __device__ constexpr int head_waves(int mode) { return mode == HEAD_BOTH ? 4 : 8; }
+
 template <int S, class NET, int MODE>
-__global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
+__global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadArgs p) {
     constexpr int K = NET::K, NKS = NET::NKS, NFT = NET::NFT, LD = NET::LD;  // LD/2 = 4 (mod 8) dwords: conflict-free b128
-    constexpr bool AG = (MODE == HEAD_CONST), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR);
+    constexpr int NW = head_waves(MODE), NTH = 64 * NW;
+    constexpr bool BOTH = (MODE == HEAD_BOTH);
+    constexpr bool AG = (MODE == HEAD_CONST || BOTH), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR || BOTH);
+    static_assert(!BOTH || NET::critic, "HEAD_BOTH is a critic mode");
     __shared__ __attribute__((aligned(16))) f16 wimg[2][H2 * LD];
     __shared__ __attribute__((aligned(16))) float b2s[H2];
     __shared__ __attribute__((aligned(16))) float c3s[H2];
     __shared__ __attribute__((aligned(16))) unsigned waps[AG ? 48 : 4];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, q = w >> 1, rh = w & 1;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
-    for (int i = tid; i < 2 * H2 * (K / 8); i += 512) {
+    for (int i = tid; i < 2 * H2 * (K / 8); i += NTH) {
         const int hl = i / (H2 * (K / 8)), rem = i - hl * (H2 * (K / 8)), n = rem / (K / 8), c = rem - n * (K / 8);
         const f16* src = (hl ? p.net.Wlo : p.net.Whi) + ((long)set * H2 + n) * K + 8 * c;
         *(uint4*)(&wimg[hl][n * LD + 8 * c]) = *(const uint4*)src;
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
     const float d3 = vec[2 * H2];
     const f16x8* wf1 = p.net.wf1h + (long)set * NGT_MAX * 64 + lane;  // + 64 ft
     const f32x16 zero16 = {};
-    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f;
+    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f;
 #pragma unroll
     for (int t = 0; t < (BWD ? 4 : 1); ++t)
 #pragma unroll
@@ -391,12 +419,13 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;  // tiles of this workgroup: j0, j0 + J, ..
     const int row = 32 * rh + r;
     f16x8 nx = {};
-    float na = 0.f, ny = 0.f, nw = 1.f;
+    float na = 0.f, nb = 0.f, ny = 0.f, nw = 1.f;
     auto fetch_in = [&](int k) {  // one unit (32 rows of a tile) ahead
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
         nx = p.xf[2 * ri + h];
         if (NET::critic) na = p.act[ri];
+        if (BOTH) nb = p.act2[ri];
         if (MODE == OUT_TD) ny = p.r[ri];
         if (BWD) ny = p.yin[ri];
         if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
@@ -404,13 +433,15 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
     if (q < ntile) fetch_in(q);
     const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
     const f16* wlo0 = &wimg[1][r * LD + 8 * h];
-    for (int k = q; k < ntile; k += 4) {
+    // the sequence of feature tiles of a unit: tiles 0 .. NFT - 1; HEAD_BOTH: + the action tiles 8, 9 once more (input mu)
+    constexpr int NSEQ = BOTH ? NFT + 2 : NFT;
+    for (int k = q; k < ntile; k += NW / 2) {
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
-        const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h);
+        const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h), xb = BOTH ? make_xh(nb, 0.f, 0.f, 0.f, h) : xa;
         const float ty = ny, tw = nw;
-        if (k + 4 < ntile) fetch_in(k + 4);
-        f32x16 acc[4], M[AG ? 4 : 1];
+        if (k + NW / 2 < ntile) fetch_in(k + NW / 2);
+        f32x16 acc[4], accA[4], M[AG ? 4 : 1];  // (accA: HEAD_BOTH only, dead otherwise)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -426,11 +457,73 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), ph[m], pl[m]);
         };
+        // ---- epilogues -----------------------------------------------------------------------------------------------
+        auto out_z = [&](f32x16 (&ac)[4]) {  // relu in place, output layer: z = d3 + sum_n c3[n] relu(z2[n])
+            float zp = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                    const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ac[t][4 * g + j] = relu(ac[t][4 * g + j]);
+                        zp = fmaf(ac[t][4 * g + j], cc[j], zp);
+                    }
+                }
+            zp += __shfl_xor(zp, 32);
+            return d3 + zp;
+        };
+        auto epi_bwd = [&](f32x16 (&ac)[4], float g3) {  // row factor, masks and T1 of a backward pass
+            if (h == 0) p.g3[ri] = g3;
+            const float g3i = g3 * isc;  // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc)
+            const unsigned s16 = g3 < 0.f ? 0xbf80u : 0x3f80u;  // bf16 -1 / +1
+            bf16* dst = p.sm + ri * H2 + 8 * h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 4 * g + 2 * e;
+                        T1[t][i] = fmaf(g3i, ac[t][i], T1[t][i]);
+                        T1[t][i + 1] = fmaf(g3i, ac[t][i + 1], T1[t][i + 1]);
+                        pk[g][e] = (ac[t][i] > 0.f ? s16 : 0u) | (ac[t][i + 1] > 0.f ? s16 << 16 : 0u);
+                    }
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                    uint4 o;
+                    o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                    *(uint4*)(dst + 32 * t + 16 * gg) = o;
+                }
+            }
+        };
+        auto epi_dmu = [&](f32x16 (&ac)[4], float g3) {
+            // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
+            // (the accumulators hold SW S1 M -- SW from the weights, S1 from the scaled wa -- and c3s carries 1 / (SW S1))
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                    const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += ac[t][4 * g + j] > 0.f ? cc[j] * M[AG ? t : 0][4 * g + j] : 0.f;
+                }
+            sum += __shfl_xor(sum, 32);
+            if (h == 0) p.dmu[ri] = g3 * sum;
+        };
+        // ---- the tiles ---------------------------------------------------------------------------------------------------
         split16(mfmah(wf1[0], xs, zero16));
         f16x8 wfn = wf1[64];
         // Weight fragments are read ONE GROUP AHEAD (group = k-step x pair of column tiles: hi and lo of two tiles, 16
         // registers, six MFMAs): a ds_read_b128 issued right in front of the MFMA that consumes it exposes the LDS latency
-        // four times per feature tile (measured: s_waitcnt lgkmcnt behind every read burst). wg[parity][2 t][hi, lo].
+        // four times per feature tile. wg[parity][2 t][hi, lo].
         f16x8 wg[2][2][2];
         auto read_group = [&](int g, f16x8 (&dst)[2][2]) {  // g = 2 ks + th
             const int ks = g >> 1, th = g & 1;
@@ -441,12 +534,18 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
             }
         };
         read_group(0, wg[0]);
-#pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
+        auto tile = [&](auto si_c, f32x16 (&ac)[4]) {
+            constexpr int si = decltype(si_c)::value;
+            constexpr int ft = si < NFT ? si : si - 2;    // feature tile
+            constexpr bool brB = BOTH && si >= NFT;        // HEAD_BOTH: second time through the action tiles (input mu)
+            constexpr bool with_m = AG && ft >= 8 && (!BOTH || brB);
+            // the first layer of the next tile of the sequence
             f32x16 p1n = zero16;
-            if (ft + 1 < NFT) {
-                p1n = mfmah(wfn, (NET::critic && ft + 1 >= 8) ? xa : xs, zero16);
-                if (ft + 2 < NFT) wfn = wf1[64 * (ft + 2)];
+            if constexpr (si + 1 < NSEQ) {
+                constexpr int fn = si + 1 < NFT ? si + 1 : si - 1;
+                constexpr bool nB = BOTH && si + 1 >= NFT;
+                p1n = mfmah(wfn, (NET::critic && fn >= 8) ? (nB ? xb : xa) : xs, zero16);
+                if constexpr (si + 2 < NSEQ) wfn = wf1[64 * (si + 2 < NFT ? si + 2 : si)];
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -455,7 +554,7 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
                 const f16x8 bhi = fragh(ph[4 * s], ph[4 * s + 1], ph[4 * s + 2], ph[4 * s + 3]);
                 const f16x8 blo = fragh(pl[4 * s], pl[4 * s + 1], pl[4 * s + 2], pl[4 * s + 3]);
                 f16x8 mhi = {}, mlo = {};
-                if (AG && ft >= 8) {
+                if constexpr (with_m) {
                     // action features: B operand of M = mask_a * wa (hi, lo), from the packed constants and the relu'd hi
                     // pairs (a half is non-zero exactly where the activation is positive)
                     const int kk = ks - 16;
@@ -474,15 +573,18 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
 #pragma unroll
                 for (int th = 0; th < 2; ++th) {
                     const int g = 2 * ks + th;
-                    if (g + 1 < 2 * NKS) read_group(g + 1, wg[(g + 1) & 1]);
+                    // the next group of the sequence (after the last k-step: the first action k-step again, HEAD_BOTH)
+                    int gn = g + 1;
+                    if (gn >= 2 * NKS) gn = (BOTH && !brB) ? 2 * 16 : -1;
+                    if (gn >= 0) read_group(gn, wg[(g + 1) & 1]);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const int t = 2 * th + tt;
                         const f16x8 whi = wg[g & 1][tt][0], wlo = wg[g & 1][tt][1];
-                        acc[t] = mfmah(whi, bhi, acc[t]);
-                        acc[t] = mfmah(wlo, bhi, acc[t]);
-                        acc[t] = mfmah(whi, blo, acc[t]);
-                        if (AG && ft >= 8) {
+                        ac[t] = mfmah(whi, bhi, ac[t]);
+                        ac[t] = mfmah(wlo, bhi, ac[t]);
+                        ac[t] = mfmah(whi, blo, ac[t]);
+                        if constexpr (with_m) {
                             M[t] = mfmah(whi, mhi, M[t]);
                             M[t] = mfmah(wlo, mhi, M[t]);
                             M[t] = mfmah(whi, mlo, M[t]);
@@ -490,7 +592,7 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
                     }
                 }
             }
-            if (ft + 1 < NFT) split16(p1n);
+            if constexpr (si + 1 < NSEQ) split16(p1n);
             // Issue order inside the tile (an MFMA holds the SIMD's issue port for 8 of its 32 cycles: the next tile's relu /
             // split VALU goes INTO the gaps, the next group's four fragment reads in front of each group of six MFMAs)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // first-layer MFMA of the next tile
@@ -498,34 +600,42 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
             for (int gi = 0; gi < 4; ++gi) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int i = 0; i < ((AG && ft >= 8) ? 12 : 6); ++i) {
+                for (int i = 0; i < (with_m ? 12 : 6); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 }
             }
             // (tiles stay in program order: hoisting every tile's first-layer MFMA and weight reads costs hundreds of registers)
             __builtin_amdgcn_sched_barrier(0);
-        }
-        float zp = 0.f;
+        };
+        static_for<0, NSEQ>([&](auto si_c) {
+            constexpr int si = decltype(si_c)::value;
+            if constexpr (BOTH && si == 8) {  // branch A starts from a copy of the state part
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
-                const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[t][4 * g + j] = relu(acc[t][4 * g + j]);
-                    zp = fmaf(acc[t][4 * g + j], cc[j], zp);
-                }
+                for (int t = 0; t < 4; ++t) accA[t] = acc[t];
             }
-        zp += __shfl_xor(zp, 32);
-        const float z = d3 + zp;
+            if constexpr (BOTH && si >= 8 && si < NFT) tile(si_c, accA);
+            else tile(si_c, acc);
+            if constexpr (BOTH && si == NFT - 1) {
+                // branch A is complete: critic(s, a) -> TD seed, masks, T1 (workers/trainer.py:494-498)
+                const float z = out_z(accA);
+                const float diff = z - ty, g3 = 2.f * diff * p.inv_n * tw;
+                epi_bwd(accA, g3);
+                if (h == 0) Dacc += g3, Lacc += diff * diff;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        const float z = out_z(acc);
         if (MODE == OUT_TANH) {
             const float o = tanhf(z) * p.high;
             if (h == 0) p.out[ri] = o;
         } else if (MODE == OUT_TD) {
             if (h == 0) p.out[ri] = ty + p.gamma * z;
+        } else if (BOTH) {
+            // branch B: critic(s, mu) -> the actor loss -mean(q) and its gradient w.r.t. the action (:501-504)
+            const float g3 = -p.inv_n * tw;
+            epi_dmu(acc, g3);
+            if (h == 0) Dacc2 += g3, Lacc2 += z;
         } else {
             float g3, loss;
             if (MODE == HEAD_CRITIC) {
@@ -537,53 +647,14 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
                 const float t = tanhf(z);
                 g3 = ty * p.high * (1.f - t * t), loss = 0.f;
             }
-            if (AG) {
-                // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
-                // (the accumulators hold SW S1 M -- SW from the weights, S1 from the scaled wa -- and c3s carries 1 / (SW S1))
-                float sum = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
-                        const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) sum += acc[t][4 * g + j] > 0.f ? cc[j] * M[t][4 * g + j] : 0.f;
-                    }
-                sum += __shfl_xor(sum, 32);
-                if (h == 0) p.dmu[ri] = g3 * sum;
-            } else {
-                if (h == 0) p.g3[ri] = g3;
-                const float g3i = g3 * isc;  // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc)
-                const unsigned s16 = g3 < 0.f ? 0xbf80u : 0x3f80u;  // bf16 -1 / +1
-                bf16* dst = p.sm + ri * H2 + 8 * h;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    unsigned pk[4][2];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int i = 4 * g + 2 * e;
-                            T1[t][i] = fmaf(g3i, acc[t][i], T1[t][i]);
-                            T1[t][i + 1] = fmaf(g3i, acc[t][i + 1], T1[t][i + 1]);
-                            pk[g][e] = (acc[t][i] > 0.f ? s16 : 0u) | (acc[t][i + 1] > 0.f ? s16 << 16 : 0u);
-                        }
-#pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                        uint4 o;
-                        o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
-                        *(uint4*)(dst + 32 * t + 16 * gg) = o;
-                    }
-                }
-            }
+            if (AG) epi_dmu(acc, g3);
+            else epi_bwd(acc, g3);
             if (h == 0) Dacc += g3, Lacc += loss;
         }
     }
     if (MODE >= HEAD_CRITIC) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
+        // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
         if (BWD) {
             float* pt = p.part + ((long)blockIdx.x * 8 + w) * H2;
 #pragma unroll
@@ -593,17 +664,26 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs p) {
                     float v = T1[t][i];
 #pragma unroll
                     for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
-                    if (r == 0) pt[32 * t + acc_row(i, h)] = v;
+                    if (r == 0) {
+                        pt[32 * t + acc_row(i, h)] = v;
+                        if (NW == 4) pt[4 * H2 + 32 * t + acc_row(i, h)] = 0.f;
+                    }
                 }
         }
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
             Dacc += __shfl_xor(Dacc, o);
             Lacc += __shfl_xor(Lacc, o);
+            if (BOTH) Dacc2 += __shfl_xor(Dacc2, o), Lacc2 += __shfl_xor(Lacc2, o);
         }
         if (lane == 0) {
             p.part_s[((long)blockIdx.x * 8 + w) * 2] = Dacc;
             p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc;
+            if (BOTH) p.part_s2[((long)blockIdx.x * 8 + w) * 2] = Dacc2, p.part_s2[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc2;
+            if (NW == 4) {
+                p.part_s[((long)blockIdx.x * 8 + w + 4) * 2] = 0.f, p.part_s[((long)blockIdx.x * 8 + w + 4) * 2 + 1] = 0.f;
+                if (BOTH) p.part_s2[((long)blockIdx.x * 8 + w + 4) * 2] = 0.f, p.part_s2[((long)blockIdx.x * 8 + w + 4) * 2 + 1] = 0.f;
+            }
         }
     }
 }
@@ -912,13 +992,15 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         const bool more = pi + J < P;
         const f16x8 xf[2] = {xfn[0], xfn[1]};
         if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            bf16x8 smf[8];
+        // The two row halves as a software pipeline: [dC of half 0] [dC of half 1 | BN/ReLU backward + split VALU of half 0]
+        // [V of half 0 | VALU of half 1] [V of half 1]. One half after the other, the two waves of a SIMD run their MFMA phases
+        // together and their VALU phases together (one barrier per tile) and the pipes never overlap (dw_kernel, measured).
+        auto read_a = [&](int e, bf16x8 (&smf)[8]) {
             const bf16* arow = smimg[buf] + (32 * e + r) * LDZ + 8 * h;
 #pragma unroll
             for (int s = 0; s < 8; ++s) smf[s] = *(const bf16x8*)(arow + 16 * s);
-            bf16x8 xb[2];
+        };
+        auto read_xb = [&](int e, bf16x8 (&xb)[2]) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x4 lo = *(const bf16x4*)(&xt[buf][e][r * 32 + 16 * s + 4 * h]);
@@ -926,12 +1008,9 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
             }
-            f32x16 dc = zero16;  // [row][feature]: feature on the lane
-#pragma unroll
-            for (int s = 0; s < 8; ++s) dc = mfma(smf[s], wch[s], dc), dc = mfma(smf[s], wcl[s], dc);
-            const f32x16 p1 = mfmah(xf[e], wf, zero16);
+        };
+        auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8]) {
             float u0 = 0.f, u1 = 0.f;
-            unsigned vh[8], vl[8];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 gq = *(const float4*)(&g3s[buf][32 * e + 8 * g + 4 * h]);
@@ -949,11 +1028,44 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
                 split2(dm[2], dm[3], vh[2 * g + 1], vl[2 * g + 1]);
             }
             U0 += u0, U1 += u1;
+        };
+        bf16x8 smf[8], xb0[2], xb1[2];
+        unsigned vh0[8], vl0[8], vh1[8], vl1[8];
+        // stage 0: dC of row half 0
+        read_a(0, smf);
+        f32x16 dc0 = zero16;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                V = mfma(frag(vh[4 * s], vh[4 * s + 1], vh[4 * s + 2], vh[4 * s + 3]), xb[s], V);
-                V = mfma(frag(vl[4 * s], vl[4 * s + 1], vl[4 * s + 2], vl[4 * s + 3]), xb[s], V);
-            }
+        for (int s = 0; s < 8; ++s) dc0 = mfma(smf[s], wch[s], dc0), dc0 = mfma(smf[s], wcl[s], dc0);
+        const f32x16 p10 = mfmah(xf[0], wf, zero16);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage 1: dC of row half 1 | backward VALU of row half 0
+        read_a(1, smf);
+        read_xb(0, xb0);
+        f32x16 dc1 = zero16;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dc1 = mfma(smf[s], wch[s], dc1), dc1 = mfma(smf[s], wcl[s], dc1);
+        const f32x16 p11 = mfmah(xf[1], wf, zero16);
+        backward(0, dc0, p10, vh0, vl0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // stage 2: V of row half 0 | backward VALU of row half 1; then V of row half 1
+        read_xb(1, xb1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            V = mfma(frag(vh0[4 * s], vh0[4 * s + 1], vh0[4 * s + 2], vh0[4 * s + 3]), xb0[s], V);
+            V = mfma(frag(vl0[4 * s], vl0[4 * s + 1], vl0[4 * s + 2], vl0[4 * s + 3]), xb0[s], V);
+        }
+        backward(1, dc1, p11, vh1, vl1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            V = mfma(frag(vh1[4 * s], vh1[4 * s + 1], vh1[4 * s + 2], vh1[4 * s + 3]), xb1[s], V);
+            V = mfma(frag(vl1[4 * s], vl1[4 * s + 1], vl1[4 * s + 2], vl1[4 * s + 3]), xb1[s], V);
         }
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
         __syncthreads();
@@ -1178,10 +1290,13 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
+    h.act2 = nullptr, h.part_s2 = nullptr;
+    int head_threads = NT;
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {
         h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
-        hipLaunchKernelGGL(kern, grid, block, 0, st, h);
+        hipLaunchKernelGGL(kern, grid, dim3(head_threads), 0, st, h);
+        head_threads = NT;
     };
     DwArgs dw;
     dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr;
@@ -1226,17 +1341,24 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     // 1-2: targets
     head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
     head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
-    // 3: mu (independent of the critic passes)
+    // 3: mu
     head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
-    // 4-6: critic loss and gradients
-    head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    // 4-6 (+ 7): critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH) unless
+    // AVD_FSPLIT_TWO_HEADS is set (diagnostics: the two-launch form)
+    const bool two_heads = getenv("AVD_FSPLIT_TWO_HEADS") != nullptr;
+    h.act2 = mu, h.part_s2 = F(pl.partHs[2]);
+    if (two_heads) head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    else {
+        head_threads = 64 * head_waves(HEAD_BOTH);
+        head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    }
     dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]);
     hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
     dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
     hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
     hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
     // 7-8: actor loss through the critic, gradient w.r.t. the action
-    head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
+    if (two_heads) head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
     // 9-11: actor gradients
     head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
     dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]);
