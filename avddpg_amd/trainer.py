@@ -64,7 +64,8 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
-                 pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None, fused_step=None):
+                 pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None, fused_step=None,
+                 replay_ring=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'.
@@ -108,7 +109,7 @@ class VecTrainer:
         # platoons over all ranks: a constant, reduced once here (the federated mean's divisor)
         self.total_platoons = _dist.total_platoons(self.P, group, self.device)
         self.replay = vec.VecReplay(n_agents, conf.buffer_size, conf.batch_size, self.S, self.A, self.device, rng=rng,
-                                    seed=seed)
+                                    seed=seed, ring=replay_ring)
         f32 = dict(dtype=torch.float32, device=self.device)
         # Shared weight sets: "per_agent" = the f32 LDS-resident kernel per agent + fed_sum (exact f32, widths up to
         # 256); "batched" = one learn over each set's P x 64 rows as bf16 MFMA GEMMs (csrc/wide.hip; any width multiple

@@ -183,12 +183,19 @@ class VecReplay:
     """One ring buffer per agent: ring[n_agents][cap][2S+A+1] float32 (reference src/replaybuffer.py)."""
 
     def __init__(self, n_agents, buffer_capacity, batch_size, num_states, num_actions, device=None, rng="host",
-                 seed=1):
+                 seed=1, ring=None):
+        """ring: an existing [n_agents, capacity, 2S+A+1] float32 device tensor to use instead of allocating one (two trainers
+        of the same shape measured in one process share the 82 GB ring of BASELINE configs[1])."""
         self.n, self.cap, self.B = int(n_agents), int(buffer_capacity), int(batch_size)
         self.S, self.A = int(num_states), int(num_actions)
         self.row = 2 * self.S + self.A + 1
         self.device, self.rng, self.seed = _dev(device), rng, int(seed)
-        self.ring = torch.zeros(self.n, self.cap, self.row, dtype=torch.float32, device=self.device)
+        if ring is not None:
+            if tuple(ring.shape) != (self.n, self.cap, self.row) or ring.dtype != torch.float32 or not ring.is_contiguous():
+                raise _hip.AvdError(f"replay ring must be contiguous float32 {(self.n, self.cap, self.row)}, got {tuple(ring.shape)}")
+            self.ring = ring
+        else:
+            self.ring = torch.zeros(self.n, self.cap, self.row, dtype=torch.float32, device=self.device)
         self.buffer_counter = 0  # identical for all agents: they are written in lock step
         self.samples = 0
         f32 = dict(dtype=torch.float32, device=self.device)

@@ -190,10 +190,7 @@ def spawn_ranks(args):
     return rc
 
 
-def run_workload(args, mode, engine, rank, world, group):
-    """Build the trainer for one workload, time args.steps steps of it, return the fields of the JSON line."""
-    import torch
-
+def build_trainer(args, mode, engine, rank, group, ring=None):
     from avddpg_amd import config, trainer
 
     P, L = args.platoons, args.pl_size
@@ -202,10 +199,19 @@ def run_workload(args, mode, engine, rank, world, group):
                          weighted_average_enabled=False, random_seed=1, framework=args.framework)  # random_seed: initial weights, the same on every rank
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
-    vt = trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
-                            seed=1 + rank, pipeline_chunks=args.chunks,
-                            fused_update=(mode == "nofrl" and not args.no_fused),
-                            shared_engine=engine if mode == "interfrl" else None)
+    return trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
+                              seed=1 + rank, pipeline_chunks=args.chunks,
+                              fused_update=(mode == "nofrl" and not args.no_fused),
+                              shared_engine=engine if mode == "interfrl" else None, replay_ring=ring)
+
+
+def run_workload(args, mode, engine, rank, world, group, vt=None):
+    """Time args.steps steps of one workload (trainer `vt`, built here when not given); return the fields of the JSON line."""
+    import torch
+
+    P, L = args.platoons, args.pl_size
+    if vt is None:
+        vt = build_trainer(args, mode, engine, rank, group)
     batched = vt.shared and vt.shared_engine in ("batched", "fused", "fused3")
     fset = vt.shared and vt.shared_engine in ("fused", "fused3")
     split3 = vt.shared and vt.shared_engine == "fused3"
@@ -318,6 +324,16 @@ def run_workload(args, mode, engine, rank, world, group):
                 r["traffic"] = sum(per_unit) * n_agents
                 r["traffic_note"] = ("HBM-side bytes per step of these kernels, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/"
                                      + os.path.basename(pmc_path))
+    # the split set learner's chain: HBM-side bytes per learn from the committed PMC passes of `bench.py --mode interfrl`
+    pmc_split = os.path.join(ROOT, "profiles", "pmc_traffic_interfrl_split.json")
+    if split3 and os.path.exists(pmc_split) and P == 4096 and L == 5:
+        pk = json.load(open(pmc_split))["kernels"]
+        per_step = next((v["launches"] for k, v in pk.items() if "dw_kernel" in k and "CriticS" in k), 0)
+        if per_step:
+            chain = [v for k, v in pk.items() if "fsplit" in k or "finalize" in k]
+            roofs[0]["traffic"] = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in chain) / per_step
+            roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE(x2: gfx950 correction)+WRITE_SIZE, "
+                                        "profiles/pmc_traffic_interfrl_split.json (matrix-core bound: reported, not the binding roof)")
     for r in roofs:
         r["frac"] = r["achieved"] / r["peak"]
     if fused:
@@ -395,7 +411,17 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(args.backend)
+            # (gloo's C++ side prints a connection banner to stdout: keep rank 0's stdout to the ONE JSON line)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(args.backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         group = dist.group.WORLD
 
     if args.mode:
@@ -407,13 +433,20 @@ def main():
     engine = args.engine or ("fused3" if (not args.hidden and args.framework == "decentralized") else None)
     if os.environ.get("AVD_BENCH_ORDER") == "rev":  # diagnostics: measure the secondary workload first
         modes = modes[::-1]
+    # Two workloads: BOTH trainers are built before anything is timed -- the one with per-agent slabs (nofrl: 25 GB of
+    # weights / moments + the 82 GB replay ring) first, on a pristine heap, and the other one sharing its ring. Building the
+    # second trainer after freeing the first one's 100+ GB left it ~5 % slow (page placement of the re-allocated slabs).
+    trainers = {}
+    if len(modes) == 2:
+        first = "nofrl" if "nofrl" in modes else modes[0]
+        trainers[first] = build_trainer(args, first, engine, rank, group)
+        other = modes[1] if modes[0] == first else modes[0]
+        trainers[other] = build_trainer(args, other, engine, rank, group, ring=trainers[first].replay.ring)
     results = []
     for i, m in enumerate(modes):
         if i:
-            # idle gap between the two workloads (outside both timed regions): measured back to back, the second one ran up to
-            # 5 % slow (clocks / freed-and-reallocated 100 GB); with 2-3 s between them each reproduces its stand-alone figure
-            time.sleep(float(os.environ.get("AVD_BENCH_PAUSE", "2.5")))
-        results.append(run_workload(args, m, engine, rank, world, group))
+            time.sleep(float(os.environ.get("AVD_BENCH_PAUSE", "1.0")))  # idle gap, outside both timed regions
+        results.append(run_workload(args, m, engine, rank, world, group, vt=trainers.pop(m, None)))
     if os.environ.get("AVD_BENCH_ORDER") == "rev":
         results = results[::-1]
 
