@@ -449,8 +449,10 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 const float4 b = *(const float4*)(b2s + 32 * t + 8 * g + 4 * h);
                 acc[t][4 * g] = b.x, acc[t][4 * g + 1] = b.y, acc[t][4 * g + 2] = b.z, acc[t][4 * g + 3] = b.w;
             }
+        if (!BOTH) {
 #pragma unroll
-        for (int t = 0; t < (AG ? 4 : 1); ++t) M[t] = zero16;
+            for (int t = 0; t < (AG ? 4 : 1); ++t) M[t] = zero16;
+        }
         // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
         unsigned ph[8], pl[8];
         auto split16 = [&](const f32x16& p1) {
@@ -623,6 +625,9 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 epi_bwd(accA, g3);
                 if (h == 0) Dacc += g3, Lacc += diff * diff;
                 __builtin_amdgcn_sched_barrier(0);
+                // branch B's M accumulators come alive only now (they can take over branch A's registers)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) M[t] = zero16;
             }
         });
         const float z = out_z(acc);
