@@ -935,6 +935,7 @@ struct DxArgs {
     const bf16* sm;
     float* partU;      // [grid][2 h][KP][2]   sum dC, sum dC * p1 per feature
     float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
+    unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only
 };
 // Wave w = state feature tile w (8 tiles), both row halves. Resident: hi and lo of the tile's rows of W2c as B fragments
 // (reduction over the 128 columns; A = the sm rows, exact). dC comes out [row][feature] (feature on the lane) like the
@@ -992,11 +993,18 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     __syncthreads();  // the zero / ones fill above before the first stage_x
     if (j0 < P) fetch(j0 * p.n_sets + set), fetch_x(j0 * p.n_sets + set), stage(0), stage_x(0);
     __syncthreads();
+#ifdef AVD_STAMP
+    unsigned long long dacc[4] = {0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
+#define DXSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dacc[i] += t_ - dlast; dlast = t_; }
+#else
+#define DXSTAMP(i)
+#endif
     int buf = 0;
     for (int pi = j0; pi < P; pi += J, buf ^= 1) {
         const bool more = pi + J < P;
         const f16x8 xf[2] = {xfn[0], xfn[1]};
         if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
+        DXSTAMP(0);
         // The two row halves as a software pipeline: [dC of half 0] [dC of half 1 | BN/ReLU backward + split VALU of half 0]
         // [V of half 0 | VALU of half 1] [V of half 1]. One half after the other, the two waves of a SIMD run their MFMA phases
         // together and their VALU phases together (one barrier per tile) and the pipes never overlap (dw_kernel, measured).
@@ -1072,9 +1080,16 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
             V = mfma(frag(vh1[4 * s], vh1[4 * s + 1], vh1[4 * s + 2], vh1[4 * s + 3]), xb1[s], V);
             V = mfma(frag(vl1[4 * s], vl1[4 * s + 1], vl1[4 * s + 2], vl1[4 * s + 3]), xb1[s], V);
         }
+        DXSTAMP(1);
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
+        DXSTAMP(2);
         __syncthreads();
+        DXSTAMP(3);
     }
+#ifdef AVD_STAMP
+    if (p.stamp && blockIdx.x == 16 && lane == 0)
+        for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = dacc[i];
+#endif
     float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
     pu[0] = U0, pu[1] = U1 * (1.f / S1);
     if (r < 16) {
@@ -1311,7 +1326,10 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     dw.stamp = d_stamp;
 #endif
     DxArgs dx;
-    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xf = (const bf16*)xfb, dx.xfh = xfs;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xf = (const bf16*)xfb, dx.xfh = xfs, dx.stamp = nullptr;
+#ifdef AVD_STAMP
+    dx.stamp = d_stamp;
+#endif
     // diagnostics (tools/fsplit_ablate.sh): AVD_FSPLIT_ONLY = dw | dx | head runs only those kernels of the chain (results
     // are then meaningless, the inputs of the skipped stages are whatever the workspace holds)
     const char* only = getenv("AVD_FSPLIT_ONLY");
@@ -1340,6 +1358,16 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         if (do_dx) {
             dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
             hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
+#ifdef AVD_STAMP
+            unsigned long long hst[64];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
+            static int printed = 0;
+            if (printed++ == 3)
+                for (int w_ = 0; w_ < 8; ++w_)
+                    fprintf(stderr, "dx wave %d: fetch-issue %llu compute %llu stage %llu barrier %llu cycles over all tiles\n", w_, hst[w_ * 8],
+                            hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
+#endif
         }
         return check_launch("avd_learn_set_split_bf16x3 (diagnostic subset)");
     }

@@ -72,9 +72,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(seconds, pl_size):
+def cpu_baseline(seconds, pl_size, mode="nofrl"):
     """The oracle's reference-shaped Python loop (oracle/trainer.py, kind "port": TensorFlow is not installable,
-    so the NN arithmetic is NumPy float32) on ONE host thread -- the reference's own setting (src/rand.py:14-15)."""
+    so the NN arithmetic is NumPy float32) on ONE host thread -- the reference's own setting (src/rand.py:14-15) -- in the
+    same federated mode as the line's primary workload (the reference's per-agent cost is the same in both: every agent
+    learns on its own batch; interfrl adds the server's averaging)."""
     import numpy as np
     from threadpoolctl import threadpool_limits
 
@@ -82,7 +84,8 @@ def cpu_baseline(seconds, pl_size):
 
     P = 2
     with threadpool_limits(limits=1):
-        tr = trainer.RefTrainer(platoon.EnvParams(), P, pl_size, seed=1, buffer_size=4096)
+        tr = trainer.RefTrainer(platoon.EnvParams(), P, pl_size, seed=1, buffer_size=4096,
+                                fed_method="interfrl" if mode == "interfrl" else "normal")
         tr.reset_episode()
         for _ in range(65):  # replay warm-up: updates start at the 65th add
             if tr.step():
@@ -95,17 +98,17 @@ def cpu_baseline(seconds, pl_size):
         dt = time.perf_counter() - t0
     return {"value": P * n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "updates_per_s": (tr.updates - u0) / dt,
-            "sample": f"{P} platoons x {pl_size} vehicles (={P * pl_size} agents), nofrl, {n} training steps after a "
+            "sample": f"{P} platoons x {pl_size} vehicles (={P * pl_size} agents), {mode}, {n} training steps after a "
                       f"65-step replay warm-up, {dt:.1f} s on 1 thread; the per-platoon cost of the reference loop "
                       "does not depend on the number of platoons"}
 
 
-def _cpu_worker(seconds, pl_size, q):
-    r = cpu_baseline(seconds, pl_size)
+def _cpu_worker(seconds, pl_size, q, mode="nofrl"):
+    r = cpu_baseline(seconds, pl_size, mode)
     q.put((r["value"], r["updates_per_s"]))
 
 
-def cpu_baseline_all_cores(seconds, pl_size, max_workers=None):
+def cpu_baseline_all_cores(seconds, pl_size, max_workers=None, mode="nofrl"):
     """platoons are independent, so the host's whole-socket figure is N independent single-thread copies of
     the reference-shaped loop, N = the cores this process may run on. Reported beside the 1-thread figure, never as it.
     Opt-in (--cpu-all-cores). One overall deadline; stragglers are terminated together and the sum over the workers that
@@ -118,7 +121,7 @@ def cpu_baseline_all_cores(seconds, pl_size, max_workers=None):
         n = min(n, max_workers)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_worker, args=(seconds, pl_size, q)) for _ in range(n)]
+    procs = [ctx.Process(target=_cpu_worker, args=(seconds, pl_size, q, mode)) for _ in range(n)]
     for p in procs:
         p.start()
     res, deadline = [], time.monotonic() + seconds * 3 + 90
@@ -296,7 +299,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x6, dw x2, dx x2, dxa persistent kernels + scale, prep, "
+        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x5, dw x2, dx x2, dxa persistent kernels + scale, prep, "
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
                                  "matrix work is ~2.6x the algorithmic FLOPs priced here)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
@@ -350,9 +353,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         "unit": "env-steps/s",
         "updates_per_s": updates_per_s,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "dtype": ("f32-class: every matrix-product operand an exact 16-bit pair hi+lo (fp16 pairs, 2^-24, in the forward passes and "
-                  "every relu mask; bf16 pairs, 2^-18, times exact masks in the weight/input-gradient products), A_hi B_hi + A_lo B_hi + "
-                  "A_hi B_lo on the matrix cores, f32 accumulation, parameters, gradients and optimiser" if split3 else
+        "dtype": ("f32-class (fp16/bf16 hi+lo operand pairs on the 16-bit matrix cores, f32 accumulate)" if split3 else
                   "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32"),
         "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
                                + ("centralized " if args.framework == "centralized" else "")
@@ -364,6 +365,10 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                    "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": mode,
                    "parallelism": f"platoon shards x{world}" + (f" + one {args.backend} all-reduce(sum) of the [M, theta] gradient slab per step"
                                                                 if rccl else " (no data-path collective)")},
+        "dtype_note": ("every matrix-product operand an exact 16-bit pair hi+lo (fp16 pairs, residual 2^-24, in the forward passes and "
+                       "for every relu mask; bf16 pairs, 2^-18, times exact +-1/0 masks in the weight / input-gradient products), "
+                       "A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, gradients and optimiser; 1e-4 of each gradient "
+                       "tensor's max against the float64 oracle, the f32 kernels' tolerance (tests/test_gpu_fsplit.py)" if split3 else None),
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
         "stages_ms": stage_ms,
         "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
@@ -463,10 +468,10 @@ def main():
                                                           + (("rccl_ranks", "collective_backend") if "rccl_ranks" in r else ())}
                                     for r in results[1:]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size, modes[0])
             if args.cpu_all_cores:  # the whole host beside the reference's own 1-thread setting (opt-in side figure)
                 try:
-                    out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), args.pl_size)
+                    out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), args.pl_size, mode=modes[0])
                 except Exception as e:  # never let the side figure break the bench line
                     out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
