@@ -211,3 +211,32 @@ def test_trainer_split_engine_weighted_federation_runs_model_a():
     assert vt.fed_weights is not None and vt.fed_weights[0] == 3
     assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) == 4 * 30 - 64
     assert not torch.equal(vt.agents.theta, th0)
+
+
+@pytest.mark.parametrize("scale_w2,scale_in", [(1e-3, 1.0), (300.0, 1.0), (1.0, 12.0), (0.0, 1.0)])
+def test_split_set_learner_fp16_scaling_is_robust_to_weight_and_state_magnitudes(scale_w2, scale_in):
+    """The heads carry their operands as fp16 pairs (5-bit exponent): second-layer weights are rescaled per set and net by a
+    power of two (scale_kernel), first-layer weights by 2^6, and the scales are folded into f32 constants. Weights 1e-3 ... 300 x
+    their usual size, states up to the env's bounds (|x| ~ 20), and an all-zero second layer (max = 0: no scale to derive) must
+    give the exact engine's gradients all the same -- ten weight sets (BASELINE configs[2]'s vehicle count)."""
+    need_gpu()
+    P, M, S = 9, 10, 4
+    conf, grp = _perturbed_group(M, S=S, seed=141)
+    lay = grp.lay
+    for th in (grp.theta, grp.theta_t):
+        th[:, lay.aW2:lay.aW2 + 256 * 128] *= scale_w2
+        th[:, lay.actor_size + lay.cW2:lay.actor_size + lay.cW2 + 304 * 128] *= scale_w2
+    s, a, r, s2 = _batch(np.random.RandomState(142), P * M, S)
+    s, s2 = s * scale_in, s2 * scale_in
+    exact = vec.fed_mean(grp.learn(t(s), t(a), t(r), t(s2), M), P, M, method=conf.interfrl).cpu().numpy()
+    got = grp.learn_set_split(t(s), t(a), t(r), t(s2), P * M).cpu().numpy()
+    assert np.isfinite(got).all()
+    for k in range(M):
+        ce, ae = grp.grads_as_lists(torch.from_numpy(exact[k]).cuda())
+        cg, ag = grp.grads_as_lists(torch.from_numpy(got[k]).cuda())
+        for name, x, z in zip(NAMES, cg + ag, ce + ae):
+            scale = np.abs(z).max()
+            if scale > 0:
+                assert np.abs(x - z).max() <= GRAD_TOL * scale, (k, name, np.abs(x - z).max() / scale)
+            else:
+                assert np.abs(x).max() == 0.0, (k, name)
