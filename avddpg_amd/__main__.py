@@ -33,6 +33,10 @@ def get_cmdl_args(argv, conf):
     tr.add_argument("--intra_directional_averaging", type=bool, default=True)
     tr.add_argument("--rng", choices=["host", "device"], default="host",
                     help="host: reference RNG stream (fixed-seed parity); device: Philox in the kernels (throughput)")
+    tr.add_argument("--engine", choices=["per_agent", "batched", "fused", "fused3"], default=None,
+                    help="interfrl with every step federated (shared weight sets): per_agent = exact f32 kernel per agent + federated "
+                         "sum (default); fused3 = split-operand set learner, f32-class results, ~4x faster; fused / batched = bf16 "
+                         "operands (not in the reference CLI)")
     tr.add_argument("--out", type=str, default=".outputs")
     es = sub.add_parser("esim", help="run in evaluation/simulator mode")
     es.add_argument("exp_path", type=str)
@@ -70,7 +74,7 @@ def main(argv=None, conf=None):
         np.random.seed(conf.random_seed)  # rand.set_global_seed (src/rand.py:6-15)
         base = os.path.join(args.out, datetime.datetime.now().strftime("%y%m%d_%H%M%S"))
         os.makedirs(base, exist_ok=True)
-        vt = trainer.VecTrainer(conf, rng=args.rng, auto_reset=False)
+        vt = trainer.VecTrainer(conf, rng=args.rng, auto_reset=False, shared_engine=args.engine)
         ep, avg = vt.run()
         artifacts.generate_csvs(base, conf, ep, avg)
         artifacts.save_agents(base, vt.agents, vt.P, vt.M, shared=vt.shared)
