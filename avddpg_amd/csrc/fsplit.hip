@@ -93,6 +93,16 @@ __device__ __forceinline__ void split1h(float x, f16& hi, f16& lo) {
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
 }
+// an optimisation barrier on 16 accumulator registers: what was computed into them is computed HERE
+template <class V>
+__device__ __forceinline__ void pin16(V& x) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float a = x[8 * q], b = x[8 * q + 1], c = x[8 * q + 2], d = x[8 * q + 3], e = x[8 * q + 4], f = x[8 * q + 5], g = x[8 * q + 6], h = x[8 * q + 7];
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+        x[8 * q] = a, x[8 * q + 1] = b, x[8 * q + 2] = c, x[8 * q + 3] = d, x[8 * q + 4] = e, x[8 * q + 5] = f, x[8 * q + 6] = g, x[8 * q + 7] = h;
+    }
+}
 __device__ __forceinline__ f16x8 fragh(unsigned a, unsigned b, unsigned c, unsigned d) {
     uint4 o;
     o.x = a, o.y = b, o.z = c, o.w = d;
@@ -378,10 +388,8 @@ struct HeadArgs {
 // same weights, so 8 of their 10 first-layer tiles and 192 of their 228 second-layer MFMAs per 32 rows are the SAME work --
 // one pass over the state tiles, then the action tiles twice: branch A (input a: TD seed, masks, T1) from a copy of the
 // accumulators, branch B (input mu: the action gradient through M) in place.
-// HEAD_BOTH keeps the state part (64 registers), the branch-A accumulators (64), T1 (64) and M (64) alive: it runs ONE wave
-// per SIMD (4 waves, up to 512 registers each) and relies on the in-wave interleave of split VALU and MFMAs; the other modes
-// run two waves per SIMD at <= 256 registers.
-__host__ __device__ constexpr int head_waves(int mode) { return mode == HEAD_BOTH ? 4 : 8; }
+// waves per workgroup (every mode: 8 = two per SIMD at <= 256 registers)
+__host__ __device__ constexpr int head_waves(int mode) { return 8; }
 
 template <int S, class NET, int MODE>
 __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadArgs p) {
@@ -434,14 +442,14 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
     const f16* wlo0 = &wimg[1][r * LD + 8 * h];
     // the sequence of feature tiles of a unit: tiles 0 .. NFT - 1; HEAD_BOTH: + the action tiles 8, 9 once more (input mu)
-    constexpr int NSEQ = BOTH ? NFT + 2 : NFT;
+    constexpr int NSEQ = BOTH ? 8 : NFT;  // HEAD_BOTH: the state tiles; the action tiles are streamed per column tile below
     for (int k = q; k < ntile; k += NW / 2) {
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
         const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h), xb = BOTH ? make_xh(nb, 0.f, 0.f, 0.f, h) : xa;
         const float ty = ny, tw = nw;
         if (k + NW / 2 < ntile) fetch_in(k + NW / 2);
-        f32x16 acc[4], accA[4], M[AG ? 4 : 1];  // (accA: HEAD_BOTH only, dead otherwise)
+        f32x16 acc[4], M[(AG && !BOTH) ? 4 : 1];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -449,10 +457,8 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 const float4 b = *(const float4*)(b2s + 32 * t + 8 * g + 4 * h);
                 acc[t][4 * g] = b.x, acc[t][4 * g + 1] = b.y, acc[t][4 * g + 2] = b.z, acc[t][4 * g + 3] = b.w;
             }
-        if (!BOTH) {
 #pragma unroll
-            for (int t = 0; t < (AG ? 4 : 1); ++t) M[t] = zero16;
-        }
+        for (int t = 0; t < ((AG && !BOTH) ? 4 : 1); ++t) M[t] = zero16;
         // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
         unsigned ph[8], pl[8];
         auto split16 = [&](const f32x16& p1) {
@@ -460,63 +466,82 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), ph[m], pl[m]);
         };
         // ---- epilogues -----------------------------------------------------------------------------------------------
+        // per 32-column tile t (the lane holds columns 32 t + 8 g + 4 h + j of its row, its partner the other half):
+        auto zdot_t = [&](f32x16& a, int t) {  // relu in place; returns this lane's part of sum_n c3[n] relu(z2[n])
+            float zp = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[4 * g + j] = relu(a[4 * g + j]);
+                    zp = fmaf(a[4 * g + j], cc[j], zp);
+                }
+            }
+            return zp;
+        };
+        auto zdot_nd = [&](const f32x16& a, int t) {  // the same without touching a
+            float zp = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zp = fmaf(relu(a[4 * g + j]), cc[j], zp);
+            }
+            return zp;
+        };
+        auto bwd_t = [&](const f32x16& a, int t, float g3i, unsigned s16, bf16* dst) {  // T1 and the signed mask of tile t (a = z2 or relu(z2))
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 4 * g + 2 * e;
+                    T1[BWD ? t : 0][i] = fmaf(g3i, BOTH ? relu(a[i]) : a[i], T1[BWD ? t : 0][i]);
+                    T1[BWD ? t : 0][i + 1] = fmaf(g3i, BOTH ? relu(a[i + 1]) : a[i + 1], T1[BWD ? t : 0][i + 1]);
+                    pk[g][e] = (a[i] > 0.f ? s16 : 0u) | (a[i + 1] > 0.f ? s16 << 16 : 0u);
+                }
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                uint4 o;
+                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                *(uint4*)(dst + 32 * t + 16 * gg) = o;
+            }
+        };
+        auto dmu_t = [&](const f32x16& a, const f32x16& m, int t) {  // this lane's part of sum_n c3[n] [z2 > 0] M[n]
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += a[4 * g + j] > 0.f ? cc[j] * m[4 * g + j] : 0.f;
+            }
+            return sum;
+        };
         auto out_z = [&](f32x16 (&ac)[4]) {  // relu in place, output layer: z = d3 + sum_n c3[n] relu(z2[n])
             float zp = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
-                    const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ac[t][4 * g + j] = relu(ac[t][4 * g + j]);
-                        zp = fmaf(ac[t][4 * g + j], cc[j], zp);
-                    }
-                }
+            for (int t = 0; t < 4; ++t) zp += zdot_t(ac[t], t);
             zp += __shfl_xor(zp, 32);
             return d3 + zp;
         };
         auto epi_bwd = [&](f32x16 (&ac)[4], float g3) {  // row factor, masks and T1 of a backward pass
             if (h == 0) p.g3[ri] = g3;
-            const float g3i = g3 * isc;  // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc)
-            const unsigned s16 = g3 < 0.f ? 0xbf80u : 0x3f80u;  // bf16 -1 / +1
-            bf16* dst = p.sm + ri * H2 + 8 * h;
+            // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc); the mask carries the sign of g3 as bf16 -1 / +1
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                unsigned pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int i = 4 * g + 2 * e;
-                        T1[t][i] = fmaf(g3i, ac[t][i], T1[t][i]);
-                        T1[t][i + 1] = fmaf(g3i, ac[t][i + 1], T1[t][i + 1]);
-                        pk[g][e] = (ac[t][i] > 0.f ? s16 : 0u) | (ac[t][i + 1] > 0.f ? s16 << 16 : 0u);
-                    }
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                    uint4 o;
-                    o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
-                    *(uint4*)(dst + 32 * t + 16 * gg) = o;
-                }
-            }
+            for (int t = 0; t < 4; ++t) bwd_t(ac[t], t, g3 * isc, g3 < 0.f ? 0xbf80u : 0x3f80u, p.sm + ri * H2 + 8 * h);
         };
         auto epi_dmu = [&](f32x16 (&ac)[4], float g3) {
             // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
             // (the accumulators hold SW S1 M -- SW from the weights, S1 from the scaled wa -- and c3s carries 1 / (SW S1))
             float sum = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
-                    const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sum += ac[t][4 * g + j] > 0.f ? cc[j] * M[AG ? t : 0][4 * g + j] : 0.f;
-                }
+            for (int t = 0; t < 4; ++t) sum += dmu_t(ac[t], M[AG ? t : 0], t);
             sum += __shfl_xor(sum, 32);
             if (h == 0) p.dmu[ri] = g3 * sum;
         };
@@ -538,16 +563,13 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         read_group(0, wg[0]);
         auto tile = [&](auto si_c, f32x16 (&ac)[4]) {
             constexpr int si = decltype(si_c)::value;
-            constexpr int ft = si < NFT ? si : si - 2;    // feature tile
-            constexpr bool brB = BOTH && si >= NFT;        // HEAD_BOTH: second time through the action tiles (input mu)
-            constexpr bool with_m = AG && ft >= 8 && (!BOTH || brB);
+            constexpr int ft = si;                          // feature tile
+            constexpr bool with_m = AG && !BOTH && ft >= 8;  // (HEAD_BOTH streams its action tiles after the sequence)
             // the first layer of the next tile of the sequence
             f32x16 p1n = zero16;
             if constexpr (si + 1 < NSEQ) {
-                constexpr int fn = si + 1 < NFT ? si + 1 : si - 1;
-                constexpr bool nB = BOTH && si + 1 >= NFT;
-                p1n = mfmah(wfn, (NET::critic && fn >= 8) ? (nB ? xb : xa) : xs, zero16);
-                if constexpr (si + 2 < NSEQ) wfn = wf1[64 * (si + 2 < NFT ? si + 2 : si)];
+                p1n = mfmah(wfn, (NET::critic && si + 1 >= 8) ? xa : xs, zero16);
+                if constexpr (si + 2 < NSEQ) wfn = wf1[64 * (si + 2)];
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -575,10 +597,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #pragma unroll
                 for (int th = 0; th < 2; ++th) {
                     const int g = 2 * ks + th;
-                    // the next group of the sequence (after the last k-step: the first action k-step again, HEAD_BOTH)
-                    int gn = g + 1;
-                    if (gn >= 2 * NKS) gn = (BOTH && !brB) ? 2 * 16 : -1;
-                    if (gn >= 0) read_group(gn, wg[(g + 1) & 1]);
+                    if (g + 1 < 2 * (BOTH ? 16 : NKS)) read_group(g + 1, wg[(g + 1) & 1]);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const int t = 2 * th + tt;
@@ -610,37 +629,118 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             // (tiles stay in program order: hoisting every tile's first-layer MFMA and weight reads costs hundreds of registers)
             __builtin_amdgcn_sched_barrier(0);
         };
-        static_for<0, NSEQ>([&](auto si_c) {
-            constexpr int si = decltype(si_c)::value;
-            if constexpr (BOTH && si == 8) {  // branch A starts from a copy of the state part
+        static_for<0, NSEQ>([&](auto si_c) { tile(si_c, acc); });
+        if constexpr (BOTH) {
+            // acc = the state part of z2 (+ bias); the action part is 3 k-steps. Three sweeps of 36 MFMAs over the four column
+            // tiles, all on the ONE set of accumulators (acc + T1 + M never coexist: <= 256 registers, two waves per SIMD):
+            //   A : acc += W2T[:, action] . f(a)             -> z, TD seed, masks, T1 (acc left as z2, not relu'd)
+            //   B1: acc += W2T[:, action] . (f(mu) - f(a))   -> z2 of the mu branch by linearity: q and 64 relu bits per lane
+            //   B2: M = W2T[:, action] . (mask_a (.) wa)     -> dmu
+            // (an earlier form kept both branches' accumulators and M alive: 256 + 244 registers, one wave per SIMD, 456 us)
+            f16x8 fh[3], fl[3];
+            auto act_sweep = [&](f32x16 (&c)[4]) {  // c[t] += W2T[tile t, action k-steps] . (fh, fl)
+                f16x8 wq[2][2][2];
+                read_group(2 * 16, wq[0]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accA[t] = acc[t];
-            }
-            if constexpr (BOTH && si >= 8 && si < NFT) tile(si_c, accA);
-            else tile(si_c, acc);
-            if constexpr (BOTH && si == NFT - 1) {
-                // branch A is complete: critic(s, a) -> TD seed, masks, T1 (workers/trainer.py:494-498)
-                const float z = out_z(accA);
-                const float diff = z - ty, g3 = 2.f * diff * p.inv_n * tw;
-                epi_bwd(accA, g3);
-                if (h == 0) Dacc += g3, Lacc += diff * diff;
-                __builtin_amdgcn_sched_barrier(0);
-                // branch B's M accumulators come alive only now (they can take over branch A's registers)
+                for (int g = 0; g < 6; ++g) {
+                    if (g + 1 < 6) read_group(2 * 16 + g + 1, wq[(g + 1) & 1]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) M[t] = zero16;
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * (g & 1) + tt;
+                        const f16x8 whi = wq[g & 1][tt][0], wlo = wq[g & 1][tt][1];
+                        c[t] = mfmah(whi, fh[g >> 1], c[t]);
+                        c[t] = mfmah(wlo, fh[g >> 1], c[t]);
+                        c[t] = mfmah(whi, fl[g >> 1], c[t]);
+                    }
+                }
+            };
+            // ---- branch A: critic(s, a) -> TD seed, masks, T1 (workers/trainer.py:494-498)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const f32x16 p1 = mfmah(wf1[64 * (8 + tl)], xa, zero16);
+                split16(p1);
+#pragma unroll
+                for (int ss = 0; ss < 2 - tl; ++ss) {
+                    fh[2 * tl + ss] = fragh(ph[4 * ss], ph[4 * ss + 1], ph[4 * ss + 2], ph[4 * ss + 3]);
+                    fl[2 * tl + ss] = fragh(pl[4 * ss], pl[4 * ss + 1], pl[4 * ss + 2], pl[4 * ss + 3]);
+                }
             }
-        });
+            act_sweep(acc);
+            {
+                float zp = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) zp += zdot_nd(acc[t], t);
+                zp += __shfl_xor(zp, 32);
+                const float diff = d3 + zp - ty, g3a = 2.f * diff * p.inv_n * tw;
+                if (h == 0) p.g3[ri] = g3a, Dacc += g3a, Lacc += diff * diff;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bwd_t(acc[t], t, g3a * isc, g3a < 0.f ? 0xbf80u : 0x3f80u, p.sm + ri * H2 + 8 * h);
+                    // (pin the update HERE: the optimiser otherwise sinks it below branch B and keeps relu(z2) alive across it)
+                    pin16(T1[BWD ? t : 0]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- branch B: critic(s, mu) -> the actor loss -mean(q) and its gradient w.r.t. the action (:501-504)
+            f16x8 mh[3], ml[3];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const f32x16 pa = mfmah(wf1[64 * (8 + tl)], xa, zero16), pm = mfmah(wf1[64 * (8 + tl)], xb, zero16);
+                unsigned dh[8], dl[8], mk[8];
+#pragma unroll
+                for (int m = 0; m < 4 * (2 - tl); ++m) {
+                    split2h(relu(pm[2 * m]) - relu(pa[2 * m]), relu(pm[2 * m + 1]) - relu(pa[2 * m + 1]), dh[m], dl[m]);
+                    mk[m] = (pm[2 * m] > 0.f ? 0xffffu : 0u) | (pm[2 * m + 1] > 0.f ? 0xffff0000u : 0u);
+                }
+#pragma unroll
+                for (int ss = 0; ss < 2 - tl; ++ss) {
+                    const int kk = 2 * tl + ss;
+                    fh[kk] = fragh(dh[4 * ss], dh[4 * ss + 1], dh[4 * ss + 2], dh[4 * ss + 3]);
+                    fl[kk] = fragh(dl[4 * ss], dl[4 * ss + 1], dl[4 * ss + 2], dl[4 * ss + 3]);
+                    // B operand of M = mask_a * wa (hi, lo): the packed constants where the mu branch's activation is positive
+                    const uint4 ch = *(const uint4*)(waps + (0 * 2 + h) * 12 + 4 * kk), cl = *(const uint4*)(waps + (1 * 2 + h) * 12 + 4 * kk);
+                    mh[kk] = fragh(ch.x & mk[4 * ss], ch.y & mk[4 * ss + 1], ch.z & mk[4 * ss + 2], ch.w & mk[4 * ss + 3]);
+                    ml[kk] = fragh(cl.x & mk[4 * ss], cl.y & mk[4 * ss + 1], cl.z & mk[4 * ss + 2], cl.w & mk[4 * ss + 3]);
+                }
+            }
+            act_sweep(acc);
+            float zq = 0.f;
+            unsigned pos[2] = {0u, 0u};  // bit 16 (t & 1) + i of pos[t >> 1]: column i of tile t is active in the mu branch
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                zq += zdot_nd(acc[t], t);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pos[t >> 1] |= acc[t][i] > 0.f ? 1u << (16 * (t & 1) + i) : 0u;
+            }
+            zq += __shfl_xor(zq, 32);
+            asm volatile("" : "+v"(pos[0]), "+v"(pos[1]));  // (acc dies here)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) fh[kk] = mh[kk], fl[kk] = ml[kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = zero16;
+            act_sweep(acc);
+            // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row] (the accumulators hold SW S1 M, c3s carries 1 / (SW S1))
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
+                    const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += (pos[t >> 1] >> (16 * (t & 1) + 4 * g + j) & 1u) ? cc[j] * acc[t][4 * g + j] : 0.f;
+                }
+            sum += __shfl_xor(sum, 32);
+            const float g3b = -p.inv_n * tw;
+            if (h == 0) p.dmu[ri] = g3b * sum, Dacc2 += g3b, Lacc2 += d3 + zq;
+            continue;
+        }
         const float z = out_z(acc);
         if (MODE == OUT_TANH) {
             const float o = tanhf(z) * p.high;
             if (h == 0) p.out[ri] = o;
         } else if (MODE == OUT_TD) {
             if (h == 0) p.out[ri] = ty + p.gamma * z;
-        } else if (BOTH) {
-            // branch B: critic(s, mu) -> the actor loss -mean(q) and its gradient w.r.t. the action (:501-504)
-            const float g3 = -p.inv_n * tw;
-            epi_dmu(acc, g3);
-            if (h == 0) Dacc2 += g3, Lacc2 += z;
         } else {
             float g3, loss;
             if (MODE == HEAD_CRITIC) {

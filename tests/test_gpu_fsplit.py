@@ -16,6 +16,46 @@ from tests.test_gpu_mlp import GRAD_TOL, _nets, _perturbed_group, _relerr
 pytestmark = pytest.mark.gpu
 
 
+def _untie(grp, M, S, s, a, tie=1e-6):
+    """The relu derivative is discontinuous at 0: a row with a pre-activation within float32 resolution of 0 in a layer that is
+    differentiated (actor(s), critic(s, a), critic(s, mu)) has no defined float32 gradient -- the same arithmetic in another
+    order decides the sign the other way, and ONE such row moves the actor's first-layer gradient of a 4480-row batch by 1e-3
+    of its max (seen: |z2| = 1.1e-8 at scale 0.8 in one row of 22400; tools/fsplit_both_debug.py). The inputs of the
+    oracle-tolerance tests are conditioned instead: rows with any pre-activation closer to 0 than `tie` x its layer's largest
+    are nudged (in place, deterministically) until none is left. Returns the number of nudges."""
+    nudged = 0
+    for _ in range(8):
+        bad = np.zeros(s.shape[:2], bool)
+        for k in range(M):
+            an, cn, _, _ = _nets(grp, k, np.float64)
+            sel = np.arange(k, s.shape[0], M)
+            x = s[sel].reshape(-1, s.shape[2])[:, :S].astype(np.float64)
+            act = a[sel].reshape(-1, 1).astype(np.float64)
+            W1, b1, _, _, _, _, W2, b2 = an[:8]
+            z1 = x @ W1 + b1
+            y1 = np.maximum(z1, 0) * omlp._bn_coeffs(*an[2:6])[0] + omlp._bn_coeffs(*an[2:6])[1]
+            pre = [z1, y1 @ W2 + b2]
+            mu = omlp.actor_forward(an, x, 2.5)
+            Ws, bs, Wa, ba = cn[:4]
+            CW2, cb2 = cn[12], cn[13]
+            ys = np.maximum(x @ Ws + bs, 0) * omlp._bn_coeffs(*cn[4:8])[0] + omlp._bn_coeffs(*cn[4:8])[1]
+            pre.append(x @ Ws + bs)
+            for u in (act, mu):
+                za = u @ Wa + ba
+                ya = np.maximum(za, 0) * omlp._bn_coeffs(*cn[8:12])[0] + omlp._bn_coeffs(*cn[8:12])[1]
+                pre += [za, np.concatenate([ys, ya], axis=1) @ CW2 + cb2]
+            t_ = np.zeros(len(x), bool)
+            for z in pre:
+                t_ |= (np.abs(z) < tie * np.abs(z).max()).any(axis=1)
+            bad[sel] = t_.reshape(len(sel), -1)
+        if not bad.any():
+            return nudged
+        nudged += int(bad.sum())
+        s[bad] += np.float32(0.0173)
+        a[bad] = np.clip(a[bad] + np.float32(0.0091), -2.5, 2.5)
+    raise AssertionError("could not condition the batch")
+
+
 @pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
 def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     """The mean over a set's P agents of their 64-row batch gradients == the gradient of the P*64-row batch (inference-mode
@@ -27,6 +67,7 @@ def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     rs = np.random.RandomState(62)
     n = P * M  # agent v = p*M + m uses set m
     s, a, r, s2 = _batch(rs, n, S)
+    _untie(grp, M, S, s, a)
     losses = torch.zeros(M, 2, device="cuda")
     g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n, losses=losses)
     torch.cuda.synchronize()
@@ -59,6 +100,7 @@ def test_split_set_learner_equals_per_agent_f32_kernel_plus_federated_mean(P, M)
     rs = np.random.RandomState(72)
     n = P * M
     s, a, r, s2 = _batch(rs, n, S)
+    _untie(grp, M, S, s, a)
     per_agent = grp.learn(t(s), t(a), t(r), t(s2), M)
     avg = vec.fed_mean(per_agent, P, M, method=conf.interfrl).cpu().numpy()  # [M, theta]
     split = grp.learn_set_split(t(s), t(a), t(r), t(s2), n).cpu().numpy()
