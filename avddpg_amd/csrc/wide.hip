@@ -430,7 +430,7 @@ __global__ void bn_tables_kernel(const float* th, const float* st, long set_th, 
 // Layer-2 weights W[K][N] (f32, Keras layout) -> WT[N][Kp] = bf16(inv[k] * W[k][n]) (forward B operand) and
 // Wn[K][N] = bf16(W[k][n]) (dX B operand: rows = features, reduction over n). 32x32 LDS transpose tiles.
 __global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, int N, int Kp, const float* inv, long set_tab,
-                               bf16* WT, long set_wt, bf16* Wn, long set_wn) {
+                               bf16* WT, long set_wt, bf16* Wn, long set_wn, int perm) {
     __shared__ float tile[32][33];
     const int set = blockIdx.z, k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const float* W = th + (long)set * set_th + w_off;
@@ -447,7 +447,9 @@ __global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, i
         const int n = n0 + r, k = k0 + tx;
         if (n < N && k < Kp) {
             const float iv = (k < K) ? inv[(long)set * set_tab + k] : 0.f;
-            WT[(long)set * set_wt + (long)n * Kp + k] = (bf16)(tile[tx][r] * iv);
+            // perm: bits 2 and 3 of k swapped (the k order of fw::fwd_gen_kernel's generated operand)
+            const int kd = perm ? ((k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)) : k;
+            WT[(long)set * set_wt + (long)n * Kp + kd] = (bf16)(tile[tx][r] * iv);
         }
     }
 }
@@ -771,6 +773,350 @@ extern "C" int avd_gemm_bt_bf16(int M, int Nc, int K, const void* A, long lda, c
     return launch_gemm(p, e, 1, (hipStream_t)stream, "avd_gemm_bt_bf16");
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused forward pass for second layers of n x 512 columns (BASELINE config 5: hidden 1024): first layer -> second layer ->
+// output-layer dot in ONE persistent kernel; the [N x K] first-layer activation matrix never exists in memory.
+//   * unit of work = 128 rows x 512 columns on 4 waves (one per SIMD, 64 rows x 256 columns each = 256 accumulator registers,
+//     pinned to the AGPRs);
+//   * the A operand is GENERATED: per 32-feature chunk one v_mfma_f32_32x32x16_bf16 per 32 rows evaluates x . W1 + b1 from
+//     bf16 hi/lo pairs of x, W1 and b1 in the 16 k slots (2^-16); relu + bf16 pack turns its accumulator tile
+//     [feature][row] into the B operand of the two k-steps of the main product (k order = accumulator order: the weight
+//     image is stored with bits 2 and 3 of k swapped);
+//   * the other operand, bf16(inv (.) W2)^T, streams L2 -> LDS by global_load_lds in chunks of 32 k (+ the chunk's 1 KiB of
+//     first-layer fragments) through FOUR stages = three chunks (99 KiB) in flight per CU: the stream is periodic in K and
+//     carries on across the row tiles of a (set, column block) pair, whose tiles are dealt over ALL workgroups, so the chip
+//     streams one 1.1 MB weight block at a time (resident in every XCD's L2). 64-byte image rows, 16-byte chunks XOR-swizzled by
+//     bits 2..3 of the row: conflict-free for the lane groups ds_read_b128 is served in;
+//   * the loop is rotated: the fragment reads of the next chunk, the counted vmcnt wait and the barrier sit between two
+//     blocks of 16 MFMAs whose operands are already in registers.
+// 128 FLOP per byte moved from L2 into LDS. The width-1 output layer rides along (rows complete in the kernel at 512 columns;
+// one f32 atomic per row and column block beyond).
+// ------------------------------------------------------------------------------------------
+namespace avd { namespace fset { int cu_count(); } }
+namespace fw {
+constexpr int FR = 128, FC = 512, FK = 32, FSTG = 4, FT = 512;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split_bf(float x, bf16& hi, bf16& lo) {
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+__host__ __device__ constexpr int kpos(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }  // swap bits 2 and 3
+
+// k slots of the first-layer MFMA (lane half h holds slots 8h .. 8h + 7):
+//   states : x = [xh0..3 | xl0..3 | xh0..3 | 1 1 0 0],  w = [wh0..3 | wh0..3 | wl0..3 | bh bl 0 0]
+//   action : x = [ah al ah 1 | 1 0 0 0 | 0 ...],        w = [wh wh wl bh | bl 0 0 0 | 0 ...]
+__device__ __forceinline__ bf16x8 x_frag_state(const float (&x)[4], bool live, int h) {
+    bf16 hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf(live ? x[j] : 0.f, hi[j], lo[j]);
+    const bf16 one = (bf16)(live ? 1.f : 0.f), zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = hi[0], v[1] = hi[1], v[2] = hi[2], v[3] = hi[3];
+    v[4] = h ? one : lo[0], v[5] = h ? one : lo[1], v[6] = h ? zero : lo[2], v[7] = h ? zero : lo[3];
+    return v;
+}
+__device__ __forceinline__ bf16x8 x_frag_action(float a, bool live, int h) {
+    bf16 hi, lo;
+    split_bf(live ? a : 0.f, hi, lo);
+    const bf16 one = (bf16)(live ? 1.f : 0.f), zero = (bf16)0.f;
+    bf16x8 v;
+    v[0] = h ? zero : hi, v[1] = h ? zero : lo, v[2] = h ? zero : hi, v[3] = h ? zero : one;
+    v[4] = h ? zero : one, v[5] = zero, v[6] = zero, v[7] = zero;
+    return v;
+}
+
+// first-layer weight fragments [sets][nft][64 lanes] (tile t < nfs: 32 state features, else 32 action features)
+__global__ void prep_wf1_kernel(const float* th, long set_th, int S, int ws_off, int bs_off, int H1, int wa_off, int ba_off, int Ha,
+                                int nfs, int nft, bf16x8* wf1) {
+    const int set = blockIdx.y, t = blockIdx.x, lane = threadIdx.x, f = lane & 31, h = lane >> 5;
+    const float* T = th + (long)set * set_th;
+    const bf16 zero = (bf16)0.f;
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = zero;
+    if (t < nfs) {
+        const int k = 32 * t + f;
+        bf16 wh[4], wl[4], bh, bl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_bf((j < S && k < H1) ? T[ws_off + (long)j * H1 + k] : 0.f, wh[j], wl[j]);
+        split_bf(k < H1 ? T[bs_off + k] : 0.f, bh, bl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = h ? wl[j] : wh[j];
+        v[4] = h ? bh : wh[0], v[5] = h ? bl : wh[1], v[6] = h ? zero : wh[2], v[7] = h ? zero : wh[3];
+    } else if (h == 0) {
+        const int k = 32 * (t - nfs) + f;
+        bf16 wh, wl, bh, bl;
+        split_bf(k < Ha ? T[wa_off + k] : 0.f, wh, wl);
+        split_bf(k < Ha ? T[ba_off + k] : 0.f, bh, bl);
+        v[0] = wh, v[1] = wh, v[2] = wl, v[3] = bh, v[4] = bl;
+    }
+    wf1[((long)set * nft + t) * 64 + lane] = v;
+}
+
+struct FwdP {
+    const float* X;      // [sets][Ns][S]
+    long setX;
+    const float* act;    // critic: [sets][setAct] actions, else NULL
+    long setAct;
+    const bf16x8* wf1;   // [sets][nft][64]
+    int nft, nfs;        // 32-feature tiles: all / state
+    const bf16* WT;      // [sets][512][ldw], k permuted by kpos within groups of 16
+    long setWT, ldw;
+    const float *bias, *cf, *c0;  // [sets][512], [sets][512], [sets]
+    bf16* P2;            // [sets][Np][512] or NULL
+    long setP2;
+    float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
+    long setZ;
+    int Ns, Np, H2, n_sets;  // Np: padded rows (multiple of 128); H2: multiple of 512
+    int dbg;                 // diagnostics (AVD_FW_DBG bits: 1 no refill DMA, 2 no relu / pack, 4 no step barrier, 8 no epilogue): wrong results
+};
+
+// diagnostics build (-DAVD_FW_DBG): AVD_FW_DBG=<bits> switches pieces of the kernel off (tools/c5_dbg.sh; results wrong)
+#ifdef AVD_FW_DBG
+#define FW_DBG(bit) (p.dbg & (bit))
+#else
+#define FW_DBG(bit) false
+#endif
+// One stage = the 32 k x 512 column chunk (32 KiB) + the first-layer fragments of that chunk's 32 features (1 KiB).
+constexpr int STG_BYTES = FC * FK * 2 + 1024;
+constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
+              L_XF = L_AR + FR * 4, L_TOTAL = L_XF + 2 * 8 * 1024;  // XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B
+template <bool CRITIC>
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_gen_kernel(FwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* zs = (float*)(smem_raw + L_ZS);      // [4 column quarters][FR]
+    float* sbias = (float*)(smem_raw + L_BIAS);  // [FC]
+    float* scf = (float*)(smem_raw + L_CF);      // [FC]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int rh = wave & 1, cq = wave >> 1;  // 64-row half, 128-column quarter
+    const int nk = p.nft, ncb = p.H2 / FC, ntile = p.Np / FR;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
+    // relu + bf16 of half a first-layer tile: k-step ks of the chunk <- registers 8 ks .. 8 ks + 7
+    // (one v_cvt_pk_bf16_f32 + one v_pk_max_i16 per pair: a negative bf16 is a negative int16)
+    auto pack = [&](const f32x16& p1, int ks, bf16x8& b) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x2 v;
+            v[0] = (bf16)p1[8 * ks + 2 * i], v[1] = (bf16)p1[8 * ks + 2 * i + 1];
+            const s16x2 z = {0, 0};
+            w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+        }
+        wide::u32x4 o;
+        o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+        b = __builtin_bit_cast(bf16x8, o);
+    };
+    // fragment reads: image row = 128 cq + 32 ct + r, logical 16-byte chunk 2 ks + h, swizzled by bits 2..3 of the row
+    const int sw = (r >> 2) & 3;
+    const int rd0 = ((128 * cq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rd1 = ((128 * cq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+    auto read_frags = [&](int stg, int ks, bf16x8 (&a)[4]) {
+        const unsigned char* b = smem_raw + stg * STG_BYTES + (ks ? rd1 : rd0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
+    };
+    auto wf_at = [&](int stg) { return *(const bf16x8*)(smem_raw + stg * STG_BYTES + FC * FK * 2 + lane * 16); };
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+    // every workgroup walks the (set, 512-column block) pairs in the same order and takes its share of each pair's row tiles:
+    // at any time the chip streams ONE 512 x K weight block (1.1 MB: every XCD's L2 holds it)
+    for (int pair = 0; pair < p.n_sets * ncb; ++pair) {
+        const int set = pair / ncb, cb = pair - set * ncb;
+        int tile = blockIdx.x;
+        if (tile >= ntile) continue;  // (uniform per workgroup)
+        // wave w fills image rows (= output columns) [64 w, 64 w + 64), 16 rows per instruction (lane -> row l / 4, slot l % 4),
+        // and dwords [64 (w % 4), ..) of the chunk's first-layer fragments (waves 4..7 repeat what waves 0..3 write: one
+        // instruction count for everybody). Addresses are wave-uniform base + one 32-bit lane offset (scalar-base form).
+        const char* ubw = (const char*)(p.WT + (long)set * p.setWT + (long)(FC * cb + 64 * wv) * p.ldw);
+        const unsigned vow = (unsigned)(((lane >> 2) * p.ldw + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+        const long g16 = 32 * p.ldw;  // bytes between instructions (16 image rows)
+        const char* ubf = (const char*)((const float*)(p.wf1 + (long)set * nk * 64) + 64 * (wv & 3));
+        const unsigned vof = (unsigned)lane * 4u;
+        // one chunk = 5 wave-instructions, issued in two parts (0: 2 image instructions, 1: 2 + the fragments)
+        auto dma = [&](int stg, int kc, int part) {
+            unsigned char* l = smem_raw + stg * STG_BYTES;
+            unsigned vw = vow;
+            asm volatile("" : "+v"(vw));  // (opaque per call: keeps the scalar-base + lane-offset address form)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((i >> 1) == part)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + kc * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
+            if (part == 1)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kc * 1024 + (vw & 0u) + vof), (lptr_t)(l + FC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
+        };
+        // raw inputs of a row tile into LDS buffer b (every wave issues the same 4 instructions: uniform counts). Rows beyond
+        // Ns are clamped to row Ns - 1 here and zeroed when the fragments are built.
+        auto dma_x = [&](int t) {
+            if (t >= ntile) t = ntile - 1;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int n = t * FR + 64 * half + lane;
+                n = n < p.Ns ? n : p.Ns - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + L_XR + (64 * half) * 16), 16, 0, 0);
+                if (CRITIC)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + L_AR + (64 * half) * 4), 4, 0, 0);
+            }
+        };
+        // fragments of row tile t from the raw rows, into fragment buffer b (the two waves with cq == 0 do it for their row half)
+        auto build_x = [&](int t, int b) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = rh * 64 + 32 * rt + r, n = t * FR + row;
+                const bool live = t < ntile && n < p.Ns;
+                const f32x4 xv = *(const f32x4*)(smem_raw + L_XR + row * 16);
+                const float x[4] = {xv[0], xv[1], xv[2], xv[3]};
+                bf16x8* d = (bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + rt) * 1024) + lane;
+                d[0] = x_frag_state(x, live, h);
+                if (CRITIC) d[128] = x_frag_action(*(const float*)(smem_raw + L_AR + row * 4), live, h);
+            }
+        };
+        auto x_frag = [&](int b, bool action, int rt) {
+            return *((const bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
+        };
+        __syncthreads();  // (the previous pair's LDS reads are done)
+        sbias[tid] = p.bias[(long)set * p.H2 + FC * cb + tid];
+        scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+        dma_x(tile);
+        // ---- start the stream: chunks 0 .. 3 into stages 0 .. 3
+#pragma unroll
+        for (int c = 0; c < FSTG; ++c) dma(c, c % nk, 0), dma(c, c % nk, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
+        if (cq == 0) build_x(tile, 0);
+        __syncthreads();
+        bf16x8 bfr[2][2], A0[4], A1[4];
+        {
+            const bf16x8 wf0 = wf_at(0);
+
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x16 p1 = mfma(wf0, x_frag(0, false, rt), zero16);
+                pack(p1, 0, bfr[rt][0]), pack(p1, 1, bfr[rt][1]);
+            }
+        }
+        read_frags(0, 0, A0);
+        int stg = 0;  // stage of the chunk being multiplied (the stream is periodic in nk and carries on across row tiles)
+        int pstg = FSTG - 1, pkc = (FSTG - 1) % nk;  // chunk whose part 1 is still to be requested (first: a re-load of identical bytes)
+        int xb = 0;   // fragment buffer of the current tile's inputs
+        for (; tile < ntile; tile += gridDim.x) {
+            // accumulators start at the folded bias: tile (rt, ct), register 4 g + j <-> column 128 cq + 32 ct + 8 g + 4 h + j
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4*)(sbias + 128 * cq + 32 * ct + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[0][ct][4 * g + j] = bv[j], acc[1][ct][4 * g + j] = bv[j];
+                }
+            dma_x(tile + gridDim.x);  // the next tile's raw inputs (fragments are built in step nk - 2, used in step nk - 1)
+            for (int kt = 0; kt < nk; ++kt) {
+                const int sn = (stg + 1) & (FSTG - 1);
+                // ---- first half: k-step 0 of chunk kt, the fragments of k-step 1, part 1 of the previous refill
+                read_frags(stg, 1, A1);
+                if (!FW_DBG(1)) dma(pstg, pkc, 1);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(A0[ct], bfr[rt][0], acc[rt][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- this wave's reads of chunk kt are complete (lgkmcnt 0) and its share of chunk kt + 1 has landed: the loads
+                // in flight, oldest first, are those of chunks kt + 1, kt + 2, kt + 3 (5 each) -> all but the 10 youngest
+                __builtin_amdgcn_s_waitcnt(0x007A);  // vmcnt(10) lgkmcnt(0)
+                if (!FW_DBG(4)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- second half: fragments of chunk kt + 1 and its first layer (the next tile's chunk 0 after the last step); the
+                // stage just read starts to refill with chunk kt + 4; k-step 1 of chunk kt, relu / pack of chunk kt + 1
+                read_frags(sn, 0, A0);
+                const bf16x8 wfn = wf_at(sn);
+                if (kt + 2 == nk && cq == 0) build_x(tile + gridDim.x, xb ^ 1);  // (published by the next step's barrier)
+                const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
+                const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
+                {
+                    int kc = kt + FSTG;
+                    kc -= kc >= nk ? nk : 0;
+                    kc -= kc >= nk ? nk : 0;
+                    if (!FW_DBG(1)) dma(stg, kc, 0);
+                    pstg = stg, pkc = kc;
+                }
+                bf16x8 bn[2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const f32x16 p1n = mfma(wfn, x_frag(xbuf, act_next, rt), zero16);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2) acc[r2][2 * rt + c2] = mfma(A1[2 * rt + c2], bfr[r2][1], acc[r2][2 * rt + c2]);
+                    if (!FW_DBG(2)) pack(p1n, 0, bfr[rt][0]), pack(p1n, 1, bn[rt]);  // (bfr[.][0] is dead here, bfr[.][1] still an operand)
+                    else bn[rt] = bfr[rt][1];
+                }
+                bfr[0][1] = bn[0], bfr[1][1] = bn[1];
+                __builtin_amdgcn_sched_barrier(0);
+                stg = sn;
+            }
+            xb ^= 1;
+            // ---- epilogue: relu, bf16, output-layer dot on the stored (rounded) activations, row-major store
+            float zp[2] = {0.f, 0.f};
+            if (FW_DBG(8)) {
+                if (acc[0][0][0] == 123.456f) zs[tid] = acc[1][3][5];
+                continue;
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                bf16* dst = p.P2 ? p.P2 + (long)set * p.setP2 + n * p.H2 + FC * cb + 128 * cq + 8 * h : nullptr;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 cv = *(const f32x4*)(scf + 128 * cq + 32 * ct + 8 * g + 4 * h);
+                        bf16 o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = (bf16)fmaxf(acc[rt][ct][4 * g + j], 0.f);
+                            zp[rt] = fmaf((float)o[j], cv[j], zp[rt]);
+                        }
+                        pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
+                        pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
+                    }
+                    if (dst) {
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                            wide::u32x4 o;
+                            o[0] = s0[0], o[1] = s1[0], o[2] = s0[1], o[3] = s1[1];
+                            *(wide::u32x4*)(dst + 32 * ct + 16 * gg) = o;
+                        }
+                    }
+                }
+                zp[rt] += __shfl_xor(zp[rt], 32);
+                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp[rt];
+            }
+            // (the barriers below are matched by every wave; the DMA stream stays in flight across them. The stores above are
+            // vm operations YOUNGER than the stream's: they only make the counted wait of the next steps stricter)
+            __syncthreads();
+            if (tid < FR) {
+                float* zd = p.z + (long)set * p.setZ + (long)tile * FR + tid;
+                const float zt = (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]);
+                if (ncb == 1)
+                    *zd = p.c0[set] + zt;
+                else
+                    atomicAdd(zd, zt);
+            }
+            __syncthreads();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream before the next pair re-uses the stages / the LDS is released
+    }
+}
+}  // namespace fw
+
 // ---- workspace plan -------------------------------------------------------------------------
 namespace {
 struct Plan {
@@ -784,6 +1130,7 @@ struct Plan {
     size_t q, y, dq, a1, tt, da, zbuf;               // row vectors [sets][Np]
     size_t u, cs, acc;                               // [sets][H2] x 2, [sets][4]
     size_t bnacc;                                    // first-layer dgamma | dbeta partial tables [2][NSLICE][sets][ldT]
+    size_t wf1[4];                                   // fused forward: first-layer fragments [sets][KCp / 32][64] x 16 B per net
     size_t total;
     long ldT;  // table stride per set: KCp + H2
 };
@@ -814,6 +1161,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int row
     p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4), p.zbuf = take(sets * Np * 4);
     p.u = take(sets * d.H2 * 4), p.cs = take(sets * d.H2 * 4), p.acc = take(sets * 4 * 4);
     p.bnacc = take(2 * (size_t)NSLICE * sets * p.ldT * 4);
+    for (int i = 0; i < 4; ++i) p.wf1[i] = take(sets * (KCp / 32 + 1) * 64 * 16);
     p.total = o;
     return p;
 }
@@ -847,6 +1195,7 @@ struct NetOps {
     float *inv, *sh, *rs, *mean;  // tables [sets][ldT]: first-layer features at [0, KCp), second layer at [KCp, KCp + H2)
     bf16 *WT, *Wn;
     float *bias, *cf, *c0;
+    const void* wf1;  // fused forward: first-layer fragments
 };
 }  // namespace
 
@@ -885,6 +1234,16 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // (activation buffers need no clearing: their producers write every row < Np and every column < KCp, zeros in the
     //  padding; rows/columns beyond that only ever feed output elements the GEMM epilogues do not store)
 
+    // second layers of 512 n columns (config 5: 1024): the forward passes run fused (fw::fwd_gen_kernel); AVD_WIDE_FUSED_FWD=0: layer-wise
+    static const char* ff_env = getenv("AVD_WIDE_FUSED_FWD");
+    const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
+    static bool fw_attr = false;
+    constexpr size_t fw_lds = fw::L_TOTAL;
+    if (fused_fwd && !fw_attr) {
+        (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        fw_attr = true;
+    }
     // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
     NetOps net[4];  // 0 actor, 1 critic, 2 target actor, 3 target critic
     for (int i = 0; i < 4; ++i) {
@@ -895,7 +1254,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         float* tab = F32(pl.tabs[i]);
         n.inv = tab, n.sh = tab + (long)sets * ldT, n.rs = tab + 2L * sets * ldT, n.mean = tab + 3L * sets * ldT;
         n.WT = B16(pl.WT[i]), n.Wn = target ? nullptr : B16(pl.Wn[i]);
-        n.bias = F32(pl.bias[i]), n.cf = F32(pl.cf[i]), n.c0 = F32(pl.c0[i]);
+        n.bias = F32(pl.bias[i]), n.cf = F32(pl.cf[i]), n.c0 = F32(pl.c0[i]), n.wf1 = ws + pl.wf1[i];
         const int K = critic ? KC : H1;
         auto tables = [&](int g, int be, int mm, int mv, int len, int t_off, int pad_to) {
             hipLaunchKernelGGL(bn_tables_kernel, dim3((unsigned)rup(pad_to, 256) / 256, sets), dim3(256), 0, st, n.th, n.st,
@@ -912,7 +1271,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         }
         const int w2 = critic ? L.cW2 : L.aW2, b2 = critic ? L.cb2 : L.ab2, w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3;
         hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, n.th,
-                           (long)L.theta_size, w2, K, H2, KCp, n.inv, ldT, n.WT, setWT, n.Wn, setWn);
+                           (long)L.theta_size, w2, K, H2, KCp, n.inv, ldT, n.WT, setWT, n.Wn, setWn, fused_fwd ? 1 : 0);
+        if (fused_fwd) {
+            const int nfs = H1 / 32, nft = critic ? KCp / 32 : nfs;
+            hipLaunchKernelGGL(fw::prep_wf1_kernel, dim3((unsigned)nft, sets), dim3(64), 0, st, n.th, (long)L.theta_size, L.S,
+                               critic ? L.cWs : L.aW1, critic ? L.cbs : L.ab1, H1, critic ? L.cWa : 0, critic ? L.cba : 0,
+                               critic ? Ha : 0, nfs, nft, (bf16x8*)(ws + pl.wf1[i]));
+        }
         hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w2, b2, K,
                            H2, n.sh, ldT, n.bias, (long)H2);
         hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3, b3, H2, n.inv + KCp,
@@ -948,6 +1313,24 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                                Np, C, (long)KCp, setC, ct, (long)Np, setCT);
     };
     // second layer forward: P2 = relu(C @ WT^T + bias)
+    // fused: first layer + second layer + output-layer dot from the raw inputs (X, act): C is not read
+    auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2) {
+        fw::FwdP f;
+        f.X = X, f.setX = setX, f.act = critic ? act : nullptr, f.setAct = set_act;
+        f.wf1 = (const bf16x8*)n.wf1, f.nfs = H1 / 32, f.nft = critic ? KCp / 32 : H1 / 32;
+        f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
+        f.P2 = keep_p2 ? P2 : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
+        static const char* dbg_env = getenv("AVD_FW_DBG");
+        f.dbg = dbg_env ? atoi(dbg_env) : 0;
+        if (H2 > fw::FC)
+            hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, f.z, (long)Np, n.c0, Np);
+        const dim3 grid((unsigned)std::min<long>(avd::fset::cu_count(), Np / fw::FR));
+        if (critic)
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, f);
+        else
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, f);
+        return check_launch("avd_learn_shared_bf16: fused forward");
+    };
     auto l2 = [&](const NetOps& n, bool critic) {
         GemmP p = {C, n.WT, KCp, KCp, setC, setWT, Ns, H2, critic ? KCp : (int)rup(H1, 64), 1};
         // the output layer rides on the GEMM epilogue: q (critic) or z (actor, in `da`-free scratch `zbuf`) = c0 + P2 . cf
@@ -967,16 +1350,25 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     // Note on row-vector strides: r arrives as [sets][Ns] (stride Ns), internal vectors use stride Np. The TD kernel
     // reads r with the internal stride, so r is first copied into `da` (free at that point) with the padded stride.
+    // `transpose` = a backward pass follows: the first-layer activations (and their transposes) are materialised for it
     auto actor_forward = [&](const NetOps& n, const float* X, bool transpose) {
-        l1(n, false, false, X, setX, transpose);
-        WIDE_CHECK(l2(n, false));
+        if (!fused_fwd || transpose) l1(n, false, false, X, setX, transpose);
+        if (fused_fwd)
+            WIDE_CHECK(l2f(n, false, X, nullptr, 0, transpose));
+        else
+            WIDE_CHECK(l2(n, false));
         out_layer(n, 1, a1);
         return AVD_OK;
     };
     auto critic_forward = [&](const NetOps& n, const float* X, const float* act, long set_act, bool transpose) {
-        l1(n, true, false, X, setX, transpose);
-        l1(n, true, true, act, set_act, transpose);
-        WIDE_CHECK(l2(n, true));
+        if (!fused_fwd || transpose) {
+            l1(n, true, false, X, setX, transpose);
+            l1(n, true, true, act, set_act, transpose);
+        }
+        if (fused_fwd)
+            WIDE_CHECK(l2f(n, true, X, act, set_act, transpose));
+        else
+            WIDE_CHECK(l2(n, true));
         out_layer(n, 0, q);
         return AVD_OK;
     };
@@ -1063,8 +1455,11 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(actor_forward(net[0], s, true));  // activations and transposes stay for pass 3
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
-    l1(net[1], true, true, a1, (long)Np, false);
-    WIDE_CHECK(l2(net[1], true));
+    l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
+    if (fused_fwd)
+        WIDE_CHECK(l2f(net[1], true, s, a1, (long)Np, true));
+    else
+        WIDE_CHECK(l2(net[1], true));
     out_layer(net[1], 0, q);
     rows(2, q, nullptr, nullptr, 0.f, dq);
     WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
@@ -1118,7 +1513,7 @@ extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_ag
     tables(L.ag1, L.abe1, L.amm1, L.amv1, H1, 0, KCp);
     tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
     hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, theta,
-                       (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L);
+                       (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L, 0);
     hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW2, L.ab2,
                        H1, H2, sh, ldT, bias, (long)H2);
     hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW3, L.ab3, H2, inv + KCp, sh + KCp,
