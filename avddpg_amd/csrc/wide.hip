@@ -454,15 +454,23 @@ __global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, i
     }
 }
 
-// bias2[n] = b2[n] + sum_k sh[k] * W[k][n]
-__global__ void bias2_kernel(const float* th, long set_th, int w_off, int b_off, int K, int N, const float* sh, long set_tab,
-                             float* bias, long set_bias) {
-    const int set = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// bias2[n] = b2[n] + sum_k sh[k] * W[k][n]: one block per 64 columns, 16 k-groups of 64 threads (coalesced rows of W), LDS reduction
+__global__ __launch_bounds__(1024) void bias2_kernel(const float* th, long set_th, int w_off, int b_off, int K, int N, const float* sh,
+                                                     long set_tab, float* bias, long set_bias) {
+    __shared__ float part[16][64];
+    const int set = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
     const float* t = th + (long)set * set_th;
-    float acc = t[b_off + n];
-    for (int k = 0; k < K; ++k) acc = fmaf(sh[(long)set * set_tab + k], t[w_off + (long)k * N + n], acc);
-    bias[(long)set * set_bias + n] = acc;
+    float acc = 0.f;
+    if (n < N)
+        for (int k = g; k < K; k += 16) acc = fmaf(sh[(long)set * set_tab + k], t[w_off + (long)k * N + n], acc);
+    part[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float sum = t[b_off + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += part[i][c];
+        bias[(long)set * set_bias + n] = sum;
+    }
 }
 
 // First layer of a branch: C[n][c0 + k] = bf16(relu(sum_j X[n][j] W[j][k] + b[k])) for k < H (pad columns up to Hpad get 0),
@@ -1278,7 +1286,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                                critic ? L.cWs : L.aW1, critic ? L.cbs : L.ab1, H1, critic ? L.cWa : 0, critic ? L.cba : 0,
                                critic ? Ha : 0, nfs, nft, (bf16x8*)(ws + pl.wf1[i]));
         }
-        hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w2, b2, K,
+        hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, n.th, (long)L.theta_size, w2, b2, K,
                            H2, n.sh, ldT, n.bias, (long)H2);
         hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3, b3, H2, n.inv + KCp,
                            n.sh + KCp, ldT, n.cf, n.c0, (long)H2);
@@ -1514,7 +1522,7 @@ extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_ag
     tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
     hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, theta,
                        (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L, 0);
-    hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW2, L.ab2,
+    hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, theta, (long)L.theta_size, L.aW2, L.ab2,
                        H1, H2, sh, ldT, bias, (long)H2);
     hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW3, L.ab3, H2, inv + KCp, sh + KCp,
                        ldT, cf, c0, (long)H2);
