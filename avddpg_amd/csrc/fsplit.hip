@@ -86,7 +86,14 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned
     const f32x2 f = {a, b};
     const f16x2 h = __builtin_convertvector(f, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    const f32x2 l = {a - (float)h[0], b - (float)h[1]};
+    // residuals a - hi.lo16, b - hi.hi16 in one v_fma_mix_f32 each (the f16 halves are read in place: no conversion back)
+    f32x2 l;
+#ifdef __HIP_DEVICE_COMPILE__
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l[0]) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l[1]) : "v"(hi), "v"(b));
+#else
+    l[0] = a - (float)h[0], l[1] = b - (float)h[1];
+#endif
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2));
 }
 __device__ __forceinline__ void split1h(float x, f16& hi, f16& lo) {
