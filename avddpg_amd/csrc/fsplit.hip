@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
 // ---- head: first layer -> second-layer GEMM (three MFMAs per product) -> output layer [-> its backward] -------------------
 enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4, HEAD_BOTH = 5 };
 struct HeadArgs {
+    unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
     NetP net;
     int n_agents, n_sets;
     const f16x8* xf;   // [n_agents][64][2] packed first-layer input fragments of the states, fp16 pairs (pack_x_kernel)
@@ -397,6 +398,10 @@ struct HeadArgs {
 // accumulators, branch B (input mu: the action gradient through M) in place.
 // waves per workgroup (every mode: 8 = two per SIMD at <= 256 registers)
 __host__ __device__ constexpr int head_waves(int mode) { return 8; }
+#ifndef HEAD_FAST
+#define HEAD_FAST 5
+#define HEAD_SLOW 3
+#endif
 
 template <int S, class NET, int MODE>
 __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadArgs p) {
@@ -424,6 +429,13 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     const float d3 = vec[2 * H2];
     const f16x8* wf1 = p.net.wf1h + (long)set * NGT_MAX * 64 + lane;  // + 64 ft
     const f32x16 zero16 = {};
+#ifdef AVD_STAMP
+    unsigned long long hacc[4] = {0, 0, 0, 0}, hlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long hstart = hlast;
+#define HSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); hacc[i] += t_ - hlast; hlast = t_; }
+#else
+#define HSTAMP(i)
+#endif
     float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f;
 #pragma unroll
     for (int t = 0; t < (BWD ? 4 : 1); ++t)
@@ -445,17 +457,27 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         if (BWD) ny = p.yin[ri];
         if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
     };
-    if (q < ntile) fetch_in(q);
     const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
     const f16* wlo0 = &wimg[1][r * LD + 8 * h];
     // the sequence of feature tiles of a unit: tiles 0 .. NFT - 1; HEAD_BOTH: + the action tiles 8, 9 once more (input mu)
     constexpr int NSEQ = BOTH ? 8 : NFT;  // HEAD_BOTH: the state tiles; the action tiles are streamed per column tile below
-    for (int k = q; k < ntile; k += NW / 2) {
+    HSTAMP(3);  // image fill, tables, first fetch
+    // The two waves of a SIMD (w and w + 4) are arbitrated oldest first: with equal shares, waves 0..3 ran 12.0 k cycles per unit
+    // and waves 4..7 20.4 k until the old ones were done, then finished alone at 61 % of the matrix pipe (s_memtime stamps, r03;
+    // s_setprio does not change it). The tiles are therefore dealt FAST : SLOW per wave pair in periods of 2 (FAST + SLOW) tiles
+    // -- a static map, so the grouping of the partial sums (the bits of the result) stays a function of the plan.
+    constexpr int FAST = NW == 8 ? HEAD_FAST : 1, SLOW = NW == 8 ? HEAD_SLOW : 1, PERIOD = 2 * (FAST + SLOW);
+    const int qs = __builtin_amdgcn_readfirstlane(q);  // (scalar tile arithmetic)
+    const int cnt = (qs < 2 || NW != 8) ? FAST : SLOW, start = NW != 8 ? qs : (qs < 2 ? qs * FAST : 2 * FAST + (qs - 2) * SLOW);
+    int k = start, pos = 0;  // the wave pair's current tile and its place in the pair's group of cnt
+    auto next_tile = [&](int kk, int pp) { return pp + 1 == cnt ? kk + PERIOD - cnt + 1 : kk + 1; };
+    if (k < ntile) fetch_in(k);
+    for (int ui = 0; k < ntile; ++ui, k = next_tile(k, pos), pos = pos + 1 == cnt ? 0 : pos + 1) {
         const int agent = (j0 + k * J) * p.n_sets + set;
         const long ri = (long)agent * TILE + row;
         const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h), xb = BOTH ? make_xh(nb, 0.f, 0.f, 0.f, h) : xa;
         const float ty = ny, tw = nw;
-        if (k + NW / 2 < ntile) fetch_in(k + NW / 2);
+        if (next_tile(k, pos) < ntile) fetch_in(next_tile(k, pos));
         f32x16 acc[4], M[(AG && !BOTH) ? 4 : 1];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -636,7 +658,9 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             // (tiles stay in program order: hoisting every tile's first-layer MFMA and weight reads costs hundreds of registers)
             __builtin_amdgcn_sched_barrier(0);
         };
+        HSTAMP(0);  // unit start: inputs, bias
         static_for<0, NSEQ>([&](auto si_c) { tile(si_c, acc); });
+        HSTAMP(1);  // the feature tiles
         if constexpr (BOTH) {
             // acc = the state part of z2 (+ bias); the action part is 3 k-steps. Three sweeps of 36 MFMAs over the four column
             // tiles, all on the ONE set of accumulators (acc + T1 + M never coexist: <= 256 registers, two waves per SIMD):
@@ -763,7 +787,16 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             else epi_bwd(acc, g3);
             if (h == 0) Dacc += g3, Lacc += loss;
         }
+        HSTAMP(2);  // epilogue
+#ifdef AVD_STAMP
+        if (blockIdx.x == 16 && lane == 0 && p.stamp && (w == 0 || w == 4) && ui < 28)
+            p.stamp[64 + (w >> 2) * 28 + ui] = hlast - hstart;  // end time of every unit of waves 0 and 4
+#endif
     }
+#ifdef AVD_STAMP
+    if (blockIdx.x == 16 && lane == 0 && p.stamp)
+        for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = hacc[i];
+#endif
     if (MODE >= HEAD_CRITIC) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
         // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
@@ -1417,7 +1450,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
-    h.act2 = nullptr, h.part_s2 = nullptr;
+    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr;
     int head_threads = NT;
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {
@@ -1429,7 +1462,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr;
 #ifdef AVD_STAMP
     static unsigned long long* d_stamp = nullptr;
-    if (!d_stamp) (void)hipMalloc(&d_stamp, 64 * 8);
+    if (!d_stamp) (void)hipMalloc(&d_stamp, 128 * 8);
     dw.stamp = d_stamp;
 #endif
     DxArgs dx;
@@ -1443,7 +1476,29 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     const bool do_head = !only || !strcmp(only, "head"), do_dw = !only || !strcmp(only, "dw"), do_dx = !only || !strcmp(only, "dx");
     if (only) {
         if (do_head) {
+#ifdef AVD_STAMP
+            h.stamp = d_stamp;
+#endif
             head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+#ifdef AVD_STAMP
+            {
+                unsigned long long hst[128];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
+                static int printed = 0;
+                if (printed++ == 3) {
+                    for (int w_ = 0; w_ < 8; ++w_)
+                        fprintf(stderr, "head OUT_TANH wave %d: unit-start %llu tiles %llu epilogue %llu prologue %llu cycles (20 units)\n", w_, hst[w_ * 8],
+                                hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
+                    for (int g_ = 0; g_ < 2; ++g_) {
+                        fprintf(stderr, "wave %d unit end times:", 4 * g_);
+                        for (int u_ = 0; u_ < 21; ++u_) fprintf(stderr, " %llu", hst[64 + g_ * 28 + u_]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+                h.stamp = nullptr;
+            }
+#endif
             head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
             head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
             head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, a2, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));

@@ -2,6 +2,7 @@
 // with one and two waves per SIMD. Build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_dep.hip -o tools/probes/mfma_dep
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int MODE>  // 0: chain of 3 on one accumulator then next (t-major), 1: round robin over 4, 2: single accumulator
@@ -35,7 +36,7 @@ template <int MODE>
 void run(const char* name, int threads) {
     float* d;
     hipMalloc(&d, 256 * 512 * 4);
-    const int iters = 20000;
+    const int iters = getenv("MFMA_ITERS") ? atoi(getenv("MFMA_ITERS")) : 20000;  // 20000: a 4-7 ms burst; 5000000: ~1.5 s under the power cap
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     k<MODE><<<256, threads>>>(d, 100);
