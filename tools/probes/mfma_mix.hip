@@ -3,6 +3,8 @@
 // Build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_mix.hip -o tools/probes/mfma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int V, int R4>  // V VALU per MFMA; R4 = LDS reads per 4 MFMAs
@@ -31,7 +33,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
                 __builtin_amdgcn_sched_group_barrier(0x002, 2 * V, 0);
             }
         }
-        asm volatile("" : "+v"(a));
+        {
+            auto u = __builtin_bit_cast(uint4, a);
+            u.x = u.x * 1664525u + 1013904223u, u.y ^= u.x >> 3, u.z += u.y, u.w ^= u.z;  // (operands that toggle: realistic power)
+            u.x &= 0x3bff3bffu, u.y &= 0x3bff3bffu, u.z &= 0x3bff3bffu, u.w &= 0x3bff3bffu;  // finite fp16, |x| < 2
+            a = __builtin_bit_cast(f16x8, u);
+        }
     }
     float s = 0;
     for (int t = 0; t < 4; ++t)
@@ -43,7 +50,7 @@ template <int V, int R4>
 void run(int threads) {
     float* d;
     (void)hipMalloc(&d, 256 * 512 * 4);
-    const int iters = 10000;
+    const int iters = getenv("MFMA_ITERS") ? atoi(getenv("MFMA_ITERS")) : 10000;  // 2000000: ~1-2 s per line (power sampling)
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
     k<V, R4><<<256, threads>>>(d, 100);
@@ -58,7 +65,15 @@ void run(int threads) {
            mf * 32768 / (ms * 1e-3) / 1e15, mf * 32768 / (ms * 1e-3) / 2.5e13);
     (void)hipFree(d);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc >= 4) {  // one configuration: mfma_mix V R4 threads  (MFMA_ITERS for the length; tools/power_mix.sh samples rocm-smi)
+        const int V = atoi(argv[1]), R4 = atoi(argv[2]), th = atoi(argv[3]);
+        if (V == 0 && R4 == 0) run<0, 0>(th);
+        else if (V == 3 && R4 == 0) run<3, 0>(th);
+        else if (V == 0 && R4 == 3) run<0, 3>(th);
+        else run<3, 3>(th);
+        return 0;
+    }
     for (int th : {256, 512}) {
         run<0, 0>(th), run<1, 0>(th), run<2, 0>(th), run<3, 0>(th), run<0, 3>(th), run<1, 3>(th), run<2, 3>(th), run<3, 3>(th);
     }
