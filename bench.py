@@ -369,7 +369,11 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                        "for every relu mask; bf16 pairs, 2^-18, times exact +-1/0 masks in the weight / input-gradient products), "
                        "A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, gradients and optimiser; 1e-4 of each gradient "
                        "tensor's max against the float64 oracle, the f32 kernels' tolerance (tests/test_gpu_fsplit.py)" if split3 else None),
-        "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]},
+        "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
+                    | ({"executed_over_algorithmic": 2.6, "executed_frac": 2.6 * dominant["frac"],
+                        "power": "rocm-smi reads 1398-1399 W of the 1400 W package cap at 2.16 GHz while this chain runs back to back; dense fp16 "
+                                 "MFMA on toggling operands holds 2.32 PFLOP/s under the same cap (profiles/r03_power_and_clocks.txt, "
+                                 "r03_power_of_instruction_mixes.txt)"} if split3 else {}),
         "stages_ms": stage_ms,
         "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
