@@ -40,8 +40,10 @@ ADAM_BYTES_PER_AGENT = 2.47e6  # r/w of W, W_target, m, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: long enough for the clocks to settle (the first ~20 steps after an idle chip run 5 % slow; r03: 20 / 3 steps read
+    # 1.65 M where 100+ steps read 1.74 M), short enough for the default run to finish in about a minute
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--platoons", type=int, default=4096, help="platoons per GPU")
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
