@@ -1045,6 +1045,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (kt + 2 == nk && cq == 0) build_x(tile + gridDim.x, xb ^ 1);  // (published by the next step's barrier)
                 const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
                 const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
+                const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
+                __builtin_amdgcn_sched_barrier(0);  // (all LDS reads of the half-step are requested before anything else)
                 {
                     int kc = kt + FSTG;
                     kc -= kc >= nk ? nk : 0;
@@ -1053,15 +1055,26 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     pstg = stg, pkc = kc;
                 }
                 bf16x8 bn[2];
+                f32x16 p1n[2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) p1n[rt] = mfma(wfn, xf[rt], zero16);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) acc[r2][ct] = mfma(A1[ct], bfr[r2][1], acc[r2][ct]);
+                // (bfr[.][0] is dead here, bfr[.][1] an operand until the last MFMA: its successor waits in bn)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const f32x16 p1n = mfma(wfn, x_frag(xbuf, act_next, rt), zero16);
-#pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; ++r2) acc[r2][2 * rt + c2] = mfma(A1[2 * rt + c2], bfr[r2][1], acc[r2][2 * rt + c2]);
-                    if (!FW_DBG(2)) pack(p1n, 0, bfr[rt][0]), pack(p1n, 1, bn[rt]);  // (bfr[.][0] is dead here, bfr[.][1] still an operand)
+                    if (!FW_DBG(2)) pack(p1n[rt], 0, bfr[rt][0]), pack(p1n[rt], 1, bn[rt]);
                     else bn[rt] = bfr[rt][1];
+                }
+                // issue order: the two first-layer MFMAs, two of the eight accumulating ones, then the relu / pack VALU (16 per
+                // half tile) in the gaps of the other six
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
                 bfr[0][1] = bn[0], bfr[1][1] = bn[1];
                 __builtin_amdgcn_sched_barrier(0);
