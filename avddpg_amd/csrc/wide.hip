@@ -877,7 +877,9 @@ struct FwdP {
     float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
     long setZ;
     int Ns, Np, H2, n_sets;  // Np: padded rows (multiple of 128); H2: multiple of 512
-    int dbg;                 // diagnostics (AVD_FW_DBG bits: 1 no refill DMA, 2 no relu / pack, 4 no step barrier, 8 no epilogue): wrong results
+    unsigned long long* stamp;  // -DAVD_FW_STAMP: [8 waves][4] s_memtime sums of workgroup 16 (prepare, barrier, multiply, barrier)
+    int dbg;                 // diagnostics build (AVD_FW_DBG bits: 1 no refill DMA, 2 no relu / pack, 4 no phase barriers, 8 no epilogue,
+                             // 16 four of the 16 accumulating MFMAs, 32 no fragment reads): wrong results
 };
 
 // diagnostics build (-DAVD_FW_DBG): AVD_FW_DBG=<bits> switches pieces of the kernel off (tools/c5_dbg.sh; results wrong)
@@ -888,7 +890,7 @@ struct FwdP {
 #endif
 // One stage = the 32 k x 512 column chunk (32 KiB) + the first-layer fragments of that chunk's 32 features (1 KiB).
 constexpr int STG_BYTES = FC * FK * 2 + 1024;
-constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
+constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
               L_XF = L_AR + FR * 4, L_TOTAL = L_XF + 2 * 8 * 1024;  // XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_gen_kernel(FwdP p) {
@@ -908,11 +910,12 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto pack = [&](const f32x16& p1, int ks, bf16x8& b) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         unsigned w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bf16x2 v;
-            v[0] = (bf16)p1[8 * ks + 2 * i], v[1] = (bf16)p1[8 * ks + 2 * i + 1];
+            const f32x2 f = {p1[8 * ks + 2 * i], p1[8 * ks + 2 * i + 1]};
+            const bf16x2 v = __builtin_convertvector(f, bf16x2);  // one v_cvt_pk_bf16_f32
             const s16x2 z = {0, 0};
             w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
         }
@@ -930,6 +933,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     auto wf_at = [&](int stg) { return *(const bf16x8*)(smem_raw + stg * STG_BYTES + FC * FK * 2 + lane * 16); };
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // Workgroups start up to one row tile apart (16 steps of ~2 us): in step, all 256 would write their 128 KiB of activations at
+    // the same moment, every tile boundary a 32 MB burst that the stores sit out in the issue queue
+    if (p.P2)
+        for (int i = 0; i < (int)(blockIdx.x & 15); ++i) __builtin_amdgcn_s_sleep(72);
 
     // every workgroup walks the (set, 512-column block) pairs in the same order and takes its share of each pair's row tiles:
     // at any time the chip streams ONE 512 x K weight block (1.1 MB: every XCD's L2 holds it)
@@ -954,8 +961,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int i = 0; i < 4; ++i)
                 if ((i >> 1) == part)
                     __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + kc * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
-            if (part == 1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kc * 1024 + (vw & 0u) + vof), (lptr_t)(l + FC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
+            if (part == 1) {  // the first-layer fragments of the FOLLOWING chunk travel with this one
+                const int kf = kc + 1 == nk ? 0 : kc + 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kf * 1024 + (vw & 0u) + vof), (lptr_t)(l + FC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
+            }
         };
         // raw inputs of a row tile into LDS buffer b (every wave issues the same 4 instructions: uniform counts). Rows beyond
         // Ns are clamped to row Ns - 1 here and zeroed when the fragments are built.
@@ -990,30 +999,57 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         sbias[tid] = p.bias[(long)set * p.H2 + FC * cb + tid];
         scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
         dma_x(tile);
-        // ---- start the stream: chunks 0 .. 3 into stages 0 .. 3
+        // ---- start the stream: chunks 0 .. 2 into stages 0 .. 2 (a stage also carries the first-layer fragments of the NEXT chunk)
 #pragma unroll
-        for (int c = 0; c < FSTG; ++c) dma(c, c % nk, 0), dma(c, c % nk, 1);
+        for (int c = 0; c < FSTG - 1; ++c) dma(c, c % nk, 0), dma(c, c % nk, 1);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
         if (cq == 0) build_x(tile, 0);
         __syncthreads();
-        bf16x8 bfr[2][2], A0[4], A1[4];
+        // PING-PONG: waves 0..3 (group 0, one per SIMD) and waves 4..7 (group 1) alternate between two kinds of phase, a barrier
+        // after each: "prepare" (fragment reads, relu / pack of the first layer, the refill DMA, epilogues) and "multiply"
+        // (16 + 2 MFMAs at raised priority). Group 1 runs one phase behind, so on every SIMD one wave multiplies while the
+        // other prepares -- left in step (one barrier per chunk, same program) the two waves of a SIMD ran their MFMAs
+        // together and their VALU / DMA together and the pipe idled through the latter (41-45 % MfmaUtil).
+        //   prepare(k) : A <- stage of chunk k (both k-steps); wfn <- that stage's fragments of chunk k + 1; pack(p1n) -> bfr;
+        //                request chunk k + 3 into the stage of chunk k - 1 (read by both groups two barriers ago)
+        //   multiply(k): acc += A . bfr; p1n = first layer of chunk k + 1
+        // Every wave waits for vmcnt(10) before every barrier: its share of every chunk but the two youngest has landed, which
+        // covers whatever anybody reads in the next phase.
+        const int grp = wave >> 2;
+        bf16x8 bfr[2][2];  // the chunk's B operand (k-step ks of row tile rt: bfr[rt][ks]): relu'd first layer, built one multiply phase ahead
         {
-            const bf16x8 wf0 = wf_at(0);
-
+            const bf16x8 wf0 = p.wf1[(long)set * nk * 64 + lane];  // (chunk 0's fragments travel with chunk nk - 1: not here yet)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const f32x16 p1 = mfma(wf0, x_frag(0, false, rt), zero16);
                 pack(p1, 0, bfr[rt][0]), pack(p1, 1, bfr[rt][1]);
             }
         }
-        read_frags(0, 0, A0);
-        int stg = 0;  // stage of the chunk being multiplied (the stream is periodic in nk and carries on across row tiles)
-        int pstg = FSTG - 1, pkc = (FSTG - 1) % nk;  // chunk whose part 1 is still to be requested (first: a re-load of identical bytes)
-        int xb = 0;   // fragment buffer of the current tile's inputs
-        for (; tile < ntile; tile += gridDim.x) {
-            // accumulators start at the folded bias: tile (rt, ct), register 4 g + j <-> column 128 cq + 32 ct + 8 g + 4 h + j
-            f32x16 acc[2][4];
+        int stg = 0;   // stage of the chunk being prepared / multiplied (the stream is periodic in nk, across row tiles)
+        int xb = 0;    // fragment buffer of the current tile's inputs
+        // output-layer sums: every wave leaves its 128-column partial of tile t in zs[t & 1]; the two waves with cq == 2 add the
+        // four partials a whole tile later (both groups have written and passed barriers by then)
+        auto z_flush = [&](int zt_) {
+            if (zt_ >= 0 && cq == 2) {
+                const int row = rh * 64 + lane;
+                float* zd = p.z + (long)set * p.setZ + (long)zt_ * FR + row;
+                const float* zq = zs + (zt_ / (int)gridDim.x & 1) * 4 * FR;
+                const float zt = (zq[row] + zq[FR + row]) + (zq[2 * FR + row] + zq[3 * FR + row]);
+                if (ncb == 1)
+                    *zd = p.c0[set] + zt;
+                else
+                    atomicAdd(zd, zt);
+            }
+        };
+#ifdef AVD_FW_STAMP
+        unsigned long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime();
+#define FW_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); facc[i] += t_ - flast; flast = t_; }
+#else
+#define FW_STAMP(i)
+#endif
+        f32x16 acc[2][4];
+        auto init_acc = [&]() {  // the folded bias: tile (rt, ct), register 4 g + j <-> column 128 cq + 32 ct + 8 g + 4 h + j
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -1022,74 +1058,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[0][ct][4 * g + j] = bv[j], acc[1][ct][4 * g + j] = bv[j];
                 }
-            dma_x(tile + gridDim.x);  // the next tile's raw inputs (fragments are built in step nk - 2, used in step nk - 1)
-            for (int kt = 0; kt < nk; ++kt) {
-                const int sn = (stg + 1) & (FSTG - 1);
-                // ---- first half: k-step 0 of chunk kt, the fragments of k-step 1, part 1 of the previous refill
-                read_frags(stg, 1, A1);
-                if (!FW_DBG(1)) dma(pstg, pkc, 1);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(A0[ct], bfr[rt][0], acc[rt][ct]);
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- this wave's reads of chunk kt are complete (lgkmcnt 0) and its share of chunk kt + 1 has landed: the loads
-                // in flight, oldest first, are those of chunks kt + 1, kt + 2, kt + 3 (5 each) -> all but the 10 youngest
-                __builtin_amdgcn_s_waitcnt(0x007A);  // vmcnt(10) lgkmcnt(0)
-                if (!FW_DBG(4)) __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- second half: fragments of chunk kt + 1 and its first layer (the next tile's chunk 0 after the last step); the
-                // stage just read starts to refill with chunk kt + 4; k-step 1 of chunk kt, relu / pack of chunk kt + 1
-                read_frags(sn, 0, A0);
-                const bf16x8 wfn = wf_at(sn);
-                if (kt + 2 == nk && cq == 0) build_x(tile + gridDim.x, xb ^ 1);  // (published by the next step's barrier)
-                const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
-                const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
-                const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
-                __builtin_amdgcn_sched_barrier(0);  // (all LDS reads of the half-step are requested before anything else)
-                {
-                    int kc = kt + FSTG;
-                    kc -= kc >= nk ? nk : 0;
-                    kc -= kc >= nk ? nk : 0;
-                    if (!FW_DBG(1)) dma(stg, kc, 0);
-                    pstg = stg, pkc = kc;
-                }
-                bf16x8 bn[2];
-                f32x16 p1n[2];
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) p1n[rt] = mfma(wfn, xf[rt], zero16);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2) acc[r2][ct] = mfma(A1[ct], bfr[r2][1], acc[r2][ct]);
-                // (bfr[.][0] is dead here, bfr[.][1] an operand until the last MFMA: its successor waits in bn)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    if (!FW_DBG(2)) pack(p1n[rt], 0, bfr[rt][0]), pack(p1n[rt], 1, bn[rt]);
-                    else bn[rt] = bfr[rt][1];
-                }
-                // issue order: the two first-layer MFMAs, two of the eight accumulating ones, then the relu / pack VALU (16 per
-                // half tile) in the gaps of the other six
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-                bfr[0][1] = bn[0], bfr[1][1] = bn[1];
-                __builtin_amdgcn_sched_barrier(0);
-                stg = sn;
-            }
-            xb ^= 1;
-            // ---- epilogue: relu, bf16, output-layer dot on the stored (rounded) activations, row-major store
+        };
+        // relu, bf16, output-layer dot on the stored (rounded) activations, row-major store
+        auto epilogue = [&](int pt) {
             float zp[2] = {0.f, 0.f};
-            if (FW_DBG(8)) {
-                if (acc[0][0][0] == 123.456f) zs[tid] = acc[1][3][5];
-                continue;
-            }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
                 bf16* dst = p.P2 ? p.P2 + (long)set * p.setP2 + n * p.H2 + FC * cb + 128 * cq + 8 * h : nullptr;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
@@ -1118,21 +1093,112 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
                 zp[rt] += __shfl_xor(zp[rt], 32);
-                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp[rt];
+                if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = zp[rt];
             }
-            // (the barriers below are matched by every wave; the DMA stream stays in flight across them. The stores above are
-            // vm operations YOUNGER than the stream's: they only make the counted wait of the next steps stricter)
-            __syncthreads();
-            if (tid < FR) {
-                float* zd = p.z + (long)set * p.setZ + (long)tile * FR + tid;
-                const float zt = (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]);
-                if (ncb == 1)
-                    *zd = p.c0[set] + zt;
-                else
-                    atomicAdd(zd, zt);
-            }
-            __syncthreads();
+        };
+        if (grp == 1) {  // one phase behind
+            __builtin_amdgcn_s_waitcnt(0x0F7A);
+            __builtin_amdgcn_s_barrier();
         }
+        init_acc();
+        int prev = -1;  // tile whose partial output-layer sums were written in the previous epilogue
+        for (; tile < ntile; tile += gridDim.x) {
+            dma_x(tile + gridDim.x);  // the next tile's raw inputs (fragments are built in step nk - 2, used in step nk - 1)
+            // one step = prepare(kt), barrier, multiply(kt), barrier. The first two steps of a tile wait for no vm operation (see the
+            // tile boundary below), the others for all but the two youngest chunks
+            auto step = [&](int kt, auto wait_c) {
+                constexpr bool WAIT = decltype(wait_c)::value;
+                // ================= prepare(kt)
+                FW_STAMP(3);
+                bf16x8 A[2][4];
+                if (!FW_DBG(32)) {
+                    read_frags(stg, 0, A[0]);
+                    read_frags(stg, 1, A[1]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) A[0][i] = A[1][i] = x_frag(0, false, 0);
+                }
+                const bf16x8 wfn = wf_at(stg);
+                const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
+                const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
+                const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
+                if (kt + 2 == nk && cq == 0) build_x(tile + gridDim.x, xb ^ 1);  // (read from the next prepare phase on)
+                if (!FW_DBG(1)) {
+                    int kc = kt + FSTG - 1;
+                    kc -= kc >= nk ? nk : 0;
+                    kc -= kc >= nk ? nk : 0;
+                    const int sd = (stg + FSTG - 1) & (FSTG - 1);
+                    dma(sd, kc, 0), dma(sd, kc, 1);
+                }
+                // (vm operations complete in issue order per kind only: the tile boundary drains the stream before its stores, so
+                // the first two steps of a tile have nothing to wait for, and from step 2 on the counted wait also retires those stores)
+                if (WAIT)
+                    __builtin_amdgcn_s_waitcnt(0x007A);  // vmcnt(10) lgkmcnt(0)
+                else
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                FW_STAMP(0);
+                if (!FW_DBG(4)) __builtin_amdgcn_s_barrier();
+                FW_STAMP(1);
+                __builtin_amdgcn_sched_barrier(0);
+                // ================= multiply(kt)
+                __builtin_amdgcn_s_setprio(3);
+                // the first layer of chunk kt + 1 first; its relu / pack (32 VALU) rides in the gaps of the 16 accumulating MFMAs
+                f32x16 p1n[2];
+                bf16x8 bnx[2][2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) p1n[rt] = mfma(wfn, xf[rt], zero16);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(A[ks][ct], bfr[rt][ks], acc[rt][ct]);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) pack(p1n[rt], 0, bnx[rt][0]), pack(p1n[rt], 1, bnx[rt][1]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+                for (int i = 0; i < 11; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) bfr[rt][0] = bnx[rt][0], bfr[rt][1] = bnx[rt][1];
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10)
+                FW_STAMP(2);
+                if (!FW_DBG(4)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                stg = (stg + 1) & (FSTG - 1);
+            };
+            step(0, std::false_type{});
+            step(1, std::false_type{});
+            for (int kt = 2; kt < nk; ++kt) step(kt, std::true_type{});
+            xb ^= 1;
+            // (this group is in a prepare phase here: the tile's epilogue and the next tile's start share it with prepare(0))
+            FW_STAMP(3);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunks 0 and 1 of the next period have landed; nothing older than the stores
+            FW_STAMP(4);
+            if (!FW_DBG(8)) epilogue(tile);
+            FW_STAMP(5);
+            z_flush(prev);
+            prev = tile;
+            init_acc();
+            FW_STAMP(6);
+        }
+#ifdef AVD_FW_STAMP
+        if (blockIdx.x == 16 && lane == 0 && p.stamp && pair == 0)
+            for (int i = 0; i < 8; ++i) p.stamp[wave * 8 + i] = facc[i];
+#endif
+        // ---- group 0 makes up the phase it is ahead; the last output-layer sums
+        if (grp == 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F7A);
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream (vmcnt 0)
+        __syncthreads();
+        z_flush(prev);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream before the next pair re-uses the stages / the LDS is released
     }
 }
@@ -1343,6 +1409,12 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         f.P2 = keep_p2 ? P2 : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
         static const char* dbg_env = getenv("AVD_FW_DBG");
         f.dbg = dbg_env ? atoi(dbg_env) : 0;
+        f.stamp = nullptr;
+#ifdef AVD_FW_STAMP
+        static unsigned long long* d_fst = nullptr;
+        if (!d_fst) (void)hipMalloc(&d_fst, 64 * 8);
+        f.stamp = d_fst;
+#endif
         if (H2 > fw::FC)
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, f.z, (long)Np, n.c0, Np);
         const dim3 grid((unsigned)std::min<long>(avd::fset::cu_count(), Np / fw::FR));
@@ -1350,6 +1422,19 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             hipLaunchKernelGGL((fw::fwd_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, f);
         else
             hipLaunchKernelGGL((fw::fwd_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, f);
+#ifdef AVD_FW_STAMP
+        {
+            static int printed = 0;
+            if (printed++ == 7) {
+                unsigned long long hst[64];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(hst, f.stamp, sizeof(hst), hipMemcpyDeviceToHost);
+                for (int w_ = 0; w_ < 8; ++w_)
+                    fprintf(stderr, "fwd_gen wave %d: prepare %llu barrier %llu multiply %llu barrier %llu | boundary: drain %llu epilogue %llu flush+init %llu  (P2 %d) cycles, pair 0\n", w_,
+                            hst[w_ * 8], hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3], hst[w_ * 8 + 4], hst[w_ * 8 + 5], hst[w_ * 8 + 6], f.P2 != nullptr);
+            }
+        }
+#endif
         return check_launch("avd_learn_shared_bf16: fused forward");
     };
     auto l2 = [&](const NetOps& n, bool critic) {
