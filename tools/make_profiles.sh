@@ -24,7 +24,7 @@ python bench.py --mode interfrl --engine fused3 $N > $OUT/${TAG}_bench_interfrl_
 python tools/fsplit_check.py > $OUT/${TAG}_fsplit_accuracy_and_time.txt 2>/dev/null
 python tools/time_fset.py > $OUT/${TAG}_fset_vs_other_learners.txt 2>/dev/null
 # other BASELINE configs
-python bench.py --mode interfrl --hidden 1024 --steps 5 --warmup 2 $N > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
+python bench.py --mode interfrl --hidden 1024 --steps 20 --warmup 3 $N > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
 python bench.py --mode nofrl --pl-size 10 --buffer-size 50000 --steps 5 --warmup 2 $N > $OUT/${TAG}_bench_config3_4096x10_nofrl.json 2>/dev/null
 python bench.py --mode interfrl --pl-size 10 --buffer-size 50000 --steps 20 --warmup 5 $N > $OUT/${TAG}_bench_config3_4096x10_interfrl_split.json 2>/dev/null
 python bench.py --mode nofrl --framework centralized $N > $OUT/${TAG}_bench_centralized_4096x5.json 2>/dev/null
@@ -40,6 +40,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_nofrl -o run 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_nofrl_unfused -o run -- $B --mode nofrl --no-fused > $OUT/${TAG}_bench_under_rocprof_nofrl_unfused.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_interfrl_per_agent -o run -- $B --mode interfrl --engine per_agent > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_interfrl_fused_bf16 -o run -- $B --mode interfrl --engine fused > /dev/null 2>&1
+# config 5 (hidden 1024): per-kernel table and MfmaUtil
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config5 -o run -- $B --steps 5 --mode interfrl --hidden 1024 > /dev/null 2>&1
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/mfma_config5 -o run -- $B --steps 2 --warmup 1 --mode interfrl --hidden 1024 > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fused_$c -o run -- $B --steps 3 --mode nofrl > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_unfused_$c -o run -- $B --steps 3 --mode nofrl --no-fused > /dev/null 2>&1
@@ -54,9 +57,10 @@ python tools/pmc_summary.py "$(f pmc_unfused_FETCH_SIZE)" "$(f pmc_unfused_WRITE
 python tools/pmc_summary.py "$(f pmc_split_FETCH_SIZE)" "$(f pmc_split_WRITE_SIZE)" $OUT/pmc_traffic_interfrl_split.json > $OUT/pmc_split.log 2>&1
 python tools/pmc_avg.py "$(f mfma_nofrl)" MfmaUtil $OUT/${TAG}_mfma_util_nofrl.json > /dev/null 2>&1
 python tools/pmc_avg.py "$(f mfma_split)" MfmaUtil $OUT/${TAG}_mfma_util_interfrl_split.json > /dev/null 2>&1
-for d in stats_default stats_interfrl_split stats_nofrl stats_nofrl_unfused stats_interfrl_per_agent stats_interfrl_fused_bf16; do
+python tools/pmc_avg.py "$(f mfma_config5)" MfmaUtil $OUT/${TAG}_mfma_util_config5.json > /dev/null 2>&1
+for d in stats_default stats_interfrl_split stats_nofrl stats_nofrl_unfused stats_interfrl_per_agent stats_interfrl_fused_bf16 stats_config5; do
   s=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp "$s" $OUT/${TAG}_kernel_stats_${d#stats_}.csv
 done
 # the raw per-dispatch traces are large: keep the summaries only
-rm -rf $OUT/stats_* $OUT/pmc_fused_* $OUT/pmc_unfused_* $OUT/pmc_split_* $OUT/mfma_nofrl $OUT/mfma_split
+rm -rf $OUT/stats_* $OUT/pmc_fused_* $OUT/pmc_unfused_* $OUT/pmc_split_* $OUT/mfma_nofrl $OUT/mfma_split $OUT/mfma_config5
 ls -la $OUT
