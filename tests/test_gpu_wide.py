@@ -222,3 +222,57 @@ def test_shared_learner_weighted_mean_matches_weighted_fed_mean():
         scale = np.abs(avg[:, lo:hi]).max()
         assert np.abs(avg[:, lo:hi] - g[:, lo:hi]).max() <= 2e-2 * scale
         assert np.abs(avg[:, lo:hi] - unweighted[:, lo:hi]).max() > 5e-2 * scale  # the weights matter in this case
+
+
+_FWD_AB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from tests.gpu_util import t
+from tests.test_gpu_mlp import _perturbed_group
+n_sets, P, S = 2, 12, 4
+conf, grp = _perturbed_group(n_sets, S=S, seed=91, actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024,
+                             critic_layer2_size=1024)
+rs = np.random.RandomState(92)
+rows = P * 64
+s = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
+a = rs.uniform(-2.5, 2.5, size=(n_sets, rows, 1)).astype(np.float32)
+r = -np.abs(rs.normal(0, 0.3, size=(n_sets, rows))).astype(np.float32)
+s2 = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
+losses = torch.zeros(n_sets, 2, device="cuda")
+g = grp.learn_shared(t(s), t(a), t(r), t(s2), n_sets * P, losses=losses)
+torch.cuda.synchronize()
+np.save(sys.argv[2], np.concatenate([g.cpu().numpy().ravel(), losses.cpu().numpy().ravel()]))
+"""
+
+
+def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_path):
+    """csrc/wide.hip, fw::fwd_gen_kernel (first layer generated on the matrix cores as the GEMM operand, W2 streamed through
+    LDS, output layer in the kernel) against the layer-wise l1_fwd + GEMM + bias kernels it replaces (AVD_WIDE_FUSED_FWD=0),
+    the whole learn chain on the same inputs in two processes (the switch is read once per process). The two differ by the
+    first layer's rounding before its bf16 cast (2^-16 against exact f32) and by summation order: 3e-3 of each block's max,
+    where the bf16 operands themselves cost 8e-2 against the float64 oracle."""
+    import os
+    import subprocess
+    import sys
+
+    need_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(_FWD_AB_SCRIPT)
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, AVD_WIDE_FUSED_FWD=flag)
+        out = tmp_path / f"g{flag}.npy"
+        p = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(out))
+    fused, layerwise = outs
+    assert np.isfinite(fused).all() and np.abs(layerwise).max() > 0
+    n = fused.size - 4
+    lay = vec.AgentGroup(2, 4, 1, config.Config(actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024,
+                                                  critic_layer2_size=1024)).lay
+    gf, gl = fused[:n].reshape(2, -1), layerwise[:n].reshape(2, -1)
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        scale = np.abs(gl[:, lo:hi]).max()
+        assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 3e-3 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
+    assert np.allclose(fused[n:], layerwise[n:], rtol=2e-3, atol=1e-6)
