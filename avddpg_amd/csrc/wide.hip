@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const bf16* P, long ldp, l
 // (also transposed), u[k] += sum_n P2[n][k] d[n], cs[k] += sum_n dZ2[n][k].  Block = 64 rows x 64 columns, 8-byte accesses.
 __global__ __launch_bounds__(256) void out_bwd_kernel(const bf16* P2, long ldp, long set_p, const float* d, long set_d,
                                                        const float* cvec, long set_c, int H2, int Ns, int Np, bf16* dZ,
-                                                       bf16* dZT, long ldt, long set_t, float* u, float* cs, long set_u) {
+                                                       bf16* dZT, long ldt, long set_t, float* u, float* cs, long set_u, int perm) {
     __shared__ bf16 so[64][68];
     __shared__ float sd[64];
     __shared__ float red[2][16][64];
@@ -589,10 +589,13 @@ __global__ __launch_bounds__(256) void out_bwd_kernel(const bf16* P2, long ldp, 
         const int ng = tid & 15;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const int cidx = (tid >> 4) + 16 * cc, n = n0 + 4 * ng;
+            // perm: rows in the k order of fw::dw_gen_kernel's generated operand (bits 2 and 3 of n swapped: the second and third
+            // group of four of every 16 rows trade places)
+            const int q4 = ng & 3, qs = perm ? ((q4 == 1) ? 2 : (q4 == 2) ? 1 : q4) : q4;
+            const int cidx = (tid >> 4) + 16 * cc, n = n0 + 16 * (ng >> 2) + 4 * qs;
             bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = so[4 * ng + e][cidx];
+            for (int e = 0; e < 4; ++e) o[e] = so[4 * ng + e][cidx];  // (rows 4 ng .. 4 ng + 3 of the block, stored at position n)
             if (n < Np) *(bf16x4*)(dZT + (long)set * set_t + (long)(k0 + cidx) * ldt + n) = o;
         }
     }
@@ -1202,6 +1205,232 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream before the next pair re-uses the stages / the LDS is released
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the second layer in the same style: dW2[f][c] = inv[f] sum_n y1[n][f] dZ2[n][c] (+ sh[f] db2[c]) with the
+// first-layer activations y1 GENERATED per 32-row chunk (one MFMA per 32 rows x 32 features from the raw inputs) instead of read
+// from a transposed activation matrix, and dZ2^T [c][n] -- written by out_bwd_kernel with the rows of every group of 16 in the
+// k order of the generated operand -- streamed L2 -> LDS through the four stages. Transposed product D[c][f] = sum_n dZ2T[c][n]
+// y1[n][f]: A = dZ2T fragments (LDS), B = relu'd first-layer tile (lane = feature, registers = rows). A work item = 128
+// features x 512 columns x one eighth of a set's rows (1024 chunks), dealt over the persistent workgroups so that the nine
+// feature blocks of a (set, column block, row range) run side by side on the same stream; f32 atomics at the end of an item.
+// Same ping-pong of the two wave groups as fwd_gen_kernel.
+struct DwP {
+    const float* X;     // [sets][Ns][4]
+    long setX;
+    const float* act;   // critic: [sets][setAct], else NULL
+    long setAct;
+    const bf16x8* wf1;  // [sets][nft][64] (the same fragments: lane = feature)
+    int nft, nfs;
+    const bf16* ZT;     // [sets][H2n][ldz]: dZ2^T, rows permuted within groups of 16
+    long setZT, ldz;
+    const float *inv, *sh;  // [sets][setTab] first-layer BN tables (feature index)
+    const float* db;        // [sets][H2] column sums of dZ2
+    long setTab;
+    float* dW;              // [sets][setW] + offset of W2: [K][H2]
+    long setW;
+    int Ns, Np, H2, K, n_sets, nsplit;
+};
+
+template <bool CRITIC>
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_gen_kernel(DwP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int rh = wave & 1, cq = wave >> 1, grp = wave >> 2;  // 64-feature half, 128-column quarter, ping-pong group
+    const int ncb = p.H2 / FC, nfb = (p.nft * 32 + 127) / 128;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
+    auto pack = [&](const f32x16& p1, int ks, bf16x8& b) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 f = {p1[8 * ks + 2 * i], p1[8 * ks + 2 * i + 1]};
+            const bf16x2 v = __builtin_convertvector(f, bf16x2);
+            const s16x2 z = {0, 0};
+            w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+        }
+        wide::u32x4 o;
+        o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+        b = __builtin_bit_cast(bf16x8, o);
+    };
+    const int sw = (r >> 2) & 3;
+    const int rd0 = ((128 * cq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rd1 = ((128 * cq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+    auto read_frags = [&](int stg, int ks, bf16x8 (&a)[4]) {
+        const unsigned char* b = smem_raw + stg * STG_BYTES + (ks ? rd1 : rd0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
+    };
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int rows_per = p.Np / p.nsplit, nk = rows_per / FK;  // chunks of an item (Np is a multiple of 256, nsplit of 8: whole chunks)
+    // A stream = (set, column block, row range); its nfb feature blocks are the items that read it. Workgroup ids go round the
+    // eight XCDs, and every XCD has its own L2: XCD x takes streams x, x + 8, .. and its workgroups walk that list stream by
+    // stream, so the feature blocks of a stream run side by side behind ONE L2 (dealt by plain item number they landed on all
+    // eight, and every XCD fetched every stream from memory: 2.7 GB became ~20)
+    const int nstreams = p.n_sets * ncb * p.nsplit, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    for (int li = slot;; li += nslots) {
+        const int stream = xcd + 8 * (li / nfb), fb = li % nfb;
+        if (stream >= nstreams) break;
+        const int split = stream % p.nsplit, rest2 = stream / p.nsplit, cb = rest2 % ncb, set = rest2 / ncb;
+        const int row_base = split * rows_per;
+        // the wave's two feature tiles and their (fixed) first-layer fragments: B operand, lane = feature
+        const int t0 = fb * 4 + rh * 2;
+        const bool action = CRITIC && t0 >= p.nfs;
+        bf16x8 wf[2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const bf16 zb = (bf16)0.f;
+            wf[ft] = (bf16x8){zb, zb, zb, zb, zb, zb, zb, zb};
+            if (t0 + ft < p.nft) wf[ft] = p.wf1[((long)set * p.nft + t0 + ft) * 64 + lane];
+        }
+        // stream: image rows (= columns of dZ2) [64 w, 64 w + 64) of the column block, 16 per instruction; + the raw inputs of the
+        // NEXT chunk's 32 rows (16 B of state per row, 4 B of action), every wave the same bytes (uniform instruction counts)
+        const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(FC * cb + 64 * wv) * p.ldz + row_base);
+        const unsigned vow = (unsigned)(((lane >> 2) * p.ldz + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+        const long g16 = 32 * p.ldz;
+        auto dma = [&](int stg, int kc) {  // chunk kc of the item into stage stg: 4 + 1 (+ 1) wave-instructions
+            unsigned char* l = smem_raw + stg * STG_BYTES;
+            unsigned vw = vow;
+            asm volatile("" : "+v"(vw));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + (long)kc * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
+            const int kn = kc + 1 < nk ? kc + 1 : kc;  // (the last chunk carries its own rows again: never used)
+            int n = row_base + kn * FK + (lane & 31);
+            n = n < p.Ns ? n : p.Ns - 1;
+            if (lane < 32) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FC * FK * 2), 16, 0, 0);
+                if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FC * FK * 2 + 512), 4, 0, 0);
+            }
+        };
+        constexpr int NDMA = CRITIC ? 6 : 5;
+        // x fragment (A operand of the first layer: lane = row of the chunk) from the raw rows in stage stg = rows of chunk kc + 1
+        auto x_of = [&](int stg, int kc) {  // stage stg carries the raw rows of chunk kc + 1
+            const int n = row_base + (kc + 1) * FK + r;
+            const bool live = kc + 1 < nk && n < p.Ns;
+            const unsigned char* l = smem_raw + stg * STG_BYTES + FC * FK * 2;
+            if (action) return x_frag_action(*(const float*)(l + 512 + r * 4), live, h);
+            const f32x4 xv = *(const f32x4*)(l + r * 16);
+            const float x[4] = {xv[0], xv[1], xv[2], xv[3]};
+            return x_frag_state(x, live, h);
+        };
+        __syncthreads();  // (the previous item's LDS reads are done)
+#pragma unroll
+        for (int c = 0; c < FSTG - 1; ++c) dma(c, c < nk ? c : nk - 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
+        f32x16 acc[2][4];  // [feature tile][column tile]: lane = feature, register 4 g + j <-> column 128 cq + 32 ct + 8 g + 4 h + j
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ft][ct] = zero16;
+        bf16x8 bfr[2][2];  // relu'd first layer of the chunk: [feature tile][k-step]
+        {
+            // chunk 0's own rows are not in a stage (a stage carries the NEXT chunk's): read them directly
+            const int n = row_base + r;
+            const bool live = n < p.Ns;
+            bf16x8 x0;
+            if (action) {
+                x0 = x_frag_action(live ? p.act[(long)set * p.setAct + n] : 0.f, live, h);
+            } else {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    const f32x4 xv = *(const f32x4*)(p.X + (long)set * p.setX + (long)n * 4);
+                    x[0] = xv[0], x[1] = xv[1], x[2] = xv[2], x[3] = xv[3];
+                }
+                x0 = x_frag_state(x, live, h);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const f32x16 p1 = mfma(x0, wf[ft], zero16);
+                pack(p1, 0, bfr[ft][0]), pack(p1, 1, bfr[ft][1]);
+            }
+        }
+        if (grp == 1) {  // one phase behind
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NDMA));
+            __builtin_amdgcn_s_barrier();
+        }
+        int stg = 0;
+        bf16x8 xn = x_of(0, 0);  // x fragment of chunk kt + 1, built one multiply phase ahead (in the MFMA shadows)
+        auto step = [&](int kt, auto wait_c) {
+            constexpr bool WAIT = decltype(wait_c)::value;
+            // ================= prepare(kt)
+            bf16x8 A[2][4];
+            read_frags(stg, 0, A[0]);
+            read_frags(stg, 1, A[1]);
+            {
+                int kc = kt + FSTG - 1;
+                kc = kc < nk ? kc : nk - 1;  // (tail: harmless re-loads keep the vmcnt arithmetic uniform)
+                dma((stg + FSTG - 1) & (FSTG - 1), kc);
+            }
+            if (WAIT)
+                __builtin_amdgcn_s_waitcnt(0x0070 | (2 * NDMA));  // vmcnt(2 chunks) lgkmcnt(0)
+            else
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= multiply(kt)
+            __builtin_amdgcn_s_setprio(3);
+            f32x16 p1n[2];
+            bf16x8 bnx[2][2];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) p1n[ft] = mfma(xn, wf[ft], zero16);
+            xn = x_of((stg + 1) & (FSTG - 1), kt + 1);  // (chunk kt + 1 has landed: the wait before this phase's barrier)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) acc[ft][ct] = mfma(A[ks][ct], bfr[ft][ks], acc[ft][ct]);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) pack(p1n[ft], 0, bnx[ft][0]), pack(p1n[ft], 1, bnx[ft][1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) bfr[ft][0] = bnx[ft][0], bfr[ft][1] = bnx[ft][1];
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NDMA));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stg = (stg + 1) & (FSTG - 1);
+        };
+        step(0, std::false_type{});
+        step(1, std::false_type{});
+        for (int kt = 2; kt < nk; ++kt) step(kt, std::true_type{});
+        if (grp == 0) {  // make up the phase this group is ahead
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NDMA));
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream
+        // ---- dW2[f][c] += inv[f] acc (+ sh[f] db2[c] from the first row range), f32 atomics
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const int f = 32 * (t0 + ft) + r;
+            if (f >= p.K) continue;
+            const float iv = p.inv[(long)set * p.setTab + f], sf = split == 0 ? p.sh[(long)set * p.setTab + f] : 0.f;
+            float* o = p.dW + (long)set * p.setW + (long)f * p.H2 + FC * cb + 128 * cq + 4 * h;
+            const float* dbp = p.db + (long)set * p.H2 + FC * cb + 128 * cq + 4 * h;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dbv = *(const f32x4*)(dbp + 32 * ct + 8 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(o + 32 * ct + 8 * g + j, fmaf(iv, acc[ft][ct][4 * g + j], sf * dbv[j]));
+                }
+        }
+    }
+}
 }  // namespace fw
 
 // ---- workspace plan -------------------------------------------------------------------------
@@ -1324,11 +1553,15 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // second layers of 512 n columns (config 5: 1024): the forward passes run fused (fw::fwd_gen_kernel); AVD_WIDE_FUSED_FWD=0: layer-wise
     static const char* ff_env = getenv("AVD_WIDE_FUSED_FWD");
     const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
+    static const char* fd_env = getenv("AVD_WIDE_FUSED_DW");
+    const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && !(fd_env && fd_env[0] == '0');
     static bool fw_attr = false;
     constexpr size_t fw_lds = fw::L_TOTAL;
     if (fused_fwd && !fw_attr) {
         (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         fw_attr = true;
     }
     // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
@@ -1458,7 +1691,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // reads r with the internal stride, so r is first copied into `da` (free at that point) with the padded stride.
     // `transpose` = a backward pass follows: the first-layer activations (and their transposes) are materialised for it
     auto actor_forward = [&](const NetOps& n, const float* X, bool transpose) {
-        if (!fused_fwd || transpose) l1(n, false, false, X, setX, transpose);
+        if (!fused_fwd || transpose) l1(n, false, false, X, setX, transpose && !fused_dw);  // (fused dw: no transposed copy)
         if (fused_fwd)
             WIDE_CHECK(l2f(n, false, X, nullptr, 0, transpose));
         else
@@ -1468,8 +1701,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     auto critic_forward = [&](const NetOps& n, const float* X, const float* act, long set_act, bool transpose) {
         if (!fused_fwd || transpose) {
-            l1(n, true, false, X, setX, transpose);
-            l1(n, true, true, act, set_act, transpose);
+            l1(n, true, false, X, setX, transpose && !fused_dw);
+            l1(n, true, true, act, set_act, transpose && !fused_dw);
         }
         if (fused_fwd)
             WIDE_CHECK(l2f(n, true, X, act, set_act, transpose));
@@ -1479,11 +1712,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         return AVD_OK;
     };
     // backward of layers 3 and 2 of `n` given the seed d[n]; weight gradients when `wg`
-    auto backward = [&](const NetOps& n, bool critic, const float* dvec, bool wg, int acc_idx, float* gnet) {
+    auto backward = [&](const NetOps& n, bool critic, const float* dvec, bool wg, int acc_idx, float* gnet, const float* bX = nullptr,
+                        const float* bAct = nullptr, long bSetAct = 0) {
         (void)hipMemsetAsync(u, 0, sizeof(float) * sets * H2, st);
         (void)hipMemsetAsync(cs, 0, sizeof(float) * sets * H2, st);
         hipLaunchKernelGGL(out_bwd_kernel, dim3((unsigned)rup(H2, 64) / 64, g64.y, sets), dim3(256), 0, st, P2, (long)H2, setP2, dvec,
-                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, wg ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2);
+                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, wg ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2,
+                           (wg && fused_dw) ? 1 : 0);
         const int K = critic ? KC : H1;
         if (wg) {
             const int w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3, gg = critic ? L.cg3 : L.ag2,
@@ -1491,6 +1726,22 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,
                                H2, n.inv + KCp, n.sh + KCp, n.rs + KCp, n.mean + KCp, ldT, u, cs, (long)H2, acc, acc_idx, gnet,
                                (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
+            if (fused_dw) {  // the same from the raw inputs: first layer generated per 32-row chunk, dZ2^T streamed (fw::dw_gen_kernel)
+                fw::DwP d2;
+                d2.X = bX, d2.setX = setX, d2.act = critic ? bAct : nullptr, d2.setAct = bSetAct;
+                d2.wf1 = (const bf16x8*)n.wf1, d2.nfs = H1 / 32, d2.nft = critic ? KCp / 32 : H1 / 32;
+                d2.ZT = dZ2T, d2.setZT = setZT, d2.ldz = Np, d2.inv = n.inv, d2.sh = n.sh, d2.db = cs, d2.setTab = ldT;
+                d2.dW = gnet + (critic ? L.cW2 : L.aW2), d2.setW = L.theta_size;
+                d2.Ns = Ns, d2.Np = Np, d2.H2 = H2, d2.K = K, d2.n_sets = sets, d2.nsplit = 8;  // (16 row ranges: more streams side by side per XCD, slower)
+                const int nfb = (d2.nft * 32 + 127) / 128, items = sets * (H2 / fw::FC) * d2.nsplit * nfb;
+                (void)items;
+                const dim3 grid((unsigned)(avd::fset::cu_count() / 8 * 8));  // (a multiple of the XCD count: see the kernel's item map)
+                if (critic)
+                    hipLaunchKernelGGL((fw::dw_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, d2);
+                else
+                    hipLaunchKernelGGL((fw::dw_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, d2);
+                return check_launch("avd_learn_shared_bf16: fused weight gradient");
+            }
             // dW2 = inv (.) (C^T dZ2) + sh (x) db2: reduction over the rows, split into chunks with f32 atomics
             int ksplit = 1;
             while (Np / ksplit > 16384 && Np % (ksplit * 2 * BK) == 0) ksplit *= 2;  // f32 atomics cost ~ one MFMA K-chunk of 4096
@@ -1550,7 +1801,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     float* gcrit = grads + asz;
     WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
     rows(1, q, y, nullptr, 0.f, dq);
-    WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit));
+    WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
     WIDE_CHECK(dx(net[1], 0, KC, true, true));
     l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
     l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
@@ -1577,7 +1828,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // ---- pass 3: actor gradient from the activations kept in pass 2
     use_actor_buffers(true);
     rows(3, nullptr, tt, da, high, dq);
-    WIDE_CHECK(backward(net[0], false, dq, true, 3, grads));
+    WIDE_CHECK(backward(net[0], false, dq, true, 3, grads, s));
     WIDE_CHECK(dx(net[0], 0, H1, true, false));
     l1_grads(s, setX, L.S, 0, H1, grads, L.aW1, L.ab1);
     flush_bn1(false, grads);
