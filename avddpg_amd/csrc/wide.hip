@@ -197,6 +197,51 @@ __global__ __launch_bounds__(TNV * 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int nk = p.K / TK;
     WIDE_GLDS3(0, 0)
     WIDE_GLDS3(1, min(1, nk - 1) * TK)
+    if constexpr (NWV == 8) {
+        // PING-PONG (r03): waves 0..3 (one per SIMD) and waves 4..7 alternate between "prepare" (the 12 fragment reads of a K
+        // step, the refill DMA of the stage both groups finished with) and "multiply" (its 32 MFMAs at raised priority), a barrier
+        // after each phase, the second group one phase behind: one wave per SIMD multiplies while the other prepares. With one
+        // barrier per K step and all eight waves in the same program the two waves of a SIMD read together and multiplied together.
+        // Every wave waits for all but its youngest step's loads before every barrier: whatever is read next phase has landed.
+        const int grp = wave >> 2;
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (IA + IB));
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) {
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (IA + IB));
+            __builtin_amdgcn_s_barrier();
+        }
+        int stg = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bf16* a_s = sA + stg * TM * TK;
+            const bf16* b_s = sB + stg * TNV * TK;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_s + swz32(wm * 128 + 16 * i + lr, lg));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_s + swz32(wn * 64 + 16 * j + lr, lg));
+            const int nstg = (stg + 2 >= NSTG) ? stg + 2 - NSTG : stg + 2;
+            WIDE_GLDS3(nstg, min(kt + 2, nk - 1) * TK)  // into the stage of step kt - 1; (tail: harmless re-loads)
+            __builtin_amdgcn_s_waitcnt(0x0070 | (IA + IB));  // vmcnt(one step) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (IA + IB));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stg = (stg + 1 == NSTG) ? 0 : stg + 1;
+        }
+        if (grp == 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (IA + IB));
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
     int stg = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // step kt's IA + IB loads are the oldest in flight; those of step kt+1 may stay in flight
@@ -217,6 +262,7 @@ __global__ __launch_bounds__(TNV * 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         stg = (stg + 1 == NSTG) ? 0 : stg + 1;
+    }
     }
 #undef WIDE_GLDS3
     __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the tail re-loads before the workgroup's LDS is released
