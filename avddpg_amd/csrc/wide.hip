@@ -921,8 +921,10 @@ struct FwdP {
     const bf16* WT;      // [sets][512][ldw], k permuted by kpos within groups of 16
     long setWT, ldw;
     const float *bias, *cf, *c0;  // [sets][512], [sets][512], [sets]
-    bf16* P2;            // [sets][Np][512] or NULL
+    bf16* P2;            // [sets][Np][H2] or NULL
     long setP2;
+    float dz_scale;      // != 0: store dZ2 = (relu(z2) > 0) * dz_scale * rw[row] * cf[col] there INSTEAD of the activations (the
+    const float* rw;     // output-layer backward of a pass whose seed is the constant -1/N: critic(s, mu)); rw [sets][Ns] or NULL
     float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
     long setZ;
     int Ns, Np, H2, n_sets;  // Np: padded rows (multiple of 128); H2: multiple of 512
@@ -1115,6 +1117,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int rt = 0; rt < 2; ++rt) {
                 const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
                 bf16* dst = p.P2 ? p.P2 + (long)set * p.setP2 + n * p.H2 + FC * cb + 128 * cq + 8 * h : nullptr;
+                const float drow = (p.dz_scale != 0.f && n < p.Ns) ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     unsigned pk[4][2];
@@ -1126,6 +1129,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         for (int j = 0; j < 4; ++j) {
                             o[j] = (bf16)fmaxf(acc[rt][ct][4 * g + j], 0.f);
                             zp[rt] = fmaf((float)o[j], cv[j], zp[rt]);
+                        }
+                        if (p.dz_scale != 0.f) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
                         }
                         pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
                         pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
@@ -1680,12 +1687,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     // second layer forward: P2 = relu(C @ WT^T + bias)
     // fused: first layer + second layer + output-layer dot from the raw inputs (X, act): C is not read
-    auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2) {
+    auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2, bool dz_out = false) {
         fw::FwdP f;
         f.X = X, f.setX = setX, f.act = critic ? act : nullptr, f.setAct = set_act;
         f.wf1 = (const bf16x8*)n.wf1, f.nfs = H1 / 32, f.nft = critic ? KCp / 32 : H1 / 32;
         f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
-        f.P2 = keep_p2 ? P2 : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
+        f.P2 = keep_p2 ? (dz_out ? dZ2 : P2) : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
+        f.dz_scale = dz_out ? -1.0f / (float)Ns : 0.f, f.rw = row_weight;
         static const char* dbg_env = getenv("AVD_FW_DBG");
         f.dbg = dbg_env ? atoi(dbg_env) : 0;
         f.stamp = nullptr;
@@ -1859,13 +1867,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
     l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
-    if (fused_fwd)
-        WIDE_CHECK(l2f(net[1], true, s, a1, (long)Np, true));
+    if (fused_fwd)  // (its output-layer backward too: the seed of this pass is the constant -1/N, so dZ2 leaves the forward kernel)
+        WIDE_CHECK(l2f(net[1], true, s, a1, (long)Np, true, true));
     else
         WIDE_CHECK(l2(net[1], true));
     out_layer(net[1], 0, q);
     rows(2, q, nullptr, nullptr, 0.f, dq);
-    WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
+    if (!fused_fwd) WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
     WIDE_CHECK(dx(net[1], H1, KC, false, true));
     // da[n] = sum_k dZ1[n][H1 + k] * Wa[0][k]
     hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,

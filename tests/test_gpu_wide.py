@@ -238,16 +238,22 @@ s = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
 a = rs.uniform(-2.5, 2.5, size=(n_sets, rows, 1)).astype(np.float32)
 r = -np.abs(rs.normal(0, 0.3, size=(n_sets, rows))).astype(np.float32)
 s2 = rs.normal(0, 1.5, size=(n_sets, rows, S)).astype(np.float32)
+rw = None
+if len(sys.argv) > 3 and sys.argv[3] == "weighted":  # per-platoon weights w_p * P / sum(w) on the platoon's 64 rows
+    w = rs.uniform(0.3, 2.5, size=(n_sets, P)).astype(np.float32)
+    rw = t(np.repeat(w * (P / w.sum(axis=1, keepdims=True)), 64, axis=1).astype(np.float32))
 losses = torch.zeros(n_sets, 2, device="cuda")
-g = grp.learn_shared(t(s), t(a), t(r), t(s2), n_sets * P, losses=losses)
+g = grp.learn_shared(t(s), t(a), t(r), t(s2), n_sets * P, losses=losses, row_weight=rw)
 torch.cuda.synchronize()
 np.save(sys.argv[2], np.concatenate([g.cpu().numpy().ravel(), losses.cpu().numpy().ravel()]))
 """
 
 
-def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_path):
+@pytest.mark.parametrize("mode", ["plain", "weighted"])
+def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_path, mode):
     """csrc/wide.hip, fw::fwd_gen_kernel (first layer generated on the matrix cores as the GEMM operand, W2 streamed through
-    LDS, output layer in the kernel) against the layer-wise l1_fwd + GEMM + bias kernels it replaces (AVD_WIDE_FUSED_FWD=0),
+    LDS, output layer in the kernel, the mu pass's dZ2 written by the forward kernel) and fw::dw_gen_kernel (the weight gradient
+    in the same style) against the layer-wise l1_fwd + GEMM + bias + out_bwd kernels they replace (AVD_WIDE_FUSED_FWD=0),
     the whole learn chain on the same inputs in two processes (the switch is read once per process). The two differ by the
     first layer's rounding before its bf16 cast (2^-16 against exact f32) and by summation order: 3e-3 of each block's max,
     where the bf16 operands themselves cost 8e-2 against the float64 oracle."""
@@ -263,7 +269,7 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     for flag in ("1", "0"):
         env = dict(os.environ, AVD_WIDE_FUSED_FWD=flag)
         out = tmp_path / f"g{flag}.npy"
-        p = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, str(script), root, str(out), mode], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(np.load(out))
     fused, layerwise = outs
