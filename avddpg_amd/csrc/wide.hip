@@ -862,7 +862,7 @@ __host__ __device__ constexpr int kpos(int k) { return (k & ~12) | ((k & 4) << 1
 
 // k slots of the first-layer MFMA (lane half h holds slots 8h .. 8h + 7):
 //   states : x = [xh0..3 | xl0..3 | xh0..3 | 1 1 0 0],  w = [wh0..3 | wh0..3 | wl0..3 | bh bl 0 0]
-//   action : x = [ah al ah 1 | 1 0 0 0 | 0 ...],        w = [wh wh wl bh | bl 0 0 0 | 0 ...]
+//   action : the same slots with x = (a, 0, 0, 0)
 __device__ __forceinline__ bf16x8 x_frag_state(const float (&x)[4], bool live, int h) {
     bf16 hi[4], lo[4];
 #pragma unroll
@@ -873,14 +873,10 @@ __device__ __forceinline__ bf16x8 x_frag_state(const float (&x)[4], bool live, i
     v[4] = h ? one : lo[0], v[5] = h ? one : lo[1], v[6] = h ? zero : lo[2], v[7] = h ? zero : lo[3];
     return v;
 }
+// (the action branch uses the same slots with the action in input 0 and zeros elsewhere)
 __device__ __forceinline__ bf16x8 x_frag_action(float a, bool live, int h) {
-    bf16 hi, lo;
-    split_bf(live ? a : 0.f, hi, lo);
-    const bf16 one = (bf16)(live ? 1.f : 0.f), zero = (bf16)0.f;
-    bf16x8 v;
-    v[0] = h ? zero : hi, v[1] = h ? zero : lo, v[2] = h ? zero : hi, v[3] = h ? zero : one;
-    v[4] = h ? zero : one, v[5] = zero, v[6] = zero, v[7] = zero;
-    return v;
+    const float x[4] = {a, 0.f, 0.f, 0.f};
+    return x_frag_state(x, live, h);
 }
 
 // first-layer weight fragments [sets][nft][64 lanes] (tile t < nfs: 32 state features, else 32 action features)
@@ -901,12 +897,12 @@ __global__ void prep_wf1_kernel(const float* th, long set_th, int S, int ws_off,
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = h ? wl[j] : wh[j];
         v[4] = h ? bh : wh[0], v[5] = h ? bl : wh[1], v[6] = h ? zero : wh[2], v[7] = h ? zero : wh[3];
-    } else if (h == 0) {
+    } else {
         const int k = 32 * (t - nfs) + f;
         bf16 wh, wl, bh, bl;
         split_bf(k < Ha ? T[wa_off + k] : 0.f, wh, wl);
         split_bf(k < Ha ? T[ba_off + k] : 0.f, bh, bl);
-        v[0] = wh, v[1] = wh, v[2] = wl, v[3] = bh, v[4] = bl;
+        v[0] = h ? wl : wh, v[4] = h ? bh : wh, v[5] = h ? bl : zero;  // the state layout with one input
     }
     wf1[((long)set * nft + t) * 64 + lane] = v;
 }
@@ -1484,6 +1480,288 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Input gradient of the second layer + everything behind it, without an activation or gradient matrix of the first layer:
+//   dy[n][f] = sum_c dZ2[n][c] W2[f][c]            (MFMA, K = H2; D[row][feature]: lane = feature, registers = rows)
+//   p[n][f]  = x[n] . W1[:, f] + b1[f]              (regenerated: one MFMA per 32 x 32 tile, same layout)
+//   dgamma1[f] = rs (S1 - mean S2), dbeta1[f] = S2, db1[f] = inv S3, dW1[s][f] = inv S4[s]   with the per-feature sums over rows
+//   S1 = sum dy relu(p), S2 = sum dy, S3 = sum [p > 0] dy, S4[s] = sum x[n][s] [p > 0] dy
+// -- sums over the REGISTERS of a lane (rows), kept in registers across all row tiles of a workgroup and added to the gradient
+// slab once at the end (f32 atomics). Replaces the input-gradient GEMM with its BN / ReLU epilogue (which read C and wrote dZ1),
+// l1_fwd (C), l1_grads and the BN flush. A workgroup = 256 rows x 256 features per step of 32 c: both operands stream through
+// LDS (dZ2 rows from memory, the W2 block from L2), 8 waves = 4 row quarters x 2 feature halves (the two ping-pong groups).
+// Workgroup ids -> XCD x = id % 8, slot id / 8 -> (row group, feature block): the feature blocks of a row group share an L2.
+struct DxP {
+    const float* X;     // [sets][Ns][4]
+    long setX;
+    const float* act;   // critic: [sets][setAct]
+    long setAct;
+    const bf16x8* wf1;  // [sets][nft][64]
+    int nft, nfs;
+    const bf16* dZ;     // [sets][Np][H2]
+    long setDZ;
+    const bf16* Wn;     // [sets][>= 256 nfb][H2]: bf16(W2), row = feature
+    long setWn;
+    const float *inv, *rs, *mean;  // [sets][setTab]
+    long setTab;
+    float* g;           // [sets][setG] gradient slab of the net
+    long setG;
+    int w_off[2], b_off[2], g_off[2], be_off[2];  // [0] state branch, [1] action branch
+    int Ns, Np, H2, H1, Ha, n_sets, nfb, groups_per_xcd;
+};
+
+constexpr int DX_STG = 2 * 256 * FK * 2, DX_NS = 3;  // A tile + B tile; three stages (two chunks in flight)
+// raw inputs three tiles deep; the running sums of a wave's 128 features (7 per feature) live in LDS between tile epilogues
+constexpr int DXL_X = DX_NS * DX_STG, DXL_A = DXL_X + 3 * 256 * 16, DXL_S = DXL_A + 3 * 256 * 4, DXL_TOTAL = DXL_S + 8 * 28 * 32 * 4;
+
+template <bool CRITIC>
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dx_gen_kernel(DxP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int rq = wave & 3, fh = wave >> 2, grp = fh;  // 64-row quarter, 128-feature half = ping-pong group
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nk = p.H2 / FK, ntile = p.Np / 256;
+    // slot -> (row group, feature block)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rg = slot / p.nfb, fb = slot - rg * p.nfb;
+    if (rg >= p.groups_per_xcd) return;
+    const int ngroups = 8 * p.groups_per_xcd, group = xcd * p.groups_per_xcd + rg;
+    const int total = p.n_sets * ntile;  // (set, row tile) pairs, dealt in contiguous runs to the row groups
+    const int t_begin = (int)((long)total * group / ngroups), t_end = (int)((long)total * (group + 1) / ngroups);
+    if (t_begin >= t_end) return;
+    // fragment read offsets (64-byte image rows, 16-byte pieces swizzled by bits 2..3 of the row)
+    const int sw = (r >> 2) & 3;
+    const int ra0 = ((64 * rq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, ra1 = ((64 * rq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+    const int rb0 = 256 * FK * 2 + ((128 * fh + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rb1 = 256 * FK * 2 + ((128 * fh + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+    const unsigned vo_a = (unsigned)(((lane >> 2) * p.H2 + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+
+    // running sums per feature, halves already added: [wave][7 ft-major quantities x 4 ft][32 lanes] floats in LDS
+    float* sums = (float*)(smem_raw + DXL_S) + wave * 28 * 32 + r;
+    auto clear_sums = [&]() {
+        if (h == 0)
+#pragma unroll
+            for (int q = 0; q < 28; ++q) sums[q * 32] = 0.f;
+    };
+    clear_sums();
+    const int f0 = fb * 256 + fh * 128;               // the wave's first feature
+    const bool action = CRITIC && f0 >= p.H1;          // (H1 is a multiple of 128: a wave's features lie on one side)
+    int set = t_begin / ntile;
+    // per-set state: first-layer fragments (B operand of the regenerated first layer), stream bases
+    const char *ub_a = nullptr, *ub_b = nullptr;
+    auto load_set = [&]() {
+        ub_a = (const char*)(p.dZ + (long)set * p.setDZ + (long)(32 * wv) * p.H2);             // + row tile, chunk
+        ub_b = (const char*)(p.Wn + (long)set * p.setWn + (long)(fb * 256 + 32 * wv) * p.H2);  // + chunk
+    };
+    // chunk kc of row tile tl into stage stg: wave w fills image rows [32 w, 32 w + 32) of both tiles (2 + 2 instructions)
+    auto dma = [&](int stg, int tl, int kc) {
+        unsigned char* l = smem_raw + stg * DX_STG;
+        unsigned vw = vo_a;
+        asm volatile("" : "+v"(vw));
+        const long ta = (long)tl * 256 * p.H2 * 2 + (long)kc * FK * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub_a + ta + (long)i * 32 * p.H2 + vw), (lptr_t)(l + (32 * wv + 16 * i) * FK * 2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub_b + (long)kc * FK * 2 + (long)i * 32 * p.H2 + vw), (lptr_t)(l + 256 * FK * 2 + (32 * wv + 16 * i) * FK * 2), 16, 0, 0);
+        }
+    };
+    // raw inputs of row tile tl into buffer b: 64 rows per instruction, waves 4..7 repeat waves 0..3 (uniform counts)
+    auto dma_x = [&](int tl, int b) {
+        int n = tl * 256 + 64 * (wv & 3) + lane;
+        n = n < p.Ns ? n : p.Ns - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + DXL_X + (b * 256 + 64 * (wv & 3)) * 16), 16, 0, 0);
+        if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + DXL_A + (b * 256 + 64 * (wv & 3)) * 4), 4, 0, 0);
+    };
+    constexpr int NDMA = 4;  // per chunk; the counted waits leave ONE chunk in flight (three stages)
+    // the sums of the finished set go to the gradient slab
+    auto flush = [&]() {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const float s1 = sums[(7 * ft + 0) * 32], s2 = sums[(7 * ft + 1) * 32], s3 = sums[(7 * ft + 2) * 32];
+            const float s4[4] = {sums[(7 * ft + 3) * 32], sums[(7 * ft + 4) * 32], sums[(7 * ft + 5) * 32], sums[(7 * ft + 6) * 32]};
+            const int f = f0 + 32 * ft + r, br = action ? 1 : 0, fl = action ? f - p.H1 : f, Hn = action ? p.Ha : p.H1;
+            if (h == 0 && fl < Hn) {
+                const long tb = (long)set * p.setTab + f;
+                const float iv = p.inv[tb], rsv = p.rs[tb], mv = p.mean[tb];
+                float* g = p.g + (long)set * p.setG;
+                atomicAdd(g + p.g_off[br] + fl, rsv * (s1 - mv * s2));
+                atomicAdd(g + p.be_off[br] + fl, s2);
+                atomicAdd(g + p.b_off[br] + fl, iv * s3);
+                const int ns = action ? 1 : 4;  // (action: input 0 is the action, the others are zeros)
+                for (int sI = 0; sI < ns; ++sI) atomicAdd(g + p.w_off[br] + (long)sI * Hn + fl, iv * s4[sI]);
+            }
+        }
+        clear_sums();
+    };
+    load_set();
+    // ---- start the stream: chunks 0 .. 2 of the first row tile
+    {
+        const int tl = t_begin - set * ntile;
+        dma_x(tl, 0);
+#pragma unroll
+        for (int c = 0; c < DX_NS - 1; ++c) dma(c, tl, c);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (grp == 1) {  // one phase behind
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
+        __builtin_amdgcn_s_barrier();
+    }
+    int stg = 0, xb = 0;
+    f32x16 acc[2][4];
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tl = t - set * ntile;
+        // where the stream goes after this tile: the next tile of the run (same set or the next one), or nowhere
+        const int tn = t + 1 < t_end ? t + 1 : t;
+        const int set_n = tn / ntile, tln = tn - set_n * ntile;
+        const bool same_set = set_n == set;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) acc[rt][ft] = zero16;
+        auto step = [&](int kt, auto wait_c) {
+            constexpr bool WAIT = decltype(wait_c)::value;
+            // ================= prepare(kt)
+            bf16x8 A[2][2], B[2][4];
+            const unsigned char* l = smem_raw + stg * DX_STG;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) A[0][rt] = *(const bf16x8*)(l + ra0 + rt * 32 * FK * 2), A[1][rt] = *(const bf16x8*)(l + ra1 + rt * 32 * FK * 2);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) B[0][ft] = *(const bf16x8*)(l + rb0 + ft * 32 * FK * 2), B[1][ft] = *(const bf16x8*)(l + rb1 + ft * 32 * FK * 2);
+            {   // refill: chunk kt + 3 of this tile, or the first chunks of the next tile (a new set only after the flush: see below)
+                const int kc = kt + DX_NS - 1, sd = (stg + DX_NS - 1) % DX_NS;
+                if (kc < nk)
+                    dma(sd, tl, kc);
+                else if (same_set)
+                    dma(sd, tln, kc - nk);
+                else
+                    dma(sd, tl, nk - 1);  // (harmless re-load: uniform counts; the next set's stream starts at the tile boundary)
+            }
+            if (WAIT)
+                __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+            else
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= multiply(kt)
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc[rt][ft] = mfma(A[ks][rt], B[ks][ft], acc[rt][ft]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stg = stg + 1 == DX_NS ? 0 : stg + 1;
+        };
+        // (three buffers: the other group is still folding the previous tile while this one requests the tile after next)
+        const int xbn = xb == 2 ? 0 : xb + 1;
+        if (same_set && tn != t) dma_x(tln, xbn);
+        step(0, std::false_type{});
+        step(1, std::false_type{});
+        for (int kt = 2; kt < nk; ++kt) step(kt, std::true_type{});
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain: nothing older than what follows
+        // ---- tile epilogue (a prepare phase of this group): regenerate the first layer, fold the tile into the sums.
+        // S1..S3 on the VALU (5 per element); S4[s] = sum_rows x[row][s] mdy[row][f] is one more product over the rows: A = x^T as
+        // bf16 hi (m = s) and lo (m = 4 + s) rows in the accumulator's row order, B = bf16(mdy) as it stands (lane = feature).
+        auto raw_x1 = [&](int row, int sI) {  // input sI of a row (the kernel serves the state features; action features: dx() + l1_grads)
+            return *(const float*)(smem_raw + DXL_X + (xb * 256 + row) * 16 + 4 * sI);
+        };
+        bf16x8 xT[2][2];  // [rt][ks]: lane m = lane & 31 (m < 4: hi of input m, m < 8: lo of input m - 4, else 0), element e <-> row below
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16 zb = (bf16)0.f;
+                bf16x8 v = {zb, zb, zb, zb, zb, zb, zb, zb};
+                if (r < 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = 64 * rq + 32 * rt + 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3);
+                        const float xs = raw_x1(row, r & 3);
+                        const bf16 hi = (bf16)xs;
+                        v[e] = r < 4 ? hi : (bf16)(xs - (float)hi);
+                    }
+                }
+                xT[rt][ks] = v;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const bf16 zb = (bf16)0.f;
+            bf16x8 wf = {zb, zb, zb, zb, zb, zb, zb, zb};
+            const int wt = f0 / 32 + ft;
+            if (wt < p.nft) wf = p.wf1[((long)set * p.nft + wt) * 64 + lane];
+            f32x16 G = zero16;
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = 64 * rq + 32 * rt + r;
+                const float x0[4] = {raw_x1(row, 0), raw_x1(row, 1), raw_x1(row, 2), raw_x1(row, 3)};
+                const f32x16 p1 = mfma(x_frag_state(x0, tl * 256 + row < p.Ns, h), wf, zero16);  // [row (registers)][feature (lane)]
+                float md[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float dy = acc[rt][ft][i], pp = fmaxf(p1[i], 0.f);
+                    md[i] = p1[i] > 0.f ? dy : 0.f;
+                    s1 = fmaf(dy, pp, s1);
+                    s2 += dy;
+                    s3 += md[i];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 mb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mb[e] = (bf16)md[8 * ks + e];
+                    G = mfma(xT[rt][ks], mb, G);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // G[m][f]: register 4 g + j <-> m = 8 g + 4 h + j: registers 0..3 of the h = 0 half are the hi products of inputs 0..3,
+            // of the h = 1 half the lo products (the halves are added in flush())
+            float q7[7] = {s1, s2, s3, G[0], G[1], G[2], G[3]};
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                q7[q] += __shfl_xor(q7[q], 32);  // (the two halves hold different rows of the same feature; G: hi + lo products)
+                if (h == 0) sums[(7 * ft + q) * 32] += q7[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        xb = xbn;
+        if (!same_set || tn == t) {
+            flush();
+            if (tn != t) {
+                // a new set: its fragments, bases and stream start here. The groups are a phase apart and each wave requests its
+                // own share, so they are brought level first, as at the start and the end of the kernel
+                if (grp == 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __builtin_amdgcn_s_barrier();
+                }
+                set = set_n;
+                load_set();
+                dma_x(tln, xb);
+#pragma unroll
+                for (int c = 0; c < DX_NS - 1; ++c) dma((stg + c) % DX_NS, tln, c);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_s_barrier();
+                if (grp == 1) __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    if (grp == 0) {  // make up the phase this group is ahead
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+}
 }  // namespace fw
 
 // ---- workspace plan -------------------------------------------------------------------------
@@ -1608,6 +1886,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
     static const char* fd_env = getenv("AVD_WIDE_FUSED_DW");
     const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && !(fd_env && fd_env[0] == '0');
+    static const char* fx_env = getenv("AVD_WIDE_FUSED_DX");
+    const bool fused_dx = fused_dw && Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fx_env && fx_env[0] == '0');
     static bool fw_attr = false;
     constexpr size_t fw_lds = fw::L_TOTAL;
     if (fused_fwd && !fw_attr) {
@@ -1615,6 +1895,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        (void)hipFuncSetAttribute((const void*)fw::dx_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw::DXL_TOTAL);
         fw_attr = true;
     }
     // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
@@ -1745,7 +2026,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     // reads r with the internal stride, so r is first copied into `da` (free at that point) with the padded stride.
     // `transpose` = a backward pass follows: the first-layer activations (and their transposes) are materialised for it
     auto actor_forward = [&](const NetOps& n, const float* X, bool transpose) {
-        if (!fused_fwd || transpose) l1(n, false, false, X, setX, transpose && !fused_dw);  // (fused dw: no transposed copy)
+        // (fused: the forward generates the first layer, dw_gen generates it again, dx_gen regenerates it: no copy in memory)
+        if (!fused_fwd || (transpose && !(fused_dw && fused_dx))) l1(n, false, false, X, setX, transpose && !fused_dw);
         if (fused_fwd)
             WIDE_CHECK(l2f(n, false, X, nullptr, 0, transpose));
         else
@@ -1754,7 +2036,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         return AVD_OK;
     };
     auto critic_forward = [&](const NetOps& n, const float* X, const float* act, long set_act, bool transpose) {
-        if (!fused_fwd || transpose) {
+        if (!fused_fwd || (transpose && !(fused_dw && fused_dx))) {
             l1(n, true, false, X, setX, transpose && !fused_dw);
             l1(n, true, true, act, set_act, transpose && !fused_dw);
         }
@@ -1830,7 +2112,22 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             hipLaunchKernelGGL((l1_grads_kernel<3>), grid, dim3(256), 0, st, X, set_x, dZ1, (long)KCp, setC, c0, H, Ns, rpb, 1.0f, gnet,
                                (long)L.theta_size, w_off, b_off);
     };
-    auto flush_bn1 = [&](bool critic, float* gnet) {
+    // fused input gradient + first-layer gradients (fw::dx_gen_kernel)
+    auto dx_fused = [&](const NetOps& n, bool critic, float* gnet, const float* X, const float* act, long set_act) {
+        fw::DxP d3;
+        d3.X = X, d3.setX = setX, d3.act = critic ? act : nullptr, d3.setAct = set_act;
+        d3.wf1 = (const bf16x8*)n.wf1, d3.nfs = H1 / 32, d3.nft = critic ? KCp / 32 : H1 / 32;
+        d3.dZ = dZ2, d3.setDZ = setP2, d3.Wn = n.Wn, d3.setWn = setWn, d3.inv = n.inv, d3.rs = n.rs, d3.mean = n.mean, d3.setTab = ldT;
+        d3.g = gnet, d3.setG = L.theta_size;
+        d3.w_off[0] = critic ? L.cWs : L.aW1, d3.b_off[0] = critic ? L.cbs : L.ab1, d3.g_off[0] = critic ? L.cgs : L.ag1, d3.be_off[0] = critic ? L.cbes : L.abe1;
+        d3.w_off[1] = L.cWa, d3.b_off[1] = L.cba, d3.g_off[1] = L.cga, d3.be_off[1] = L.cbea;
+        d3.Ns = Ns, d3.Np = Np, d3.H2 = H2, d3.H1 = H1, d3.Ha = Ha, d3.n_sets = sets;
+        d3.nfb = H1 / 256, d3.groups_per_xcd = 32 / d3.nfb;  // (the state features; the critic's 48 action features go the GEMM way)
+        // (state features only: the <false> form -- no action inputs -- serves both nets)
+        hipLaunchKernelGGL((fw::dx_gen_kernel<false>), dim3(256), dim3(fw::FT), (size_t)fw::DXL_TOTAL, st, d3);
+        return check_launch("avd_learn_shared_bf16: fused input gradient");
+    };
+    auto flush_bn1 = [&](bool critic, float* gnet, bool state_part = true) {
         const float* dg = F32(pl.bnacc);
         const float* dbe = dg + (long)NSLICE * sets * ldT;
         auto go = [&](int t_off, int len, int gg, int gbe) {
@@ -1838,7 +2135,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                                (long)sets * ldT, t_off, len, gnet, (long)L.theta_size, gg, gbe);
         };
         if (critic) {
-            go(0, H1, L.cgs, L.cbes);
+            if (state_part) go(0, H1, L.cgs, L.cbes);
             go(H1, Ha, L.cga, L.cbea);
         } else {
             go(0, H1, L.ag1, L.abe1);
@@ -1856,10 +2153,19 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
     rows(1, q, y, nullptr, 0.f, dq);
     WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
-    WIDE_CHECK(dx(net[1], 0, KC, true, true));
-    l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
-    l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
-    flush_bn1(true, gcrit);
+    if (fused_dx) {
+        WIDE_CHECK(dx_fused(net[1], true, gcrit, s, a, (long)Ns));
+        // the action branch (48 features): its activations, the small GEMM with the BN / ReLU epilogue, first-layer gradients
+        l1(net[1], true, true, a, (long)Ns, false);
+        WIDE_CHECK(dx(net[1], H1, KC, true, true));
+        l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+        flush_bn1(true, gcrit, false);
+    } else {
+        WIDE_CHECK(dx(net[1], 0, KC, true, true));
+        l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
+        l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+        flush_bn1(true, gcrit);
+    }
 
     // ---- pass 2: actor through the critic, gradient w.r.t. the action                       (trainer.py:502-506)
     use_actor_buffers(true);
@@ -1883,9 +2189,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     use_actor_buffers(true);
     rows(3, nullptr, tt, da, high, dq);
     WIDE_CHECK(backward(net[0], false, dq, true, 3, grads, s));
-    WIDE_CHECK(dx(net[0], 0, H1, true, false));
-    l1_grads(s, setX, L.S, 0, H1, grads, L.aW1, L.ab1);
-    flush_bn1(false, grads);
+    if (fused_dx) {
+        WIDE_CHECK(dx_fused(net[0], false, grads, s, nullptr, 0));
+    } else {
+        WIDE_CHECK(dx(net[0], 0, H1, true, false));
+        l1_grads(s, setX, L.S, 0, H1, grads, L.aW1, L.ab1);
+        flush_bn1(false, grads);
+    }
     hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(64), 0, st, acc, Ns, sets, losses);
     return check_launch("avd_learn_shared_bf16");
 }
