@@ -1885,7 +1885,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     static const char* ff_env = getenv("AVD_WIDE_FUSED_FWD");
     const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
     static const char* fd_env = getenv("AVD_WIDE_FUSED_DW");
-    const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && !(fd_env && fd_env[0] == '0');
+    const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
+                          !(fd_env && fd_env[0] == '0');
     static const char* fx_env = getenv("AVD_WIDE_FUSED_DX");
     const bool fused_dx = fused_dw && Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fx_env && fx_env[0] == '0');
     static bool fw_attr = false;
