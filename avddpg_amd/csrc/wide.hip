@@ -1271,7 +1271,7 @@ struct DwP {
     long setAct;
     const bf16x8* wf1;  // [sets][nft][64] (the same fragments: lane = feature)
     int nft, nfs;
-    const bf16* ZT;     // [sets][H2n][ldz]: dZ2^T, rows permuted within groups of 16
+    const bf16* ZT;     // [sets][Np][ldz]: dZ2, row-major (ldz = H2)
     long setZT, ldz;
     const float *inv, *sh;  // [sets][setTab] first-layer BN tables (feature index)
     const float* db;        // [sets][H2] column sums of dZ2
@@ -1281,6 +1281,9 @@ struct DwP {
     int Ns, Np, H2, K, n_sets, nsplit;
 };
 
+// stage = the chunk's 32 rows of dZ2 (512 columns each, row stride 1088 B: the transposed reads below are conflict-free) + the next
+// chunk's raw inputs
+constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + 1024;
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_gen_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1307,12 +1310,21 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
         b = __builtin_bit_cast(bf16x8, o);
     };
-    const int sw = (r >> 2) & 3;
-    const int rd0 = ((128 * cq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rd1 = ((128 * cq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+    // A fragments (lane = column of dZ2, k = rows) from the row-major chunk by ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x
+    // 16 columns comes back column-major; lane 4 q + pp of the group addresses row q, columns 4 pp .. 4 pp + 3. Two reads per fragment:
+    // element 4 g + j of lane half h is row 8 g + 4 h + j of the k-step -- the k order of the generated operand as it stands.
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tmb = 16 * ((lane >> 4) & 1);
+    const int rdt = (4 * h + tq) * DW_ROWB + (128 * cq + tmb + 4 * tp) * 2;
     auto read_frags = [&](int stg, int ks, bf16x8 (&a)[4]) {
-        const unsigned char* b = smem_raw + stg * STG_BYTES + (ks ? rd1 : rd0);
+        const unsigned char* b = smem_raw + stg * DW_STG + rdt + 16 * ks * DW_ROWB;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(b + 8 * g * DW_ROWB + ct * 64));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[ct][4 * g + j] = t[j];
+            }
     };
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int rows_per = p.Np / p.nsplit, nk = rows_per / FK;  // chunks of an item (Np is a multiple of 256, nsplit of 8: whole chunks)
@@ -1338,22 +1350,21 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         // stream: image rows (= columns of dZ2) [64 w, 64 w + 64) of the column block, 16 per instruction; + the raw inputs of the
         // NEXT chunk's 32 rows (16 B of state per row, 4 B of action), every wave the same bytes (uniform instruction counts)
-        const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(FC * cb + 64 * wv) * p.ldz + row_base);
-        const unsigned vow = (unsigned)(((lane >> 2) * p.ldz + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
-        const long g16 = 32 * p.ldz;
+        const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(row_base + 4 * wv) * p.ldz + FC * cb);  // rows 4 w .. 4 w + 3 of a chunk
+        const unsigned vow = (unsigned)lane * 16u;
         auto dma = [&](int stg, int kc) {  // chunk kc of the item into stage stg: 4 + 1 (+ 1) wave-instructions
-            unsigned char* l = smem_raw + stg * STG_BYTES;
+            unsigned char* l = smem_raw + stg * DW_STG;
             unsigned vw = vow;
             asm volatile("" : "+v"(vw));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + (long)kc * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
+            for (int i = 0; i < 4; ++i)  // one row (512 columns = 1 KiB) per instruction
+                __builtin_amdgcn_global_load_lds((gptr_t)(ubw + ((long)kc * FK + i) * p.ldz * 2 + vw), (lptr_t)(l + (4 * wv + i) * DW_ROWB), 16, 0, 0);
             const int kn = kc + 1 < nk ? kc + 1 : kc;  // (the last chunk carries its own rows again: never used)
             int n = row_base + kn * FK + (lane & 31);
             n = n < p.Ns ? n : p.Ns - 1;
             if (lane < 32) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FC * FK * 2), 16, 0, 0);
-                if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FC * FK * 2 + 512), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FK * DW_ROWB), 16, 0, 0);
+                if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FK * DW_ROWB + 512), 4, 0, 0);
             }
         };
         constexpr int NDMA = CRITIC ? 6 : 5;
@@ -1361,7 +1372,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         auto x_of = [&](int stg, int kc) {  // stage stg carries the raw rows of chunk kc + 1
             const int n = row_base + (kc + 1) * FK + r;
             const bool live = kc + 1 < nk && n < p.Ns;
-            const unsigned char* l = smem_raw + stg * STG_BYTES + FC * FK * 2;
+            const unsigned char* l = smem_raw + stg * DW_STG + FK * DW_ROWB;
             if (action) return x_frag_action(*(const float*)(l + 512 + r * 4), live, h);
             const f32x4 xv = *(const f32x4*)(l + r * 16);
             const float x[4] = {xv[0], xv[1], xv[2], xv[3]};
@@ -2054,8 +2065,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         (void)hipMemsetAsync(u, 0, sizeof(float) * sets * H2, st);
         (void)hipMemsetAsync(cs, 0, sizeof(float) * sets * H2, st);
         hipLaunchKernelGGL(out_bwd_kernel, dim3((unsigned)rup(H2, 64) / 64, g64.y, sets), dim3(256), 0, st, P2, (long)H2, setP2, dvec,
-                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, wg ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2,
-                           (wg && fused_dw) ? 1 : 0);
+                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, (wg && !fused_dw) ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2, 0);
         const int K = critic ? KC : H1;
         if (wg) {
             const int w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3, gg = critic ? L.cg3 : L.ag2,
@@ -2067,7 +2077,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 fw::DwP d2;
                 d2.X = bX, d2.setX = setX, d2.act = critic ? bAct : nullptr, d2.setAct = bSetAct;
                 d2.wf1 = (const bf16x8*)n.wf1, d2.nfs = H1 / 32, d2.nft = critic ? KCp / 32 : H1 / 32;
-                d2.ZT = dZ2T, d2.setZT = setZT, d2.ldz = Np, d2.inv = n.inv, d2.sh = n.sh, d2.db = cs, d2.setTab = ldT;
+                d2.ZT = dZ2, d2.setZT = setP2, d2.ldz = H2, d2.inv = n.inv, d2.sh = n.sh, d2.db = cs, d2.setTab = ldT;
                 d2.dW = gnet + (critic ? L.cW2 : L.aW2), d2.setW = L.theta_size;
                 d2.Ns = Ns, d2.Np = Np, d2.H2 = H2, d2.K = K, d2.n_sets = sets, d2.nsplit = 8;  // (16 row ranges: more streams side by side per XCD, slower)
                 const int nfb = (d2.nft * 32 + 127) / 128, items = sets * (H2 / fw::FC) * d2.nsplit * nfb;
