@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void out_bwd_kernel(const bf16* P2, long ldp, 
         if (n < Ns) pv = *(const bf16x4*)(P2 + (long)set * set_p + (long)n * ldp + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float p = (float)pv[e];
+            const float p = fmaxf((float)pv[e], 0.f);  // (the fused forward may leave the sign on: relu commutes with the bf16 rounding)
             const float dz = (p > 0.f) ? sd[r] * c[e] : 0.f;
             su[e] = fmaf(p, sd[r], su[e]);
             sc[e] += dz;
@@ -919,6 +919,7 @@ struct FwdP {
     const float *bias, *cf, *c0;  // [sets][512], [sets][512], [sets]
     bf16* P2;            // [sets][Np][H2] or NULL
     long setP2;
+    int store_pre;       // != 0: the stored activations keep their sign (bf16 of z2, not of relu(z2)): fwd_delta_kernel continues from them
     float dz_scale;      // != 0: store dZ2 = (relu(z2) > 0) * dz_scale * rw[row] * cf[col] there INSTEAD of the activations (the
     const float* rw;     // output-layer backward of a pass whose seed is the constant -1/N: critic(s, mu)); rw [sets][Ns] or NULL
     float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
@@ -1129,6 +1130,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         if (p.dz_scale != 0.f) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
+                        } else if (p.store_pre) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[rt][ct][4 * g + j];
                         }
                         pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
                         pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
@@ -1773,6 +1777,147 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 }
+
+// ------------------------------------------------------------------------------------------
+// critic(s, mu) as a delta on critic(s, a): the two passes share the states and the weights, so
+//   z2(mu) = z2(a) + W2[action features] . (f(mu) - f(a)),   f = the relu'd first layer of the action branch (64 padded features)
+// -- 4 k-steps instead of the pass's 68. z2(a) comes back from the activations critic(s, a) stored with their sign (bf16), the
+// 64 action columns of the weight block stay in LDS, and the epilogue is fwd_gen_kernel's for this pass: q partial sums and
+// dZ2 = [z2 > 0] (-w/N) cf. HBM-bound: reads and writes one activation matrix.
+struct DeltaP {
+    const bf16* Zin;    // [sets][Np][H2]
+    long setZ;
+    const float *a, *mu;  // [sets][setA], [sets][setMu]
+    long setA, setMu;
+    const bf16x8* wf1;  // [sets][nft][64]
+    int nft, nfs;
+    const bf16* WT;     // [sets][H2n][ldw], k permuted
+    long setWT, ldw;
+    const float* cf;    // [sets][H2]
+    bf16* dZ;           // [sets][Np][H2]
+    float* z;           // [sets][setQ], pre-filled with c0: one f32 atomic per row and column block
+    long setQ;
+    float dz_scale;
+    const float* rw;
+    int Ns, Np, H2, H1, n_sets;
+};
+constexpr int DL_W = 0, DL_CF = DL_W + FC * 64 * 2, DL_ZS = DL_CF + FC * 4, DL_TOTAL = DL_ZS + 4 * FR * 4;
+
+__global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_delta_kernel(DeltaP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* sWa = (bf16*)(smem_raw + DL_W);   // [512 columns][64 k]: 128-byte rows, 16-byte pieces XOR-swizzled by bits 1..3 of the row
+    float* scf = (float*)(smem_raw + DL_CF);
+    float* zs = (float*)(smem_raw + DL_ZS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int rh = wave & 1, cq = wave >> 1, ncb = p.H2 / FC, ntile = p.Np / FR;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
+    for (int pair = 0; pair < p.n_sets * ncb; ++pair) {
+        const int set = pair / ncb, cb = pair - set * ncb;
+        if ((int)blockIdx.x >= ntile) continue;
+        __syncthreads();
+        {   // the weight block's 64 action columns (k = H1 .. H1 + 63) of image row (= output column) tid
+            const bf16* src = p.WT + (long)set * p.setWT + (long)(FC * cb + tid) * p.ldw + p.H1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *(wide::u32x4*)(sWa + tid * 64 + ((c ^ ((tid >> 1) & 7)) << 3)) = *(const wide::u32x4*)(src + 8 * c);
+            scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+        }
+        bf16x8 wf[2];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+            const bf16 zb = (bf16)0.f;
+            wf[ta] = (bf16x8){zb, zb, zb, zb, zb, zb, zb, zb};
+            if (p.nfs + ta < p.nft) wf[ta] = p.wf1[((long)set * p.nft + p.nfs + ta) * 64 + lane];
+        }
+        __syncthreads();
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            f32x16 acc[2][4];
+            bf16x8 dfr[2][2][2];  // [row tile][action tile][k-step]: bf16 of relu(p1(mu)) - relu(p1(a))
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                const bool live = n < p.Ns;
+                const bf16x8 xa = x_frag_action(live ? p.a[(long)set * p.setA + n] : 0.f, live, h);
+                const bf16x8 xm = x_frag_action(live ? p.mu[(long)set * p.setMu + n] : 0.f, live, h);
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    const f32x16 pa = mfma(wf[ta], xa, zero16), pm = mfma(wf[ta], xm, zero16);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) dfr[rt][ta][ks][i] = (bf16)(fmaxf(pm[8 * ks + i], 0.f) - fmaxf(pa[8 * ks + i], 0.f));
+                }
+                // z2(a), this wave's 128 columns of the row: 16-byte pieces, the row's two lanes swap halves (the store's inverse)
+                const bf16* src = p.Zin + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const wide::u32x4 u = *(const wide::u32x4*)(src + 32 * ct + 16 * gg);
+                        const auto t0 = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
+                        const auto t1 = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
+                        const unsigned pk[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                acc[rt][ct][4 * (2 * gg + g2) + 2 * e] = __uint_as_float(pk[g2][e] << 16);
+                                acc[rt][ct][4 * (2 * gg + g2) + 2 * e + 1] = __uint_as_float(pk[g2][e] & 0xffff0000u);
+                            }
+                    }
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const int row = 128 * cq + 32 * ct + r, c = 4 * ta + 2 * ks + h;
+                        const bf16x8 aw = *(const bf16x8*)(sWa + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(aw, dfr[rt][ta][ks], acc[rt][ct]);
+                    }
+            // ---- epilogue (as fwd_gen_kernel's for this pass)
+            float zp[2] = {0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                bf16* dst = p.dZ + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
+                const float drow = n < p.Ns ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 cv = *(const f32x4*)(scf + 128 * cq + 32 * ct + 8 * g + 4 * h);
+                        bf16 o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = (bf16)fmaxf(acc[rt][ct][4 * g + j], 0.f);
+                            zp[rt] = fmaf((float)o[j], cv[j], zp[rt]);
+                            o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
+                        }
+                        pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
+                        pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
+                    }
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                        wide::u32x4 o;
+                        o[0] = s0[0], o[1] = s1[0], o[2] = s0[1], o[3] = s1[1];
+                        *(wide::u32x4*)(dst + 32 * ct + 16 * gg) = o;
+                    }
+                }
+                zp[rt] += __shfl_xor(zp[rt], 32);
+                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp[rt];
+            }
+            __syncthreads();
+            if (tid < FR) atomicAdd(p.z + (long)set * p.setQ + (long)tile * FR + tid, (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]));
+            __syncthreads();
+        }
+    }
+}
 }  // namespace fw
 
 // ---- workspace plan -------------------------------------------------------------------------
@@ -1900,6 +2045,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                           !(fd_env && fd_env[0] == '0');
     static const char* fx_env = getenv("AVD_WIDE_FUSED_DX");
     const bool fused_dx = fused_dw && Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fx_env && fx_env[0] == '0');
+    static const char* fl_env = getenv("AVD_WIDE_FUSED_DELTA");
+    const bool fused_delta = fused_fwd && H1 % 32 == 0 && KCp - H1 == 64 && !(fl_env && fl_env[0] == '0');
     static bool fw_attr = false;
     constexpr size_t fw_lds = fw::L_TOTAL;
     if (fused_fwd && !fw_attr) {
@@ -1908,6 +2055,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         (void)hipFuncSetAttribute((const void*)fw::dx_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw::DXL_TOTAL);
+        (void)hipFuncSetAttribute((const void*)fw::fwd_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw::DL_TOTAL);
         fw_attr = true;
     }
     // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
@@ -1980,13 +2128,14 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     // second layer forward: P2 = relu(C @ WT^T + bias)
     // fused: first layer + second layer + output-layer dot from the raw inputs (X, act): C is not read
-    auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2, bool dz_out = false) {
+    auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2, bool dz_out = false,
+                   bool store_pre = false) {
         fw::FwdP f;
         f.X = X, f.setX = setX, f.act = critic ? act : nullptr, f.setAct = set_act;
         f.wf1 = (const bf16x8*)n.wf1, f.nfs = H1 / 32, f.nft = critic ? KCp / 32 : H1 / 32;
         f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
         f.P2 = keep_p2 ? (dz_out ? dZ2 : P2) : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
-        f.dz_scale = dz_out ? -1.0f / (float)Ns : 0.f, f.rw = row_weight;
+        f.dz_scale = dz_out ? -1.0f / (float)Ns : 0.f, f.rw = row_weight, f.store_pre = store_pre ? 1 : 0;
         static const char* dbg_env = getenv("AVD_FW_DBG");
         f.dbg = dbg_env ? atoi(dbg_env) : 0;
         f.stamp = nullptr;
@@ -2052,8 +2201,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             l1(n, true, false, X, setX, transpose && !fused_dw);
             l1(n, true, true, act, set_act, transpose && !fused_dw);
         }
-        if (fused_fwd)
-            WIDE_CHECK(l2f(n, true, X, act, set_act, transpose));
+        if (fused_fwd)  // (the critic(s, a) pass of a learn keeps the sign on its stored activations: critic(s, mu) continues from them)
+            WIDE_CHECK(l2f(n, true, X, act, set_act, transpose, false, transpose && fused_delta));
         else
             WIDE_CHECK(l2(n, true));
         out_layer(n, 0, q);
@@ -2184,7 +2333,16 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
     l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
-    if (fused_fwd)  // (its output-layer backward too: the seed of this pass is the constant -1/N, so dZ2 leaves the forward kernel)
+    if (fused_delta) {  // z2(mu) = z2(a) + W2[action] (f(mu) - f(a)): 4 k-steps on top of the stored critic(s, a) activations
+        hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, q, (long)Np, net[1].c0, Np);
+        fw::DeltaP dl;
+        dl.Zin = P2, dl.setZ = setP2, dl.a = a, dl.mu = a1, dl.setA = Ns, dl.setMu = Np, dl.wf1 = (const bf16x8*)net[1].wf1, dl.nft = KCp / 32,
+        dl.nfs = H1 / 32, dl.WT = net[1].WT, dl.setWT = setWT, dl.ldw = KCp, dl.cf = net[1].cf, dl.dZ = dZ2, dl.z = q, dl.setQ = Np;
+        dl.dz_scale = -1.0f / (float)Ns, dl.rw = row_weight, dl.Ns = Ns, dl.Np = Np, dl.H2 = H2, dl.H1 = H1, dl.n_sets = sets;
+        hipLaunchKernelGGL(fw::fwd_delta_kernel, dim3((unsigned)std::min<long>(2 * avd::fset::cu_count(), Np / fw::FR)), dim3(fw::FT),
+                           (size_t)fw::DL_TOTAL, st, dl);
+        WIDE_CHECK(check_launch("avd_learn_shared_bf16: critic(s, mu) as a delta"));
+    } else if (fused_fwd)  // (its output-layer backward too: the seed of this pass is the constant -1/N, so dZ2 leaves the forward kernel)
         WIDE_CHECK(l2f(net[1], true, s, a1, (long)Np, true, true));
     else
         WIDE_CHECK(l2(net[1], true));
