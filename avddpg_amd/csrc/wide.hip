@@ -1800,8 +1800,21 @@ struct DeltaP {
     float dz_scale;
     const float* rw;
     int Ns, Np, H2, H1, n_sets;
+    // the action gradient in the same kernel: dC[n][k] = sum_c dZ2[n][c] W2[H1 + k][c] (one more product, B = the dZ2 tile as it stands),
+    // da[n] = sum_k [p1(mu)[n][k] > 0] inv[k] Wa[k] dC[n][k] -- linear in dC, so every wave adds its 128 columns' part (f32 atomics)
+    const bf16* Wn;     // [sets][..][H2]: bf16(W2), row = feature
+    long setWn;
+    const float* inv;   // [sets][setTab] (index H1 + k)
+    long setTab;
+    const float* th;    // [sets][setTh] critic parameters (wa_off: Wa[k])
+    long setTh;
+    int wa_off, Ha;
+    float* da;          // [sets][setDa], zeroed by the caller
+    long setDa;
 };
-constexpr int DL_W = 0, DL_CF = DL_W + FC * 64 * 2, DL_ZS = DL_CF + FC * 4, DL_TOTAL = DL_ZS + 4 * FR * 4;
+constexpr int DL_ROWN = FC * 2 + 16;  // row stride of the 64 action rows of W2 in LDS (1040 B: conflict-free 16-byte reads down the rows)
+constexpr int DL_W = 0, DL_CF = DL_W + FC * 64 * 2, DL_ZS = DL_CF + FC * 4, DL_WN = DL_ZS + 4 * FR * 4, DL_MK = DL_WN + 64 * DL_ROWN,
+              DL_TOTAL = DL_MK + 64 * 4;
 
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_delta_kernel(DeltaP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1821,6 +1834,15 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int c = 0; c < 8; ++c) *(wide::u32x4*)(sWa + tid * 64 + ((c ^ ((tid >> 1) & 7)) << 3)) = *(const wide::u32x4*)(src + 8 * c);
             scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+            // the 64 action rows of W2 (natural k = c order -> the accumulator's k order: the middle groups of four of every 16 swap)
+            const int fr = tid >> 3, part = tid & 7;  // row, 64-column part
+            const bf16* wsrc = p.Wn + (long)set * p.setWn + (long)(p.H1 + fr) * p.H2 + FC * cb + 64 * part;
+#pragma unroll
+            for (int q4 = 0; q4 < 16; ++q4) {
+                const int c = 4 * q4, cd = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);
+                *(unsigned long long*)(smem_raw + DL_WN + fr * DL_ROWN + (64 * part + cd) * 2) = fr < p.Ha ? *(const unsigned long long*)(wsrc + c) : 0ull;
+            }
+            if (tid < 64) ((float*)(smem_raw + DL_MK))[tid] = tid < p.Ha ? p.inv[(long)set * p.setTab + p.H1 + tid] * p.th[(long)set * p.setTh + p.wa_off + tid] : 0.f;
         }
         bf16x8 wf[2];
 #pragma unroll
@@ -1833,12 +1855,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
             f32x16 acc[2][4];
             bf16x8 dfr[2][2][2];  // [row tile][action tile][k-step]: bf16 of relu(p1(mu)) - relu(p1(a))
+            bf16x8 xmk[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
                 const bool live = n < p.Ns;
                 const bf16x8 xa = x_frag_action(live ? p.a[(long)set * p.setA + n] : 0.f, live, h);
                 const bf16x8 xm = x_frag_action(live ? p.mu[(long)set * p.setMu + n] : 0.f, live, h);
+                xmk[rt] = xm;
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta) {
                     const f32x16 pa = mfma(wf[ta], xa, zero16), pm = mfma(wf[ta], xm, zero16);
@@ -1877,13 +1901,15 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                         for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(aw, dfr[rt][ta][ks], acc[rt][ct]);
                     }
-            // ---- epilogue (as fwd_gen_kernel's for this pass)
-            float zp[2] = {0.f, 0.f};
+            // ---- epilogue (as fwd_gen_kernel's for this pass) + the action gradient
+            const float* mk = (const float*)(smem_raw + DL_MK);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
-                bf16* dst = p.dZ + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
                 const float drow = n < p.Ns ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
+                float zp = 0.f;
+                asm volatile("" ::: "memory");  // (the column coefficients are read again per row tile rather than held: registers)
+                f32x16 E[2] = {zero16, zero16};  // [action feature tile]: dC partial over this wave's 128 columns (lane = row, registers = features)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     unsigned pk[4][2];
@@ -1894,23 +1920,50 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             o[j] = (bf16)fmaxf(acc[rt][ct][4 * g + j], 0.f);
-                            zp[rt] = fmaf((float)o[j], cv[j], zp[rt]);
+                            zp = fmaf((float)o[j], cv[j], zp);
                             o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
                         }
                         pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
                         pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
                     }
 #pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                        wide::u32x4 o;
-                        o[0] = s0[0], o[1] = s1[0], o[2] = s0[1], o[3] = s1[1];
-                        *(wide::u32x4*)(dst + 32 * ct + 16 * gg) = o;
+                    for (int ks = 0; ks < 2; ++ks) {  // the dZ2 tile as the B operand: k = its columns (registers 8 ks .. 8 ks + 7), n = row
+                        wide::u32x4 bw;
+                        bw[0] = pk[2 * ks][0], bw[1] = pk[2 * ks][1], bw[2] = pk[2 * ks + 1][0], bw[3] = pk[2 * ks + 1][1];
+                        const bf16x8 bz = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const bf16x8 wn = *(const bf16x8*)(smem_raw + DL_WN + (32 * mt + r) * DL_ROWN + (128 * cq + 32 * ct + 16 * ks + 8 * h) * 2);
+                            E[mt] = mfma(wn, bz, E[mt]);
+                        }
+                    }
+                    if (p.dZ) {
+                        bf16* dst = p.dZ + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                            wide::u32x4 o;
+                            o[0] = s0[0], o[1] = s1[0], o[2] = s0[1], o[3] = s1[1];
+                            *(wide::u32x4*)(dst + 32 * ct + 16 * gg) = o;
+                        }
                     }
                 }
-                zp[rt] += __shfl_xor(zp[rt], 32);
-                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp[rt];
+                float dap = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f32x16 pm = mfma(wf[mt], xmk[rt], zero16);  // the action layer's pre-activations of mu again: its relu mask
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 mv = *(const f32x4*)(mk + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dap += pm[4 * g + j] > 0.f ? mv[j] * E[mt][4 * g + j] : 0.f;
+                    }
+                }
+                dap += __shfl_xor(dap, 32);
+                if (h == 0 && n < p.Ns) atomicAdd(p.da + (long)set * p.setDa + n, dap);
+                zp += __shfl_xor(zp, 32);
+                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp;
             }
             __syncthreads();
             if (tid < FR) atomicAdd(p.z + (long)set * p.setQ + (long)tile * FR + tid, (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]));
@@ -2332,13 +2385,17 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(actor_forward(net[0], s, true));  // activations and transposes stay for pass 3
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
-    l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
+    if (!fused_delta) l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
     if (fused_delta) {  // z2(mu) = z2(a) + W2[action] (f(mu) - f(a)): 4 k-steps on top of the stored critic(s, a) activations
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, q, (long)Np, net[1].c0, Np);
         fw::DeltaP dl;
         dl.Zin = P2, dl.setZ = setP2, dl.a = a, dl.mu = a1, dl.setA = Ns, dl.setMu = Np, dl.wf1 = (const bf16x8*)net[1].wf1, dl.nft = KCp / 32,
         dl.nfs = H1 / 32, dl.WT = net[1].WT, dl.setWT = setWT, dl.ldw = KCp, dl.cf = net[1].cf, dl.dZ = dZ2, dl.z = q, dl.setQ = Np;
         dl.dz_scale = -1.0f / (float)Ns, dl.rw = row_weight, dl.Ns = Ns, dl.Np = Np, dl.H2 = H2, dl.H1 = H1, dl.n_sets = sets;
+        dl.dZ = nullptr;  // (nobody reads dZ2 of this pass: the action gradient leaves the kernel)
+        dl.Wn = net[1].Wn, dl.setWn = setWn, dl.inv = net[1].inv, dl.setTab = ldT, dl.th = net[1].th, dl.setTh = L.theta_size, dl.wa_off = L.cWa, dl.Ha = Ha;
+        dl.da = da, dl.setDa = Np;
+        (void)hipMemsetAsync(da, 0, sizeof(float) * sets * Np, st);
         hipLaunchKernelGGL(fw::fwd_delta_kernel, dim3((unsigned)std::min<long>(2 * avd::fset::cu_count(), Np / fw::FR)), dim3(fw::FT),
                            (size_t)fw::DL_TOTAL, st, dl);
         WIDE_CHECK(check_launch("avd_learn_shared_bf16: critic(s, mu) as a delta"));
@@ -2349,10 +2406,12 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     out_layer(net[1], 0, q);
     rows(2, q, nullptr, nullptr, 0.f, dq);
     if (!fused_fwd) WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
-    WIDE_CHECK(dx(net[1], H1, KC, false, true));
-    // da[n] = sum_k dZ1[n][H1 + k] * Wa[0][k]
-    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,
-                       net[1].th + L.cWa, (long)L.theta_size, (const float*)nullptr, Ns, 0, 0.f, da, (float*)nullptr, (long)Np);
+    if (!fused_delta) {
+        WIDE_CHECK(dx(net[1], H1, KC, false, true));
+        // da[n] = sum_k dZ1[n][H1 + k] * Wa[0][k]
+        hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,
+                           net[1].th + L.cWa, (long)L.theta_size, (const float*)nullptr, Ns, 0, 0.f, da, (float*)nullptr, (long)Np);
+    }
 
     // ---- pass 3: actor gradient from the activations kept in pass 2
     use_actor_buffers(true);
