@@ -1783,7 +1783,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //   z2(mu) = z2(a) + W2[action features] . (f(mu) - f(a)),   f = the relu'd first layer of the action branch (64 padded features)
 // -- 4 k-steps instead of the pass's 68. z2(a) comes back from the activations critic(s, a) stored with their sign (bf16), the
 // 64 action columns of the weight block stay in LDS, and the epilogue is fwd_gen_kernel's for this pass: q partial sums and
-// dZ2 = [z2 > 0] (-w/N) cf. HBM-bound: reads and writes one activation matrix.
+// dZ2 = [z2 > 0] (-w/N) cf -- which never leaves the kernel: the only thing the pass wants from it is the action gradient
+// (below). HBM-bound: reads one activation matrix.
 struct DeltaP {
     const bf16* Zin;    // [sets][Np][H2]
     long setZ;
@@ -1794,7 +1795,6 @@ struct DeltaP {
     const bf16* WT;     // [sets][H2n][ldw], k permuted
     long setWT, ldw;
     const float* cf;    // [sets][H2]
-    bf16* dZ;           // [sets][Np][H2]
     float* z;           // [sets][setQ], pre-filled with c0: one f32 atomic per row and column block
     long setQ;
     float dz_scale;
@@ -1837,10 +1837,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // the 64 action rows of W2 (natural k = c order -> the accumulator's k order: the middle groups of four of every 16 swap)
             const int fr = tid >> 3, part = tid & 7;  // row, 64-column part
             const bf16* wsrc = p.Wn + (long)set * p.setWn + (long)(p.H1 + fr) * p.H2 + FC * cb + 64 * part;
-#pragma unroll
-            for (int q4 = 0; q4 < 16; ++q4) {
-                const int c = 4 * q4, cd = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);
-                *(unsigned long long*)(smem_raw + DL_WN + fr * DL_ROWN + (64 * part + cd) * 2) = fr < p.Ha ? *(const unsigned long long*)(wsrc + c) : 0ull;
+            const unsigned keep = fr < p.Ha ? 0xffffffffu : 0u;  // (rows past the action layer's width: allocated, never written)
+#pragma unroll 2
+            for (int q16 = 0; q16 < 4; ++q16) {
+                const wide::u32x4 lo = *(const wide::u32x4*)(wsrc + 16 * q16), hi = *(const wide::u32x4*)(wsrc + 16 * q16 + 8);
+                unsigned char* d = smem_raw + DL_WN + fr * DL_ROWN + (64 * part + 16 * q16) * 2;
+                *(wide::u32x4*)d = wide::u32x4{lo[0] & keep, lo[1] & keep, hi[0] & keep, hi[1] & keep};         // columns 0-3, 8-11
+                *(wide::u32x4*)(d + 16) = wide::u32x4{lo[2] & keep, lo[3] & keep, hi[2] & keep, hi[3] & keep};  // columns 4-7, 12-15
             }
             if (tid < 64) ((float*)(smem_raw + DL_MK))[tid] = tid < p.Ha ? p.inv[(long)set * p.setTab + p.H1 + tid] * p.th[(long)set * p.setTh + p.wa_off + tid] : 0.f;
         }
@@ -1852,122 +1855,129 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (p.nfs + ta < p.nft) wf[ta] = p.wf1[((long)set * p.nft + p.nfs + ta) * 64 + lane];
         }
         __syncthreads();
-        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-            f32x16 acc[2][4];
-            bf16x8 dfr[2][2][2];  // [row tile][action tile][k-step]: bf16 of relu(p1(mu)) - relu(p1(a))
-            bf16x8 xmk[2];
+        // Half tiles (32 rows per wave) in a register pipeline: the next half tile's z2(a) rows (8 x 16 B per lane) and action pair
+        // are requested before this one's products and epilogue. Loading, multiplying and storing one tile after the other
+        // left the kernel waiting on memory: 1.4 TB/s with eight waves per CU.
+        const int nu = (int)blockIdx.x < ntile ? 2 * ((ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1) : 0;
+        wide::u32x4 raw[8];
+        float av = 0.f, mv = 0.f;
+        auto request = [&](int u) {
+            const int tile = blockIdx.x + (u >> 1) * gridDim.x, rt = u & 1;
+            const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+            // z2(a), this wave's 128 columns of the row: 16-byte pieces, the row's two lanes swap halves below (the store's inverse)
+            const bf16* src = p.Zin + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
-                const bool live = n < p.Ns;
-                const bf16x8 xa = x_frag_action(live ? p.a[(long)set * p.setA + n] : 0.f, live, h);
-                const bf16x8 xm = x_frag_action(live ? p.mu[(long)set * p.setMu + n] : 0.f, live, h);
-                xmk[rt] = xm;
+            for (int i = 0; i < 8; ++i) raw[i] = *(const wide::u32x4*)(src + 16 * i);
+            const long nc = n < p.Ns ? n : p.Ns - 1;  // (rows past the batch: any row's pair, the fragments are built dead)
+            av = p.a[(long)set * p.setA + nc];
+            mv = p.mu[(long)set * p.setMu + nc];
+        };
+        if (nu > 0) request(0);
+        const float* mk = (const float*)(smem_raw + DL_MK);
+        for (int u = 0; u < nu; ++u) {
+            const int tile = blockIdx.x + (u >> 1) * gridDim.x, rt = u & 1;
+            const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+            const bool live = n < p.Ns;
+            f32x16 acc[4];
 #pragma unroll
-                for (int ta = 0; ta < 2; ++ta) {
-                    const f32x16 pa = mfma(wf[ta], xa, zero16), pm = mfma(wf[ta], xm, zero16);
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                for (int gg = 0; gg < 2; ++gg) {
+                    const wide::u32x4 v = raw[2 * ct + gg];
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+                    const unsigned pk[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) dfr[rt][ta][ks][i] = (bf16)(fmaxf(pm[8 * ks + i], 0.f) - fmaxf(pa[8 * ks + i], 0.f));
+                    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            acc[ct][4 * (2 * gg + g2) + 2 * e] = __uint_as_float(pk[g2][e] << 16);
+                            acc[ct][4 * (2 * gg + g2) + 2 * e + 1] = __uint_as_float(pk[g2][e] & 0xffff0000u);
+                        }
                 }
-                // z2(a), this wave's 128 columns of the row: 16-byte pieces, the row's two lanes swap halves (the store's inverse)
-                const bf16* src = p.Zin + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
+            const bf16x8 xa = x_frag_action(av, live, h), xm = x_frag_action(mv, live, h);
+            bf16x8 dfr[2][2];  // [action tile][k-step]: bf16 of relu(p1(mu)) - relu(p1(a))
+            unsigned long long pos = 0;  // relu mask of p1(mu), bit 16 ta + register
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+            for (int ta = 0; ta < 2; ++ta) {
+                const f32x16 pa = mfma(wf[ta], xa, zero16), pm = mfma(wf[ta], xm, zero16);
 #pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const wide::u32x4 u = *(const wide::u32x4*)(src + 32 * ct + 16 * gg);
-                        const auto t0 = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
-                        const auto t1 = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
-                        const unsigned pk[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int g2 = 0; g2 < 2; ++g2)
+                    for (int i = 0; i < 8; ++i) dfr[ta][ks][i] = (bf16)(fmaxf(pm[8 * ks + i], 0.f) - fmaxf(pa[8 * ks + i], 0.f));
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                acc[rt][ct][4 * (2 * gg + g2) + 2 * e] = __uint_as_float(pk[g2][e] << 16);
-                                acc[rt][ct][4 * (2 * gg + g2) + 2 * e + 1] = __uint_as_float(pk[g2][e] & 0xffff0000u);
-                            }
-                    }
+                for (int i = 0; i < 16; ++i) pos |= (unsigned long long)(pm[i] > 0.f) << (16 * ta + i);
             }
+            // (after the last use of what the allocator spills in this loop: a scratch reload is a vm operation, and waiting for
+            //  it would wait for everything requested before it)
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < nu) request(u + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
                         const int row = 128 * cq + 32 * ct + r, c = 4 * ta + 2 * ks + h;
                         const bf16x8 aw = *(const bf16x8*)(sWa + row * 64 + ((c ^ ((row >> 1) & 7)) << 3));
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(aw, dfr[rt][ta][ks], acc[rt][ct]);
+                        acc[ct] = mfma(aw, dfr[ta][ks], acc[ct]);
                     }
+                }
             // ---- epilogue (as fwd_gen_kernel's for this pass) + the action gradient
-            const float* mk = (const float*)(smem_raw + DL_MK);
+            const float drow = live ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
+            float zp = 0.f;
+            f32x16 E[2] = {zero16, zero16};  // [action feature tile]: dC partial over this wave's 128 columns (lane = row, registers = features)
+            asm volatile("" ::: "memory");  // (the coefficient tables are read from LDS every time: hoisted out of the loop they take 96 registers)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
-                const float drow = n < p.Ns ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
-                float zp = 0.f;
-                asm volatile("" ::: "memory");  // (the column coefficients are read again per row tile rather than held: registers)
-                f32x16 E[2] = {zero16, zero16};  // [action feature tile]: dC partial over this wave's 128 columns (lane = row, registers = features)
+            for (int ct = 0; ct < 4; ++ct) {
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned pk[4][2];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    unsigned pk[4][2];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 cv = *(const f32x4*)(scf + 128 * cq + 32 * ct + 8 * g + 4 * h);
+                    bf16 o[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 cv = *(const f32x4*)(scf + 128 * cq + 32 * ct + 8 * g + 4 * h);
-                        bf16 o[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            o[j] = (bf16)fmaxf(acc[rt][ct][4 * g + j], 0.f);
-                            zp = fmaf((float)o[j], cv[j], zp);
-                            o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
-                        }
-                        pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
-                        pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (bf16)fmaxf(acc[ct][4 * g + j], 0.f);
+                        zp = fmaf((float)o[j], cv[j], zp);
+                        o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
                     }
+                    pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
+                    pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
+                }
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {  // the dZ2 tile as the B operand: k = its columns (registers 8 ks .. 8 ks + 7), n = row
-                        wide::u32x4 bw;
-                        bw[0] = pk[2 * ks][0], bw[1] = pk[2 * ks][1], bw[2] = pk[2 * ks + 1][0], bw[3] = pk[2 * ks + 1][1];
-                        const bf16x8 bz = __builtin_bit_cast(bf16x8, bw);
+                for (int ks = 0; ks < 2; ++ks) {  // the dZ2 tile as the B operand: k = its columns (registers 8 ks .. 8 ks + 7), n = row
+                    wide::u32x4 bw;
+                    bw[0] = pk[2 * ks][0], bw[1] = pk[2 * ks][1], bw[2] = pk[2 * ks + 1][0], bw[3] = pk[2 * ks + 1][1];
+                    const bf16x8 bz = __builtin_bit_cast(bf16x8, bw);
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const bf16x8 wn = *(const bf16x8*)(smem_raw + DL_WN + (32 * mt + r) * DL_ROWN + (128 * cq + 32 * ct + 16 * ks + 8 * h) * 2);
-                            E[mt] = mfma(wn, bz, E[mt]);
-                        }
-                    }
-                    if (p.dZ) {
-                        bf16* dst = p.dZ + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                            wide::u32x4 o;
-                            o[0] = s0[0], o[1] = s1[0], o[2] = s0[1], o[3] = s1[1];
-                            *(wide::u32x4*)(dst + 32 * ct + 16 * gg) = o;
-                        }
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const bf16x8 wn = *(const bf16x8*)(smem_raw + DL_WN + (32 * mt + r) * DL_ROWN + (128 * cq + 32 * ct + 16 * ks + 8 * h) * 2);
+                        E[mt] = mfma(wn, bz, E[mt]);
                     }
                 }
-                float dap = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f32x16 pm = mfma(wf[mt], xmk[rt], zero16);  // the action layer's pre-activations of mu again: its relu mask
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 mv = *(const f32x4*)(mk + 32 * mt + 8 * g + 4 * h);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dap += pm[4 * g + j] > 0.f ? mv[j] * E[mt][4 * g + j] : 0.f;
-                    }
-                }
-                dap += __shfl_xor(dap, 32);
-                if (h == 0 && n < p.Ns) atomicAdd(p.da + (long)set * p.setDa + n, dap);
-                zp += __shfl_xor(zp, 32);
-                if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp;
             }
-            __syncthreads();
-            if (tid < FR) atomicAdd(p.z + (long)set * p.setQ + (long)tile * FR + tid, (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]));
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            float dap = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 mvv = *(const f32x4*)(mk + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dap += ((pos >> (16 * mt + 4 * g + j)) & 1) ? mvv[j] * E[mt][4 * g + j] : 0.f;
+                }
+            dap += __shfl_xor(dap, 32);
+            if (h == 0 && live) atomicAdd(p.da + (long)set * p.setDa + n, dap);
+            zp += __shfl_xor(zp, 32);
+            if (h == 0) zs[cq * FR + rh * 64 + 32 * rt + r] = zp;
+            if (rt == 1) {
+                __syncthreads();
+                if (tid < FR) atomicAdd(p.z + (long)set * p.setQ + (long)tile * FR + tid, (zs[tid] + zs[FR + tid]) + (zs[2 * FR + tid] + zs[3 * FR + tid]));
+                __syncthreads();
+            }
         }
     }
 }
@@ -2390,9 +2400,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, q, (long)Np, net[1].c0, Np);
         fw::DeltaP dl;
         dl.Zin = P2, dl.setZ = setP2, dl.a = a, dl.mu = a1, dl.setA = Ns, dl.setMu = Np, dl.wf1 = (const bf16x8*)net[1].wf1, dl.nft = KCp / 32,
-        dl.nfs = H1 / 32, dl.WT = net[1].WT, dl.setWT = setWT, dl.ldw = KCp, dl.cf = net[1].cf, dl.dZ = dZ2, dl.z = q, dl.setQ = Np;
+        dl.nfs = H1 / 32, dl.WT = net[1].WT, dl.setWT = setWT, dl.ldw = KCp, dl.cf = net[1].cf, dl.z = q, dl.setQ = Np;
         dl.dz_scale = -1.0f / (float)Ns, dl.rw = row_weight, dl.Ns = Ns, dl.Np = Np, dl.H2 = H2, dl.H1 = H1, dl.n_sets = sets;
-        dl.dZ = nullptr;  // (nobody reads dZ2 of this pass: the action gradient leaves the kernel)
         dl.Wn = net[1].Wn, dl.setWn = setWn, dl.inv = net[1].inv, dl.setTab = ldT, dl.th = net[1].th, dl.setTh = L.theta_size, dl.wa_off = L.cWa, dl.Ha = Ha;
         dl.da = da, dl.setDa = Np;
         (void)hipMemsetAsync(da, 0, sizeof(float) * sets * Np, st);
