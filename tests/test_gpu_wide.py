@@ -282,3 +282,37 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
         scale = np.abs(gl[:, lo:hi]).max()
         assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 3e-3 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
     assert np.allclose(fused[n:], layerwise[n:], rtol=2e-3, atol=1e-6)
+
+
+def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
+    """csrc/wide.hip, fw::fwd_delta_kernel: critic(s, mu) = critic(s, a) + W2[action rows] (f(mu) - f(a)) on the activations pass 1
+    stored, the action gradient from the same kernel (the dZ2 tile as the next product's operand) -- against the full fused forward
+    pass + the input-gradient GEMM of the action columns + the row dot it replaces (AVD_WIDE_FUSED_DELTA=0), same inputs, two
+    processes. Only the actor gradient and the two losses depend on the pass (`workers/trainer.py:502-506`); the stored
+    activations cost one more bf16 rounding of z2(a) before the delta is added: 3e-3 of the block's max as for the forward pair."""
+    import os
+    import subprocess
+    import sys
+
+    need_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(_FWD_AB_SCRIPT)
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, AVD_WIDE_FUSED_DELTA=flag)
+        out = tmp_path / f"d{flag}.npy"
+        p = subprocess.run([sys.executable, str(script), root, str(out), "weighted"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(out))
+    delta, full = outs
+    assert np.isfinite(delta).all() and np.abs(full).max() > 0
+    n = delta.size - 4
+    lay = vec.AgentGroup(2, 4, 1, config.Config(actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024,
+                                                  critic_layer2_size=1024)).lay
+    gd, gf = delta[:n].reshape(2, -1), full[:n].reshape(2, -1)
+    assert np.abs(gd[:, :lay.actor_size] - gf[:, :lay.actor_size]).max() > 0  # (the switch did switch)
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        scale = np.abs(gf[:, lo:hi]).max()
+        assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 3e-3 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
+    assert np.allclose(delta[n:], full[n:], rtol=2e-3, atol=1e-6)

@@ -13,7 +13,7 @@ for row in csv.DictReader(open(path)):
     k = row["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][0] += float(row["Counter_Value"])
     agg[k][1] += 1
-res = {k: {"launches": n, "mean_" + counter: s / n} for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]) if k.startswith("avd::")}
+res = {k: {"launches": n, "mean_" + counter: s / n} for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]) if k.startswith(("avd::", "fw::"))}
 for k, v in res.items():
     print(f"{k[:70]:70s} launches={v['launches']:4d} {counter}={v['mean_' + counter]:.2f}")
 if len(sys.argv) > 3:
