@@ -1622,13 +1622,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (grp == 1) {  // one phase behind
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
-        __builtin_amdgcn_s_barrier();
-    }
     int stg = 0, xb = 0;
     f32x16 acc[2][4];
     for (int t = t_begin; t < t_end; ++t) {
+        // The two groups run the K loop a phase apart and the tile epilogue level: group 1 drops a phase behind here and group 0
+        // waits for it after the loop. (With the offset kept across tiles each group's epilogue ran beside the other's LAST or FIRST
+        // multiply phase only -- 12 k cycles of latency-bound work, twice per tile, with the matrix pipes idle.)
+        if (grp == 1) __builtin_amdgcn_s_barrier();
         const int tl = t - set * ntile;
         // where the stream goes after this tile: the next tile of the run (same set or the next one), or nowhere
         const int tn = t + 1 < t_end ? t + 1 : t;
@@ -1684,6 +1684,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         step(1, std::false_type{});
         for (int kt = 2; kt < nk; ++kt) step(kt, std::true_type{});
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain: nothing older than what follows
+        if (grp == 0) __builtin_amdgcn_s_barrier();  // level again (pairs with group 1's last barrier of the loop)
         // ---- tile epilogue (a prepare phase of this group): regenerate the first layer, fold the tile into the sums.
         // S1..S3 on the VALU (5 per element); S4[s] = sum_rows x[row][s] mdy[row][f] is one more product over the rows: A = x^T as
         // bf16 hi (m = s) and lo (m = 4 + s) rows in the accumulator's row order, B = bf16(mdy) as it stands (lane = feature).
@@ -1754,12 +1755,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (!same_set || tn == t) {
             flush();
             if (tn != t) {
-                // a new set: its fragments, bases and stream start here. The groups are a phase apart and each wave requests its
-                // own share, so they are brought level first, as at the start and the end of the kernel
-                if (grp == 0) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    __builtin_amdgcn_s_barrier();
-                }
+                // a new set: its fragments, bases and stream start here (the groups are level: see the top of the tile loop)
                 set = set_n;
                 load_set();
                 dma_x(tln, xb);
@@ -1767,13 +1763,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int c = 0; c < DX_NS - 1; ++c) dma((stg + c) % DX_NS, tln, c);
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 __builtin_amdgcn_s_barrier();
-                if (grp == 1) __builtin_amdgcn_s_barrier();
             }
         }
-    }
-    if (grp == 0) {  // make up the phase this group is ahead
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
-        __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
 }
