@@ -1152,13 +1152,12 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = zp[rt];
             }
         };
-        if (grp == 1) {  // one phase behind
-            __builtin_amdgcn_s_waitcnt(0x0F7A);
-            __builtin_amdgcn_s_barrier();
-        }
         init_acc();
         int prev = -1;  // tile whose partial output-layer sums were written in the previous epilogue
         for (; tile < ntile; tile += gridDim.x) {
+            // K loop a phase apart, tile boundary level (as in dx_gen_kernel): group 1 drops a phase behind here, group 0 waits for it
+            // after the loop -- the two epilogues run side by side instead of one after the other beside an idle matrix pipe
+            if (grp == 1) __builtin_amdgcn_s_barrier();
             dma_x(tile + gridDim.x);  // the next tile's raw inputs (fragments are built in step nk - 2, used in step nk - 1)
             // one step = prepare(kt), barrier, multiply(kt), barrier. The first two steps of a tile wait for no vm operation (see the
             // tile boundary below), the others for all but the two youngest chunks
@@ -1235,6 +1234,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // (this group is in a prepare phase here: the tile's epilogue and the next tile's start share it with prepare(0))
             FW_STAMP(3);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunks 0 and 1 of the next period have landed; nothing older than the stores
+            if (grp == 0) __builtin_amdgcn_s_barrier();  // level (pairs with group 1's last barrier of the loop)
             FW_STAMP(4);
             if (!FW_DBG(8)) epilogue(tile);
             FW_STAMP(5);
@@ -1247,11 +1247,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (blockIdx.x == 16 && lane == 0 && p.stamp && pair == 0)
             for (int i = 0; i < 8; ++i) p.stamp[wave * 8 + i] = facc[i];
 #endif
-        // ---- group 0 makes up the phase it is ahead; the last output-layer sums
-        if (grp == 0) {
-            __builtin_amdgcn_s_waitcnt(0x0F7A);
-            __builtin_amdgcn_s_barrier();
-        }
+        // ---- the last output-layer sums (the groups are level)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream (vmcnt 0)
         __syncthreads();
         z_flush(prev);
