@@ -1472,27 +1472,41 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream
-        // ---- dW2[f][c] += inv[f] acc (+ sh[f] db2[c] from the first row range), f32 atomics
+        // ---- dW2[f][c] += inv[f] acc (+ sh[f] db2[c] from the first row range), f32 atomics. The accumulator holds a feature per lane
+        // (rows of dW2, 4 KB apart): added as it stands, every atomic instruction touched 32 cache lines with two floats each, and
+        // the epilogues of an item cost as much as 260 of its 1024 steps (0.23 ms: a fifth of the kernel). Each 32 x 32 tile goes
+        // through a private 4.5 KB of LDS instead and is added with a COLUMN per lane: 2 lines x 32 floats per instruction.
+        __syncthreads();  // (the stages are scratch from here: every wave is past its last fragment / raw-row read)
+        float* tr = (float*)(smem_raw + wv * (32 * 36 * 4));  // [32 features][36]: 16-byte rows, private to the wave
+        const int tc = lane & 31, tf = lane >> 5;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             const int f = 32 * (t0 + ft) + r;
-            if (f >= p.K) continue;
-            const float iv = p.inv[(long)set * p.setTab + f], sf = split == 0 ? p.sh[(long)set * p.setTab + f] : 0.f;
-            float* o = p.dW + (long)set * p.setW + (long)f * p.H2 + FC * cb + 128 * cq + 4 * h;
+            const bool fok = f < p.K;
+            const float iv = fok ? p.inv[(long)set * p.setTab + f] : 0.f, sf = (fok && split == 0) ? p.sh[(long)set * p.setTab + f] : 0.f;
             const float* dbp = p.db + (long)set * p.H2 + FC * cb + 128 * cq + 4 * h;
+            float* o = p.dW + (long)set * p.setW + (long)(32 * (t0 + ft) + tf) * p.H2 + FC * cb + 128 * cq + tc;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 dbv = *(const f32x4*)(dbp + 32 * ct + 8 * g);
+                    f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(o + 32 * ct + 8 * g + j, fmaf(iv, acc[ft][ct][4 * g + j], sf * dbv[j]));
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(iv, acc[ft][ct][4 * g + j], sf * dbv[j]);
+                    *(f32x4*)(tr + r * 36 + 8 * g + 4 * h) = v;
                 }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {  // features 2 i + tf of the tile, column tc
+                    const float v = tr[(2 * i + tf) * 36 + tc];
+                    if (32 * (t0 + ft) + 2 * i + tf < p.K) atomicAdd(o + (long)(2 * i) * p.H2 + 32 * ct, v);
+                }
+            }
         }
+        __syncthreads();  // (before the next item's stream lands in the stages)
     }
 }
 
-// ------------------------------------------------------------------------------------------
 // Input gradient of the second layer + everything behind it, without an activation or gradient matrix of the first layer:
 //   dy[n][f] = sum_c dZ2[n][c] W2[f][c]            (MFMA, K = H2; D[row][feature]: lane = feature, registers = rows)
 //   p[n][f]  = x[n] . W1[:, f] + b1[f]              (regenerated: one MFMA per 32 x 32 tile, same layout)
@@ -2278,7 +2292,18 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 d2.wf1 = (const bf16x8*)n.wf1, d2.nfs = H1 / 32, d2.nft = critic ? KCp / 32 : H1 / 32;
                 d2.ZT = dZ2, d2.setZT = setP2, d2.ldz = H2, d2.inv = n.inv, d2.sh = n.sh, d2.db = cs, d2.setTab = ldT;
                 d2.dW = gnet + (critic ? L.cW2 : L.aW2), d2.setW = L.theta_size;
-                d2.Ns = Ns, d2.Np = Np, d2.H2 = H2, d2.K = K, d2.n_sets = sets, d2.nsplit = 8;  // (16 row ranges: more streams side by side per XCD, slower)
+                d2.Ns = Ns, d2.Np = Np, d2.H2 = H2, d2.K = K, d2.n_sets = sets, d2.nsplit = 8;
+                {   // row ranges per (set, column block): the split whose items fill whole rounds of an XCD's workgroups best
+                    // (rounds x chunks per item; the smaller split on a tie: fewer epilogues)
+                    const int nfb_ = (d2.nft * 32 + 127) / 128, wgs = std::max(1, avd::fset::cu_count() / 8);
+                    long best = -1;
+                    for (int ns = 8; ns <= 32; ns *= 2) {
+                        if (Np % (ns * 32) != 0 || Np / (ns * 32) < 2) continue;
+                        const long items = ((long)sets * (H2 / fw::FC) * ns + 7) / 8 * nfb_;
+                        const long cost = (items + wgs - 1) / wgs * (Np / (ns * 32));
+                        if (best < 0 || cost < best) best = cost, d2.nsplit = ns;
+                    }
+                }
                 const int nfb = (d2.nft * 32 + 127) / 128, items = sets * (H2 / fw::FC) * d2.nsplit * nfb;
                 (void)items;
                 const dim3 grid((unsigned)(avd::fset::cu_count() / 8 * 8));  // (a multiple of the XCD count: see the kernel's item map)
