@@ -1538,7 +1538,9 @@ struct DxP {
 
 constexpr int DX_STG = 2 * 256 * FK * 2, DX_NS = 3;  // A tile + B tile; three stages (two chunks in flight)
 // raw inputs three tiles deep; the running sums of a wave's 128 features (7 per feature) live in LDS between tile epilogues
-constexpr int DXL_X = DX_NS * DX_STG, DXL_A = DXL_X + 3 * 256 * 16, DXL_S = DXL_A + 3 * 256 * 4, DXL_TOTAL = DXL_S + 8 * 28 * 32 * 4;
+// + the first-layer fragments of every wave's four feature tiles (per set: the epilogue read them from memory one after the other)
+constexpr int DXL_X = DX_NS * DX_STG, DXL_A = DXL_X + 3 * 256 * 16, DXL_S = DXL_A + 3 * 256 * 4, DXL_W = DXL_S + 8 * 28 * 32 * 4,
+              DXL_TOTAL = DXL_W + 2 * 4 * 64 * 16;
 
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dx_gen_kernel(DxP p) {
@@ -1581,6 +1583,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto load_set = [&]() {
         ub_a = (const char*)(p.dZ + (long)set * p.setDZ + (long)(32 * wv) * p.H2);             // + row tile, chunk
         ub_b = (const char*)(p.Wn + (long)set * p.setWn + (long)(fb * 256 + 32 * wv) * p.H2);  // + chunk
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {  // the four first-layer fragments of the wave's feature half (its four row quarters write the same bytes)
+            const bf16 zb = (bf16)0.f;
+            bf16x8 v = {zb, zb, zb, zb, zb, zb, zb, zb};
+            const int wt = (fb * 256 + fh * 128) / 32 + ft;
+            if (wt < p.nft) v = p.wf1[((long)set * p.nft + wt) * 64 + lane];
+            *(bf16x8*)(smem_raw + DXL_W + ((fh * 4 + ft) * 64 + lane) * 16) = v;
+        }
     };
     // chunk kc of row tile tl into stage stg: wave w fills image rows [32 w, 32 w + 32) of both tiles (2 + 2 instructions)
     auto dma = [&](int stg, int tl, int kc) {
@@ -1722,10 +1732,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
-            const bf16 zb = (bf16)0.f;
-            bf16x8 wf = {zb, zb, zb, zb, zb, zb, zb, zb};
-            const int wt = f0 / 32 + ft;
-            if (wt < p.nft) wf = p.wf1[((long)set * p.nft + wt) * 64 + lane];
+            const bf16x8 wf = *(const bf16x8*)(smem_raw + DXL_W + ((fh * 4 + ft) * 64 + lane) * 16);
             f32x16 G = zero16;
             float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -1771,7 +1778,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 dma_x(tln, xb);
 #pragma unroll
                 for (int c = 0; c < DX_NS - 1; ++c) dma((stg + c) % DX_NS, tln, c);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the stream's first chunks and the fragments load_set() stored
                 __builtin_amdgcn_s_barrier();
             }
         }
