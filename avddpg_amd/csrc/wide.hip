@@ -1415,13 +1415,17 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_s_barrier();
         }
         int stg = 0;
-        bf16x8 xn = x_of(0, 0);  // x fragment of chunk kt + 1, built one multiply phase ahead (in the MFMA shadows)
+        bf16x8 xn;
+        if constexpr (!CRITIC) xn = x_of(0, 0);
         auto step = [&](int kt, auto wait_c) {
             constexpr bool WAIT = decltype(wait_c)::value;
             // ================= prepare(kt)
             bf16x8 A[2][4];
             read_frags(stg, 0, A[0]);
             read_frags(stg, 1, A[1]);
+            // x fragment of chunk kt + 1 (its raw rows ride in this stage). Critic: built here, where the VALU is idle (its action
+            // branch between the MFMAs cost 8 %); actor: one multiply phase ahead, in the MFMA shadows (2 % the other way)
+            if constexpr (CRITIC) xn = x_of(stg, kt);
             {
                 int kc = kt + FSTG - 1;
                 kc = kc < nk ? kc : nk - 1;  // (tail: harmless re-loads keep the vmcnt arithmetic uniform)
@@ -1439,7 +1443,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             bf16x8 bnx[2][2];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) p1n[ft] = mfma(xn, wf[ft], zero16);
-            xn = x_of((stg + 1) & (FSTG - 1), kt + 1);  // (chunk kt + 1 has landed: the wait before this phase's barrier)
+            if constexpr (!CRITIC) xn = x_of((stg + 1) & (FSTG - 1), kt + 1);  // (chunk kt + 1 has landed: the wait before this phase's barrier)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
