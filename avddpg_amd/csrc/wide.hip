@@ -1662,8 +1662,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) acc[rt][ft] = zero16;
-        auto step = [&](int kt, auto wait_c) {
-            constexpr bool WAIT = decltype(wait_c)::value;
+        auto step = [&](int kt, auto wait_c, auto tail_c) {
+            constexpr bool WAIT = decltype(wait_c)::value, TAIL = decltype(tail_c)::value;
             // ================= prepare(kt)
             bf16x8 A[2][2], B[2][4];
             const unsigned char* l = smem_raw + stg * DX_STG;
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int ft = 0; ft < 4; ++ft) B[0][ft] = *(const bf16x8*)(l + rb0 + ft * 32 * FK * 2), B[1][ft] = *(const bf16x8*)(l + rb1 + ft * 32 * FK * 2);
             {   // refill: chunk kt + 3 of this tile, or the first chunks of the next tile (a new set only after the flush: see below)
                 const int kc = kt + DX_NS - 1, sd = (stg + DX_NS - 1) % DX_NS;
-                if (kc < nk)
+                if (!TAIL)  // (the loop body proper carries no branch: the last two steps are peeled below)
                     dma(sd, tl, kc);
                 else if (same_set)
                     dma(sd, tln, kc - nk);
@@ -1704,9 +1704,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // (three buffers: the other group is still folding the previous tile while this one requests the tile after next)
         const int xbn = xb == 2 ? 0 : xb + 1;
         if (same_set && tn != t) dma_x(tln, xbn);
-        step(0, std::false_type{});
-        step(1, std::false_type{});
-        for (int kt = 2; kt < nk; ++kt) step(kt, std::true_type{});
+        step(0, std::false_type{}, std::false_type{});  // (nk >= 4: H2 >= 128)
+        step(1, std::false_type{}, std::false_type{});
+        for (int kt = 2; kt < nk - 2; ++kt) step(kt, std::true_type{}, std::false_type{});
+        step(nk - 2, std::true_type{}, std::true_type{});
+        step(nk - 1, std::true_type{}, std::true_type{});
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain: nothing older than what follows
         if (grp == 0) __builtin_amdgcn_s_barrier();  // level again (pairs with group 1's last barrier of the loop)
         // ---- tile epilogue (a prepare phase of this group): regenerate the first layer, fold the tile into the sums.
