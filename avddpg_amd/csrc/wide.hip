@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
                 const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
                 const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
-                if (kt + 2 == nk && cq == 0) build_x(tile + gridDim.x, xb ^ 1);  // (read from the next prepare phase on)
+                if (__builtin_expect(kt + 2 == nk && (wv >> 1) == 0, 0)) build_x(tile + gridDim.x, xb ^ 1);  // (scalar, out of line; read from the next prepare phase on)
                 if (!FW_DBG(1)) {
                     int kc = kt + FSTG - 1;
                     kc -= kc >= nk ? nk : 0;
