@@ -1362,9 +1362,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int kn = kc + 1 < nk ? kc + 1 : kc;  // (the last chunk carries its own rows again: never used)
             int n = row_base + kn * FK + (lane & 31);
             n = n < p.Ns ? n : p.Ns - 1;
-            if (lane < 32) {
+            if constexpr (CRITIC) {
+                if (lane < 32) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FK * DW_ROWB), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FK * DW_ROWB + 512), 4, 0, 0);
+                }
+            } else {  // (no branch: the upper lanes repeat the rows into the spare bytes behind them; -3 %. The critic's actions merged
+                      //  into the same instruction as 16-byte groups cost more in lane-address arithmetic than the instruction: +2.5 %)
                 __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FK * DW_ROWB), 16, 0, 0);
-                if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FK * DW_ROWB + 512), 4, 0, 0);
             }
         };
         constexpr int NDMA = CRITIC ? 6 : 5;
