@@ -714,25 +714,28 @@ __global__ void tanh_rows_kernel(const float* z, long set_z, int Ns, float high,
     a[o] = th * high, t[o] = th;
 }
 
+constexpr int ROWS_PER_BLOCK = 256 * 16;  // (a block walks 16 x 256 rows: its two atomics meet 1/16 as many others on the set's address)
 __global__ __launch_bounds__(256) void rows_kernel(int mode, int Ns, long set_o, const float* q, const float* y_or_t,
                                                     const float* r_or_da, float gamma_or_high, float* out, float* acc,
                                                     const float* row_weight) {
-    const int set = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    const long o = (long)set * set_o + n;
+    const int set = blockIdx.y;
     float a0 = 0.f, a1 = 0.f;
-    // weighted federated mean (src/server/federated.py:99-118): each row's loss seed carries its platoon's weight
-    const float rw = (row_weight && n < Ns) ? row_weight[(long)set * Ns + n] : 1.0f;
-    if (n < Ns) {
+    for (int i = 0; i < ROWS_PER_BLOCK / 256; ++i) {
+        const int n = blockIdx.x * ROWS_PER_BLOCK + i * 256 + threadIdx.x;
+        if (n >= Ns) break;
+        const long o = (long)set * set_o + n;
+        // weighted federated mean (src/server/federated.py:99-118): each row's loss seed carries its platoon's weight
+        const float rw = row_weight ? row_weight[(long)set * Ns + n] : 1.0f;
         if (mode == 0) {
             out[o] = fmaf(gamma_or_high, q[o], r_or_da[o]);
         } else if (mode == 1) {
             const float e = y_or_t[o] - q[o], d = -2.0f * e * rw / (float)Ns;
-            out[o] = d, a0 = e * e, a1 = d;
+            out[o] = d, a0 += e * e, a1 += d;
         } else if (mode == 2) {
-            out[o] = -rw / (float)Ns, a0 = q[o];
+            out[o] = -rw / (float)Ns, a0 += q[o];
         } else {
             const float t = y_or_t[o], d = r_or_da[o] * gamma_or_high * (1.0f - t * t);
-            out[o] = d, a0 = d;
+            out[o] = d, a0 += d;
         }
     }
     if (mode == 0) return;
@@ -1783,7 +1786,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (!same_set || tn == t) {
             flush();
             if (tn != t) {
-                // a new set: its fragments, bases and stream start here (the groups are level: see the top of the tile loop)
+                // a new set: its fragments, bases and stream start here (the groups are level: see the top of the tile loop).
+                // load_set() overwrites the first-layer fragments in LDS that a slower wave of the same feature half may still be
+                // reading in its epilogue: everybody is past it first
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
                 set = set_n;
                 load_set();
                 dma_x(tln, xb);
@@ -2262,7 +2269,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                                out, tt);
     };
     auto rows = [&](int mode, const float* qv, const float* yt, const float* rd, float gh, float* out) {
-        hipLaunchKernelGGL(rows_kernel, dim3((unsigned)rup(Ns, 256) / 256, sets), dim3(256), 0, st, mode, Ns, (long)Np, qv, yt, rd, gh,
+        hipLaunchKernelGGL(rows_kernel, dim3((unsigned)(rup(Ns, ROWS_PER_BLOCK) / ROWS_PER_BLOCK), sets), dim3(256), 0, st, mode, Ns, (long)Np, qv, yt, rd, gh,
                            out, acc, row_weight);
     };
     // Note on row-vector strides: r arrives as [sets][Ns] (stride Ns), internal vectors use stride Np. The TD kernel
