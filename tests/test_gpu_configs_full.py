@@ -162,3 +162,28 @@ def test_config5_hidden1024_full_size_mean_of_halves_and_determinism_of_the_step
     assert vt.updates == 3 * P * M and torch.isfinite(vt.agents.theta).all() and not torch.equal(vt.agents.theta, th0)
     assert (vt.set_losses[:, 0] >= 0).all() and int(vt.agents.step[0]) == 3
     _free(vt)
+
+
+def test_config5_hidden1024_repeats_of_a_learn_agree():
+    """A race detector for the streamed kernels of the wide learner (csrc/wide.hip, fw::*): the same learn_shared call 120 times
+    on the same inputs at configs[4]'s full size. Beyond the summation order of f32 atomics (~1e-6 of a slab's max) every
+    repeat must agree -- a fragment read that beats its LDS-DMA request shows up as garbage in one wave's features once in a
+    few dozen launches (r03: fw::dx_gen_kernel read chunk 2 of a tile unwaited; tools/determinism_c5.py runs longer)."""
+    need_gpu()
+    P, M, B, S = 4096, 5, 64, 4
+    conf, grp = _wide_group(M, 131)
+    g = torch.Generator(device="cuda").manual_seed(132)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    s, a = 1.5 * rn(M, P * B, S), 2.5 * (2 * torch.rand(M, P * B, 1, device="cuda", generator=g) - 1)
+    r, s2 = -rn(M, P * B).abs() * 0.3, 1.5 * rn(M, P * B, S)
+    lay = grp.lay
+    ref = grp.learn_shared(s, a, r, s2, P * M).clone()
+    scale = [ref[:, :lay.actor_size].abs().max(), ref[:, lay.actor_size:].abs().max()]
+    worst = torch.zeros(2, device="cuda")
+    for _ in range(120):
+        out = grp.learn_shared(s, a, r, s2, P * M)
+        worst[0] = torch.maximum(worst[0], (out[:, :lay.actor_size] - ref[:, :lay.actor_size]).abs().max() / scale[0])
+        worst[1] = torch.maximum(worst[1], (out[:, lay.actor_size:] - ref[:, lay.actor_size:]).abs().max() / scale[1])
+    w = worst.tolist()
+    assert torch.isfinite(ref).all() and max(w) <= 1e-4, w
+    _free(grp, ref, s, a, r, s2)
