@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Race detector for the learners at the reference widths (4096 platoons x 5 sets): each engine's learn N times on the same
+inputs. The set learners (fset.hip / fsplit.hip) and the per-agent kernels promise bit-identical repeats; the batched wide
+learner adds with f32 atomics (~1e-6). Usage: tools/determinism_engines.py [repeats]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.test_gpu_mlp import _perturbed_group
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+P, M, B, S = 4096, 5, 64, 4
+conf, grp = _perturbed_group(M, S=S, seed=7)
+g = torch.Generator(device="cuda").manual_seed(8)
+rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+nA = P * M
+s, a = 1.5 * rn(nA, B, S), 2.5 * (2 * torch.rand(nA, B, 1, device="cuda", generator=g) - 1)
+r, s2 = -rn(nA, B).abs() * 0.3, 1.5 * rn(nA, B, S)
+sm = lambda x: x.view(P, M, *x.shape[1:]).transpose(0, 1).reshape(M, P * B, *x.shape[2:]).contiguous()  # set-major for learn_shared
+engines = {
+    "split (fsplit.hip)": lambda: grp.learn_set_split(s, a, r, s2, nA),
+    "fused bf16 (fset.hip)": lambda: grp.learn_set_fused(s, a, r, s2, nA),
+    "batched (wide.hip, reference widths)": lambda: grp.learn_shared(sm(s), sm(a), sm(r), sm(s2), nA),
+}
+for name, fn in engines.items():
+    ref = fn().clone()
+    worst, bad = 0.0, 0
+    for _ in range(N):
+        out = fn()
+        d = ((out - ref).abs().max() / ref.abs().max()).item()
+        worst = max(worst, d)
+        bad += d > 1e-4 or d != d
+    print(f"{name:40s}: worst deviation over {N} repeats {worst:.2e}; repeats off: {bad}")
+# per-agent f32 kernel on a subset of agents per set (its gradients are per agent)
+sub = 4096
+gs = torch.empty(sub, grp.lay.theta_size, device="cuda")
+big = None
+try:
+    from avddpg_amd import vec
+    ag = vec.AgentGroup(sub, S, 1, conf, seed=3)
+    ref = ag.learn(s[:sub], a[:sub], r[:sub], s2[:sub], 0).clone()
+    worst, bad = 0.0, 0
+    for _ in range(max(20, N // 10)):
+        out = ag.learn(s[:sub], a[:sub], r[:sub], s2[:sub], 0)
+        d = ((out - ref).abs().max() / ref.abs().max()).item()
+        worst = max(worst, d)
+        bad += d > 1e-6
+    print(f"{'per-agent f32 (lean.hip), 4096 agents':40s}: worst deviation {worst:.2e}; repeats off: {bad}")
+except Exception as e:  # noqa
+    print("per-agent check skipped:", e)
