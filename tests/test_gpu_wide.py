@@ -229,7 +229,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from tests.gpu_util import t
 from tests.test_gpu_mlp import _perturbed_group
-n_sets, P, S = 2, (3 if len(sys.argv) > 3 and sys.argv[3] == "small" else 12), 4
+n_sets, P, S = 2, {"small": 3, "padded": 15}.get(sys.argv[3] if len(sys.argv) > 3 else "", 12), 4
 conf, grp = _perturbed_group(n_sets, S=S, seed=91, actor_layer1_size=1024, actor_layer2_size=1024, critic_layer1_size=1024,
                              critic_layer2_size=1024)
 rs = np.random.RandomState(92)
@@ -249,7 +249,8 @@ np.save(sys.argv[2], np.concatenate([g.cpu().numpy().ravel(), losses.cpu().numpy
 """
 
 
-@pytest.mark.parametrize("mode", ["plain", "weighted", "small"])  # small: 192 rows per set (256 padded): forward fused, gradients layer-wise
+# small: 192 rows per set (256 padded): forward fused, gradients layer-wise; padded: 960 rows per set (1024 padded), every fused kernel
+@pytest.mark.parametrize("mode", ["plain", "weighted", "small", "padded"])
 def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_path, mode):
     """csrc/wide.hip, fw::fwd_gen_kernel (first layer generated on the matrix cores as the GEMM operand, W2 streamed through
     LDS, output layer in the kernel, the mu pass's dZ2 written by the forward kernel) and fw::dw_gen_kernel (the weight gradient
