@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Race detector for the learners at the reference widths (4096 platoons x 5 sets): each engine's learn N times on the same
-inputs. The set learners (fset.hip / fsplit.hip) and the per-agent kernels promise bit-identical repeats; the batched wide
+inputs (optionally [sets per platoon], 10 = BASELINE config 3). The set learners (fset.hip / fsplit.hip) and the per-agent kernels promise bit-identical repeats; the batched wide
 learner adds with f32 atomics (~1e-6). Usage: tools/determinism_engines.py [repeats]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ import torch
 from tests.test_gpu_mlp import _perturbed_group
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-P, M, B, S = 4096, 5, 64, 4
+P, M, B, S = 4096, (int(sys.argv[2]) if len(sys.argv) > 2 else 5), 64, 4
 conf, grp = _perturbed_group(M, S=S, seed=7)
 g = torch.Generator(device="cuda").manual_seed(8)
 rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
