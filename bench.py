@@ -376,7 +376,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
                     | ({"executed_over_algorithmic": 2.6, "executed_frac": 2.6 * dominant["frac"],
                         "power": "rocm-smi reads 1398-1399 W of the 1400 W package cap at 2.16 GHz while this chain runs back to back; dense fp16 "
-                                 "MFMA holds 2.32 PFLOP/s under the same cap when one operand changes every 12 MFMAs, and ~1.35 PFLOP/s when both are fresh "
+                                 "MFMA holds 2.32 PFLOP/s under the same cap when one operand changes every 12 MFMAs, and 1.30-1.35 PFLOP/s (bf16 or fp16 alike) when both are fresh "
                                  "random fragments from LDS on every MFMA, as in a GEMM (1.55 GHz, pipe 85 % busy): the executed rate here is "
                                  "within 10-15 % of what the package power pays for (profiles/r03_power_and_clocks.txt, "
                                  "r03_power_of_instruction_mixes.txt, r03_power_gemm_like_probe.txt)"} if split3 else {}),

@@ -151,7 +151,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
+#ifdef PROBE_F16  // (the same bytes as fp16 operands: v_mfma_f32_32x32x16_f16, the split learner's forward type)
+                for (int rt = 0; rt < 2; ++rt) {
+                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    acc[rt][ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[ks][rt]), __builtin_bit_cast(f16x8, B[ks][ft]), acc[rt][ft], 0, 0, 0);
+                }
+#else
                 for (int rt = 0; rt < 2; ++rt) acc[rt][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks][rt], B[ks][ft], acc[rt][ft], 0, 0, 0);
+#endif
         if (PP) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
