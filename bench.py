@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: long enough for the clocks to settle (the first ~20 steps after an idle chip run 5 % slow; r03: 20 / 3 steps read
     # 1.65 M where 100+ steps read 1.74 M), short enough for the default run to finish in about a minute
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # >= 2000 timed steps after 200 warm-up. (The first ~0.5 s after an idle chip run 3-5 % slow: 20 + 200 steps of
+    # the 2.3 ms interfrl step read 1.64-1.74 M where 2000 sustained read 1.69-1.79 M on the same box.)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--platoons", type=int, default=4096, help="platoons per GPU")
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)

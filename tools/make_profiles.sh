@@ -6,12 +6,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-N="--no-cpu-baseline"
+N="--no-cpu-baseline --steps 200 --warmup 20"
 # the driver's line: interfrl (f32-class set learner) as `value`, nofrl under `also_measured`, CPU baseline
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 # sustained figures (>= 2000 timed steps after 200 warm-up)
-python bench.py --mode interfrl --steps 2000 --warmup 200 $N > $OUT/${TAG}_bench_interfrl_split_sustained_2000.json 2>/dev/null
-python bench.py --mode nofrl --steps 2000 --warmup 200 $N > $OUT/${TAG}_bench_nofrl_sustained_2000.json 2>/dev/null
+python bench.py --mode interfrl --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/${TAG}_bench_interfrl_split_sustained_2000.json 2>/dev/null
+python bench.py --mode nofrl --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/${TAG}_bench_nofrl_sustained_2000.json 2>/dev/null
 # nofrl variants
 python bench.py --mode nofrl $N > $OUT/${TAG}_bench_nofrl.json 2>/dev/null
 AVD_LEARN_KERNEL=fast python bench.py --mode nofrl $N > $OUT/${TAG}_bench_nofrl_learn_kernel_t.json 2>/dev/null
@@ -24,9 +24,9 @@ python bench.py --mode interfrl --engine fused3 $N > $OUT/${TAG}_bench_interfrl_
 python tools/fsplit_check.py > $OUT/${TAG}_fsplit_accuracy_and_time.txt 2>/dev/null
 python tools/time_fset.py > $OUT/${TAG}_fset_vs_other_learners.txt 2>/dev/null
 # other BASELINE configs
-python bench.py --mode interfrl --hidden 1024 --steps 20 --warmup 3 $N > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
-python bench.py --mode nofrl --pl-size 10 --buffer-size 50000 --steps 5 --warmup 2 $N > $OUT/${TAG}_bench_config3_4096x10_nofrl.json 2>/dev/null
-python bench.py --mode interfrl --pl-size 10 --buffer-size 50000 --steps 20 --warmup 5 $N > $OUT/${TAG}_bench_config3_4096x10_interfrl_split.json 2>/dev/null
+python bench.py --mode interfrl --hidden 1024 $N > $OUT/${TAG}_bench_config5_hidden1024.json 2>/dev/null
+python bench.py --mode nofrl --pl-size 10 --buffer-size 50000 $N --steps 50 --warmup 5 > $OUT/${TAG}_bench_config3_4096x10_nofrl.json 2>/dev/null
+python bench.py --mode interfrl --pl-size 10 --buffer-size 50000 $N > $OUT/${TAG}_bench_config3_4096x10_interfrl_split.json 2>/dev/null
 python bench.py --mode nofrl --framework centralized $N > $OUT/${TAG}_bench_centralized_4096x5.json 2>/dev/null
 # two self-spawned ranks on this one GPU (gloo: RCCL refuses two ranks per device); the same command without the last two flags is
 # what runs over RCCL on an N-GPU node
