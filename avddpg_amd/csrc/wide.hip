@@ -1524,6 +1524,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //   p[n][f]  = x[n] . W1[:, f] + b1[f]              (regenerated: one MFMA per 32 x 32 tile, same layout)
 //   dgamma1[f] = rs (S1 - mean S2), dbeta1[f] = S2, db1[f] = inv S3, dW1[s][f] = inv S4[s]   with the per-feature sums over rows
 //   S1 = sum dy relu(p), S2 = sum dy, S3 = sum [p > 0] dy, S4[s] = sum x[n][s] [p > 0] dy
+// (S1 as sum [p > 0] dy p; S3 rides on S4's product as a row of ones in x^T: one compare, one select, one fma, one add per element)
 // -- sums over the REGISTERS of a lane (rows), kept in registers across all row tiles of a workgroup and added to the gradient
 // slab once at the end (f32 atomics). Replaces the input-gradient GEMM with its BN / ReLU epilogue (which read C and wrote dZ1),
 // l1_fwd (C), l1_grads and the BN flush. A workgroup = 256 rows x 256 features per step of 32 c: both operands stream through
@@ -1744,6 +1745,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         const bf16 hi = (bf16)xs;
                         v[e] = r < 4 ? hi : (bf16)(xs - (float)hi);
                     }
+                } else if (r == 8) {  // m = 8: a row of ones -- its product is S3 = sum of the masked tile over the rows, for free
+                    const bf16 ob = (bf16)1.f;
+                    v = (bf16x8){ob, ob, ob, ob, ob, ob, ob, ob};
                 }
                 xT[rt][ks] = v;
             }
@@ -1752,7 +1756,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int ft = 0; ft < 4; ++ft) {
             const bf16x8 wf = *(const bf16x8*)(smem_raw + DXL_W + ((fh * 4 + ft) * 64 + lane) * 16);
             f32x16 G = zero16;
-            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int row = 64 * rq + 32 * rt + r;
@@ -1761,11 +1765,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 float md[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float dy = acc[rt][ft][i], pp = fmaxf(p1[i], 0.f);
+                    const float dy = acc[rt][ft][i];
                     md[i] = p1[i] > 0.f ? dy : 0.f;
-                    s1 = fmaf(dy, pp, s1);
+                    s1 = fmaf(md[i], p1[i], s1);  // = dy relu(p)
                     s2 += dy;
-                    s3 += md[i];
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -1778,7 +1781,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             // G[m][f]: register 4 g + j <-> m = 8 g + 4 h + j: registers 0..3 of the h = 0 half are the hi products of inputs 0..3,
             // of the h = 1 half the lo products (the halves are added in flush())
-            float q7[7] = {s1, s2, s3, G[0], G[1], G[2], G[3]};
+            // (register 4 of the h = 0 half: m = 8, the ones row = S3; of the h = 1 half: m = 12, zero)
+            float q7[7] = {s1, s2, G[4], G[0], G[1], G[2], G[3]};
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
                 q7[q] += __shfl_xor(q7[q], 32);  // (the two halves hold different rows of the same feature; G: hi + lo products)
