@@ -32,6 +32,8 @@ python bench.py --mode nofrl --framework centralized $N > $OUT/${TAG}_bench_cent
 # what runs over RCCL on an N-GPU node
 python bench.py --gpus 2 --backend gloo --single-device --platoons 2048 --buffer-size 20000 $N > $OUT/${TAG}_bench_2ranks_one_gpu_gloo.json 2>/dev/null
 bash tools/fsplit_pmc.sh > $OUT/${TAG}_fsplit_kernels_and_sq_counters.txt 2>/dev/null
+# race detectors: the same learn repeated on the same inputs (every engine at the reference widths; the wide learner at config 5)
+(echo "# tools/determinism_engines.py 1000 and tools/determinism_c5.py 1000: the same learn call repeated on the same inputs"; python tools/determinism_engines.py 1000 2>/dev/null | tail -4; python tools/determinism_c5.py 1000 2>/dev/null | grep worst) > $OUT/${TAG}_determinism_of_repeated_learns.txt
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o run -- $B > $OUT/${TAG}_bench_under_rocprof_default.json 2>/dev/null
