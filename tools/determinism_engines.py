@@ -47,3 +47,20 @@ try:
     print(f"{'per-agent f32 (lean.hip), 4096 agents':40s}: worst deviation {worst:.2e}; repeats off: {bad}")
 except Exception as e:  # noqa
     print("per-agent check skipped:", e)
+
+# centralized framework (general kernel gen::learn_kernel_g: S = 4 L, A = L, widths x 1.2), 2048 models
+try:
+    L = 5
+    cg = vec.AgentGroup(2048, 4 * L, L, conf, seed=5, hidd_mult=1.2)
+    cs, ca = 1.5 * rn(2048, B, 4 * L), 2.5 * (2 * torch.rand(2048, B, L, device="cuda", generator=g) - 1)
+    cr, cs2 = -rn(2048, B).abs() * 0.3, 1.5 * rn(2048, B, 4 * L)
+    ref = cg.learn(cs, ca, cr, cs2, 0).clone()
+    worst, bad = 0.0, 0
+    for _ in range(max(20, N // 10)):
+        out = cg.learn(cs, ca, cr, cs2, 0)
+        d = ((out - ref).abs().max() / ref.abs().max()).item()
+        worst = max(worst, d)
+        bad += d > 1e-6
+    print(f"{'centralized f32 (mlp.hip), 2048 models':40s}: worst deviation {worst:.2e}; repeats off: {bad}")
+except Exception as e:  # noqa
+    print("centralized check skipped:", repr(e))
