@@ -89,26 +89,54 @@ _PROTOS = {
 }
 
 _lib = None
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libavddpg_hip_diag.so")
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise AvdError(f"{path} not found: build the HIP extension first (__graft_entry__.build()); "
+                       "avddpg_amd has no CPU fallback")
+    l = C.CDLL(path)
+    for name, args in _PROTOS.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    l.avd_last_error.restype = C.c_char_p
+    l.avd_last_error.argtypes = []
+    for name in ("avd_version", "avd_diagnostics_enabled"):
+        getattr(l, name).restype = C.c_int
+        getattr(l, name).argtypes = []
+    return l
 
 
 def lib():
     """The loaded library; raises AvdError when it has not been built (no CPU fallback exists)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise AvdError(f"{LIB_PATH} not found: build the HIP extension first (__graft_entry__.build()); "
-                           "avddpg_amd has no CPU fallback")
-        l = C.CDLL(LIB_PATH)
-        for name, args in _PROTOS.items():
-            fn = getattr(l, name)
-            fn.argtypes = args
-            fn.restype = C.c_int
-        l.avd_last_error.restype = C.c_char_p
-        l.avd_last_error.argtypes = []
-        l.avd_version.restype = C.c_int
-        l.avd_version.argtypes = []
-        _lib = l
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+class diag_library:
+    """Context manager: route every call of this process through the DIAGNOSTIC build (`make -C avddpg_amd/csrc diag`,
+    -DAVD_DIAG) while it is active. Only that build reads the AVD_* environment switches (kernel variants for cross-checks
+    and A/B runs); the shipped library reads none. Test / tool infrastructure: nothing in the package enters it."""
+    _cached = None
+
+    def __enter__(self):
+        global _lib
+        if diag_library._cached is None:
+            diag_library._cached = _load(DIAG_LIB_PATH)
+            if not diag_library._cached.avd_diagnostics_enabled():
+                raise AvdError(f"{DIAG_LIB_PATH} is not a diagnostic build")
+        self._saved = lib()
+        _lib = diag_library._cached
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 def call(name, *args):

@@ -15,3 +15,11 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* avd_last_error(void) { return avd::g_err; }
 extern "C" int avd_version(void) { return 1; }
+// 1 in the diagnostic build (-DAVD_DIAG: the AVD_* environment switches exist), 0 in the shipped library
+extern "C" int avd_diagnostics_enabled(void) {
+#ifdef AVD_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}

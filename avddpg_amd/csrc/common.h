@@ -20,6 +20,17 @@ inline int check_launch(const char* what) {
     return AVD_OK;
 }
 
+// Diagnostic switches (kernel / tile choices for A/B runs and cross-checks, work-skipping ablations) exist ONLY in the
+// diagnostic build (`make diag`: -DAVD_DIAG -> lib/libavddpg_hip_diag.so). The shipped library reads no environment
+// variable: AVD_DIAG_ENV("X") is getenv("AVD_X") there and a null constant here (the name is not even in the binary;
+// tests/test_abi_cpu.py asserts it).
+#ifdef AVD_DIAG
+#include <stdlib.h>
+#define AVD_DIAG_ENV(name) getenv("AVD_" name)
+#else
+#define AVD_DIAG_ENV(name) ((const char*)nullptr)
+#endif
+
 #define AVD_REQUIRE(cond, ...)        \
     do {                              \
         if (!(cond)) {                \

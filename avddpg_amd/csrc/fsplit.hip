@@ -1366,7 +1366,7 @@ static Plan make_plan(int n_agents, int n_sets) {
     Plan pl;
     const int P = n_agents / n_sets;
     int J = cu_count() / n_sets;  // one 512-thread workgroup per CU, every workgroup bound to one set
-    if (const char* e = getenv("AVD_FSPLIT_J")) J = atoi(e);  // diagnostics
+    if (const char* e = AVD_DIAG_ENV("FSPLIT_J")) J = atoi(e);  // diagnostics
     if (J < 1) J = 1;
     if (J > P) J = P;
     pl.J = J, pl.grid = J * n_sets;
@@ -1472,7 +1472,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
 #endif
     // diagnostics (tools/fsplit_ablate.sh): AVD_FSPLIT_ONLY = dw | dx | head runs only those kernels of the chain (results
     // are then meaningless, the inputs of the skipped stages are whatever the workspace holds)
-    const char* only = getenv("AVD_FSPLIT_ONLY");
+    const char* only = AVD_DIAG_ENV("FSPLIT_ONLY");
     const bool do_head = !only || !strcmp(only, "head"), do_dw = !only || !strcmp(only, "dw"), do_dx = !only || !strcmp(only, "dx");
     if (only) {
         if (do_head) {
@@ -1540,7 +1540,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
     // 4-6 (+ 7): critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH) unless
     // AVD_FSPLIT_TWO_HEADS is set (diagnostics: the two-launch form)
-    const bool two_heads = getenv("AVD_FSPLIT_TWO_HEADS") != nullptr;
+    const bool two_heads = AVD_DIAG_ENV("FSPLIT_TWO_HEADS") != nullptr;
     h.act2 = mu, h.part_s2 = F(pl.partHs[2]);
     if (two_heads) head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
     else {

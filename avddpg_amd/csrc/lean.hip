@@ -883,7 +883,7 @@ static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const fl
                   float gamma, float high, float* grads, float* losses, UpdArgs upd, void* stream) {
     constexpr int H1 = 256, H2 = 128, HA = 48;
     size_t lds = sizeof(float) * lds_floats(H1 + HA, H2);
-    if (const char* kb = getenv("AVD_LEAN_LDS_KB")) {  // diagnostics: force 1 workgroup per CU; never below what the kernel needs
+    if (const char* kb = AVD_DIAG_ENV("LEAN_LDS_KB")) {  // diagnostics: force 1 workgroup per CU; never below what the kernel needs
         const size_t want = (size_t)atoi(kb) * 1024;
         if (want > lds && want <= 160 * 1024) lds = want;
     }

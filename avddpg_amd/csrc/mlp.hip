@@ -1521,7 +1521,7 @@ extern "C" int avd_mlp_layout_init(avd_mlp_layout* o, int S, int A, int H1, int 
 // Which kernel serves the reference widths: learn_kernel_l (lean.hip, two workgroups per CU) unless
 // AVD_LEARN_KERNEL=fast asks for learn_kernel_t (one workgroup per CU, first-layer activations in LDS).
 static bool use_lean_kernel() {
-    const char* k = getenv("AVD_LEARN_KERNEL");
+    const char* k = AVD_DIAG_ENV("LEARN_KERNEL");
     return !(k && !strcmp(k, "fast"));
 }
 
@@ -1610,7 +1610,7 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
     AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads, "avd_learn_f32: null pointer");
     // reference widths (src/config.py:112-117) take the dimension-specialised kernel; anything else the general one
     if (lay->A == 1 && lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && (lay->S == 3 || lay->S == 4) &&
-        !getenv("AVD_LEARN_GENERAL")) {
+        !AVD_DIAG_ENV("LEARN_GENERAL")) {
         const UpdArgs none = {};
         if (use_lean_kernel())
             return lean_launch(lay, false, n_agents, set_mod, theta, stats, (float*)theta_t, (float*)stats_t, s, a, r, s2,
@@ -1690,7 +1690,7 @@ static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const floa
         return AVD_E_UNSUPPORTED;
     }
     if (!(lay->A == 1 && lay->H1 == 256 && lay->H2 == 128 && lay->Ha == 48 && (lay->S == 3 || lay->S == 4)) ||
-        getenv("AVD_LEARN_GENERAL")) {
+        AVD_DIAG_ENV("LEARN_GENERAL")) {
         // any other shape the general kernel serves (centralized framework, non-default widths): its fused form
         const size_t lds = sizeof(float) * gen::lds_floats(*lay);
         if (lds > 160 * 1024) {

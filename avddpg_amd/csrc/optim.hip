@@ -186,7 +186,7 @@ extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float*
     const int n4 = lay->theta_size / 4;
     int gx = (n4 + 255) / 256;
     if (n_sets >= 256 && gx > 8) gx = 8;  // many sets: fewer, longer-lived blocks per set
-    if (const char* e = getenv("AVD_ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh)
+    if (const char* e = AVD_DIAG_ENV("ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh)
     hipLaunchKernelGGL(adam_polyak_kernel, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size,
                        lay->actor_size, (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v,
                        (const float4*)grads, step, actor_lr, critic_lr, tauf, omt);

@@ -427,7 +427,7 @@ static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st,
         (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256x128);
         attr_set = true;
     }
-    static const char* force = getenv("AVD_GEMM_TILE");  // diagnostics: "128", "256x128", "256"
+    static const char* force = AVD_DIAG_ENV("GEMM_TILE");  // diagnostics: "128", "256x128", "256"
     int tile = (p.M >= 2 * TM && p.Nc >= 2 * 256) ? 256 : 128;  // large problems: 256^2 tiles
     if (force) tile = !strcmp(force, "128") ? 128 : (!strcmp(force, "256x128") ? 192 : 256);
     if (tile != 128 && (p.M < TM || p.K % TK)) tile = 128;
@@ -2135,25 +2135,35 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     //  padding; rows/columns beyond that only ever feed output elements the GEMM epilogues do not store)
 
     // second layers of 512 n columns (config 5: 1024): the forward passes run fused (fw::fwd_gen_kernel); AVD_WIDE_FUSED_FWD=0: layer-wise
-    static const char* ff_env = getenv("AVD_WIDE_FUSED_FWD");
+    static const char* ff_env = AVD_DIAG_ENV("WIDE_FUSED_FWD");
     const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
-    static const char* fd_env = getenv("AVD_WIDE_FUSED_DW");
+    static const char* fd_env = AVD_DIAG_ENV("WIDE_FUSED_DW");
     const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
                           !(fd_env && fd_env[0] == '0');
-    static const char* fx_env = getenv("AVD_WIDE_FUSED_DX");
+    static const char* fx_env = AVD_DIAG_ENV("WIDE_FUSED_DX");
     const bool fused_dx = fused_dw && Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fx_env && fx_env[0] == '0');
-    static const char* fl_env = getenv("AVD_WIDE_FUSED_DELTA");
+    static const char* fl_env = AVD_DIAG_ENV("WIDE_FUSED_DELTA");
     const bool fused_delta = fused_fwd && H1 % 32 == 0 && KCp - H1 == 64 && !(fl_env && fl_env[0] == '0');
-    static bool fw_attr = false;
     constexpr size_t fw_lds = fw::L_TOTAL;
-    if (fused_fwd && !fw_attr) {
-        (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-        (void)hipFuncSetAttribute((const void*)fw::fwd_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-        (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-        (void)hipFuncSetAttribute((const void*)fw::dw_gen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-        (void)hipFuncSetAttribute((const void*)fw::dx_gen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw::DXL_TOTAL);
-        (void)hipFuncSetAttribute((const void*)fw::fwd_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw::DL_TOTAL);
-        fw_attr = true;
+    if (fused_fwd) {
+        // the > 64 KB dynamic-LDS opt-in, once per DEVICE of this process (the attribute belongs to the device's copy of the function)
+        static unsigned long long fw_attr_done = 0;  // bit = device ordinal
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 64 || !((fw_attr_done >> dev) & 1ull)) {
+            hipError_t e = hipSuccess;
+            auto opt_in = [&](const void* fn, size_t bytes) {
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            };
+            opt_in((const void*)fw::fwd_gen_kernel<false>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true>, fw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true>, fw_lds);
+            opt_in((const void*)fw::dx_gen_kernel<false>, fw::DXL_TOTAL), opt_in((const void*)fw::fwd_delta_kernel, fw::DL_TOTAL);
+            if (e != hipSuccess) {
+                set_error("avd_learn_shared_bf16: hipFuncSetAttribute(dynamic LDS %zu B) on device %d: %s", fw_lds, dev, hipGetErrorString(e));
+                return AVD_E_LAUNCH;
+            }
+            if (dev < 64) fw_attr_done |= 1ull << dev;
+        }
     }
     // ---- per-net operand preparation: BN tables, folded/transposed bf16 weights, output-layer vectors
     NetOps net[4];  // 0 actor, 1 critic, 2 target actor, 3 target critic
@@ -2233,7 +2243,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
         f.P2 = keep_p2 ? (dz_out ? dZ2 : P2) : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
         f.dz_scale = dz_out ? -1.0f / (float)Ns : 0.f, f.rw = row_weight, f.store_pre = store_pre ? 1 : 0;
-        static const char* dbg_env = getenv("AVD_FW_DBG");
+        static const char* dbg_env = AVD_DIAG_ENV("FW_DBG");
         f.dbg = dbg_env ? atoi(dbg_env) : 0;
         f.stamp = nullptr;
 #ifdef AVD_FW_STAMP
@@ -2390,9 +2400,11 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         d3.w_off[0] = critic ? L.cWs : L.aW1, d3.b_off[0] = critic ? L.cbs : L.ab1, d3.g_off[0] = critic ? L.cgs : L.ag1, d3.be_off[0] = critic ? L.cbes : L.abe1;
         d3.w_off[1] = L.cWa, d3.b_off[1] = L.cba, d3.g_off[1] = L.cga, d3.be_off[1] = L.cbea;
         d3.Ns = Ns, d3.Np = Np, d3.H2 = H2, d3.H1 = H1, d3.Ha = Ha, d3.n_sets = sets;
-        d3.nfb = H1 / 256, d3.groups_per_xcd = 32 / d3.nfb;  // (the state features; the critic's 48 action features go the GEMM way)
+        // one workgroup per CU, dealt round-robin over the 8 XCDs: slots per XCD = CUs / 8 (32 on MI355X), each row group = nfb slots
+        const int slots = std::max(1, avd::fset::cu_count() / 8);
+        d3.nfb = H1 / 256, d3.groups_per_xcd = std::max(1, slots / d3.nfb);  // (the state features; the critic's 48 action features go the GEMM way)
         // (state features only: the <false> form -- no action inputs -- serves both nets)
-        hipLaunchKernelGGL((fw::dx_gen_kernel<false>), dim3(256), dim3(fw::FT), (size_t)fw::DXL_TOTAL, st, d3);
+        hipLaunchKernelGGL((fw::dx_gen_kernel<false>), dim3((unsigned)(8 * d3.groups_per_xcd * d3.nfb)), dim3(fw::FT), (size_t)fw::DXL_TOTAL, st, d3);
         return check_launch("avd_learn_shared_bf16: fused input gradient");
     };
     auto flush_bn1 = [&](bool critic, float* gnet, bool state_part = true) {

@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
     ap.add_argument("--master-port", type=int, default=0, help="self-spawned ranks: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--allow-diagnostics", action="store_true",
+                    help="run although AVD_* / AVDDPG_HIP_LIB environment overrides are set or the loaded library is a diagnostic "
+                         "build (the line then lists them under env_overrides / diagnostic_library); without it bench.py refuses")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -156,6 +159,22 @@ def cpu_baseline_all_cores(seconds, pl_size, max_workers=None, mode="nofrl"):
 PRIMARY_MODE = "interfrl"
 
 
+def env_overrides():
+    """Names of the environment variables that could change what the timed region executes: every AVD_* variable (switches
+    of the diagnostic library build, bench-order / pause knobs) and AVDDPG_HIP_LIB (another build of the library). The
+    shipped library reads none of them (tests/test_abi_cpu.py); bench.py refuses to run when any is set unless
+    --allow-diagnostics, and always prints the list."""
+    return sorted(k for k in os.environ if (k.startswith("AVD_") and k != "AVD_BENCH_SPAWN_PROBE") or k == "AVDDPG_HIP_LIB")
+
+
+def refuse_diagnostics(args):
+    ov = env_overrides()
+    if ov and not args.allow_diagnostics:
+        sys.exit(f"bench.py: refusing to measure with diagnostic environment overrides set: {', '.join(ov)} "
+                 "(unset them, or pass --allow-diagnostics to run anyway and have them recorded in the line)")
+    return ov
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one, which has not
     touched the GPU (no torch import, no HIP call) and only waits. Each child is this script with RANK / LOCAL_RANK /
@@ -163,12 +182,14 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
-    port = args.master_port
+    port, holder = args.master_port, None
     if not port:
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
+        # pick a free port and KEEP it bound (never listening, SO_REUSEADDR) until the ranks are done: the kernel will not hand
+        # it to another process's port-0 bind meanwhile, and rank 0's store (which also sets SO_REUSEADDR) can still bind + listen
+        holder = socket.socket()
+        holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        holder.bind(("127.0.0.1", 0))
+        port = holder.getsockname()[1]
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -194,6 +215,8 @@ def spawn_ranks(args):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        if holder is not None:
+            holder.close()
     return rc
 
 
@@ -280,7 +303,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         assert abs(adam_bytes - ADAM_BYTES_PER_AGENT) < 0.01 * ADAM_BYTES_PER_AGENT
     roofs = []
     # the reference widths run learn_kernel_l (lean.hip: two workgroups per CU) unless AVD_LEARN_KERNEL=fast (learn_kernel_t)
-    lk = "learn_kernel_t" if os.environ.get("AVD_LEARN_KERNEL") == "fast" else "learn_kernel_l"
+    from avddpg_amd import _hip
+    lk = ("learn_kernel_t" if (os.environ.get("AVD_LEARN_KERNEL") == "fast" and _hip.lib().avd_diagnostics_enabled())
+          else "learn_kernel_l")
     # learn_kernel_l<fused> updates the small tensors itself (one launch); learn_kernel_t leaves them to a second kernel
     fused_name = lk + "<fused>" + ("" if lk == "learn_kernel_l" else " + adam_polyak_ranges_kernel")
     if args.framework != "decentralized":
@@ -406,6 +431,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
 
 def main():
     args = parse()
+    if not os.environ.get("AVD_BENCH_SPAWN_PROBE"):
+        overrides = refuse_diagnostics(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # this process never touches the GPU
     if os.environ.get("AVD_BENCH_SPAWN_PROBE"):  # launcher plumbing check (tests/test_dist_cpu.py): no GPU, no torch
@@ -418,7 +445,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
+        if args.gpus != 1:  # (a launcher's WORLD_SIZE with --gpus left at its default is taken as N; a contradiction is not)
+            sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
+        args.gpus = world
+    from avddpg_amd import _hip
+    diag_build = bool(_hip.lib().avd_diagnostics_enabled())
+    if diag_build and not args.allow_diagnostics:
+        sys.exit(f"bench.py: {_hip.LIB_PATH} is a diagnostic build (-DAVD_DIAG); pass --allow-diagnostics to measure it anyway")
     dev = 0 if args.single_device else local_rank
     torch.cuda.set_device(dev)
     group = None
@@ -472,7 +505,10 @@ def main():
         out = {"metric": "env-steps/sec + DDPG updates/sec, 4096x5-vehicle platoons", "value": first["value"],
                "unit": first["unit"], "updates_per_s": first["updates_per_s"], "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": first["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": first["dtype"], "data": "synthetic"}
+               "vs_baseline": None, "dtype": first["dtype"], "data": "synthetic",
+               "primary_mode": first["config"]["mode"],
+               # self-certification: the environment overrides in effect (none unless --allow-diagnostics) and the library build
+               "env_overrides": overrides, "diagnostic_library": diag_build}
         out.update({k: v for k, v in first.items() if k not in out})
         if len(results) > 1:
             out["also_measured"] = {r["config"]["mode"]: {k: r[k] for k in ("value", "unit", "updates_per_s", "ms_per_step", "dtype",
@@ -480,10 +516,10 @@ def main():
                                                           + (("rccl_ranks", "collective_backend") if "rccl_ranks" in r else ())}
                                     for r in results[1:]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size, modes[0])
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size, first["config"]["mode"])
             if args.cpu_all_cores:  # the whole host beside the reference's own 1-thread setting (opt-in side figure)
                 try:
-                    out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), args.pl_size, mode=modes[0])
+                    out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0), args.pl_size, mode=first["config"]["mode"])
                 except Exception as e:  # never let the side figure break the bench line
                     out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -77,6 +77,10 @@ typedef struct avd_mlp_layout {
 
 const char* avd_last_error(void);
 int avd_version(void);
+/* 0 for the shipped library: it reads NO environment variable. 1 for the diagnostic build (`make diag`,
+ * libavddpg_hip_diag.so, -DAVD_DIAG), in which AVD_* switches select kernel variants for A/B runs and cross-checks
+ * (csrc/common.h AVD_DIAG_ENV). bench.py refuses a diagnostic library unless --allow-diagnostics. */
+int avd_diagnostics_enabled(void);
 
 /* Fills `out` for the given network widths. S = num_states (<= 64), A = num_actions (<= 16; the centralized
  * framework has S = 4L, A = L), H1/H2 = layer1/layer2 size, Ha = critic action layer size (config.py:112-117),

@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def diag_lib():
+    """Route this test's C-ABI calls through the DIAGNOSTIC build (libavddpg_hip_diag.so, -DAVD_DIAG): the only build in which
+    the AVD_* environment switches (kernel variants for cross-checks) exist. The shipped library reads no environment."""
+    from avddpg_amd import _hip
+
+    with _hip.diag_library() as lib:
+        yield lib

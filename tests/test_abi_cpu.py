@@ -24,7 +24,27 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/avddpg_hip.h but not exported"
     assert lib.avd_version() >= 1
     # every int-returning entry point has a ctypes prototype in the binding
-    assert set(names) - {"avd_last_error", "avd_version"} == set(_hip._PROTOS)
+    assert set(names) - {"avd_last_error", "avd_version", "avd_diagnostics_enabled"} == set(_hip._PROTOS)
+
+
+def test_shipped_library_reads_no_environment_switch():
+    """every diagnostic switch (kernel / tile choices, work-skipping ablations) is compiled in only under
+    -DAVD_DIAG (`make diag` -> libavddpg_hip_diag.so). The product library holds no "AVD_" string at all, does not import
+    getenv, and says so through the C ABI; the diagnostic build holds the switches and says THAT."""
+    import subprocess
+
+    data = open(_hip.LIB_PATH, "rb").read()
+    assert b"AVD_" not in data, sorted(set(re.findall(rb"AVD_[A-Z0-9_]+", data)))
+    assert _hip.lib().avd_diagnostics_enabled() == 0
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _hip.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert not re.search(r"\bgetenv\b", nm.stdout), "the shipped library imports getenv"
+    if os.path.exists(_hip.DIAG_LIB_PATH):
+        diag = open(_hip.DIAG_LIB_PATH, "rb").read()
+        assert b"AVD_FSPLIT_ONLY" in diag and b"AVD_LEARN_KERNEL" in diag
+        with _hip.diag_library() as d:
+            assert d.avd_diagnostics_enabled() == 1
+        assert _hip.lib().avd_diagnostics_enabled() == 0  # (the context manager restored the product library)
 
 
 def test_error_reporting_without_gpu():

@@ -156,6 +156,13 @@ def test_bench_self_spawns_its_ranks_as_children_without_a_launcher():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=120)
     assert p.returncode == 3
+    # self-certification: any AVD_* / AVDDPG_HIP_LIB override makes the bench refuse, before anything is spawned
+    # or imported, unless --allow-diagnostics
+    env2 = {k: v for k, v in env.items() if k != "AVD_BENCH_SPAWN_PROBE"}
+    for var in ("AVD_FSPLIT_ONLY", "AVDDPG_HIP_LIB", "AVD_BENCH_ORDER"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], env=dict(env2, **{var: "x"}),
+                           capture_output=True, text=True, timeout=60)
+        assert p.returncode != 0 and var in p.stderr and "allow-diagnostics" in p.stderr and not p.stdout.strip()
     # the parent must decide to spawn before importing torch (a process that initialised the GPU may not start ranks)
     src = open(os.path.join(root, "bench.py")).read()
     main_src = src[src.index("def main():"):]

@@ -224,7 +224,7 @@ def test_unsupported_shapes_fail_loudly():
         grp.learn(z, torch.zeros(1, 64, 1, device="cuda"), torch.zeros(1, 64, device="cuda"), z, 0)
 
 
-def test_generic_and_specialised_learn_kernels_agree(monkeypatch):
+def test_generic_and_specialised_learn_kernels_agree(monkeypatch, diag_lib):
     """Reference widths run the dimension-specialised kernel, other widths the generic one: both against the
     oracle, and against each other on the same inputs."""
     need_gpu()
@@ -236,7 +236,8 @@ def test_generic_and_specialised_learn_kernels_agree(monkeypatch):
     r = -np.abs(rs.normal(0, 0.3, size=(n_agents, 64))).astype(np.float32)
     s2 = rs.normal(0, 1.5, size=(n_agents, 64, 4)).astype(np.float32)
     # three kernels serve the reference widths: learn_kernel_l (lean.hip, default: two workgroups per CU, first-layer
-    # activations recomputed), learn_kernel_t (AVD_LEARN_KERNEL=fast) and the general one (AVD_LEARN_GENERAL=1)
+    # activations recomputed), learn_kernel_t (AVD_LEARN_KERNEL=fast) and the general one (AVD_LEARN_GENERAL=1) -- switches of
+    # the diagnostic build only (diag_lib fixture); the shipped library always runs learn_kernel_l here
     lean = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()
     monkeypatch.setenv("AVD_LEARN_KERNEL", "fast")
     fast = grp.learn(t(s), t(a), t(r), t(s2), 0).cpu().numpy()

@@ -253,11 +253,13 @@ def test_model_a_and_weighted_interfrl_trainer_paths_run():
 
 @pytest.mark.parametrize("model,kernel", [("ModelB", "lean"), ("ModelA", "lean"), ("ModelB", "fast"), ("ModelA", "fast"),
                                           ("ModelB", "general"), ("ModelB", "centralized")])
-def test_fused_learn_update_is_bitwise_learn_then_apply(model, kernel, monkeypatch):
+def test_fused_learn_update_is_bitwise_learn_then_apply(model, kernel, monkeypatch, request):
     """avd_learn_update_f32 (Adam + Polyak applied where each gradient is produced, theta ping-pong) gives exactly
     the weights, targets and moments of avd_learn_f32 followed by avd_adam_polyak_f32 -- for learn_kernel_l (default),
     learn_kernel_t (AVD_LEARN_KERNEL=fast) and the general kernel (AVD_LEARN_GENERAL=1 at the reference widths; the
     centralized framework: S = 12, A = 3, widths 307/153/57 padded to 320/160/64)."""
+    if kernel in ("fast", "general"):  # kernel-variant switches exist in the diagnostic build only
+        request.getfixturevalue("diag_lib")
     if kernel == "fast":
         monkeypatch.setenv("AVD_LEARN_KERNEL", "fast")
     if kernel == "general":

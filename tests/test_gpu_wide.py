@@ -224,6 +224,7 @@ def test_shared_learner_weighted_mean_matches_weighted_fed_mean():
         assert np.abs(avg[:, lo:hi] - unweighted[:, lo:hi]).max() > 5e-2 * scale  # the weights matter in this case
 
 
+_DIAG_LIB = _hip.DIAG_LIB_PATH
 _FWD_AB_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
@@ -268,7 +269,7 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     script.write_text(_FWD_AB_SCRIPT)
     outs = []
     for flag in ("1", "0"):
-        env = dict(os.environ, AVD_WIDE_FUSED_FWD=flag)
+        env = dict(os.environ, AVD_WIDE_FUSED_FWD=flag, AVDDPG_HIP_LIB=_DIAG_LIB)  # (the switch exists in the diagnostic build only)
         out = tmp_path / f"g{flag}.npy"
         p = subprocess.run([sys.executable, str(script), root, str(out), mode], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -301,7 +302,7 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
     script.write_text(_FWD_AB_SCRIPT)
     outs = []
     for flag in ("1", "0"):
-        env = dict(os.environ, AVD_WIDE_FUSED_DELTA=flag)
+        env = dict(os.environ, AVD_WIDE_FUSED_DELTA=flag, AVDDPG_HIP_LIB=_DIAG_LIB)
         out = tmp_path / f"d{flag}.npy"
         p = subprocess.run([sys.executable, str(script), root, str(out), "weighted"], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]

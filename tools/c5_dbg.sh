@@ -2,7 +2,7 @@
 # fwd_gen_kernel with pieces switched off (AVD_FW_DBG bits; results wrong): average kernel time per variant.
 # Needs the diagnostics library: hipcc ... -DAVD_FW_DBG -c wide.hip, linked as avddpg_amd/lib/libavddpg_hip_fwdbg.so
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 export AVDDPG_HIP_LIB=$R/avddpg_amd/lib/libavddpg_hip_fwdbg.so
 for d in ${@:-0 1 2 4 8 16 32 63}; do
   rm -rf $R/gpurun_out/c5d; mkdir -p $R/gpurun_out/c5d

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel table of BASELINE config 5 (hidden 1024): tools/c5_prof.sh [extra bench args]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/c5
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c5 -o run -- python3 $R/bench.py --mode interfrl --hidden 1024 --steps 5 --warmup 2 --no-cpu-baseline "$@" > $R/gpurun_out/c5/bench.json 2>/dev/null
 python3 - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # idle time between consecutive kernels of the default (interfrl split) step: tools/gap_default.sh
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/gapd
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gapd -o run -- python3 $R/bench.py --mode interfrl --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/gapd/bench.json 2>/dev/null
 python3 - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # idle time between consecutive kernels of the default interfrl step (kernel trace): tools/gap_trace.sh
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/gap; mkdir -p $R/gpurun_out/gap
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gap -o run -- python3 $R/bench.py --mode interfrl --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python3 - <<PY
