@@ -77,11 +77,16 @@ __device__ __forceinline__ bf16x8 frag(unsigned a, unsigned b, unsigned c, unsig
 // platoons, same for the mean of 51 single-platoon calls). fp16 has a 5-bit exponent, so the static operands are scaled by
 // powers of two (exact) into its upper range and the scales are folded into f32 constants downstream: second-layer weights
 // by SW (per set and net, max |W| SW in [2^12, 2^13)), first-layer weights and biases by S1 (activations then sit 2^6 higher,
-// their lo parts stay normal numbers); overflow of an activation (P1 >= 1023) becomes inf and then NaN -- loud.
+// their lo parts stay normal numbers). An activation S1 P1 >= 65520 (P1 >= 1023.75) would round to fp16 inf -- and, the file being
+// built with -fno-honor-nans (relu = one v_max_f32, which returns its non-NaN operand), the resulting NaN accumulators would
+// silently become zeros. Every conversion to fp16 that can overflow is therefore TESTED: the scaled static operands in the prep
+// kernels, the inputs in pack_x_kernel, and the running maximum of every first-layer accumulator tile in the forward heads
+// (8 v_max3_f32 per tile); a hit sets *bad and finalize writes NaN into the whole gradient slab, like a non-finite input.
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float S1 = 64.f;
+constexpr float F16_OVERFLOW = 65520.f;  // the smallest float that rounds to fp16 infinity
 __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
     const f32x2 f = {a, b};
     const f16x2 h = __builtin_convertvector(f, f16x2);
@@ -185,11 +190,11 @@ struct NetP {
     long th_stride;
     const f16* Whi;    // [sets][H2][K]   fp16 hi of SW * inv1[f] * W2[f][n] at [n][wpos(f)]: the heads' LDS image
     const f16* Wlo;    //                 its lo
-    const bf16* Wchi;  // [sets][KP][H2]  hi of c3[n] * W2[f][n], rows >= K zero: dx_kernel's resident operand (online nets)
-    const bf16* Wclo;
+    const f16* Wchi;   // [sets][KP][H2]  fp16 hi of SWC * c3[n] * W2[f][n], rows >= K zero: dx_kernel's resident operand (online nets)
+    const f16* Wclo;   //                 its lo (SWC: vec[2 H2 + 2])
     const bf16x8* wf1; // [sets][NGT_MAX][64] first-layer weight fragments per feature tile and lane (feature K: the constant one)
     const f16x8* wf1h; // the same as fp16 pairs scaled by S1: the heads' first layers
-    const float* vec;  // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3, SW
+    const float* vec;  // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3, SW, SWC
     const unsigned* wap;  // [sets][2 hi/lo][2 h][3 k-steps][4] packed fp16 pairs of S1 * wa, the critic's action-layer weights (HEAD_CONST)
 };
 
@@ -202,7 +207,11 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float
     float v[4];
     load_x<S>(x, i >> 1, v);
     bool nf = not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
-    if (!(i & 1)) nf = nf || not_finite(extra[i >> 1]);
+    nf = nf || fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= F16_OVERFLOW;  // (fp16 input fragments)
+    if (!(i & 1)) {
+        const float e = extra[i >> 1];  // a (an fp16 input fragment of the critic too) or r
+        nf = nf || not_finite(e) || (outb && fabsf(e) >= F16_OVERFLOW);
+    }
     if (nf) atomicOr(bad, 1);
     outh[i] = make_xh(v[0], v[1], v[2], v[3], (int)(i & 1));
     if (outb) outb[i] = make_xq(v[0], v[1], v[2], v[3], 1.f, (int)(i & 1));
@@ -214,23 +223,25 @@ struct PrepArgs {
     int S;
     const float *theta, *stats, *theta_t, *stats_t;
     f16 *Whi[4], *Wlo[4];  // net 0 actor, 1 critic, 2 target actor, 3 target critic
-    bf16 *Wchi[4], *Wclo[4];  // online nets only
+    f16 *Wchi[4], *Wclo[4];  // online nets only
     bf16x8* wf1[4];
     f16x8* wf1h[4];
     float* vec[4];
     unsigned* wap;
     int* bad;
 };
-// SW per (net, set): the power of two that puts max |inv1[f] W2[f][n]| into [2^12, 2^13) -> vec[2 H2 + 1]
+// SW per (net, set): the power of two that puts max |inv1[f] W2[f][n]| into [2^12, 2^13) -> vec[2 H2 + 1]; online nets also
+// SWC, the same for dx_kernel's operand c3[n] W2[f][n] -> vec[2 H2 + 2]
 __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
-    __shared__ float red[256];
+    __shared__ float red[256], red2[256];
     const int net = blockIdx.x, set = blockIdx.y, tid = threadIdx.x;
     const bool critic = net & 1, target = net >= 2;
     const avd_mlp_layout& L = a.L;
     const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
     const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
     const int K = critic ? CriticS::K : ActorS::K, oW2 = critic ? L.cW2 : L.aW2;
-    float m = 0.f;
+    const int og2 = critic ? L.cg3 : L.ag2, omv2 = critic ? L.cmv3 : L.amv2, oW3 = critic ? L.cW3 : L.aW3;
+    float m = 0.f, m2 = 0.f;
     for (int f = tid; f < K; f += 256) {
         int og, omv, ff = f;
         if (!critic) og = L.ag1, omv = L.amv1;
@@ -238,22 +249,29 @@ __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
         else og = L.cga, omv = L.cmva, ff = f - H1;
         const float inv = fabsf((1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff]);
         float wm = 0.f;
-        for (int n = 0; n < H2; ++n) wm = fmaxf(wm, fabsf(th[oW2 + (long)f * H2 + n]));
+        for (int n = 0; n < H2; ++n) {
+            const float w = fabsf(th[oW2 + (long)f * H2 + n]);
+            wm = fmaxf(wm, w);
+            if (!target) m2 = fmaxf(m2, fabsf((1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n] * th[oW3 + n]) * w);
+        }
         m = fmaxf(m, inv * wm);
     }
-    red[tid] = m;
+    red[tid] = m, red2[tid] = m2;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]), red2[tid] = fmaxf(red2[tid], red2[tid + o]);
         __syncthreads();
     }
     if (tid == 0) {
-        int e = 0;
-        const float mx = red[0];
-        if (mx > 0.f && !not_finite(mx)) (void)frexpf(mx, &e);  // mx = fr * 2^e, fr in [0.5, 1)
-        int k = 13 - e;  // mx * 2^k in [2^12, 2^13)
-        k = k < -14 ? -14 : (k > 30 ? 30 : k);
-        a.vec[net][(long)set * VEC + 2 * H2 + 1] = ldexpf(1.f, k);
+        auto pow2_for = [](float mx) {  // the power of two that puts mx into [2^12, 2^13)
+            int e = 0;
+            if (mx > 0.f && !not_finite(mx)) (void)frexpf(mx, &e);  // mx = fr * 2^e, fr in [0.5, 1)
+            int k = 13 - e;
+            k = k < -14 ? -14 : (k > 30 ? 30 : k);
+            return ldexpf(1.f, k);
+        };
+        a.vec[net][(long)set * VEC + 2 * H2 + 1] = pow2_for(red[0]);
+        a.vec[net][(long)set * VEC + 2 * H2 + 2] = pow2_for(red2[0]);
     }
 }
 // one block per (output column n, net, set), one thread per feature f
@@ -282,13 +300,19 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             shw = sh * w;
             if (not_finite(w) || not_finite(inv) || not_finite(sh)) atomicOr(a.bad, 1);
             f16 hi, lo;
-            split1h(a.vec[net][(long)set * VEC + 2 * H2 + 1] * (inv * w), hi, lo);
+            const float ws = a.vec[net][(long)set * VEC + 2 * H2 + 1] * (inv * w);  // in [-2^13, 2^13] unless scale_kernel had to clamp SW
+            if (fabsf(ws) >= F16_OVERFLOW) atomicOr(a.bad, 1);
+            split1h(ws, hi, lo);
             const long at = ((long)set * H2 + n) * K + wpos(f);
             a.Whi[net][at] = hi, a.Wlo[net][at] = lo;
         }
         if (!target) {
-            bf16 hi, lo;
-            split1(c3n * w, hi, lo);
+            // dx_kernel's static operand c3[n] W2[f][n]: an fp16 pair too (as a bf16 pair its 2^-17 residual, the same for every
+            // batch row, stood at 1e-5 ... 2e-5 of max in the first-layer gradients: r04, tests/test_gpu_configs_full.py)
+            f16 hi, lo;
+            const float wc = a.vec[net][(long)set * VEC + 2 * H2 + 2] * (c3n * w);
+            if (fabsf(wc) >= F16_OVERFLOW) atomicOr(a.bad, 1);
+            split1h(wc, hi, lo);
             const long at = ((long)set * KP + f) * H2 + n;
             a.Wchi[net][at] = hi, a.Wclo[net][at] = lo;
         }
@@ -345,6 +369,8 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
             b = th[(critic ? L.cbs : L.ab1) + f];
         }
         if (not_finite(w[0]) || not_finite(w[1]) || not_finite(w[2]) || not_finite(w[3]) || not_finite(b)) atomicOr(a.bad, 1);
+        // the heads' and dx's fragments carry S1 w, S1 b as fp16 pairs
+        if (S1 * fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fmaxf(fabsf(w[2]), fabsf(w[3])), fabsf(b))) >= F16_OVERFLOW) atomicOr(a.bad, 1);
     }
     a.wf1[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wf(w[0], w[1], w[2], w[3], b, h);
     a.wf1h[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wh(w[0], w[1], w[2], w[3], b, S1, h);
@@ -384,8 +410,8 @@ struct HeadArgs {
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float* part_s2;    // HEAD_BOTH: the same sums of the critic(s, mu) branch (the actor loss)
     float gamma, high, inv_n;
+    int* bad;          // set when an activation would overflow fp16 (S1 P1 >= 65520): finalize then writes NaN gradients
 };
-
 // Workgroup = 8 waves bound to one weight set; LDS holds the fp16 hi and lo images of its BN-folded, scaled second-layer
 // weights for the workgroup's whole life. Wave w owns rows [32 (w & 1), +32) of every 4th tile. Per feature tile: the first layer of ITS rows
 // on the matrix cores (lane = batch row, registers = features), relu, hi / lo split of the 16 values (VALU), and per k-step
@@ -437,6 +463,16 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #define HSTAMP(i)
 #endif
     float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f;
+    // fp16 overflow watch. An activation S1 P1 >= 65520 converts to the pair (hi, lo) = (+inf, -inf), and whatever the weights,
+    // w_hi inf + w_lo inf - w_hi inf is NaN in EVERY second-layer accumulator of that batch row (0 inf is NaN too): one
+    // accumulator per row and sweep is looked at (bit test: the file is built with -fno-honor-nans), |bits| max-accumulated.
+    unsigned watch = 0;
+    auto look = [&](float x) {
+        unsigned u = __float_as_uint(x);
+        asm volatile("" : "+v"(u));  // (keeps the no-nans optimiser from reasoning about the float)
+        u &= 0x7fffffffu;
+        watch = watch > u ? watch : u;
+    };
 #pragma unroll
     for (int t = 0; t < (BWD ? 4 : 1); ++t)
 #pragma unroll
@@ -697,6 +733,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 }
             }
             act_sweep(acc);
+            look(acc[0][0]);
             {
                 float zp = 0.f;
 #pragma unroll
@@ -735,6 +772,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 }
             }
             act_sweep(acc);
+            look(acc[0][0]);  // (f(mu) - f(a) with f(mu) overflowed: +inf)
             float zq = 0.f;
             unsigned pos[2] = {0u, 0u};  // bit 16 (t & 1) + i of pos[t >> 1]: column i of tile t is active in the mu branch
 #pragma unroll
@@ -766,6 +804,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             if (h == 0) p.dmu[ri] = g3b * sum, Dacc2 += g3b, Lacc2 += d3 + zq;
             continue;
         }
+        look(acc[0][0]);
         const float z = out_z(acc);
         if (MODE == OUT_TANH) {
             const float o = tanhf(z) * p.high;
@@ -797,6 +836,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     if (blockIdx.x == 16 && lane == 0 && p.stamp)
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = hacc[i];
 #endif
+    if (watch >= 0x7f800000u) atomicOr(p.bad, 1);
     if (MODE >= HEAD_CRITIC) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
         // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
@@ -1091,12 +1131,13 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, ft = w;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const f32x16 zero16 = {};
-    bf16x8 wch[8], wcl[8];
+    f16x8 wch[8], wcl[8];
     {
         const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) wch[s] = *(const bf16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const bf16x8*)(p.net.Wclo + at + 16 * s);
+        for (int s = 0; s < 8; ++s) wch[s] = *(const f16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const f16x8*)(p.net.Wclo + at + 16 * s);
     }
+    const float iswc = 1.f / p.net.vec[(long)set * VEC + 2 * H2 + 2];  // (a power of two: the scale of the fp16 W2c operand, folded into |g3|)
     const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1: p1 = S1 z1, U1 rescaled at the end)
     f32x16 V = zero16;
     float U0 = 0.f, U1 = 0.f;
@@ -1112,10 +1153,16 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         d0 = src[0], d1 = src[1];
         if (tid < TILE) gn = p.g3[(long)agent * TILE + tid];
     };
+    // sm is stored as bf16 +-1 / 0 (0x3f80, 0xbf80, 0: dw_kernel's operand); the SAME values as fp16 are 0x3c00, 0xbc00, 0 = the
+    // upper six bits of each half: one v_and_b32 per pair on the way into LDS
+    auto as_f16 = [](uint4 v) {
+        v.x &= 0xfc00fc00u, v.y &= 0xfc00fc00u, v.z &= 0xfc00fc00u, v.w &= 0xfc00fc00u;
+        return v;
+    };
     auto stage = [&](int buf) {
         uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
-        dst[0] = d0, dst[1] = d1;
-        if (tid < TILE) g3s[buf][tid] = fabsf(gn);
+        dst[0] = as_f16(d0), dst[1] = as_f16(d1);
+        if (tid < TILE) g3s[buf][tid] = fabsf(gn) * iswc;
     };
     f16x8 xfn[2] = {};  // the rows' input fragments [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1), both row halves
     bf16x8 xbn = {};    // waves 0, 1, lane half 0: the bf16 fragment [x_hi | x_lo] of row r of row half w
@@ -1148,10 +1195,10 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         // The two row halves as a software pipeline: [dC of half 0] [dC of half 1 | BN/ReLU backward + split VALU of half 0]
         // [V of half 0 | VALU of half 1] [V of half 1]. One half after the other, the two waves of a SIMD run their MFMA phases
         // together and their VALU phases together (one barrier per tile) and the pipes never overlap (dw_kernel, measured).
-        auto read_a = [&](int e, bf16x8 (&smf)[8]) {
+        auto read_a = [&](int e, f16x8 (&smf)[8]) {
             const bf16* arow = smimg[buf] + (32 * e + r) * LDZ + 8 * h;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) smf[s] = *(const bf16x8*)(arow + 16 * s);
+            for (int s = 0; s < 8; ++s) smf[s] = *(const f16x8*)(arow + 16 * s);
         };
         auto read_xb = [&](int e, bf16x8 (&xb)[2]) {
 #pragma unroll
@@ -1182,13 +1229,14 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
             }
             U0 += u0, U1 += u1;
         };
-        bf16x8 smf[8], xb0[2], xb1[2];
+        f16x8 smf[8];
+        bf16x8 xb0[2], xb1[2];
         unsigned vh0[8], vl0[8], vh1[8], vl1[8];
         // stage 0: dC of row half 0
         read_a(0, smf);
         f32x16 dc0 = zero16;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dc0 = mfma(smf[s], wch[s], dc0), dc0 = mfma(smf[s], wcl[s], dc0);
+        for (int s = 0; s < 8; ++s) dc0 = mfmah(smf[s], wch[s], dc0), dc0 = mfmah(smf[s], wcl[s], dc0);
         const f32x16 p10 = mfmah(xf[0], wf, zero16);
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: dC of row half 1 | backward VALU of row half 0
@@ -1196,7 +1244,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         read_xb(0, xb0);
         f32x16 dc1 = zero16;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dc1 = mfma(smf[s], wch[s], dc1), dc1 = mfma(smf[s], wcl[s], dc1);
+        for (int s = 0; s < 8; ++s) dc1 = mfmah(smf[s], wch[s], dc1), dc1 = mfmah(smf[s], wcl[s], dc1);
         const f32x16 p11 = mfmah(xf[1], wf, zero16);
         backward(0, dc0, p10, vh0, vl0);
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
@@ -1253,12 +1301,13 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const f32x16 zero16 = {};
     const int ft = 8 + ftl;
-    bf16x8 wch[8], wcl[8];
+    f16x8 wch[8], wcl[8];
     {
         const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) wch[s] = *(const bf16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const bf16x8*)(p.net.Wclo + at + 16 * s);
+        for (int s = 0; s < 8; ++s) wch[s] = *(const f16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const f16x8*)(p.net.Wclo + at + 16 * s);
     }
+    const float iswc = 1.f / p.net.vec[(long)set * VEC + 2 * H2 + 2];
     const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1, like dx_kernel's)
     f32x16 V = zero16;
     float U0 = 0.f, U1 = 0.f;
@@ -1268,13 +1317,13 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     }
     __syncthreads();
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
-    bf16x8 smn[8];
+    uint4 smn[8];
     float an = 0.f, gn[16];
     auto fetch = [&](int k) {
         const long r0 = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh, ri = r0 + r;
         const bf16* src = p.sm + ri * H2 + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) smn[s] = *(const bf16x8*)(src + 16 * s);
+        for (int s = 0; s < 8; ++s) smn[s] = *(const uint4*)(src + 16 * s);
         an = p.act[ri];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1285,12 +1334,16 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     if (par < ntile) fetch(par);
     int buf = 0;
     for (int k = par; k < ntile; k += 2, buf ^= 1) {
-        bf16x8 smf[8];
+        f16x8 smf[8];
         float gg[16];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) smf[s] = smn[s];
+        for (int s = 0; s < 8; ++s) {  // bf16 +-1 / 0 -> the same values as fp16 (dx_kernel)
+            uint4 v = smn[s];
+            v.x &= 0xfc00fc00u, v.y &= 0xfc00fc00u, v.z &= 0xfc00fc00u, v.w &= 0xfc00fc00u;
+            smf[s] = __builtin_bit_cast(f16x8, v);
+        }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gg[i] = fabsf(gn[i]);
+        for (int i = 0; i < 16; ++i) gg[i] = fabsf(gn[i]) * iswc;
         const f16x8 xf = make_xh(an, 0.f, 0.f, 0.f, h);
         bf16 abh, abl;
         split1(an, abh, abl);
@@ -1311,7 +1364,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
         }
         f32x16 dc = zero16;  // [row][feature]: feature on the lane
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dc = mfma(smf[s], wch[s], dc), dc = mfma(smf[s], wcl[s], dc);
+        for (int s = 0; s < 8; ++s) dc = mfmah(smf[s], wch[s], dc), dc = mfmah(smf[s], wcl[s], dc);
         const f32x16 p1 = mfmah(xf, wf, zero16);
         float u0 = 0.f, u1 = 0.f;
         unsigned vh[8], vl[8];
@@ -1381,7 +1434,7 @@ static Plan make_plan(int n_agents, int n_sets) {
         pl.Whi[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K), pl.Wlo[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K);
         pl.vec[i] = take(sizeof(float) * (size_t)n_sets * VEC);
         pl.wf1[i] = take(16 * (size_t)n_sets * NGT_MAX * 64), pl.wf1h[i] = take(16 * (size_t)n_sets * NGT_MAX * 64);
-        if (i < 2) pl.Wchi[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2), pl.Wclo[i] = take(sizeof(bf16) * (size_t)n_sets * KP * H2);
+        if (i < 2) pl.Wchi[i] = take(sizeof(f16) * (size_t)n_sets * KP * H2), pl.Wclo[i] = take(sizeof(f16) * (size_t)n_sets * KP * H2);
     }
     pl.wap = take(4 * (size_t)n_sets * 48);
     const size_t rows = (size_t)n_agents * TILE;
@@ -1425,7 +1478,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         const bool critic = i & 1, target = i >= 2;
         pa.Whi[i] = (f16*)(ws + pl.Whi[i]), pa.Wlo[i] = (f16*)(ws + pl.Wlo[i]), pa.vec[i] = (float*)(ws + pl.vec[i]);
         pa.wf1[i] = (bf16x8*)(ws + pl.wf1[i]), pa.wf1h[i] = (f16x8*)(ws + pl.wf1h[i]);
-        pa.Wchi[i] = i < 2 ? (bf16*)(ws + pl.Wchi[i]) : nullptr, pa.Wclo[i] = i < 2 ? (bf16*)(ws + pl.Wclo[i]) : nullptr;
+        pa.Wchi[i] = i < 2 ? (f16*)(ws + pl.Wchi[i]) : nullptr, pa.Wclo[i] = i < 2 ? (f16*)(ws + pl.Wclo[i]) : nullptr;
         NetP& n = net[i];
         n.th = (target ? theta_t : theta) + (critic ? L.actor_size : 0), n.th_stride = L.theta_size;
         n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1 = pa.wf1[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
@@ -1450,7 +1503,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
-    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr;
+    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad;
     int head_threads = NT;
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {

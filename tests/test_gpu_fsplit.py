@@ -1,8 +1,17 @@
 """GPU parity of the split-operand fused set learner (csrc/fsplit.hip, avd_learn_set_split_bf16x3): Trainer.learn
 (workers/trainer.py:472-508) + federated mean (src/server/federated.py:47-63, 99-118) for agents that share their networks,
-with every GEMM operand an exact bf16 hi + lo pair. The bar is the F32 kernels' bar, not a bf16 one: GRAD_TOL = 1e-4 of each
-tensor's max against the float64 oracle (tests/test_gpu_mlp.py), the same against the exact-f32 per-agent kernel + fed_mean,
-bit-identical reruns, and at full size (4096 x 5) through the f32 engine and size-independent properties."""
+with every GEMM operand an exact 16-bit pair hi + lo. The reference multiplies float32 by float32 (agent/model.py:26-36, 63-83;
+workers/trainer.py:472-508), so the bar is float32's own, enforced here rather than quoted from a profile:
+
+  SPLIT_TOL = 2e-5 of each gradient tensor's max against the float64 oracle (or 4 x the float32 ORACLE's own error on the same
+  batch where that is larger) -- 5 x tighter than the 1e-4 the exact-f32 kernels are held to (tests/test_gpu_mlp.py GRAD_TOL).
+  Measured (tools/r04_precision_probe.py, profiles/r04_precision_probe.txt): <= 5.6e-6 at 64 ... 4480 rows per set, <= 1.1e-5
+  per tensor at 4096 x 5 (262 144 rows per set), where the exact-f32 per-agent engine + fed_mean sits at <= 1.5e-5 and the
+  float32 NumPy oracle at <= 1.8e-4.
+
+Covered: conditioned inputs (no relu ties) AND unconditioned inputs with every out-of-tolerance tensor traced to a tie row;
+the exact-f32 per-agent kernel + fed_mean; bit-identical reruns; fp16 overflow and non-finite inputs -> NaN; at 4096 x 5 the
+float64 oracle on two whole sets, the f32 engine on all five and the mean-of-halves property; VecTrainer trajectories."""
 import numpy as np
 import pytest
 import torch
@@ -15,39 +24,48 @@ from tests.test_gpu_mlp import GRAD_TOL, _nets, _perturbed_group, _relerr
 
 pytestmark = pytest.mark.gpu
 
+SPLIT_TOL = 2e-5
+
+
+def _tie_mask(grp, M, S, s, a, tie=1e-6):
+    """[agents, 64] bool: batch rows with a pre-activation closer to 0 than `tie` x its layer's largest, in any layer that is
+    differentiated (actor(s), critic(s, a), critic(s, mu)) -- evaluated in float64 with agent v's set v % M."""
+    bad = np.zeros(s.shape[:2], bool)
+    for k in range(M):
+        an, cn, _, _ = _nets(grp, k, np.float64)
+        sel = np.arange(k, s.shape[0], M)
+        x = s[sel].reshape(-1, s.shape[2])[:, :S].astype(np.float64)
+        act = a[sel].reshape(-1, 1).astype(np.float64)
+        W1, b1, _, _, _, _, W2, b2 = an[:8]
+        z1 = x @ W1 + b1
+        y1 = np.maximum(z1, 0) * omlp._bn_coeffs(*an[2:6])[0] + omlp._bn_coeffs(*an[2:6])[1]
+        pre = [z1, y1 @ W2 + b2]
+        mu = omlp.actor_forward(an, x, 2.5)
+        Ws, bs, Wa, ba = cn[:4]
+        CW2, cb2 = cn[12], cn[13]
+        ys = np.maximum(x @ Ws + bs, 0) * omlp._bn_coeffs(*cn[4:8])[0] + omlp._bn_coeffs(*cn[4:8])[1]
+        pre.append(x @ Ws + bs)
+        for u in (act, mu):
+            za = u @ Wa + ba
+            ya = np.maximum(za, 0) * omlp._bn_coeffs(*cn[8:12])[0] + omlp._bn_coeffs(*cn[8:12])[1]
+            pre += [za, np.concatenate([ys, ya], axis=1) @ CW2 + cb2]
+        t_ = np.zeros(len(x), bool)
+        for z in pre:
+            t_ |= (np.abs(z) < tie * np.abs(z).max()).any(axis=1)
+        bad[sel] = t_.reshape(len(sel), -1)
+    return bad
+
 
 def _untie(grp, M, S, s, a, tie=1e-6):
     """The relu derivative is discontinuous at 0: a row with a pre-activation within float32 resolution of 0 in a layer that is
-    differentiated (actor(s), critic(s, a), critic(s, mu)) has no defined float32 gradient -- the same arithmetic in another
-    order decides the sign the other way, and ONE such row moves the actor's first-layer gradient of a 4480-row batch by 1e-3
-    of its max (seen: |z2| = 1.1e-8 at scale 0.8 in one row of 22400; tools/fsplit_both_debug.py). The inputs of the
-    oracle-tolerance tests are conditioned instead: rows with any pre-activation closer to 0 than `tie` x its layer's largest
-    are nudged (in place, deterministically) until none is left. Returns the number of nudges."""
+    differentiated has no defined float32 gradient -- the same arithmetic in another order decides the sign the other way, and
+    ONE such row moves the actor's first-layer gradient of a 4480-row batch by 1e-3 of its max (seen: |z2| = 1.1e-8 at scale
+    0.8 in one row of 22400; tools/fsplit_both_debug.py). The CONDITIONED tests nudge such rows (in place, deterministically)
+    until none is left; the unconditioned test below runs the same inputs as they are and accounts for every tie. Returns the
+    number of nudges."""
     nudged = 0
     for _ in range(8):
-        bad = np.zeros(s.shape[:2], bool)
-        for k in range(M):
-            an, cn, _, _ = _nets(grp, k, np.float64)
-            sel = np.arange(k, s.shape[0], M)
-            x = s[sel].reshape(-1, s.shape[2])[:, :S].astype(np.float64)
-            act = a[sel].reshape(-1, 1).astype(np.float64)
-            W1, b1, _, _, _, _, W2, b2 = an[:8]
-            z1 = x @ W1 + b1
-            y1 = np.maximum(z1, 0) * omlp._bn_coeffs(*an[2:6])[0] + omlp._bn_coeffs(*an[2:6])[1]
-            pre = [z1, y1 @ W2 + b2]
-            mu = omlp.actor_forward(an, x, 2.5)
-            Ws, bs, Wa, ba = cn[:4]
-            CW2, cb2 = cn[12], cn[13]
-            ys = np.maximum(x @ Ws + bs, 0) * omlp._bn_coeffs(*cn[4:8])[0] + omlp._bn_coeffs(*cn[4:8])[1]
-            pre.append(x @ Ws + bs)
-            for u in (act, mu):
-                za = u @ Wa + ba
-                ya = np.maximum(za, 0) * omlp._bn_coeffs(*cn[8:12])[0] + omlp._bn_coeffs(*cn[8:12])[1]
-                pre += [za, np.concatenate([ys, ya], axis=1) @ CW2 + cb2]
-            t_ = np.zeros(len(x), bool)
-            for z in pre:
-                t_ |= (np.abs(z) < tie * np.abs(z).max()).any(axis=1)
-            bad[sel] = t_.reshape(len(sel), -1)
+        bad = _tie_mask(grp, M, S, s, a, tie)
         if not bad.any():
             return nudged
         nudged += int(bad.sum())
@@ -56,13 +74,36 @@ def _untie(grp, M, S, s, a, tie=1e-6):
     raise AssertionError("could not condition the batch")
 
 
+def _errors_vs_oracle(grp, g, s, a, r, s2, P, M, sets, B=64, losses=None, loss_tol=1e-4):
+    """{(set, tensor): (error, float32 oracle's error)} of the tensors of g [M, theta] that miss max(SPLIT_TOL, 4 x f32-oracle
+    error) against the float64 oracle on each set's concatenated P x 64-row batch; also checks the losses when given."""
+    errs, worst = {}, 0.0
+    for k in sets:
+        sel = np.arange(P) * M + k
+        cat = lambda x: x[sel].reshape(P * B, *x.shape[2:])
+        batch = (cat(s), cat(a), cat(r)[:, None], cat(s2))
+        cg, ag, aux = omlp.learn(batch, *_nets(grp, k, np.float64))
+        cg32, ag32, _ = omlp.learn(batch, *_nets(grp, k, np.float32))
+        gcg, gag = grp.grads_as_lists(g[k])
+        for name, got, ref, r32 in zip(NAMES, gcg + gag, cg + ag, cg32 + ag32):
+            e, e32 = _relerr(got, ref), _relerr(r32, ref)
+            worst = max(worst, e)
+            if e > max(SPLIT_TOL, 4 * e32):
+                errs[(k, name)] = (e, e32)
+        if losses is not None:
+            lo = losses[k].cpu().numpy()
+            assert abs(lo[0] - aux["critic_loss"]) <= loss_tol * abs(aux["critic_loss"])
+            assert abs(lo[1] - aux["actor_loss"]) <= loss_tol * max(1e-2, abs(aux["actor_loss"]))
+    return errs, worst
+
+
 @pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
 def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     """The mean over a set's P agents of their 64-row batch gradients == the gradient of the P*64-row batch (inference-mode
-    BN: rows are independent). Every gradient tensor within max(1e-4, 4 x the float32 oracle's own error) of the float64
-    oracle -- the assertion of the exact-f32 learn kernels (tests/test_gpu_mlp.py::test_learn_gradients_match_oracle)."""
+    BN: rows are independent). Every gradient tensor within max(SPLIT_TOL = 2e-5, 4 x the float32 oracle's own error) of the
+    float64 oracle (the exact-f32 learn kernels are asserted at 1e-4, tests/test_gpu_mlp.py::test_learn_gradients_match_oracle).
+    Inputs conditioned against relu ties (_untie); the same inputs unconditioned: next test."""
     need_gpu()
-    B = 64
     conf, grp = _perturbed_group(M, S=S, seed=61)
     rs = np.random.RandomState(62)
     n = P * M  # agent v = p*M + m uses set m
@@ -72,28 +113,68 @@ def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n, losses=losses)
     torch.cuda.synchronize()
     assert torch.isfinite(g).all()
-    errs = {}
-    for k in range(M):
-        sel = np.arange(P) * M + k
-        cat = lambda x: x[sel].reshape(P * B, *x.shape[2:])
-        batch = (cat(s), cat(a), cat(r)[:, None], cat(s2))
-        cg, ag, aux = omlp.learn(batch, *_nets(grp, k, np.float64))
-        cg32, ag32, _ = omlp.learn(batch, *_nets(grp, k, np.float32))
-        gcg, gag = grp.grads_as_lists(g[k])
-        for name, got, ref, r32 in zip(NAMES, gcg + gag, cg + ag, cg32 + ag32):
-            e = _relerr(got, ref)
-            if e > max(GRAD_TOL, 4 * _relerr(r32, ref)):
-                errs[(k, name)] = (e, _relerr(r32, ref))
-        lo = losses[k].cpu().numpy()
-        assert abs(lo[0] - aux["critic_loss"]) <= 1e-4 * abs(aux["critic_loss"])
-        assert abs(lo[1] - aux["actor_loss"]) <= 1e-4 * max(1e-2, abs(aux["actor_loss"]))
+    errs, worst = _errors_vs_oracle(grp, g, s, a, r, s2, P, M, range(M), losses=losses)
     assert not errs, errs
+    assert worst <= SPLIT_TOL, worst  # (at these sizes the float32-oracle clause is not even needed)
+
+
+@pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
+def test_split_set_learner_unconditioned_inputs_every_miss_is_a_relu_tie(S, P, M):
+    """the SAME cases without _untie, so that the conditioning is shown to hide nothing but relu ties. Every
+    tensor that misses the tolerance on the raw inputs is traced: the platoons (64-row tiles) of that set are learned one by
+    one and compared with the oracle tile by tile; each tile that misses must contain a tie row (a pre-activation within 1e-6
+    of its layer's largest of 0, where the float32 derivative is undefined), and with those tiles left out of BOTH means the
+    set is back inside the tolerance. The tie rows are reported. (Seed 62 at S = 4, P = 70, M = 5 holds the known case: one
+    row of 22 400 with |z2| = 1.1e-8 in critic(s, mu) moves every actor tensor by 5.5e-5 ... 1.1e-3.)"""
+    need_gpu()
+    B = 64
+    conf, grp = _perturbed_group(M, S=S, seed=61)
+    n = P * M
+    s, a, r, s2 = _batch(np.random.RandomState(62), n, S)
+    g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n).clone()
+    assert torch.isfinite(g).all()
+    errs, _ = _errors_vs_oracle(grp, g, s, a, r, s2, P, M, range(M))
+    if not errs:
+        return
+    ties = _tie_mask(grp, M, S, s, a)  # [agents, 64]
+    # platoon by platoon: n_agents = M, one 64-row tile per set
+    tiles = [grp.learn_set_split(t(s[p * M:(p + 1) * M]), t(a[p * M:(p + 1) * M]), t(r[p * M:(p + 1) * M]), t(s2[p * M:(p + 1) * M]), M).clone()
+             for p in range(P)]
+    report = {}
+    for k in sorted({k for k, _ in errs}):
+        missing = []
+        for p in range(P):
+            v = p * M + k
+            cg, ag, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp, k, np.float64))
+            cg32, ag32, _ = omlp.learn((s[v], a[v], r[v][:, None], s2[v]), *_nets(grp, k, np.float32))
+            gcg, gag = grp.grads_as_lists(tiles[p][k])
+            if any(_relerr(got, ref) > max(SPLIT_TOL, 4 * _relerr(r32, ref)) for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32)):
+                missing.append(p)
+        assert missing, (k, "tensors miss the tolerance but no single tile does", {n_: e for (kk, n_), e in errs.items() if kk == k})
+        for p in missing:
+            rows = np.nonzero(ties[p * M + k])[0]
+            assert len(rows) > 0, (k, p, "a tile misses the tolerance without a relu tie in it")
+            report[(k, p)] = rows.tolist()
+        # without the tie tiles, on both sides: inside the tolerance again
+        keep = [p for p in range(P) if p not in missing]
+        assert keep, "every tile of the set holds a tie"
+        sel = np.array(keep) * M + k
+        cat = lambda x: x[sel].reshape(len(keep) * B, *x.shape[2:])
+        batch = (cat(s), cat(a), cat(r)[:, None], cat(s2))
+        cg, ag, _ = omlp.learn(batch, *_nets(grp, k, np.float64))
+        cg32, ag32, _ = omlp.learn(batch, *_nets(grp, k, np.float32))
+        mean = torch.stack([tiles[p][k] for p in keep]).double().mean(dim=0).float()
+        gcg, gag = grp.grads_as_lists(mean)
+        for name, got, ref, r32 in zip(NAMES, gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(SPLIT_TOL, 4 * _relerr(r32, ref)), (k, name, _relerr(got, ref))
+        assert len(missing) <= int(ties[np.arange(P) * M + k].any(axis=1).sum())
+    print(f"unconditioned S={S} P={P} M={M}: {len(errs)} tensors over tolerance, all traced to relu-tie rows (set, platoon) -> rows: {report}")
 
 
 @pytest.mark.parametrize("P,M", [(8, 3), (1, 1), (70, 5)])
 def test_split_set_learner_equals_per_agent_f32_kernel_plus_federated_mean(P, M):
     """avd_learn_f32 per agent (exact f32 MFMA) + fed_mean over the platoons vs the split learner on the same agent-major
-    batch: 1e-4 of each block's max (the bf16 learner of fset.hip: 1.7e-2 on the actor block)."""
+    batch: SPLIT_TOL of each block's max (the bf16 learner of fset.hip: 1.7e-2 on the actor block)."""
     need_gpu()
     B, S = 64, 4
     conf, grp = _perturbed_group(M, S=S, seed=71)
@@ -109,7 +190,7 @@ def test_split_set_learner_equals_per_agent_f32_kernel_plus_federated_mean(P, M)
     for name, lo, hi in (("actor", 0, lay.actor_size), ("critic", lay.actor_size, lay.theta_size)):
         scale = np.abs(avg[:, lo:hi]).max()
         es, eb = np.abs(avg[:, lo:hi] - split[:, lo:hi]).max() / scale, np.abs(avg[:, lo:hi] - bf16[:, lo:hi]).max() / scale
-        assert es <= GRAD_TOL, (name, es, eb)
+        assert es <= SPLIT_TOL, (name, es, eb)
         assert es < 0.05 * eb or eb < 1e-4, (name, es, eb)  # two orders of magnitude closer than single-rounded operands
     # padding floats of the slab stay zero (what Adam relies on)
     assert split[:, lay.actor_size - 3:lay.actor_size].max() == 0.0 or lay.actor_size % 4 == 0
@@ -145,7 +226,7 @@ def test_split_set_learner_weighted_mean_matches_weighted_fed_mean():
     lay = grp.lay
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = np.abs(avg[:, lo:hi]).max()
-        assert np.abs(avg[:, lo:hi] - g[:, lo:hi]).max() <= GRAD_TOL * scale
+        assert np.abs(avg[:, lo:hi] - g[:, lo:hi]).max() <= SPLIT_TOL * scale
         assert np.abs(avg[:, lo:hi] - unweighted[:, lo:hi]).max() > 5e-2 * scale  # the weights matter in this case
 
 
@@ -174,11 +255,57 @@ def test_set_learners_turn_a_non_finite_input_into_nan_gradients(split, where):
         assert torch.isnan(g[:, lo:hi]).all()
 
 
-def test_full_size_split_learner_against_the_f32_engine_and_the_mean_of_its_halves():
-    """BASELINE configs[3]'s per-GPU shape (4096 platoons x 5 vehicle indices, 64-row batches): against the exact-f32
-    per-agent learn kernel + federated mean at this size (1e-4 of each block's max), and the size-independent property that
-    the mean over all platoons is the average of the means over its two halves (same operand values on both sides, only
-    the f32 summation grouping differs: 2e-5)."""
+@pytest.mark.parametrize("where", ["actor_W1", "critic_Wa", "target_critic_Ws", "target_actor_b1", "state"])
+def test_split_set_learner_turns_an_fp16_overflow_into_nan_gradients(where):
+    """first-layer activations travel as fp16 pairs scaled by S1 = 64, so relu(z1) >= 1023.75 converts to
+    (+inf, -inf); under -fno-honor-nans the NaN accumulators that follow would be relu'd to 0 and the call would return wrong,
+    finite gradients. Every such conversion is watched (one accumulator per batch row and sweep in the heads; the scaled static
+    operands in the prep kernels; the inputs in pack): the whole slab must come back NaN -- and stay finite, equal to the exact
+    engine's, just below the threshold."""
+    need_gpu()
+    P, M, S = 5, 2, 4
+    conf, grp = _perturbed_group(M, S=S, seed=83)
+    lay = grp.lay
+    s, a, r, s2 = (t(x) for x in _batch(np.random.RandomState(84), P * M, S))
+    s[:, :, 0] = 1.5  # (a known input magnitude on state 0)
+    s2[:, :, 0] = 1.5
+    a[:] = 2.5
+
+    def poke(scale):
+        if where == "actor_W1":        # z1 = 1.5 * 800 * scale + ...: activation overflow in OUT_TANH(actor, s); S1 w = 51 200 * scale is representable
+            grp.theta[1, lay.aW1 + 0 * 256 + 7] = 800.0 * scale
+        elif where == "critic_Wa":     # action layer: za = 2.5 * 480 * scale: HEAD_BOTH, branch A
+            grp.theta[0, lay.actor_size + lay.cWa + 5] = 480.0 * scale
+        elif where == "target_critic_Ws":  # OUT_TD on s'
+            grp.theta_t[1, lay.actor_size + lay.cWs + 0 * 256 + 9] = 800.0 * scale
+        elif where == "target_actor_b1":   # S1 b = 76 800: the static operand itself overflows (prep1_kernel)
+            grp.theta_t[0, lay.ab1 + 3] = 1200.0 * scale
+        else:                           # an input that fp16 cannot hold (pack_x_kernel); below: a large but harmless one
+            s.view(-1)[4 * 77 + 1] = 70000.0 if scale == 1.0 else 300.0
+
+    poke(0.5)  # z1 <= 600 < 1023.75 / bias 600 / state 300: finite, and still the exact engine's gradients
+    g = grp.learn_set_split(s, a, r, s2, P * M).clone()
+    assert torch.isfinite(g).all()
+    exact = vec.fed_mean(grp.learn(s, a, r, s2, M), P, M, method=conf.interfrl)
+    for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
+        assert (g[:, lo:hi] - exact[:, lo:hi]).abs().max().item() <= SPLIT_TOL * exact[:, lo:hi].abs().max().item()
+    poke(1.0)
+    g = grp.learn_set_split(s, a, r, s2, P * M)
+    for lo, hi in ((lay.aW2, lay.aW2 + 256 * 128), (lay.actor_size + lay.cW2, lay.actor_size + lay.cW2 + 304 * 128)):
+        assert torch.isnan(g[:, lo:hi]).all(), where
+
+
+def test_full_size_split_learner_against_the_float64_oracle_the_f32_engine_and_the_mean_of_its_halves():
+    """BASELINE configs[1] / configs[3]'s per-GPU shape (4096 platoons x 5 vehicle indices, 64-row batches = 262 144 rows per
+    weight set), VERDICT r03 #1(c):
+      * the FLOAT64 ORACLE's gradient of two whole sets (first and last; NumPy takes seconds per set): every tensor within
+        SPLIT_TOL = 2e-5 of its max -- no float32-oracle clause here (that NumPy oracle is the least accurate of the three at this
+        size: 1.8e-4), unconditioned inputs;
+      * the exact-f32 per-agent learn kernel + federated mean on all five sets: the split learner must be at least as close to
+        the oracle as that engine on the two oracle sets (2 x its error, or SPLIT_TOL), and within 5e-5 of it per block on all
+        five (the comparator's own distance from the oracle is 1.5e-5 per tensor);
+      * the size-independent property that the mean over all platoons is the average of the means over its two halves (same
+        operand values on both sides, only the f32 summation grouping differs: 2e-5); bit-identical reruns."""
     need_gpu()
     P, M, B, S = 4096, 5, 64, 4
     conf, grp = _perturbed_group(M, S=S, seed=91)
@@ -200,8 +327,21 @@ def test_full_size_split_learner_against_the_f32_engine_and_the_mean_of_its_halv
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = exact[:, lo:hi].abs().max().item()
         assert (full[:, lo:hi] - avg[:, lo:hi]).abs().max().item() <= 2e-5 * scale, lo
-        assert (full[:, lo:hi] - exact[:, lo:hi]).abs().max().item() <= GRAD_TOL * scale, lo
+        assert (full[:, lo:hi] - exact[:, lo:hi]).abs().max().item() <= 5e-5 * scale, (lo, (full[:, lo:hi] - exact[:, lo:hi]).abs().max().item() / scale)
     assert not torch.allclose(halves[0], halves[1])  # the halves are different batches
+    sn, an, rn_, s2n = (x.cpu().numpy() for x in (s, a, r, s2))
+    worst = {}
+    for k in (0, M - 1):
+        sel = np.arange(P) * M + k
+        cat = lambda x: x[sel].reshape(P * B, *x.shape[2:])
+        cg, ag, _ = omlp.learn((cat(sn), cat(an), cat(rn_)[:, None], cat(s2n)), *_nets(grp, k, np.float64))
+        gs, ge = grp.grads_as_lists(full[k]), grp.grads_as_lists(exact[k])
+        for name, got, eng, ref in zip(NAMES, gs[0] + gs[1], ge[0] + ge[1], cg + ag):
+            e, ee = _relerr(got, ref), _relerr(eng, ref)
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e <= SPLIT_TOL, (k, name, e, ee)
+            assert e <= max(SPLIT_TOL, 2 * ee), (k, name, e, ee)
+    print("4096 x 5, split learner vs float64 oracle, worst per tensor:", {n_: f"{e:.1e}" for n_, e in worst.items()})
 
 
 def test_trainer_split_engine_tracks_per_agent_engine_under_interfrl():
@@ -279,6 +419,6 @@ def test_split_set_learner_fp16_scaling_is_robust_to_weight_and_state_magnitudes
         for name, x, z in zip(NAMES, cg + ag, ce + ae):
             scale = np.abs(z).max()
             if scale > 0:
-                assert np.abs(x - z).max() <= GRAD_TOL * scale, (k, name, np.abs(x - z).max() / scale)
+                assert np.abs(x - z).max() <= SPLIT_TOL * scale, (k, name, np.abs(x - z).max() / scale)
             else:
                 assert np.abs(x).max() == 0.0, (k, name)
