@@ -123,7 +123,7 @@ __device__ __forceinline__ f16x8 fragh(unsigned a, unsigned b, unsigned c, unsig
 __device__ __forceinline__ f32x16 mfmah(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-// the first-layer fragments of the heads, fp16 (same slot layout as make_xq / make_wf below; sc scales weights and bias)
+// the first-layer fragments, fp16 pairs (slot layout: make_xg below with g = 1; sc scales weights and bias)
 __device__ __forceinline__ f16x8 make_xh(float x0, float x1, float x2, float x3, int h) {
     f16 a0, a1, a2, a3, l0, l1, l2, l3;
     split1h(x0, a0, l0), split1h(x1, a1, l1), split1h(x2, a2, l2), split1h(x3, a3, l3);
@@ -139,31 +139,21 @@ __device__ __forceinline__ f16x8 make_wh(float w0, float w1, float w2, float w3,
     const f16 zero = (f16)0.f;
     f16x8 v;
     v[0] = h ? l0 : a0, v[1] = h ? l1 : a1, v[2] = h ? l2 : a2, v[3] = h ? l3 : a3;
-    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? zero : a2, v[7] = h ? zero : a3;
+    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? bh : a2, v[7] = h ? zero : a3;  // (k slot 14 = b_hi: meets g_lo in dw_kernel, 0 in the heads)
     return v;
 }
-
-// ---- first layer on the matrix cores (see fset.hip) ---------------------------------------------------------------------
+// dw_kernel's input fragment: the row factor g = |g3| 2^kg rides in the input, (g x) and g as fp16 pairs:
 //   k slot      0..3        4..7        8..11       12       13       14      15
-//   input  x:   (gx)_hi     (gx)_lo     (gx)_hi     g_hi     g_hi     g_lo    0       (g = 1: plain forward pass)
-//   weight w:   w_hi        w_hi        w_lo        b_hi     b_lo     b_hi    0
-// = g (x . w + b) to 2^-16: the row factor g = |g3[row]| rides in the input fragment (dw_kernel).
-__device__ __forceinline__ bf16x8 make_xq(float x0, float x1, float x2, float x3, float g, int h) {
-    bf16 a0, a1, a2, a3, l0, l1, l2, l3, gh, gl;
-    split1(x0, a0, l0), split1(x1, a1, l1), split1(x2, a2, l2), split1(x3, a3, l3), split1(g, gh, gl);
-    const bf16 zero = (bf16)0.f;
-    bf16x8 v;
+//   input  x:   (gx)_hi     (gx)_lo     (gx)_hi     g_hi     g_hi     g_lo    0
+//   weight w:   w_hi        w_hi        w_lo        b_hi     b_lo     b_hi    0        (make_wh, scaled by S1)
+// = S1 g (x . w + b): relu(W1 (g x) + g b1) = g relu(z1), one MFMA like every first layer here.
+__device__ __forceinline__ f16x8 make_xg(float x0, float x1, float x2, float x3, float g, int h) {
+    f16 a0, a1, a2, a3, l0, l1, l2, l3, gh, gl;
+    split1h(x0, a0, l0), split1h(x1, a1, l1), split1h(x2, a2, l2), split1h(x3, a3, l3), split1h(g, gh, gl);
+    const f16 zero = (f16)0.f;
+    f16x8 v;
     v[0] = a0, v[1] = a1, v[2] = a2, v[3] = a3;
     v[4] = h ? gh : l0, v[5] = h ? gh : l1, v[6] = h ? gl : l2, v[7] = h ? zero : l3;
-    return v;
-}
-__device__ __forceinline__ bf16x8 make_wf(float w0, float w1, float w2, float w3, float b, int h) {
-    bf16 a0, a1, a2, a3, l0, l1, l2, l3, bh, bl;
-    split1(w0, a0, l0), split1(w1, a1, l1), split1(w2, a2, l2), split1(w3, a3, l3), split1(b, bh, bl);
-    const bf16 zero = (bf16)0.f;
-    bf16x8 v;
-    v[0] = h ? l0 : a0, v[1] = h ? l1 : a1, v[2] = h ? l2 : a2, v[3] = h ? l3 : a3;
-    v[4] = h ? bh : a0, v[5] = h ? bl : a1, v[6] = h ? bh : a2, v[7] = h ? zero : a3;
     return v;
 }
 
@@ -192,16 +182,16 @@ struct NetP {
     const f16* Wlo;    //                 its lo
     const f16* Wchi;   // [sets][KP][H2]  fp16 hi of SWC * c3[n] * W2[f][n], rows >= K zero: dx_kernel's resident operand (online nets)
     const f16* Wclo;   //                 its lo (SWC: vec[2 H2 + 2])
-    const bf16x8* wf1; // [sets][NGT_MAX][64] first-layer weight fragments per feature tile and lane (feature K: the constant one)
-    const f16x8* wf1h; // the same as fp16 pairs scaled by S1: the heads' first layers
+    const f16x8* wf1h; // [sets][NGT_MAX][64] first-layer weight fragments per feature tile and lane, fp16 pairs scaled by S1 (feature K:
+                       // the constant one, relu(0 x + 1): its row of dw_kernel's G is db2)
     const float* vec;  // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3, SW, SWC
     const unsigned* wap;  // [sets][2 hi/lo][2 h][3 k-steps][4] packed fp16 pairs of S1 * wa, the critic's action-layer weights (HEAD_CONST)
 };
 
 // ---- pack: split first-layer input fragments of every batch row, once per learn call (+ the finiteness test) ----------
-// outh: fp16 pairs (heads); outb: bf16 pairs (dx_kernel) or NULL
+// outh: fp16 pairs (heads, dx_kernel); extra: the per-row scalar that travels with x (a: an fp16 fragment too; r: only tested)
 template <int S>
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float* extra, long rows, f16x8* outh, bf16x8* outb, int* bad) {
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float* extra, bool extra_is_action, long rows, f16x8* outh, int* bad) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * rows) return;
     float v[4];
@@ -210,11 +200,10 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float
     nf = nf || fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= F16_OVERFLOW;  // (fp16 input fragments)
     if (!(i & 1)) {
         const float e = extra[i >> 1];  // a (an fp16 input fragment of the critic too) or r
-        nf = nf || not_finite(e) || (outb && fabsf(e) >= F16_OVERFLOW);
+        nf = nf || not_finite(e) || (extra_is_action && fabsf(e) >= F16_OVERFLOW);
     }
     if (nf) atomicOr(bad, 1);
     outh[i] = make_xh(v[0], v[1], v[2], v[3], (int)(i & 1));
-    if (outb) outb[i] = make_xq(v[0], v[1], v[2], v[3], 1.f, (int)(i & 1));
 }
 
 // ---- operand preparation ---------------------------------------------------------------------------------------------
@@ -224,7 +213,6 @@ struct PrepArgs {
     const float *theta, *stats, *theta_t, *stats_t;
     f16 *Whi[4], *Wlo[4];  // net 0 actor, 1 critic, 2 target actor, 3 target critic
     f16 *Wchi[4], *Wclo[4];  // online nets only
-    bf16x8* wf1[4];
     f16x8* wf1h[4];
     float* vec[4];
     unsigned* wap;
@@ -241,6 +229,9 @@ __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
     const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
     const int K = critic ? CriticS::K : ActorS::K, oW2 = critic ? L.cW2 : L.aW2;
     const int og2 = critic ? L.cg3 : L.ag2, omv2 = critic ? L.cmv3 : L.amv2, oW3 = critic ? L.cW3 : L.aW3;
+    __shared__ float c3a[H2];  // |c3[n]| = |inv2[n] w3[n]|
+    if (tid < H2) c3a[tid] = fabsf((1.0f / sqrtf(st[omv2 + tid] + BN_EPS)) * th[og2 + tid] * th[oW3 + tid]);
+    __syncthreads();
     float m = 0.f, m2 = 0.f;
     for (int f = tid; f < K; f += 256) {
         int og, omv, ff = f;
@@ -252,7 +243,7 @@ __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
         for (int n = 0; n < H2; ++n) {
             const float w = fabsf(th[oW2 + (long)f * H2 + n]);
             wm = fmaxf(wm, w);
-            if (!target) m2 = fmaxf(m2, fabsf((1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n] * th[oW3 + n]) * w);
+            if (!target) m2 = fmaxf(m2, c3a[n] * w);
         }
         m = fmaxf(m, inv * wm);
     }
@@ -372,7 +363,6 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
         // the heads' and dx's fragments carry S1 w, S1 b as fp16 pairs
         if (S1 * fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fmaxf(fabsf(w[2]), fabsf(w[3])), fabsf(b))) >= F16_OVERFLOW) atomicOr(a.bad, 1);
     }
-    a.wf1[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wf(w[0], w[1], w[2], w[3], b, h);
     a.wf1h[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wh(w[0], w[1], w[2], w[3], b, S1, h);
     if (net == 1 && ft == 0 && lane < 48) {
         // HEAD_CONST's B operand of M = W2T[:, action] . (mask_a * wa): element jj of lane half hh of action k-step ks is action
@@ -403,12 +393,13 @@ struct HeadArgs {
     const float* yin;  // HEAD_CRITIC / HEAD_BOTH: TD targets; HEAD_ACTOR: dmu
     const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
     float* out;        // OUT_*: per-row result
-    bf16* sm;          // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: sign(g3) * [z2 > 0] as bf16 +-1 / 0, [n_agents][64][128]
+    f16* sm;           // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: sign(g3) * [z2 > 0] as fp16 +-1 / 0 (EXACT), [n_agents][64][128]
     float* g3;         // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: the row factor of dZ2 [n_agents][64]
     float* dmu;        // HEAD_CONST / HEAD_BOTH: dLa/dmu per row [n_agents][64]
     float* part;       // backward modes: [grid][8 waves][128] sums T1 = sum_rows g3 * p2 per output column
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float* part_s2;    // HEAD_BOTH: the same sums of the critic(s, mu) branch (the actor loss)
+    float* part_m;     // backward modes: [grid][8 waves] max |g3| over the wave's rows (dw / dx scale their fp16 operands by it)
     float gamma, high, inv_n;
     int* bad;          // set when an activation would overflow fp16 (S1 P1 >= 65520): finalize then writes NaN gradients
 };
@@ -462,7 +453,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #else
 #define HSTAMP(i)
 #endif
-    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f;
+    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f, gmax = 0.f;
     // fp16 overflow watch. An activation S1 P1 >= 65520 converts to the pair (hi, lo) = (+inf, -inf), and whatever the weights,
     // w_hi inf + w_lo inf - w_hi inf is NaN in EVERY second-layer accumulator of that batch row (0 inf is NaN too): one
     // accumulator per row and sweep is looked at (bit test: the file is built with -fno-honor-nans), |bits| max-accumulated.
@@ -557,7 +548,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             }
             return zp;
         };
-        auto bwd_t = [&](const f32x16& a, int t, float g3i, unsigned s16, bf16* dst) {  // T1 and the signed mask of tile t (a = z2 or relu(z2))
+        auto bwd_t = [&](const f32x16& a, int t, float g3i, unsigned s16, f16* dst) {  // T1 and the signed mask of tile t (a = z2 or relu(z2))
             unsigned pk[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -597,9 +588,10 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         };
         auto epi_bwd = [&](f32x16 (&ac)[4], float g3) {  // row factor, masks and T1 of a backward pass
             if (h == 0) p.g3[ri] = g3;
-            // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc); the mask carries the sign of g3 as bf16 -1 / +1
+            // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc); the mask carries the sign of g3 as fp16 -1 / +1
+            gmax = fmaxf(gmax, fabsf(g3));
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bwd_t(ac[t], t, g3 * isc, g3 < 0.f ? 0xbf80u : 0x3f80u, p.sm + ri * H2 + 8 * h);
+            for (int t = 0; t < 4; ++t) bwd_t(ac[t], t, g3 * isc, g3 < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
         };
         auto epi_dmu = [&](f32x16 (&ac)[4], float g3) {
             // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
@@ -741,9 +733,10 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 zp += __shfl_xor(zp, 32);
                 const float diff = d3 + zp - ty, g3a = 2.f * diff * p.inv_n * tw;
                 if (h == 0) p.g3[ri] = g3a, Dacc += g3a, Lacc += diff * diff;
+                gmax = fmaxf(gmax, fabsf(g3a));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    bwd_t(acc[t], t, g3a * isc, g3a < 0.f ? 0xbf80u : 0x3f80u, p.sm + ri * H2 + 8 * h);
+                    bwd_t(acc[t], t, g3a * isc, g3a < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
                     // (pin the update HERE: the optimiser otherwise sinks it below branch B and keeps relu(z2) alive across it)
                     pin16(T1[BWD ? t : 0]);
                 }
@@ -861,6 +854,11 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             Lacc += __shfl_xor(Lacc, o);
             if (BOTH) Dacc2 += __shfl_xor(Dacc2, o), Lacc2 += __shfl_xor(Lacc2, o);
         }
+        if (BWD) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+            if (lane == 0) p.part_m[(long)blockIdx.x * 8 + w] = gmax;
+        }
         if (lane == 0) {
             p.part_s[((long)blockIdx.x * 8 + w) * 2] = Dacc;
             p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc;
@@ -873,6 +871,27 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     }
 }
 
+// ---- the row factor's scale --------------------------------------------------------------------------------------------------
+// dw and dx carry |g3[row]| inside fp16 operands; g3 is 2 (q - y) / N or d mu * high * (1 - t^2): anything from 1e-12 to 1e-3. The
+// backward heads leave max |g3| per wave (part_m); every workgroup of dw / dx reduces its set's J x 8 values to the power of two
+// 2^kg with max |g3| 2^kg in [0.5, 1) (exact scaling; max() is order-independent: every workgroup gets the same bits) and
+// divides it out of its partial sums at the end. With |g3| 2^kg < 1 an operand |g3| 2^kg S1 P1 stays below the S1 P1 the heads
+// have already watched for fp16 overflow. Block-cooperative (one barrier); red: 8 floats of LDS.
+__device__ __forceinline__ float set_gscale(const float* part_m, int set, int n_sets, int J, float* red) {
+    const int tid = threadIdx.x;
+    float m = 0.f;
+    for (int i = tid; i < J * 8; i += NT) m = fmaxf(m, part_m[((long)(i >> 3) * n_sets + set) * 8 + (i & 7)]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+    int e = 0;
+    if (m > 0.f && !not_finite(m)) (void)frexpf(m, &e);  // m = fr 2^e, fr in [0.5, 1)
+    const int k = e > 100 ? -100 : (e < -100 ? 100 : -e);
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ldexpf(1.f, k))));  // (uniform: keep it in an SGPR)
+}
+
 // ---- dw: G[f][n] += sum_rows (|g3| P1)[row][f] * sm[row][n] over all tiles of the workgroup -------------------------------
 struct DwArgs {
     NetP net;
@@ -880,7 +899,8 @@ struct DwArgs {
     const float* x;    // states [n_agents][64][S]
     const float* act;  // the critic's action input [n_agents][64]
     const float* g3;   // [n_agents][64]
-    const bf16* sm;    // [n_agents][64][128]
+    const float* part_m;  // [grid][8] max |g3| per wave of the head that wrote g3 (set_gscale)
+    const f16* sm;     // [n_agents][64][128] fp16 +-1 / 0
     float* partG;      // [grid][KG][128] (row K: the constant-one feature = sum over rows of g3 * mask -> db2 / c3)
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
 };
@@ -888,23 +908,26 @@ struct DwArgs {
 // state tiles (critic: the action tiles 8, 9; actor: the constant-one tile 8) are cut into eight equal pieces, one per wave
 // (critic: tile x row half x pair of column tiles; actor: row half x column tile; 32 more accumulator registers), whose
 // row-half partials meet in LDS at the end -- every wave then does the same work per tile. A first-layer tile is evaluated
-// with the batch rows as the M index and the row factor |g3| in its input fragment (result: feature on the lane, rows in the
-// registers = the A operand of G = Q^T . sm in permuted k order), relu'd and split ONCE and used against all four column
-// tiles: 64 VALU per 17 MFMAs. The sm tile goes through LDS (row stride 320 B: conflict-free ds_read_b64_tr_b16), fetched
+// with the batch rows as the M index and the row factor |g3| 2^kg in its input fragment (fp16 pairs: make_xg; result: feature on
+// the lane, rows in the registers = the A operand of G = Q^T . sm in permuted k order), relu'd and split ONCE into an fp16 pair
+// (r04: was a bf16 pair, 2^-17 per row -- in a noise-dominated sum that IS the relative error of the result) and used against
+// all four column tiles: 48 VALU per 17 MFMAs. The sm tile goes through LDS (row stride 320 B: conflict-free ds_read_b64_tr_b16), fetched
 // TWO tiles ahead; the |g3|-scaled input fragments are built once per tile by 128 threads and shared through LDS.
 template <int S, class NET>
 __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     constexpr int KG = NET::KG, LDZ = 160;
     constexpr int XC = NET::critic ? 2 : 1;  // column tiles of a wave's extra piece
-    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];  // (40 KB: reused for the extra pieces' partial sums)
-    __shared__ __attribute__((aligned(16))) bf16x8 fq[2][TILE * 2];      // scaled input fragments [row][lane half] of the states
-    __shared__ __attribute__((aligned(16))) bf16x8 fa[2][TILE * 2];      // ... of the action (critic)
+    __shared__ __attribute__((aligned(16))) f16 smimg[2][TILE * LDZ];  // (40 KB: reused for the extra pieces' partial sums)
+    __shared__ __attribute__((aligned(16))) f16x8 fq[2][TILE * 2];      // scaled input fragments [row][lane half] of the states
+    __shared__ __attribute__((aligned(16))) f16x8 fa[2][TILE * 2];      // ... of the action (critic)
+    __shared__ float gred[8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
-    const bf16x8* wf1 = p.net.wf1 + (long)set * NGT_MAX * 64 + lane;
+    const float gsc = set_gscale(p.part_m, set, p.n_sets, J, gred);  // 2^kg
+    const f16x8* wf1 = p.net.wf1h + (long)set * NGT_MAX * 64 + lane;
     // this wave's extra piece
     const int xt = NET::critic ? 8 + (w >> 2) : 8, xrh = NET::critic ? (w >> 1) & 1 : (w >> 2) & 1, xc0 = NET::critic ? 2 * (w & 1) : (w & 3);
-    const bf16x8 wf0 = wf1[64 * w], wfx = wf1[64 * xt];
+    const f16x8 wf0 = wf1[64 * w], wfx = wf1[64 * xt];
     f32x16 G0[4], G1[XC];
     const f32x16 zero16 = {};
 #pragma unroll
@@ -933,9 +956,9 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
         uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
         dst[0] = d0, dst[1] = d1;
         if (tid < 2 * TILE) {
-            const float g = fabsf(sg);
-            fq[buf][tid] = make_xq(g * sx[0], g * sx[1], g * sx[2], g * sx[3], g, fh);
-            if (NET::critic) fa[buf][tid] = make_xq(g * sa, 0.f, 0.f, 0.f, g, fh);
+            const float g = fabsf(sg) * gsc;  // in [0, 1)
+            fq[buf][tid] = make_xg(g * sx[0], g * sx[1], g * sx[2], g * sx[3], g, fh);
+            if (NET::critic) fa[buf][tid] = make_xg(g * sa, 0.f, 0.f, 0.f, g, fh);
         }
     };
     const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -943,38 +966,41 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     // split VALU of unit k + 1 is issued INTO the gaps between the MFMAs of unit k (sched_group_barrier). Issued one unit after
     // the other, the two waves of a SIMD run their VALU phases together and their MFMA phases together (same program, one
     // barrier per tile) and neither pipe overlaps the other: measured 5400 cycles per tile and SIMD for 2750 of MFMA.
-    auto read_b = [&](int buf, int e, int s, bf16x8 (&bfr)[4]) {  // sm fragments [column tile] of row half e, k-step s
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    auto read_tr = [&](const f16* at) {  // transposed 16-bit read (the type of the builtin's element is immaterial: bit pattern)
+        return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)at));
+    };
+    auto read_b = [&](int buf, int e, int s, f16x8 (&bfr)[4]) {  // sm fragments [column tile] of row half e, k-step s
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int R0 = 32 * e + 16 * s + 8 * hf + 4 * (g4 >> 1);
-                const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * c + 16 * (g4 & 1) + 4 * pp));
+                const f16x4 t = read_tr(smimg[buf] + (R0 + q) * LDZ + 32 * c + 16 * (g4 & 1) + 4 * pp);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bfr[c][4 * hf + j] = t[j];
             }
     };
     auto split16 = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8]) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) split2(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
+        for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
     };
     auto compute = [&](int buf) {
         unsigned ah[8], al[8], bh[8], bl[8];
         // stage 0: first layer + split of row half 0 (exposed)
-        split16(mfma(fq[buf][r * 2 + h], wf0, zero16), ah, al);
+        split16(mfmah(fq[buf][r * 2 + h], wf0, zero16), ah, al);
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: MFMAs of row half 0 | first layer + split of row half 1
         {
-            const f32x16 p1 = mfma(fq[buf][(32 + r) * 2 + h], wf0, zero16);
+            const f32x16 p1 = mfmah(fq[buf][(32 + r) * 2 + h], wf0, zero16);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 bfr[4];
+                f16x8 bfr[4];
                 read_b(buf, 0, s, bfr);
-                const bf16x8 hi = frag(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
-                const bf16x8 lo = frag(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
+                const f16x8 hi = fragh(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
+                const f16x8 lo = fragh(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) G0[c] = mfma(hi, bfr[c], G0[c]), G0[c] = mfma(lo, bfr[c], G0[c]);
+                for (int c = 0; c < 4; ++c) G0[c] = mfmah(hi, bfr[c], G0[c]), G0[c] = mfmah(lo, bfr[c], G0[c]);
             }
             split16(p1, bh, bl);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -984,23 +1010,23 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // stage 2: MFMAs of row half 1 | first layer + split of the extra piece (input fragment of ITS row half)
         {
-            const bf16x8 xin = NET::critic ? fa[buf][(32 * xrh + r) * 2 + h] : fq[buf][(32 * xrh + r) * 2 + h];
-            const f32x16 px = mfma(xin, wfx, zero16);
+            const f16x8 xin = NET::critic ? fa[buf][(32 * xrh + r) * 2 + h] : fq[buf][(32 * xrh + r) * 2 + h];
+            const f32x16 px = mfmah(xin, wfx, zero16);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 bfr[4];
+                f16x8 bfr[4];
                 read_b(buf, 1, s, bfr);
-                const bf16x8 hi = frag(bh[4 * s], bh[4 * s + 1], bh[4 * s + 2], bh[4 * s + 3]);
-                const bf16x8 lo = frag(bl[4 * s], bl[4 * s + 1], bl[4 * s + 2], bl[4 * s + 3]);
+                const f16x8 hi = fragh(bh[4 * s], bh[4 * s + 1], bh[4 * s + 2], bh[4 * s + 3]);
+                const f16x8 lo = fragh(bl[4 * s], bl[4 * s + 1], bl[4 * s + 2], bl[4 * s + 3]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) G0[c] = mfma(hi, bfr[c], G0[c]), G0[c] = mfma(lo, bfr[c], G0[c]);
+                for (int c = 0; c < 4; ++c) G0[c] = mfmah(hi, bfr[c], G0[c]), G0[c] = mfmah(lo, bfr[c], G0[c]);
             }
             split16(px, ah, al);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1010,7 +1036,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1019,21 +1045,20 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
         // address, not selected from registers)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8 hi = frag(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
-            const bf16x8 lo = frag(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
+            const f16x8 hi = fragh(ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]);
+            const f16x8 lo = fragh(al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]);
 #pragma unroll
             for (int c = 0; c < XC; ++c) {
-                bf16x8 bx;
+                f16x8 bx;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int R0 = 32 * xrh + 16 * s + 8 * hf + 4 * (g4 >> 1);
-                    const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(smimg[buf] + (R0 + q) * LDZ + 32 * (xc0 + c) + 16 * (g4 & 1) + 4 * pp));
+                    const f16x4 t = read_tr(smimg[buf] + (R0 + q) * LDZ + 32 * (xc0 + c) + 16 * (g4 & 1) + 4 * pp);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bx[4 * hf + j] = t[j];
                 }
-                G1[c] = mfma(hi, bx, G1[c]);
-                G1[c] = mfma(lo, bx, G1[c]);
+                G1[c] = mfmah(hi, bx, G1[c]);
+                G1[c] = mfmah(lo, bx, G1[c]);
             }
         }
     };
@@ -1077,6 +1102,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = tacc[i];
 #endif
     // the extra pieces: row-half partials summed through LDS (the sm images are dead now), fixed order: row half 0 + row half 1
+    const float dsc = 1.f / (gsc * S1);  // (G holds 2^kg S1 G: exact powers of two)
     float* comb = (float*)&smimg[0][0];  // [4 pieces of row half 1][XC][16 registers][64 lanes] <= 32 KB
     const int cidx = NET::critic ? 2 * (w >> 2) + (w & 1) : (w & 3);  // the same for a piece's two row-half waves
     if (xrh == 1) {
@@ -1090,14 +1116,14 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     for (int c = 0; c < 4; ++c) {
         float* dst = p.partG + ((long)blockIdx.x * KG + 32 * w) * H2 + 32 * c + r;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G0[c][k];
+        for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G0[c][k] * dsc;
     }
     if (xrh == 0) {
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
             float* dst = p.partG + ((long)blockIdx.x * KG + 32 * xt) * H2 + 32 * (xc0 + c) + r;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = G1[c][k] + comb[((cidx * XC + c) * 16 + k) * 64 + lane];
+            for (int k = 0; k < 16; ++k) dst[(long)acc_row(k, h) * H2] = (G1[c][k] + comb[((cidx * XC + c) * 16 + k) * 64 + lane]) * dsc;
         }
     }
 }
@@ -1106,44 +1132,61 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 struct DxArgs {
     NetP net;
     int n_agents, n_sets;
-    const bf16* xf;    // dx_kernel: packed state fragments, bf16 pairs (pack_x_kernel): the [k][row] image of V's B operand
-    const f16x8* xfh;  // dx_kernel: the same as fp16 pairs: the first layer, whose SIGN is the relu mask -- with bf16 pairs (2^-16)
-                       // about 1e-5 of the pre-activations land on the wrong side of zero, and one flipped row moves an entry of
-                       // dW1 / db1 by ~1e-3 of the tensor's max (measured); fp16 pairs put z1 at the f32 level
+    const f16x8* xfh;  // packed state fragments, fp16 pairs (pack_x_kernel): the rows' first-layer input AND (lane half 0: [x_hi | x_lo])
+                       // the [k][row] image of V's B operand. The first layer's SIGN is the relu mask: as bf16 pairs (2^-16) about
+                       // 1e-5 of the pre-activations landed on the wrong side of zero, and one flipped row moves an entry of dW1 / db1
+                       // by ~1e-3 of the tensor's max (r03, measured); fp16 pairs put z1 at the f32 level
     const float* act;  // dxa_kernel: the per-row action input [n_agents][64]
+    int L_cWa, L_cba;  // dxa_kernel: offsets of the critic's action-layer weights / bias inside net.th
     const float* g3;
-    const bf16* sm;
+    const float* part_m;  // [grid][8] max |g3| per wave of the head that wrote g3 (set_gscale)
+    const f16* sm;
     float* partU;      // [grid][2 h][KP][2]   sum dC, sum dC * p1 per feature
     float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only
 };
-// Wave w = state feature tile w (8 tiles), both row halves. Resident: hi and lo of the tile's rows of W2c as B fragments
+// Wave w = state feature tile w (8 tiles), both row halves. Resident: fp16 hi and lo of the tile's rows of SWC W2c as B fragments
 // (reduction over the 128 columns; A = the sm rows, exact). dC comes out [row][feature] (feature on the lane) like the
 // recomputed first layer: the per-feature sums over rows are per-lane sums over the registers, and the masked gradient tile,
-// split, is the A operand of V = (dC * mask)^T . [x_hi | x_lo | 1] -> dW1, db1 (k order permuted as in dw_kernel; the [k][row]
-// image of the inputs is staged once per tile by waves 0 and 1).
+// scaled by vs = 2^kg SWC 2^-5 (|dC_s| <= 128 x 2^13, |g3| 2^kg < 1: below 2^15, cannot overflow) and split into an fp16 pair, is
+// the A operand of V = (dC * mask)^T . [x_hi | x_lo | 1] -> dW1, db1 (k order permuted as in dw_kernel; the [k][row] image of the
+// inputs is staged once per tile by waves 0 and 1). r04: every operand of V an fp16 pair (were bf16 pairs: 2^-17 per row, which in
+// a noise-dominated sum over rows IS the relative error of the result -- 2e-5 on cWa at 4096 x 10).
+//
+// (r04: the critic's 48 action features were tried INSIDE this kernel, as one extra 32 x 32 unit per wave every second tile from
+// the sm image in LDS -- correct, and slower than the two kernels: 409 us against 229 + 91. One barrier per tile makes every tile
+// wait for the four waves that carry a unit, the unit is a serial chain -- LDS reads, 16 dependent MFMAs, ~150 VALU -- that no
+// other wave of the workgroup can overlap, and its 20 persistent registers came back as scratch reloads in the tile loop. They
+// stay in dxa_kernel.)
 template <int S, class NET>
 __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     constexpr int KP = NET::KP, LDZ = 136;  // 272-byte rows: conflict-free b128 row reads
-    __shared__ __attribute__((aligned(16))) bf16 smimg[2][TILE * LDZ];
-    __shared__ __attribute__((aligned(16))) bf16 xt[2][2][32 * 32];  // per buffer, per row half: [k column][row]
+    constexpr float VSH = 1.f / 32.f;
+    __shared__ __attribute__((aligned(16))) f16 smimg[2][TILE * LDZ];
+    __shared__ __attribute__((aligned(16))) f16 xt[2][2][32 * 32];  // per buffer, per row half: [k column][row]
     __shared__ __attribute__((aligned(16))) float g3s[2][TILE];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, ft = w;
+    __shared__ float gred[8];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5, ft = w;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const f32x16 zero16 = {};
+    const float gsc = set_gscale(p.part_m, set, p.n_sets, J, gred);  // 2^kg
     f16x8 wch[8], wcl[8];
     {
         const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) wch[s] = *(const f16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const f16x8*)(p.net.Wclo + at + 16 * s);
     }
-    const float iswc = 1.f / p.net.vec[(long)set * VEC + 2 * H2 + 2];  // (a power of two: the scale of the fp16 W2c operand, folded into |g3|)
+    // Everything behind dC runs in a SCALED domain: d_s = dC_s |g3| 2^kg / 32 = vs d with vs = 2^kg SWC / 32 (SWC: the power of two
+    // on the fp16 W2c operand) -- |dC_s| <= 128 x 2^13 and |g3| 2^kg < 1 give |d_s| < 2^15: the fp16 pair of the masked gradient
+    // cannot overflow -- and the per-feature sums are divided by vs once, at the end (powers of two: exact).
+    const float swc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.net.vec[(long)set * VEC + 2 * H2 + 2])));
+    const float gv = gsc * VSH, vs = gsc * swc * VSH;
     const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1: p1 = S1 z1, U1 rescaled at the end)
     f32x16 V = zero16;
     float U0 = 0.f, U1 = 0.f;
     for (int i = tid; i < 2 * 2 * 32 * 32; i += NT) {  // columns 9.. stay zero, column 8 is the ones column (bias)
         const int k = (i >> 5) & 31;
-        (&xt[0][0][0])[i] = (bf16)(k == 8 ? 1.f : 0.f);
+        (&xt[0][0][0])[i] = (f16)(k == 8 ? 1.f : 0.f);
     }
     const int srow = tid >> 3, sch = tid & 7;
     uint4 d0 = {}, d1 = {};
@@ -1153,28 +1196,25 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         d0 = src[0], d1 = src[1];
         if (tid < TILE) gn = p.g3[(long)agent * TILE + tid];
     };
-    // sm is stored as bf16 +-1 / 0 (0x3f80, 0xbf80, 0: dw_kernel's operand); the SAME values as fp16 are 0x3c00, 0xbc00, 0 = the
-    // upper six bits of each half: one v_and_b32 per pair on the way into LDS
-    auto as_f16 = [](uint4 v) {
-        v.x &= 0xfc00fc00u, v.y &= 0xfc00fc00u, v.z &= 0xfc00fc00u, v.w &= 0xfc00fc00u;
-        return v;
-    };
     auto stage = [&](int buf) {
         uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
-        dst[0] = as_f16(d0), dst[1] = as_f16(d1);
-        if (tid < TILE) g3s[buf][tid] = fabsf(gn) * iswc;
+        dst[0] = d0, dst[1] = d1;
+        if (tid < TILE) g3s[buf][tid] = fabsf(gn) * gv;
     };
-    f16x8 xfn[2] = {};  // the rows' input fragments [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1), both row halves
-    bf16x8 xbn = {};    // waves 0, 1, lane half 0: the bf16 fragment [x_hi | x_lo] of row r of row half w
+    f16x8 xfn0 = {}, xfn1 = {};  // the rows' input fragments [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1), both row halves (two
+                                 // variables, not an array: LLVM merges the two image copies below into one indexed by the wave number
+                                 // and then keeps the array in scratch memory)
     auto fetch_x = [&](int agent) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) xfn[e] = p.xfh[((long)agent * TILE + 32 * e + r) * 2 + h];
-        if (w < 2 && h == 0) xbn = ((const bf16x8*)p.xf)[((long)agent * TILE + 32 * w + r) * 2];
+        xfn0 = p.xfh[((long)agent * TILE + r) * 2 + h];
+        xfn1 = p.xfh[((long)agent * TILE + 32 + r) * 2 + h];
     };
     auto stage_x = [&](int buf) {  // [k][row] image of [x_hi | x_lo]: the h = 0 fragments, transposed (waves 0, 1: one row half each)
         if (w < 2 && h == 0) {
+            f16x8 src = xfn0;
+            if (w == 1) src = xfn1;
+            asm volatile("" : "+v"(src));  // (a register copy selected by the scalar wave number, not a memory index)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xt[buf][w][k * 32 + r] = xbn[k];
+            for (int k = 0; k < 8; ++k) xt[buf][w][k * 32 + r] = src[k];
         }
     };
     __syncthreads();  // the zero / ones fill above before the first stage_x
@@ -1189,27 +1229,28 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     int buf = 0;
     for (int pi = j0; pi < P; pi += J, buf ^= 1) {
         const bool more = pi + J < P;
-        const f16x8 xf[2] = {xfn[0], xfn[1]};
+        const f16x8 xf[2] = {xfn0, xfn1};
         if (more) fetch((pi + J) * p.n_sets + set), fetch_x((pi + J) * p.n_sets + set);
         DXSTAMP(0);
         // The two row halves as a software pipeline: [dC of half 0] [dC of half 1 | BN/ReLU backward + split VALU of half 0]
         // [V of half 0 | VALU of half 1] [V of half 1]. One half after the other, the two waves of a SIMD run their MFMA phases
         // together and their VALU phases together (one barrier per tile) and the pipes never overlap (dw_kernel, measured).
         auto read_a = [&](int e, f16x8 (&smf)[8]) {
-            const bf16* arow = smimg[buf] + (32 * e + r) * LDZ + 8 * h;
+            const f16* arow = smimg[buf] + (32 * e + r) * LDZ + 8 * h;
 #pragma unroll
             for (int s = 0; s < 8; ++s) smf[s] = *(const f16x8*)(arow + 16 * s);
         };
-        auto read_xb = [&](int e, bf16x8 (&xb)[2]) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        auto read_img = [&](const f16* img, f16x8 (&xb)[2]) {  // B operand of V from a [k][row] image
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x4 lo = *(const bf16x4*)(&xt[buf][e][r * 32 + 16 * s + 4 * h]);
-                const bf16x4 hi = *(const bf16x4*)(&xt[buf][e][r * 32 + 16 * s + 8 + 4 * h]);
+                const f16x4 lo = *(const f16x4*)(img + r * 32 + 16 * s + 4 * h);
+                const f16x4 hi = *(const f16x4*)(img + r * 32 + 16 * s + 8 + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
             }
         };
-        auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8]) {
+        auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8], float& A0, float& A1) {
             float u0 = 0.f, u1 = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1224,13 +1265,12 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
                     u1 = fmaf(d, pr, u1);
                     dm[j] = pr > 0.f ? d : 0.f;
                 }
-                split2(dm[0], dm[1], vh[2 * g], vl[2 * g]);
-                split2(dm[2], dm[3], vh[2 * g + 1], vl[2 * g + 1]);
+                split2h(dm[0], dm[1], vh[2 * g], vl[2 * g]);
+                split2h(dm[2], dm[3], vh[2 * g + 1], vl[2 * g + 1]);
             }
-            U0 += u0, U1 += u1;
+            A0 += u0, A1 += u1;
         };
-        f16x8 smf[8];
-        bf16x8 xb0[2], xb1[2];
+        f16x8 smf[8], xb0[2], xb1[2];
         unsigned vh0[8], vl0[8], vh1[8], vl1[8];
         // stage 0: dC of row half 0
         read_a(0, smf);
@@ -1241,12 +1281,12 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: dC of row half 1 | backward VALU of row half 0
         read_a(1, smf);
-        read_xb(0, xb0);
+        read_img(xt[buf][0], xb0);
         f32x16 dc1 = zero16;
 #pragma unroll
         for (int s = 0; s < 8; ++s) dc1 = mfmah(smf[s], wch[s], dc1), dc1 = mfmah(smf[s], wcl[s], dc1);
         const f32x16 p11 = mfmah(xf[1], wf, zero16);
-        backward(0, dc0, p10, vh0, vl0);
+        backward(0, dc0, p10, vh0, vl0, U0, U1);
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
@@ -1256,17 +1296,17 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // stage 2: V of row half 0 | backward VALU of row half 1; then V of row half 1
-        read_xb(1, xb1);
+        read_img(xt[buf][1], xb1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            V = mfma(frag(vh0[4 * s], vh0[4 * s + 1], vh0[4 * s + 2], vh0[4 * s + 3]), xb0[s], V);
-            V = mfma(frag(vl0[4 * s], vl0[4 * s + 1], vl0[4 * s + 2], vl0[4 * s + 3]), xb0[s], V);
+            V = mfmah(fragh(vh0[4 * s], vh0[4 * s + 1], vh0[4 * s + 2], vh0[4 * s + 3]), xb0[s], V);
+            V = mfmah(fragh(vl0[4 * s], vl0[4 * s + 1], vl0[4 * s + 2], vl0[4 * s + 3]), xb0[s], V);
         }
-        backward(1, dc1, p11, vh1, vl1);
+        backward(1, dc1, p11, vh1, vl1, U0, U1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            V = mfma(frag(vh1[4 * s], vh1[4 * s + 1], vh1[4 * s + 2], vh1[4 * s + 3]), xb1[s], V);
-            V = mfma(frag(vl1[4 * s], vl1[4 * s + 1], vl1[4 * s + 2], vl1[4 * s + 3]), xb1[s], V);
+            V = mfmah(fragh(vh1[4 * s], vh1[4 * s + 1], vh1[4 * s + 2], vh1[4 * s + 3]), xb1[s], V);
+            V = mfmah(fragh(vl1[4 * s], vl1[4 * s + 1], vl1[4 * s + 2], vl1[4 * s + 3]), xb1[s], V);
         }
         DXSTAMP(1);
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
@@ -1278,141 +1318,131 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     if (p.stamp && blockIdx.x == 16 && lane == 0)
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = dacc[i];
 #endif
+    const float ivs = 1.f / vs;  // (powers of two: exact)
     float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
-    pu[0] = U0, pu[1] = U1 * (1.f / S1);
+    pu[0] = U0 * ivs, pu[1] = U1 * (ivs / S1);
     if (r < 16) {
         float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft) * 16 + r;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[k];
+        for (int k = 0; k < 16; ++k) pv[(long)acc_row(k, h) * 16] = V[k] * ivs;
     }
 }
 
 // ---- dxa: the critic's ACTION feature tiles (48 features = tiles 8, 9) of dC and their parameter sums ----------------------
-// A quarter of dx_kernel's work per tile. Every wave is on its own: wave w = (rh, ft, par) takes row half rh of feature tile
-// 8 + ft of every second tile (parity par) of the workgroup and reads its 32 sm rows straight from global memory as A
-// fragments, one tile ahead; the two parities and the two row halves are combined once, at the end.
+// A quarter of dx_kernel's matrix work per tile. Every wave is on its own: wave w = (rh, ft, par) takes row half rh of feature tile
+// 8 + ft of every second tile (parity par) of the workgroup and reads its 32 sm rows straight from global memory as A fragments,
+// TWO of its tiles ahead (r03: one -- 23 % of the matrix pipe: a wave's unit takes ~0.5 us, an HBM miss under load twice that).
+// The action layer has ONE input (agent/model.py:68-71), so everything behind dC is f32 VALU work, no second product (r03: a
+// first-layer MFMA, a [k][row] LDS image per wave, four more MFMAs and their operand splits per unit): p1 = relu(a wa + ba) as
+// one fma + max -- the relu mask from an exact f32 pre-activation --, dWa = sum (dC mask) a, dba = sum (dC mask). The two
+// parities and the two row halves are combined once, at the end, in a fixed order.
 template <int S>
 __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     typedef CriticS NET;
     constexpr int KP = NET::KP;
-    __shared__ __attribute__((aligned(16))) bf16 xt[8][2][32 * 32];  // per wave, per buffer: [k column][row of its half]
-    __shared__ float comb[8][64][2 + 16];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, rh = w & 1, ftl = (w >> 1) & 1, par = w >> 2;
+    constexpr float VSH = 1.f / 32.f;
+    __shared__ __attribute__((aligned(16))) float ga[8][2][2][32];  // per wave, per buffer: |g3| gv and a of its 32 rows
+    __shared__ float comb[8][64][4];
+    __shared__ float gred[8];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int rh = w & 1, ftl = (w >> 1) & 1, par = w >> 2;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     const f32x16 zero16 = {};
-    const int ft = 8 + ftl;
+    const int ft = 8 + ftl, f = 32 * ftl + r;  // this lane's action feature (f >= 48: padding, zero weights)
+    const float gsc = set_gscale(p.part_m, set, p.n_sets, J, gred);
     f16x8 wch[8], wcl[8];
     {
         const long at = ((long)set * KP + 32 * ft + r) * H2 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) wch[s] = *(const f16x8*)(p.net.Wchi + at + 16 * s), wcl[s] = *(const f16x8*)(p.net.Wclo + at + 16 * s);
     }
-    const float iswc = 1.f / p.net.vec[(long)set * VEC + 2 * H2 + 2];
-    const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1, like dx_kernel's)
-    f32x16 V = zero16;
-    float U0 = 0.f, U1 = 0.f;
-    for (int i = lane; i < 2 * 32 * 32; i += 64) {  // columns 9.. stay zero, column 8 is the ones column (bias)
-        const int k = (i >> 5) & 31;
-        xt[w][0][i] = (bf16)(k == 8 ? 1.f : 0.f);
-    }
-    __syncthreads();
+    const float swc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.net.vec[(long)set * VEC + 2 * H2 + 2])));
+    const float gv = gsc * VSH, vs = gsc * swc * VSH;  // the scaled domain of dx_kernel (nothing here needs it for range: one scale for both kernels)
+    const float* th = p.net.th + (long)set * p.net.th_stride;
+    const float wa = f < HA ? th[p.L_cWa + f] : 0.f, ba = f < HA ? th[p.L_cba + f] : 0.f;
+    float U0 = 0.f, U1 = 0.f, Sa = 0.f, Sb = 0.f;
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
-    uint4 smn[8];
-    float an = 0.f, gn[16];
-    auto fetch = [&](int k) {
-        const long r0 = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh, ri = r0 + r;
-        const bf16* src = p.sm + ri * H2 + 8 * h;
+    // two register sets of prefetched operands, used alternately (k = par, par + 2, ..: set (k >> 1) & 1)
+    uint4 smA[8], smB[8];
+    float gA = 0.f, aA = 0.f, gB = 0.f, aB = 0.f;
+    auto fetch = [&](int k, uint4 (&sm)[8], float& g, float& a) {
+        const long ri = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh + r;
+        const f16* src = p.sm + ri * H2 + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) smn[s] = *(const uint4*)(src + 16 * s);
-        an = p.act[ri];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *(const float4*)(p.g3 + r0 + 8 * g + 4 * h);
-            gn[4 * g] = v.x, gn[4 * g + 1] = v.y, gn[4 * g + 2] = v.z, gn[4 * g + 3] = v.w;
-        }
+        for (int s = 0; s < 8; ++s) sm[s] = *(const uint4*)(src + 16 * s);
+        g = p.g3[ri], a = p.act[ri];
     };
-    if (par < ntile) fetch(par);
-    int buf = 0;
-    for (int k = par; k < ntile; k += 2, buf ^= 1) {
-        f16x8 smf[8];
-        float gg[16];
+    auto unit = [&](int buf, const uint4 (&sm)[8], float g, float a) {
+        if (h == 0) ga[w][buf][0][r] = fabsf(g) * gv, ga[w][buf][1][r] = a;
+        f32x16 dc = zero16;  // [row][feature]: feature on the lane
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {  // bf16 +-1 / 0 -> the same values as fp16 (dx_kernel)
-            uint4 v = smn[s];
-            v.x &= 0xfc00fc00u, v.y &= 0xfc00fc00u, v.z &= 0xfc00fc00u, v.w &= 0xfc00fc00u;
-            smf[s] = __builtin_bit_cast(f16x8, v);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gg[i] = fabsf(gn[i]) * iswc;
-        const f16x8 xf = make_xh(an, 0.f, 0.f, 0.f, h);
-        bf16 abh, abl;
-        split1(an, abh, abl);
-        if (k + 2 < ntile) fetch(k + 2);
-        if (h == 0) {  // [k][row] image of [a_hi 0 0 0 | a_lo 0 0 0] (bf16 pair) of the wave's 32 rows
-            xt[w][buf][r] = abh;
-            xt[w][buf][4 * 32 + r] = abl;
+        for (int s = 0; s < 8; ++s) {
+            const f16x8 af = __builtin_bit_cast(f16x8, sm[s]);
+            dc = mfmah(af, wch[s], dc), dc = mfmah(af, wcl[s], dc);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        bf16x8 xb[2];
+        float u0 = 0.f, u1 = 0.f, sa = 0.f, sb = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x4 lo = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 4 * h]);
-            const bf16x4 hi = *(const bf16x4*)(&xt[w][buf][r * 32 + 16 * s + 8 + 4 * h]);
+        for (int q = 0; q < 4; ++q) {
+            const float4 gq = *(const float4*)(&ga[w][buf][0][8 * q + 4 * h]), aq = *(const float4*)(&ga[w][buf][1][8 * q + 4 * h]);
+            const float gg[4] = {gq.x, gq.y, gq.z, gq.w}, av[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
-        }
-        f32x16 dc = zero16;  // [row][feature]: feature on the lane
-#pragma unroll
-        for (int s = 0; s < 8; ++s) dc = mfmah(smf[s], wch[s], dc), dc = mfmah(smf[s], wcl[s], dc);
-        const f32x16 p1 = mfmah(xf, wf, zero16);
-        float u0 = 0.f, u1 = 0.f;
-        unsigned vh[8], vl[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            float dm[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = 2 * m + e;
-                const float pr = relu(p1[i]), d = dc[i] * gg[i];
+            for (int j = 0; j < 4; ++j) {
+                const float pr = relu(fmaf(av[j], wa, ba)), d = dc[4 * q + j] * gg[j];
                 u0 += d;
                 u1 = fmaf(d, pr, u1);
-                dm[e] = pr > 0.f ? d : 0.f;
+                const float m = pr > 0.f ? d : 0.f;
+                sa = fmaf(m, av[j], sa);
+                sb += m;
             }
-            split2(dm[0], dm[1], vh[m], vl[m]);
         }
-        U0 += u0, U1 += u1;
+        U0 += u0, U1 += u1, Sa += sa, Sb += sb;
+    };
+    if (par < ntile) fetch(par, smA, gA, aA);
+    if (par + 2 < ntile) fetch(par + 2, smB, gB, aB);
+    for (int k = par; k < ntile; k += 4) {
+        {
+            uint4 sm[8];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            V = mfma(frag(vh[4 * s], vh[4 * s + 1], vh[4 * s + 2], vh[4 * s + 3]), xb[s], V);
-            V = mfma(frag(vl[4 * s], vl[4 * s + 1], vl[4 * s + 2], vl[4 * s + 3]), xb[s], V);
+            for (int s = 0; s < 8; ++s) sm[s] = smA[s];
+            const float g = gA, a = aA;
+            if (k + 4 < ntile) fetch(k + 4, smA, gA, aA);
+            unit(0, sm, g, a);
+        }
+        if (k + 2 < ntile) {
+            uint4 sm[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sm[s] = smB[s];
+            const float g = gB, a = aB;
+            if (k + 6 < ntile) fetch(k + 6, smB, gB, aB);
+            unit(1, sm, g, a);
         }
     }
-    // combine the four (rh, par) waves of a feature tile in a fixed order: wave (rh 0, par 0) of the tile writes
-    U1 *= 1.f / S1;
-    comb[w][lane][0] = U0, comb[w][lane][1] = U1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) comb[w][lane][2 + i] = V[i];
+    // combine: the two lane halves (16 rows each) and the four (rh, par) waves of a feature tile, fixed order; one writer per feature
+    comb[w][lane][0] = U0, comb[w][lane][1] = U1, comb[w][lane][2] = Sa, comb[w][lane][3] = Sb;
     __syncthreads();
-    if (rh == 0 && par == 0) {
-        const int o1 = w + 1, o2 = w + 4, o3 = w + 5;  // (rh 1, par 0), (rh 0, par 1), (rh 1, par 1)
-        U0 = ((U0 + comb[o1][lane][0]) + comb[o2][lane][0]) + comb[o3][lane][0];
-        U1 = ((U1 + comb[o1][lane][1]) + comb[o2][lane][1]) + comb[o3][lane][1];
-        float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
-        pu[0] = U0, pu[1] = U1;
-        if (r < 16) {
-            float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft) * 16 + r;
+    if (rh == 0 && par == 0 && h == 0) {
+        const int ws[4] = {w, w + 1, w + 4, w + 5};  // (rh 0, par 0), (rh 1, par 0), (rh 0, par 1), (rh 1, par 1)
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                pv[(long)acc_row(i, h) * 16] = ((V[i] + comb[o1][lane][2 + i]) + comb[o2][lane][2 + i]) + comb[o3][lane][2 + i];
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] += comb[ws[i]][r][c] + comb[ws[i]][32 + r][c];
+        const float ivs = 1.f / vs;  // (powers of two: exact)
+        float* pu0 = p.partU + (((long)blockIdx.x * 2 + 0) * KP + 32 * ft + r) * 2;
+        float* pu1 = p.partU + (((long)blockIdx.x * 2 + 1) * KP + 32 * ft + r) * 2;
+        pu0[0] = t[0] * ivs, pu0[1] = t[1] * ivs, pu1[0] = 0.f, pu1[1] = 0.f;
+        float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft + r) * 16;  // [feature][16]: 0 = sum (dC mask) a, 4 = its lo part (none), 8 = sum (dC mask)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) pv[c] = c == 0 ? t[2] * ivs : (c == 8 ? t[3] * ivs : 0.f);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Plan {
     int grid, J;
-    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1[4], wf1h[4], vec[4], wap, xfb, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partU[2],
+    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partM[2], partU[2],
         partV[2], partG[2], bad, total;
 };
 static Plan make_plan(int n_agents, int n_sets) {
@@ -1433,17 +1463,18 @@ static Plan make_plan(int n_agents, int n_sets) {
         const int K = (i & 1) ? CriticS::K : ActorS::K, KP = (i & 1) ? CriticS::KP : ActorS::KP;
         pl.Whi[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K), pl.Wlo[i] = take(sizeof(f16) * (size_t)n_sets * H2 * K);
         pl.vec[i] = take(sizeof(float) * (size_t)n_sets * VEC);
-        pl.wf1[i] = take(16 * (size_t)n_sets * NGT_MAX * 64), pl.wf1h[i] = take(16 * (size_t)n_sets * NGT_MAX * 64);
+        pl.wf1h[i] = take(16 * (size_t)n_sets * NGT_MAX * 64);
         if (i < 2) pl.Wchi[i] = take(sizeof(f16) * (size_t)n_sets * KP * H2), pl.Wclo[i] = take(sizeof(f16) * (size_t)n_sets * KP * H2);
     }
     pl.wap = take(4 * (size_t)n_sets * 48);
     const size_t rows = (size_t)n_agents * TILE;
     pl.a2 = take(4 * rows), pl.y = take(4 * rows), pl.mu = take(4 * rows), pl.dmu = take(4 * rows), pl.g3 = take(4 * rows);
-    pl.sm = take(sizeof(bf16) * rows * H2);
-    pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows), pl.xfb = take(32 * rows);
+    pl.sm = take(sizeof(f16) * rows * H2);
+    pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows);
     for (int i = 0; i < 2; ++i) {
         const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
         pl.partH[i] = take(4 * (size_t)pl.grid * 8 * H2);
+        pl.partM[i] = take(4 * (size_t)pl.grid * 8);
         pl.partU[i] = take(4 * (size_t)pl.grid * 2 * KP * 2);
         pl.partV[i] = take(4 * (size_t)pl.grid * KP * 16);
         pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
@@ -1477,11 +1508,11 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     for (int i = 0; i < 4; ++i) {
         const bool critic = i & 1, target = i >= 2;
         pa.Whi[i] = (f16*)(ws + pl.Whi[i]), pa.Wlo[i] = (f16*)(ws + pl.Wlo[i]), pa.vec[i] = (float*)(ws + pl.vec[i]);
-        pa.wf1[i] = (bf16x8*)(ws + pl.wf1[i]), pa.wf1h[i] = (f16x8*)(ws + pl.wf1h[i]);
+        pa.wf1h[i] = (f16x8*)(ws + pl.wf1h[i]);
         pa.Wchi[i] = i < 2 ? (f16*)(ws + pl.Wchi[i]) : nullptr, pa.Wclo[i] = i < 2 ? (f16*)(ws + pl.Wclo[i]) : nullptr;
         NetP& n = net[i];
         n.th = (target ? theta_t : theta) + (critic ? L.actor_size : 0), n.th_stride = L.theta_size;
-        n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1 = pa.wf1[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
+        n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
         n.wap = pa.wap;
     }
     if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int), st) != hipSuccess) return check_launch("avd_learn_set_split_bf16x3: memset");
@@ -1490,20 +1521,19 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
     const long nrows = (long)n_agents * TILE;
     f16x8 *xfs = (f16x8*)(ws + pl.xfs), *xfs2 = (f16x8*)(ws + pl.xfs2);
-    bf16x8* xfb = (bf16x8*)(ws + pl.xfb);
     int* bad = (int*)(ws + pl.bad);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, nrows, xfs, xfb, bad);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, nrows, xfs2, (bf16x8*)nullptr, bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, true, nrows, xfs, bad);
+    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, false, nrows, xfs2, bad);
     const int P = n_agents / n_sets;
     const float inv_n = 1.0f / ((float)P * TILE);
     float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
     float* g3 = (float*)(ws + pl.g3);
-    bf16* sm = (bf16*)(ws + pl.sm);
+    f16* sm = (f16*)(ws + pl.sm);
     auto F = [&](size_t off) { return (float*)(ws + off); };
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
-    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad;
+    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr;
     int head_threads = NT;
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {
@@ -1519,101 +1549,33 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
     dw.stamp = d_stamp;
 #endif
     DxArgs dx;
-    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xf = (const bf16*)xfb, dx.xfh = xfs, dx.stamp = nullptr;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xfh = xfs, dx.stamp = nullptr, dx.L_cWa = dx.L_cba = 0;
 #ifdef AVD_STAMP
     dx.stamp = d_stamp;
 #endif
-    // diagnostics (tools/fsplit_ablate.sh): AVD_FSPLIT_ONLY = dw | dx | head runs only those kernels of the chain (results
-    // are then meaningless, the inputs of the skipped stages are whatever the workspace holds)
-    const char* only = AVD_DIAG_ENV("FSPLIT_ONLY");
-    const bool do_head = !only || !strcmp(only, "head"), do_dw = !only || !strcmp(only, "dw"), do_dx = !only || !strcmp(only, "dx");
-    if (only) {
-        if (do_head) {
-#ifdef AVD_STAMP
-            h.stamp = d_stamp;
-#endif
-            head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
-#ifdef AVD_STAMP
-            {
-                unsigned long long hst[128];
-                (void)hipStreamSynchronize(st);
-                (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
-                static int printed = 0;
-                if (printed++ == 3) {
-                    for (int w_ = 0; w_ < 8; ++w_)
-                        fprintf(stderr, "head OUT_TANH wave %d: unit-start %llu tiles %llu epilogue %llu prologue %llu cycles (20 units)\n", w_, hst[w_ * 8],
-                                hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
-                    for (int g_ = 0; g_ < 2; ++g_) {
-                        fprintf(stderr, "wave %d unit end times:", 4 * g_);
-                        for (int u_ = 0; u_ < 21; ++u_) fprintf(stderr, " %llu", hst[64 + g_ * 28 + u_]);
-                        fprintf(stderr, "\n");
-                    }
-                }
-                h.stamp = nullptr;
-            }
-#endif
-            head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
-            head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
-            head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, a2, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
-        }
-        if (do_dw) {
-            dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]);
-            hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
-#ifdef AVD_STAMP
-            unsigned long long hst[64];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
-            static int printed = 0;
-            if (printed++ == 3)
-                for (int w_ = 0; w_ < 8; ++w_)
-                    fprintf(stderr, "dw wave %d: fetch-issue %llu compute %llu stage %llu barrier %llu cycles over all tiles\n", w_, hst[w_ * 8],
-                            hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
-#endif
-        }
-        if (do_dx) {
-            dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
-            hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
-#ifdef AVD_STAMP
-            unsigned long long hst[64];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hst, d_stamp, sizeof(hst), hipMemcpyDeviceToHost);
-            static int printed = 0;
-            if (printed++ == 3)
-                for (int w_ = 0; w_ < 8; ++w_)
-                    fprintf(stderr, "dx wave %d: fetch-issue %llu compute %llu stage %llu barrier %llu cycles over all tiles\n", w_, hst[w_ * 8],
-                            hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3]);
-#endif
-        }
-        return check_launch("avd_learn_set_split_bf16x3 (diagnostic subset)");
-    }
     // 1-2: targets
     head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
     head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
     // 3: mu
     head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
-    // 4-6 (+ 7): critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH) unless
-    // AVD_FSPLIT_TWO_HEADS is set (diagnostics: the two-launch form)
-    const bool two_heads = AVD_DIAG_ENV("FSPLIT_TWO_HEADS") != nullptr;
-    h.act2 = mu, h.part_s2 = F(pl.partHs[2]);
-    if (two_heads) head(head_kernel<S, CriticS, HEAD_CRITIC>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
-    else {
-        head_threads = 64 * head_waves(HEAD_BOTH);
-        head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
-    }
-    dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]);
+    // 4-7: critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH)
+    h.act2 = mu, h.part_s2 = F(pl.partHs[2]), h.part_m = F(pl.partM[1]);
+    head_threads = 64 * head_waves(HEAD_BOTH);
+    head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+    dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]), dw.part_m = F(pl.partM[1]);
     hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
-    dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a;
+    dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
     hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
+    dx.L_cWa = L.cWa, dx.L_cba = L.cba;
     hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
-    // 7-8: actor loss through the critic, gradient w.r.t. the action
-    if (two_heads) head(head_kernel<S, CriticS, HEAD_CONST>, 1, xfs, mu, nullptr, nullptr, nullptr, nullptr, F(pl.partHs[2]));
-    // 9-11: actor gradients
+    // 8-10: actor gradients
+    h.part_m = F(pl.partM[0]);
     head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
-    dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]);
+    dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]), dw.part_m = F(pl.partM[0]);
     hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
-    dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr;
+    dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]);
     hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
-    // 12: finalize (shared with fset.hip)
+    // 11: finalize (shared with fset.hip)
     FinArgs fa;
     fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.nrh = 1, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
     fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]), fa.bad = bad;
