@@ -216,36 +216,46 @@ struct PrepArgs {
     f16x8* wf1h[4];
     float* vec[4];
     unsigned* wap;
+    unsigned* smax;  // [4 nets][sets][2] maxima of scale_kernel (zeroed with *bad)
     int* bad;
 };
 // SW per (net, set): the power of two that puts max |inv1[f] W2[f][n]| into [2^12, 2^13) -> vec[2 H2 + 1]; online nets also
-// SWC, the same for dx_kernel's operand c3[n] W2[f][n] -> vec[2 H2 + 2]
+// SWC, the same for dx_kernel's operand c3[n] W2[f][n] -> vec[2 H2 + 2]. Two steps: scale_kernel leaves the two maxima per (net,
+// set) in smax (atomicMax on the bits of non-negative floats: order-independent, so deterministic; 16 blocks per matrix, coalesced
+// -- r03's one block per matrix walked 304 rows of 512 bytes with one thread each: 11 us, 33 with the second maximum), every
+// thread of prep_kernel turns them into the powers of two, block n = 0 writes them for the later kernels.
+constexpr int SCALE_SLICES = 16;
+__device__ __forceinline__ float pow2_for(float mx) {  // the power of two that puts mx into [2^12, 2^13)
+    int e = 0;
+    if (mx > 0.f && !not_finite(mx)) (void)frexpf(mx, &e);  // mx = fr * 2^e, fr in [0.5, 1)
+    int k = 13 - e;
+    k = k < -14 ? -14 : (k > 30 ? 30 : k);
+    return ldexpf(1.f, k);
+}
 __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
-    __shared__ float red[256], red2[256];
-    const int net = blockIdx.x, set = blockIdx.y, tid = threadIdx.x;
+    __shared__ float red[256], red2[256], c3a[H2], inva[CriticS::K];
+    const int net = blockIdx.x, set = blockIdx.y, slice = blockIdx.z, tid = threadIdx.x;
     const bool critic = net & 1, target = net >= 2;
     const avd_mlp_layout& L = a.L;
     const float* th = (target ? a.theta_t : a.theta) + (long)set * L.theta_size + (critic ? L.actor_size : 0);
     const float* st = (target ? a.stats_t : a.stats) + (long)set * L.stats_size;
     const int K = critic ? CriticS::K : ActorS::K, oW2 = critic ? L.cW2 : L.aW2;
     const int og2 = critic ? L.cg3 : L.ag2, omv2 = critic ? L.cmv3 : L.amv2, oW3 = critic ? L.cW3 : L.aW3;
-    __shared__ float c3a[H2];  // |c3[n]| = |inv2[n] w3[n]|
-    if (tid < H2) c3a[tid] = fabsf((1.0f / sqrtf(st[omv2 + tid] + BN_EPS)) * th[og2 + tid] * th[oW3 + tid]);
-    __syncthreads();
-    float m = 0.f, m2 = 0.f;
+    if (tid < H2) c3a[tid] = fabsf((1.0f / sqrtf(st[omv2 + tid] + BN_EPS)) * th[og2 + tid] * th[oW3 + tid]);  // |c3[n]| = |inv2[n] w3[n]|
     for (int f = tid; f < K; f += 256) {
         int og, omv, ff = f;
         if (!critic) og = L.ag1, omv = L.amv1;
         else if (f < H1) og = L.cgs, omv = L.cmvs;
         else og = L.cga, omv = L.cmva, ff = f - H1;
-        const float inv = fabsf((1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff]);
-        float wm = 0.f;
-        for (int n = 0; n < H2; ++n) {
-            const float w = fabsf(th[oW2 + (long)f * H2 + n]);
-            wm = fmaxf(wm, w);
-            if (!target) m2 = fmaxf(m2, c3a[n] * w);
-        }
-        m = fmaxf(m, inv * wm);
+        inva[f] = fabsf((1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff]);
+    }
+    __syncthreads();
+    const int total = K * H2, per = (total + SCALE_SLICES - 1) / SCALE_SLICES, lo = slice * per, hi = min(total, lo + per);
+    float m = 0.f, m2 = 0.f;
+    for (int i = lo + tid; i < hi; i += 256) {
+        const float w = fabsf(th[oW2 + i]);
+        m = fmaxf(m, inva[i / H2] * w);
+        m2 = fmaxf(m2, c3a[i % H2] * w);
     }
     red[tid] = m, red2[tid] = m2;
     __syncthreads();
@@ -254,15 +264,9 @@ __global__ __launch_bounds__(256) void scale_kernel(const PrepArgs a) {
         __syncthreads();
     }
     if (tid == 0) {
-        auto pow2_for = [](float mx) {  // the power of two that puts mx into [2^12, 2^13)
-            int e = 0;
-            if (mx > 0.f && !not_finite(mx)) (void)frexpf(mx, &e);  // mx = fr * 2^e, fr in [0.5, 1)
-            int k = 13 - e;
-            k = k < -14 ? -14 : (k > 30 ? 30 : k);
-            return ldexpf(1.f, k);
-        };
-        a.vec[net][(long)set * VEC + 2 * H2 + 1] = pow2_for(red[0]);
-        a.vec[net][(long)set * VEC + 2 * H2 + 2] = pow2_for(red2[0]);
+        unsigned* dst = a.smax + ((long)net * gridDim.y + set) * 2;
+        atomicMax(dst, __float_as_uint(red[0]));  // (non-negative floats order like their bits; a NaN / inf input lands on top and is
+        atomicMax(dst + 1, __float_as_uint(red2[0]));  //  caught by the finiteness tests of prep_kernel)
     }
 }
 // one block per (output column n, net, set), one thread per feature f
@@ -277,6 +281,8 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2, oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
     const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
     const float inv2n = (1.0f / sqrtf(st[omv2 + n] + BN_EPS)) * th[og2 + n], c3n = inv2n * th[oW3 + n];
+    const unsigned* smax = a.smax + ((long)net * gridDim.z + set) * 2;
+    const float SW = pow2_for(__uint_as_float(smax[0])), SWC = pow2_for(__uint_as_float(smax[1]));
     float shw = 0.f;
     if (f < KP) {
         float w = 0.f, inv = 0.f;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             shw = sh * w;
             if (not_finite(w) || not_finite(inv) || not_finite(sh)) atomicOr(a.bad, 1);
             f16 hi, lo;
-            const float ws = a.vec[net][(long)set * VEC + 2 * H2 + 1] * (inv * w);  // in [-2^13, 2^13] unless scale_kernel had to clamp SW
+            const float ws = SW * (inv * w);  // in [-2^13, 2^13] unless pow2_for had to clamp
             if (fabsf(ws) >= F16_OVERFLOW) atomicOr(a.bad, 1);
             split1h(ws, hi, lo);
             const long at = ((long)set * H2 + n) * K + wpos(f);
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
             // dx_kernel's static operand c3[n] W2[f][n]: an fp16 pair too (as a bf16 pair its 2^-17 residual, the same for every
             // batch row, stood at 1e-5 ... 2e-5 of max in the first-layer gradients: r04, tests/test_gpu_configs_full.py)
             f16 hi, lo;
-            const float wc = a.vec[net][(long)set * VEC + 2 * H2 + 2] * (c3n * w);
+            const float wc = SWC * (c3n * w);
             if (fabsf(wc) >= F16_OVERFLOW) atomicOr(a.bad, 1);
             split1h(wc, hi, lo);
             const long at = ((long)set * KP + f) * H2 + n;
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(320) void prep_kernel(const PrepArgs a) {
     }
     float* vec = a.vec[net] + (long)set * VEC;
     if (f == 0) {
+        if (n == 0) vec[2 * H2 + 1] = SW, vec[2 * H2 + 2] = SWC;
         vec[n] = th[ob2 + n] + red[0];
         vec[H2 + n] = c3n;
         if (not_finite(vec[n]) || not_finite(c3n) || not_finite(th[ob3])) atomicOr(a.bad, 1);
@@ -1330,8 +1337,12 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
 
 // ---- dxa: the critic's ACTION feature tiles (48 features = tiles 8, 9) of dC and their parameter sums ----------------------
 // A quarter of dx_kernel's matrix work per tile. Every wave is on its own: wave w = (rh, ft, par) takes row half rh of feature tile
-// 8 + ft of every second tile (parity par) of the workgroup and reads its 32 sm rows straight from global memory as A fragments,
-// TWO of its tiles ahead (r03: one -- 23 % of the matrix pipe: a wave's unit takes ~0.5 us, an HBM miss under load twice that).
+// 8 + ft of every second tile (parity par) of the workgroup and fetches its 32 sm rows (8 KB, contiguous) itself, TWO of its
+// tiles ahead, as eight COALESCED 1-KiB pieces (16 lanes per 256-byte row) that go through a wave-private LDS image (272-byte
+// rows) into the A-fragment layout -- no workgroup barrier anywhere in the loop. (r03 / early r04: the fragments straight from
+// global memory, i.e. one 16-byte piece of 32 different rows per load instruction: 91-93 us whatever the prefetch depth. Also
+// tried in r04: the tiles in pairs through a shared image, one barrier per pair like dx_kernel -- 118 us: with one pair of
+// lookahead every barrier interval pays the HBM latency; and as extra units INSIDE dx_kernel -- 409 us against 229 + 91.)
 // The action layer has ONE input (agent/model.py:68-71), so everything behind dC is f32 VALU work, no second product (r03: a
 // first-layer MFMA, a [k][row] LDS image per wave, four more MFMAs and their operand splits per unit): p1 = relu(a wa + ba) as
 // one fma + max -- the relu mask from an exact f32 pre-activation --, dWa = sum (dC mask) a, dba = sum (dC mask). The two
@@ -1341,6 +1352,8 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     typedef CriticS NET;
     constexpr int KP = NET::KP;
     constexpr float VSH = 1.f / 32.f;
+    constexpr int LDZ = 136;
+    __shared__ __attribute__((aligned(16))) f16 simg[8][32 * LDZ];     // per wave: its unit's 32 sm rows
     __shared__ __attribute__((aligned(16))) float ga[8][2][2][32];  // per wave, per buffer: |g3| gv and a of its 32 rows
     __shared__ float comb[8][64][4];
     __shared__ float gred[8];
@@ -1362,26 +1375,34 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     const float wa = f < HA ? th[p.L_cWa + f] : 0.f, ba = f < HA ? th[p.L_cba + f] : 0.f;
     float U0 = 0.f, U1 = 0.f, Sa = 0.f, Sb = 0.f;
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
-    // two register sets of prefetched operands, used alternately (k = par, par + 2, ..: set (k >> 1) & 1)
-    uint4 smA[8], smB[8];
+    // two register sets of prefetched operands, used alternately (k = par, par + 2, ..). (Plain variables through macros: as arrays
+    // handed to lambdas by reference the two sets ended up in scratch memory and -- promoted by the compiler -- in 64 KB of LDS.)
+    uint4 A0 = {}, A1 = {}, A2 = {}, A3 = {}, A4 = {}, A5 = {}, A6 = {}, A7 = {}, B0 = {}, B1 = {}, B2 = {}, B3 = {}, B4 = {}, B5 = {}, B6 = {}, B7 = {};
     float gA = 0.f, aA = 0.f, gB = 0.f, aB = 0.f;
-    auto fetch = [&](int k, uint4 (&sm)[8], float& g, float& a) {
-        const long ri = (long)((j0 + k * J) * p.n_sets + set) * TILE + 32 * rh + r;
-        const f16* src = p.sm + ri * H2 + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) sm[s] = *(const uint4*)(src + 16 * s);
-        g = p.g3[ri], a = p.act[ri];
-    };
-    auto unit = [&](int buf, const uint4 (&sm)[8], float g, float a) {
-        if (h == 0) ga[w][buf][0][r] = fabsf(g) * gv, ga[w][buf][1][r] = a;
+#define DXA_FETCH(k_, X, g_, a_)                                                                                    \
+    {                                                                                                               \
+        const long r0_ = (long)((j0 + (k_) * J) * p.n_sets + set) * TILE + 32 * rh;                                 \
+        const uint4* src_ = (const uint4*)(p.sm + r0_ * H2) + lane; /* piece i = rows 4 i .. 4 i + 3: lane = 16 (row & 3) + chunk */ \
+        X##0 = src_[0], X##1 = src_[64], X##2 = src_[128], X##3 = src_[192], X##4 = src_[256], X##5 = src_[320], X##6 = src_[384], X##7 = src_[448]; \
+        g_ = p.g3[r0_ + r], a_ = p.act[r0_ + r];                                                                    \
+    }
+#define DXA_PUT(buf_, X, g_, a_)                                                                                    \
+    {                                                                                                               \
+        if (h == 0) ga[w][buf_][0][r] = fabsf(g_) * gv, ga[w][buf_][1][r] = a_;                                     \
+        f16* dst_ = simg[w] + (lane >> 4) * LDZ + 8 * (lane & 15);                                                   \
+        *(uint4*)(dst_) = X##0, *(uint4*)(dst_ + 4 * LDZ) = X##1, *(uint4*)(dst_ + 8 * LDZ) = X##2, *(uint4*)(dst_ + 12 * LDZ) = X##3; \
+        *(uint4*)(dst_ + 16 * LDZ) = X##4, *(uint4*)(dst_ + 20 * LDZ) = X##5, *(uint4*)(dst_ + 24 * LDZ) = X##6, *(uint4*)(dst_ + 28 * LDZ) = X##7; \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                            \
+    }
+    auto unit = [&](int buf) {
         f32x16 dc = zero16;  // [row][feature]: feature on the lane
+        const f16* arow = simg[w] + r * LDZ + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const f16x8 af = __builtin_bit_cast(f16x8, sm[s]);
+            const f16x8 af = *(const f16x8*)(arow + 16 * s);
             dc = mfmah(af, wch[s], dc), dc = mfmah(af, wcl[s], dc);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         float u0 = 0.f, u1 = 0.f, sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1398,27 +1419,23 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
             }
         }
         U0 += u0, U1 += u1, Sa += sa, Sb += sb;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the image is rewritten by this wave's next unit)
+        __builtin_amdgcn_wave_barrier();
     };
-    if (par < ntile) fetch(par, smA, gA, aA);
-    if (par + 2 < ntile) fetch(par + 2, smB, gB, aB);
+    if (par < ntile) DXA_FETCH(par, A, gA, aA);
+    if (par + 2 < ntile) DXA_FETCH(par + 2, B, gB, aB);
     for (int k = par; k < ntile; k += 4) {
-        {
-            uint4 sm[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) sm[s] = smA[s];
-            const float g = gA, a = aA;
-            if (k + 4 < ntile) fetch(k + 4, smA, gA, aA);
-            unit(0, sm, g, a);
-        }
+        DXA_PUT(0, A, gA, aA);  // (the set's registers are free again: its next fetch goes out before the unit's arithmetic)
+        if (k + 4 < ntile) DXA_FETCH(k + 4, A, gA, aA);
+        unit(0);
         if (k + 2 < ntile) {
-            uint4 sm[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) sm[s] = smB[s];
-            const float g = gB, a = aB;
-            if (k + 6 < ntile) fetch(k + 6, smB, gB, aB);
-            unit(1, sm, g, a);
+            DXA_PUT(1, B, gB, aB);
+            if (k + 6 < ntile) DXA_FETCH(k + 6, B, gB, aB);
+            unit(1);
         }
     }
+#undef DXA_FETCH
+#undef DXA_PUT
     // combine: the two lane halves (16 rows each) and the four (rh, par) waves of a feature tile, fixed order; one writer per feature
     comb[w][lane][0] = U0, comb[w][lane][1] = U1, comb[w][lane][2] = Sa, comb[w][lane][3] = Sb;
     __syncthreads();
@@ -1480,7 +1497,7 @@ static Plan make_plan(int n_agents, int n_sets) {
         pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
     }
     for (int i = 0; i < 3; ++i) pl.partHs[i] = take(4 * (size_t)pl.grid * 8 * 2);
-    pl.bad = take(sizeof(int));
+    pl.bad = take(sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2);  // the flag, then scale_kernel's maxima: one memset
     pl.total = o;
     return pl;
 }
@@ -1503,7 +1520,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
                float high, float* grads, float* losses, unsigned char* ws, const Plan& pl, hipStream_t st) {
     PrepArgs pa;
     pa.L = L, pa.S = S, pa.theta = theta, pa.stats = stats, pa.theta_t = theta_t, pa.stats_t = stats_t;
-    pa.wap = (unsigned*)(ws + pl.wap), pa.bad = (int*)(ws + pl.bad);
+    pa.wap = (unsigned*)(ws + pl.wap), pa.bad = (int*)(ws + pl.bad), pa.smax = (unsigned*)(ws + pl.bad + sizeof(int));
     NetP net[4];
     for (int i = 0; i < 4; ++i) {
         const bool critic = i & 1, target = i >= 2;
@@ -1515,8 +1532,9 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
         n.wap = pa.wap;
     }
-    if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int), st) != hipSuccess) return check_launch("avd_learn_set_split_bf16x3: memset");
-    hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets), dim3(256), 0, st, pa);
+    if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
+        return check_launch("avd_learn_set_split_bf16x3: memset");
+    hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets, SCALE_SLICES), dim3(256), 0, st, pa);
     hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
     hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
     const long nrows = (long)n_agents * TILE;
