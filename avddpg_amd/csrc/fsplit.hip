@@ -420,6 +420,9 @@ struct HeadArgs {
 // same weights, so 8 of their 10 first-layer tiles and 192 of their 228 second-layer MFMAs per 32 rows are the SAME work --
 // one pass over the state tiles, then the action tiles twice: branch A (input a: TD seed, masks, T1) from a copy of the
 // accumulators, branch B (input mu: the action gradient through M) in place.
+// (r04, tried: the forward-only modes with 64 rows per wave -- both row halves against every weight fragment pair, six MFMAs per
+// two LDS reads instead of three, 128 accumulator registers: OUT_TANH 190.9 us against 190, OUT_TD 220.8 against 223 on the same
+// box. Halving the LDS bytes per MFMA buys nothing: the heads are not LDS-bound. Not kept.)
 // waves per workgroup (every mode: 8 = two per SIMD at <= 256 registers)
 __host__ __device__ constexpr int head_waves(int mode) { return 8; }
 #ifndef HEAD_FAST
