@@ -1612,6 +1612,30 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
 
 using namespace avd;
 
+// Wave-level v_mfma_f32_32x32x16_f16 instructions (32 768 FLOP each) the chain ISSUES per 64-row tile (one agent's batch), from
+// the kernels' loop structure -- every product of two f32-class operands is three MFMAs on 16-bit pairs (two where one operand is
+// an exact +-1 / 0 mask), first layers ride on the matrix cores too:
+//   head, per 32-row unit: first layer NFT + second layer 3 x 4 column tiles x NKS k-steps
+//     OUT_TANH (actor) 8 + 192 = 200, OUT_TD (critic) 10 + 228 = 238, HEAD_ACTOR 200,
+//     HEAD_BOTH 8 + 192 (state part, once) + (2 + 36) (branch A) + (4 + 36) (branch B1) + 36 (B2: M) = 314
+//   dw, per tile: 8 waves x (2 first-layer + 2 row halves x 2 k-steps x 4 column tiles x 2) + the extra pieces 8 x (1 + 2 x XC x 2)
+//   dx, per tile: 8 waves x (2 x 16 (dC) + 2 (first layer) + 2 x 4 (V));  dxa, per tile: 4 units x 16
+namespace avd { namespace fsplit {
+constexpr long MFMA_PER_TILE = 2 * (200 + 238 + 200 + 314 + 200)      /* five head launches, two 32-row units per tile */
+                               + 8 * (2 + 32 + 1 + 2 * 2 * 2)         /* dw critic */
+                               + 8 * (2 + 32 + 1 + 2 * 1 * 2)         /* dw actor */
+                               + 2 * 8 * (32 + 2 + 8)                 /* dx critic, actor */
+                               + 4 * 16;                              /* dxa */
+static_assert(MFMA_PER_TILE == 3696, "update DESIGN.md 3.1d and the count above together");
+}}
+extern "C" int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int n_sets, unsigned long long* mfma_32x32x16) {
+    int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_mfma_count");
+    if (rc) return rc;
+    AVD_REQUIRE(mfma_32x32x16, "avd_learn_set_split_mfma_count: null pointer");
+    *mfma_32x32x16 = (unsigned long long)fsplit::MFMA_PER_TILE * (unsigned long long)n_agents;
+    return AVD_OK;
+}
+
 extern "C" int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes) {
     int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_workspace");
     if (rc) return rc;

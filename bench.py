@@ -377,6 +377,21 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         for r in roofs:
             r.pop("_t", None)
     roof_learn, roof_upd = roofs[0], (roofs[1] if len(roofs) > 1 else None)
+    split_extra = {}
+    if split3:
+        # executed matrix work: the MFMA instructions the chain issues (from the kernels' loop structure, C ABI) x 32 768 FLOP
+        import ctypes
+        from avddpg_amd import _hip as hip_
+        cnt = ctypes.c_ulonglong(0)
+        hip_.call("avd_learn_set_split_mfma_count", ctypes.byref(vt.agents.lay), n_agents, vt.M, ctypes.byref(cnt))
+        executed = cnt.value * 32768.0
+        ratio = executed / (flop_per_sample * 64 * n_agents)
+        split_extra = {"executed_mfma_32x32x16_per_learn": cnt.value, "executed_over_algorithmic": ratio,
+                       "executed_frac": ratio * dominant["frac"],
+                       "power": "the chain runs at the 1400 W package cap (rocm-smi 1398-1399 W at ~2.16 GHz, in-kernel clock 1.8-1.9 GHz); "
+                                "dense fp16 MFMA holds 2.3 PFLOP/s under that cap with one operand static, 1.30-1.35 PFLOP/s with both "
+                                "operands fresh from LDS on every MFMA, ~1.35 with the heads' VALU + LDS mix in either MFMA shape "
+                                "(profiles/r03_power_*.txt, r04_mfma_shape_probe.txt)"}
     rccl = mode == "interfrl" and world > 1
 
     out = {
@@ -401,12 +416,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                        "A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, gradients and optimiser; 1e-4 of each gradient "
                        "tensor's max against the float64 oracle, the f32 kernels' tolerance (tests/test_gpu_fsplit.py)" if split3 else None),
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
-                    | ({"executed_over_algorithmic": 2.6, "executed_frac": 2.6 * dominant["frac"],
-                        "power": "rocm-smi reads 1398-1399 W of the 1400 W package cap at 2.16 GHz while this chain runs back to back; dense fp16 "
-                                 "MFMA holds 2.32 PFLOP/s under the same cap when one operand changes every 12 MFMAs, and 1.30-1.35 PFLOP/s (bf16 or fp16 alike) when both are fresh "
-                                 "random fragments from LDS on every MFMA, as in a GEMM (1.55 GHz, pipe 85 % busy): the executed rate here is "
-                                 "within 10-15 % of what the package power pays for (profiles/r03_power_and_clocks.txt, "
-                                 "r03_power_of_instruction_mixes.txt, r03_power_gemm_like_probe.txt)"} if split3 else {}),
+                    | (split_extra if split3 else {}),
         "stages_ms": stage_ms,
         "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "

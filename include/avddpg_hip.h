@@ -304,13 +304,19 @@ int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* avd_learn_set_fused_bf16 with f32-class results (csrc/fsplit.hip): same arguments, same workspace protocol, same
- * deterministic reduction, but every matrix-product operand is carried as an exact bf16 pair hi + lo (2^-17 relative) and
- * each product runs as A_hi B_hi + A_lo B_hi + A_hi B_lo on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- two MFMAs where
- * one operand is the exact relu mask: dZ2 = g3[row] c3[n] [z2 > 0] is rank one times a mask (the output layers are one unit
- * wide). The reference computes Trainer.learn in float32 (agent/model.py:26-36, 63-83; workers/trainer.py:472-508): this
- * entry point matches the f32 kernels' tolerance against the float64 oracle (1e-4 of each tensor's max), which the
- * single-rounded bf16 operands of avd_learn_set_fused_bf16 miss by two orders of magnitude on the actor gradients.
- * A non-finite input (weights, BN statistics, s, a, r, s2) gives an all-NaN gradient slab, as it would through f32 kernels. */
+ * deterministic reduction, but every matrix-product operand is carried as an fp16 PAIR hi + lo (|x - hi - lo| <= 2^-22 |x|,
+ * measured worst 2^-23; static operands and row factors scaled by exact powers of two into fp16's range) and each product runs
+ * as A_hi B_hi + A_lo B_hi + A_hi B_lo on v_mfma_f32_32x32x16_f16 with f32 accumulation -- two MFMAs where one operand is the
+ * exact relu mask: dZ2 = g3[row] c3[n] [z2 > 0] is rank one times a mask (the output layers are one unit wide). (The name keeps
+ * r03's "bf16x3"; since r04 no operand is a bf16 pair any more.) The reference computes Trainer.learn in float32
+ * (agent/model.py:26-36, 63-83; workers/trainer.py:472-508): this entry point is tested at 2e-5 of each gradient tensor's max
+ * against the float64 oracle (tests/test_gpu_fsplit.py: measured <= 1.1e-5 at 4096 x 5; the exact-f32 kernels are asserted at
+ * 1e-4), which the single-rounded bf16 operands of avd_learn_set_fused_bf16 miss by three orders of magnitude on the actor
+ * gradients. A non-finite input (weights, BN statistics, s, a, r, s2) or a value that fp16 cannot hold -- a first-layer
+ * activation relu(z1) >= 1023.75, |S1 w1| or |x| >= 65520 -- gives an all-NaN gradient slab (tested), never silently wrong
+ * finite gradients. avd_learn_set_split_mfma_count: the wave-level v_mfma_f32_32x32x16_f16 instructions (32 768 FLOP each) one
+ * call issues, from the kernels' loop structure (bench.py prices the executed matrix work from it). */
+int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int n_sets, unsigned long long* mfma_32x32x16);
 int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
 int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,

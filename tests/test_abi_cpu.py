@@ -41,7 +41,7 @@ def test_shipped_library_reads_no_environment_switch():
         assert not re.search(r"\bgetenv\b", nm.stdout), "the shipped library imports getenv"
     if os.path.exists(_hip.DIAG_LIB_PATH):
         diag = open(_hip.DIAG_LIB_PATH, "rb").read()
-        assert b"AVD_FSPLIT_ONLY" in diag and b"AVD_LEARN_KERNEL" in diag
+        assert b"AVD_FSPLIT_J" in diag and b"AVD_LEARN_KERNEL" in diag
         with _hip.diag_library() as d:
             assert d.avd_diagnostics_enabled() == 1
         assert _hip.lib().avd_diagnostics_enabled() == 0  # (the context manager restored the product library)
