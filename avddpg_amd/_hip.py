@@ -83,6 +83,8 @@ _PROTOS = {
     "avd_learn_set_fused_bf16": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
     "avd_learn_set_split_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],
     "avd_learn_set_split_mfma_count": [_LP, _i, _i, C.POINTER(C.c_ulonglong)],
+    "avd_learn_set_split_critic": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
+    "avd_learn_set_split_actor": [_LP, _i, _i, _P, _P, _P, _f, _P, _P, C.c_size_t, _P],
     "avd_learn_set_split_bf16x3": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
     "avd_actor_forward_shared_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],
     "avd_actor_forward_shared_bf16": [_LP, _i, _i, _P, _P, _P, _f, _P, _P, C.c_size_t, _P],

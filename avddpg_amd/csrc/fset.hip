@@ -798,7 +798,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 // One item per 32 lanes: output column n (items 0..127: output layer, BN2, b2) or first-layer feature f (items 128..):
 // lane jl sums the partials of workgroups jl, jl + 32, .. of the set, then a fixed shuffle tree combines the 32 lanes.
 __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
-    const int set = blockIdx.x, net = blockIdx.y, tid = threadIdx.x, jl = tid & 31;
+    const int set = blockIdx.x, net = a.net_lo + blockIdx.y, tid = threadIdx.x, jl = tid & 31;
     const int item = blockIdx.z * 16 + (tid >> 5);
     const bool critic = net;
     const avd_mlp_layout& L = a.L;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
 }
 // W2 gradients: dW2[f][n] = inv1[f] * G[f][n] + sh1[f] * db2[n] (db2 read back from the slab finalize_small wrote)
 __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
-    const int f = blockIdx.x, set = blockIdx.y, net = blockIdx.z, n = threadIdx.x;
+    const int f = blockIdx.x, set = blockIdx.y, net = a.net_lo + blockIdx.z, n = threadIdx.x;
     const bool critic = net;
     const int K = critic ? Critic::K : Actor::K, KG = critic ? Critic::KG : Actor::KG;
     if (f >= K) return;
@@ -898,9 +898,14 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
 }
 
-void launch_finalize(const FinArgs& fa, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, 2, (H2 + Critic::K + 15) / 16), dim3(512), 0, st, fa);
-    hipLaunchKernelGGL(finalize_w2_kernel, dim3(Critic::K, fa.n_sets, 2), dim3(H2), 0, st, fa);
+// nets [net_lo, net_lo + n_nets): both (default), or one block of the slab (fsplit.hip's two phases). The critic launch also writes
+// the two losses (the actor loss is the mean of q(s, mu): partLa).
+void launch_finalize(const FinArgs& fa0, hipStream_t st, int net_lo, int n_nets) {
+    FinArgs fa = fa0;
+    fa.net_lo = net_lo;
+    const int K = (net_lo + n_nets > 1) ? Critic::K : Actor::K;
+    hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (H2 + K + 15) / 16), dim3(512), 0, st, fa);
+    hipLaunchKernelGGL(finalize_w2_kernel, dim3(K, fa.n_sets, n_nets), dim3(H2), 0, st, fa);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------

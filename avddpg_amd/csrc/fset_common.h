@@ -69,8 +69,9 @@ struct FinArgs {
     float* grads;   // [n_sets][theta_size]
     float* losses;  // [n_sets][2] or NULL
     float inv_n;
+    int net_lo;     // first net of this launch (0 actor, 1 critic): set by launch_finalize
 };
-void launch_finalize(const FinArgs& fa, hipStream_t st);
+void launch_finalize(const FinArgs& fa, hipStream_t st, int net_lo = 0, int n_nets = 2);
 int cu_count();  // CUs of the current device (cached per device ordinal)
 
 // Non-finite test on the bits: these files are built with -fno-honor-nans, under which isnan() / isfinite() fold to constants.

@@ -1517,8 +1517,14 @@ static int check_shape(const avd_mlp_layout* L, int n_agents, int n_sets, const 
     return AVD_OK;
 }
 
+// The chain in two phases over one workspace (avd_learn_set_split_critic / _actor; avd_learn_set_split_bf16x3 = both):
+//   CRITIC: operand preparation, targets, mu, critic loss + gradients + the action gradient d q / d mu, finalize of the critic block
+//   ACTOR : actor gradients from the d mu the critic phase left in the workspace, finalize of the actor block
+// so that a multi-GPU caller can put the critic block's all-reduce on a side stream while the actor phase still runs
+// (avddpg_amd/trainer.py; workers/trainer.py:400-431 averages the two gradient lists independently).
+enum Phase { PH_CRITIC = 1, PH_ACTOR = 2, PH_BOTH = 3 };
 template <int S>
-static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* theta, const float* stats, const float* theta_t,
+static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, const float* theta, const float* stats, const float* theta_t,
                const float* stats_t, const float* s, const float* a, const float* r, const float* s2, const float* aw, float gamma,
                float high, float* grads, float* losses, unsigned char* ws, const Plan& pl, hipStream_t st) {
     PrepArgs pa;
@@ -1535,18 +1541,11 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         n.Whi = pa.Whi[i], n.Wlo = pa.Wlo[i], n.Wchi = pa.Wchi[i], n.Wclo = pa.Wclo[i], n.wf1h = pa.wf1h[i], n.vec = pa.vec[i];
         n.wap = pa.wap;
     }
-    if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
-        return check_launch("avd_learn_set_split_bf16x3: memset");
-    hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets, SCALE_SLICES), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
-    hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
+    const int P = n_agents / n_sets;
+    const float inv_n = 1.0f / ((float)P * TILE);
     const long nrows = (long)n_agents * TILE;
     f16x8 *xfs = (f16x8*)(ws + pl.xfs), *xfs2 = (f16x8*)(ws + pl.xfs2);
     int* bad = (int*)(ws + pl.bad);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, true, nrows, xfs, bad);
-    hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, false, nrows, xfs2, bad);
-    const int P = n_agents / n_sets;
-    const float inv_n = 1.0f / ((float)P * TILE);
     float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
     float* g3 = (float*)(ws + pl.g3);
     f16* sm = (f16*)(ws + pl.sm);
@@ -1574,37 +1573,50 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
 #ifdef AVD_STAMP
     dx.stamp = d_stamp;
 #endif
-    // 1-2: targets
-    head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
-    head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
-    // 3: mu
-    head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
-    // 4-7: critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH)
-    h.act2 = mu, h.part_s2 = F(pl.partHs[2]), h.part_m = F(pl.partM[1]);
-    head_threads = 64 * head_waves(HEAD_BOTH);
-    head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
-    dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]), dw.part_m = F(pl.partM[1]);
-    hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
-    dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
-    hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
-    dx.L_cWa = L.cWa, dx.L_cba = L.cba;
-    hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
-    // 8-10: actor gradients
-    h.part_m = F(pl.partM[0]);
-    head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
-    dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]), dw.part_m = F(pl.partM[0]);
-    hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
-    dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]);
-    hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
-    // 11: finalize (shared with fset.hip)
     FinArgs fa;
     fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.nrh = 1, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
     fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]), fa.bad = bad;
     for (int i = 0; i < 2; ++i)
         fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
-    launch_finalize(fa, st);
-    return check_launch("avd_learn_set_split_bf16x3");
+    if (phases & PH_CRITIC) {
+        if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
+            return check_launch("avd_learn_set_split: memset");
+        hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets, SCALE_SLICES), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
+        hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
+        hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, true, nrows, xfs, bad);
+        hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, false, nrows, xfs2, bad);
+        // 1-2: targets
+        head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
+        head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+        // 3: mu
+        head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+        // 4-7: critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH)
+        h.act2 = mu, h.part_s2 = F(pl.partHs[2]), h.part_m = F(pl.partM[1]);
+        head_threads = 64 * head_waves(HEAD_BOTH);
+        head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+        dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]), dw.part_m = F(pl.partM[1]);
+        hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
+        dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
+        hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
+        dx.L_cWa = L.cWa, dx.L_cba = L.cba;
+        hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
+        // 8: the critic block of the slab (+ both losses: the actor loss is the mean of q(s, mu), summed by HEAD_BOTH)
+        launch_finalize(fa, st, 1, 1);
+    }
+    if (phases & PH_ACTOR) {
+        // 9-11: actor gradients
+        h.act2 = nullptr, h.part_s2 = nullptr, h.part_m = F(pl.partM[0]);
+        head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
+        dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]), dw.part_m = F(pl.partM[0]);
+        hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
+        dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]), dx.L_cWa = dx.L_cba = 0;
+        hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
+        // 12: the actor block of the slab
+        launch_finalize(fa, st, 0, 1);
+    }
+    return check_launch("avd_learn_set_split");
 }
 
 }  // namespace fsplit
@@ -1644,22 +1656,44 @@ extern "C" int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_ag
     return AVD_OK;
 }
 
+static int split_entry(int phases, const char* who, const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                       const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r, const float* s2,
+                       const float* agent_weight, float gamma, float high, float* grads, float* losses, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    int rc = fsplit::check_shape(lay, n_agents, n_sets, who);
+    if (rc) return rc;
+    const bool cr = phases & fsplit::PH_CRITIC;
+    AVD_REQUIRE(theta && stats && s && grads && workspace && (!cr || (theta_t && stats_t && a && r && s2)), "%s: null pointer", who);
+    const fsplit::Plan pl = fsplit::make_plan(n_agents, n_sets);
+    AVD_REQUIRE(workspace_bytes >= pl.total, "%s: workspace %zu B < %zu B", who, workspace_bytes, pl.total);
+    // (padding floats of the slab are never written by finalize: keep them zero like every other gradient producer)
+    if (cr && hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream) != hipSuccess)
+        return check_launch("avd_learn_set_split: hipMemsetAsync(grads)");
+    if (lay->S == 4)
+        return fsplit::run<4>(phases, *lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
+                              losses, (unsigned char*)workspace, pl, (hipStream_t)stream);
+    return fsplit::run<3>(phases, *lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads, losses,
+                          (unsigned char*)workspace, pl, (hipStream_t)stream);
+}
+
 extern "C" int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                           const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
                                           const float* s2, const float* agent_weight, float gamma, float high, float* grads,
                                           float* losses, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_bf16x3");
-    if (rc) return rc;
-    AVD_REQUIRE(theta && stats && theta_t && stats_t && s && a && r && s2 && grads && workspace,
-                "avd_learn_set_split_bf16x3: null pointer");
-    const fsplit::Plan pl = fsplit::make_plan(n_agents, n_sets);
-    AVD_REQUIRE(workspace_bytes >= pl.total, "avd_learn_set_split_bf16x3: workspace %zu B < %zu B", workspace_bytes, pl.total);
-    // (padding floats of the slab are never written by finalize: keep them zero like every other gradient producer)
-    if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n_sets * lay->theta_size, (hipStream_t)stream) != hipSuccess)
-        return check_launch("avd_learn_set_split_bf16x3: hipMemsetAsync(grads)");
-    if (lay->S == 4)
-        return fsplit::run<4>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
-                              losses, (unsigned char*)workspace, pl, (hipStream_t)stream);
-    return fsplit::run<3>(*lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads, losses,
-                          (unsigned char*)workspace, pl, (hipStream_t)stream);
+    return split_entry(fsplit::PH_BOTH, "avd_learn_set_split_bf16x3", lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2,
+                       agent_weight, gamma, high, grads, losses, workspace, workspace_bytes, stream);
+}
+
+extern "C" int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                                          const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                                          const float* s2, const float* agent_weight, float gamma, float high, float* grads,
+                                          float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+    return split_entry(fsplit::PH_CRITIC, "avd_learn_set_split_critic", lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2,
+                       agent_weight, gamma, high, grads, losses, workspace, workspace_bytes, stream);
+}
+
+extern "C" int avd_learn_set_split_actor(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                                         const float* s, float high, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    return split_entry(fsplit::PH_ACTOR, "avd_learn_set_split_actor", lay, n_agents, n_sets, theta, stats, nullptr, nullptr, s, nullptr, nullptr,
+                       nullptr, nullptr, 0.f, high, grads, nullptr, workspace, workspace_bytes, stream);
 }

@@ -65,7 +65,7 @@ def is_valid_step_for_federated_training_with_weights(conf, training_episode, tr
 class VecTrainer:
     def __init__(self, conf, device=None, rng="device", group=None, shared_sets=None, seed=None, auto_reset=False,
                  pipeline_chunks=1, fused_update=False, shared_engine=None, init_seed=None, fused_step=None,
-                 replay_ring=None):
+                 replay_ring=None, overlap_allreduce=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
         sync per step); needs rng='device'.
@@ -160,6 +160,11 @@ class VecTrainer:
         # the per-agent weight-set regime is asserted, i.e. the per_agent engine)
         self.act_mfma = (self.shared and self.shared_engine in ("fused", "fused3")
                          and (lay.H1, lay.H2, lay.A) == (256, 128, 1) and lay.S in (3, 4))
+        self.overlap_allreduce = (group is not None and self.shared and self.shared_engine == "fused3") if overlap_allreduce is None \
+            else bool(overlap_allreduce)
+        if self.overlap_allreduce and not (group is not None and self.shared and self.shared_engine == "fused3"):
+            raise ValueError("overlap_allreduce needs a process group and shared_engine='fused3' (the two-phase learn call)")
+        self._side = None  # side stream + buffers of the overlapped exchange, made on first use
         self._step_parity = 0
         self._added = False
         self.fused_update = bool(fused_update)  # nofrl (any framework / widths the learn kernels serve): avd_learn_update_f32
@@ -336,6 +341,9 @@ class VecTrainer:
             wsum = weights.sum(dim=0)  # [M]
         if self.shared_engine in ("fused", "fused3"):  # agent-major batches as sampled, one factor per agent
             aw = None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous()
+            if self.overlap_allreduce:
+                self._learn_split_overlapped(s, a, r, s2, aw, wsum)
+                return
             self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw,
                                         split=self.shared_engine == "fused3")
         else:
@@ -347,8 +355,48 @@ class VecTrainer:
             from .dist import exchange_fed_sums
             # local (weighted) mean -> local (weighted) sum over platoons, all-reduce, divide by the global count / weight
             self.set_grads.mul_(float(P) if wsum is None else wsum.view(M, 1))
-            total = exchange_fed_sums(self.set_grads, wsum, P, self.group, total=self.total_platoons)
+            total = self._timed("allreduce", exchange_fed_sums, self.set_grads, wsum, P, self.group, total=self.total_platoons)
             self.set_grads.div_(total if wsum is None else wsum.view(M, 1))
+
+    def _learn_split_overlapped(self, s, a, r, s2, aw, wsum):
+        """The split-operand learner in its two phases (avd_learn_set_split_critic / _actor) with the exchange of the critic block
+        overlapped: as soon as the critic phase has written its block of the [M, theta] slab, a side stream turns it into the
+        local sum and all-reduces it while the actor phase -- a third of the learn call -- still computes on the main stream; the
+        actor block (with the [M] weight sums of a weighted mean riding in the same buffer) follows on the main stream, the two
+        streams join, and both blocks are divided by the global platoon count / weight. The same elementwise sums as
+        exchange_fed_sums on the whole slab (workers/trainer.py:400-431 averages the critic and the actor gradient lists
+        independently; src/server/federated.py:47-63)."""
+        import torch.distributed as dist
+
+        P, M = self.P, self.M
+        lay = self.agents.lay
+        A, T = lay.actor_size, lay.theta_size
+        if self._side is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._side = dict(stream=torch.cuda.Stream(device=self.device), ready=torch.cuda.Event(),
+                              crit=torch.empty(M, T - A, **f32), act=torch.empty(M * A + M, **f32))
+        sd = self._side
+        main = torch.cuda.current_stream()
+        scale = float(P) if wsum is None else wsum.view(M, 1)
+        self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw, split=True,
+                                    phase="critic")
+        sd["ready"].record(main)
+        with torch.cuda.stream(sd["stream"]):
+            sd["stream"].wait_event(sd["ready"])
+            torch.mul(self.set_grads[:, A:], scale, out=sd["crit"])  # local (weighted) mean -> local (weighted) sum
+            self._timed("allreduce", dist.all_reduce, sd["crit"], op=dist.ReduceOp.SUM, group=self.group)
+        self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw, split=True,
+                                    phase="actor")
+        act = sd["act"][:M * A].view(M, A)
+        torch.mul(self.set_grads[:, :A], scale, out=act)
+        if wsum is not None:
+            sd["act"][M * A:].copy_(wsum)
+        n = M * A + (M if wsum is not None else 0)
+        self._timed("allreduce", dist.all_reduce, sd["act"][:n], op=dist.ReduceOp.SUM, group=self.group)
+        main.wait_stream(sd["stream"])
+        div = self.total_platoons if wsum is None else sd["act"][M * A:].view(M, 1)
+        self.set_grads[:, A:].copy_(sd["crit"].div_(div))
+        self.set_grads[:, :A].copy_(act.div_(div))
 
     def _update(self, ep, i, fed):
         conf, P, M = self.conf, self.P, self.M

@@ -346,13 +346,16 @@ class AgentGroup:
              self.high, ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
-    def learn_set_fused(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None, split=False):
+    def learn_set_fused(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None, split=False, phase=None):
         """Trainer.learn + federated mean for agents that SHARE this group's ``n_sets`` weight sets, at the reference
         widths, as persistent resident-weight kernels. Batches are AGENT-MAJOR as sampled (agent v = p*n_sets + m uses set
         m): s, s2 [n_agents, B, S], a [n_agents, B(, 1)], r [n_agents, B].
         agent_weight [n_agents] (optional): w_p * P / sum(w) per agent = the weighted federated mean.
         split=False: bf16 GEMM operands (csrc/fset.hip, avd_learn_set_fused_bf16);
-        split=True: every operand an exact bf16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_bf16x3).
+        split=True: every operand an fp16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_bf16x3).
+        phase (split only): None = the whole call; "critic" / "actor" = its two halves over the same workspace
+        (avd_learn_set_split_critic / _actor: the critic block of ``grads`` is final after the first, the actor block after the
+        second; same stream, same ``grads``, nothing else in between -- VecTrainer overlaps the critic block's all-reduce).
         Returns the mean gradient per set [n_sets, theta_size]."""
         import ctypes
         self._check_agent_major(s, a, r, s2, n_agents, agent_weight)
@@ -366,9 +369,17 @@ class AgentGroup:
         if ws is None or ws.numel() < need.value:
             ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
             setattr(self, attr, ws)
-        call(fn, self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(self.theta_t), ptr(self.stats_t),
-             ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma, self.high, ptr(grads), ptr(losses),
-             ptr(ws), ws.numel(), stream_handle())
+        if phase is not None and not split:
+            raise _hip.AvdError("phase= needs split=True (csrc/fsplit.hip)")
+        if phase == "actor":
+            call("avd_learn_set_split_actor", self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(s), self.high,
+                 ptr(grads), ptr(ws), ws.numel(), stream_handle())
+            return grads
+        if phase not in (None, "critic"):
+            raise _hip.AvdError(f"phase={phase!r}")
+        call("avd_learn_set_split_critic" if phase == "critic" else fn, self._layp, n_agents, self.n_sets, ptr(self.theta), ptr(self.stats),
+             ptr(self.theta_t), ptr(self.stats_t), ptr(s), ptr(a), ptr(r), ptr(s2), ptr(agent_weight), self.config.gamma, self.high,
+             ptr(grads), ptr(losses), ptr(ws), ws.numel(), stream_handle())
         return grads
 
     def learn_set_split(self, s, a, r, s2, n_agents, grads=None, losses=None, agent_weight=None):

@@ -254,7 +254,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     vt.reset_episode()
 
     # per-stage / per-kernel HIP events, each recorded on the stream its kernels are launched on
-    names = ("act+env", "replay", "learn", "update", "learn+update")
+    names = ("act+env", "replay", "learn", "update", "learn+update", "allreduce")  # (allreduce: inside "learn"; its own events, on its stream)
 
     def one_step(record):
         vt.timers = ev if record else None
@@ -434,6 +434,12 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     if rccl:
         out["rccl_ranks"] = world if args.backend == "nccl" else 0
         out["collective_backend"] = args.backend
+        out["collective"] = {"per_step_ms": stage_ms["allreduce"], "overlapped": bool(getattr(vt, "overlap_allreduce", False)),
+                             "bytes_per_step": 4 * vt.M * vt.agents.lay.theta_size,
+                             "note": ("two all-reduce(sum) per step: the critic block [M, 41 412] on a side stream under the actor phase of the learn "
+                                      "call, the actor block [M, 35 076] on the main stream; per_step_ms = their summed durations on their own streams "
+                                      "(inside stages_ms.learn only as far as they are not hidden)") if getattr(vt, "overlap_allreduce", False) else
+                                     "one all-reduce(sum) of the [M, theta] slab per step, on the main stream between learn and Adam (inside stages_ms.learn)"}
     del vt
     torch.cuda.empty_cache()
     return out
@@ -523,7 +529,7 @@ def main():
         if len(results) > 1:
             out["also_measured"] = {r["config"]["mode"]: {k: r[k] for k in ("value", "unit", "updates_per_s", "ms_per_step", "dtype",
                                                                           "config", "roofline", "stages_ms", "pipeline")
-                                                          + (("rccl_ranks", "collective_backend") if "rccl_ranks" in r else ())}
+                                                          + (("rccl_ranks", "collective_backend", "collective") if "rccl_ranks" in r else ())}
                                     for r in results[1:]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size, first["config"]["mode"])

@@ -317,6 +317,20 @@ int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets
  * finite gradients. avd_learn_set_split_mfma_count: the wave-level v_mfma_f32_32x32x16_f16 instructions (32 768 FLOP each) one
  * call issues, from the kernels' loop structure (bench.py prices the executed matrix work from it). */
 int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int n_sets, unsigned long long* mfma_32x32x16);
+/* The same call in two phases over ONE workspace, for callers that exchange gradients between processes
+ * (workers/trainer.py:400-431 averages the critic and the actor gradient lists independently, src/server/federated.py:47-63):
+ *   avd_learn_set_split_critic  operand preparation, targets, mu, critic loss and gradients, d q / d mu; writes the CRITIC block
+ *                               of every set of `grads` (zeroes the slab first) and both losses;
+ *   avd_learn_set_split_actor   the actor gradients from what the critic phase left in the workspace; writes the ACTOR block.
+ * critic, then actor, on the same stream with the same workspace and nothing else touching it in between, is bit-identical to
+ * avd_learn_set_split_bf16x3 (tested). Between the two the critic block is final: a multi-GPU caller starts its all-reduce on a
+ * side stream there (avddpg_amd/trainer.py) and only the actor block's exchange stays on the critical path. */
+int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                               const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                               const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int avd_learn_set_split_actor(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                              const float* s, float high, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
 int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,

@@ -64,19 +64,23 @@ def _worker(rank, world, port, P_total, M, n, weighted, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("weighted", [False, True])
-def test_interfrl_exchange_world2_matches_oracle_mean_over_all_platoons(weighted):
-    world, P_total, M, n = 2, 7, 3, 1000  # 7 platoons -> shards of 4 and 3: unequal on purpose
+@pytest.mark.parametrize("weighted,world,P_total,M,n", [(False, 2, 7, 3, 1000), (True, 2, 7, 3, 1000),  # 7 platoons -> shards of 4 and 3: unequal on purpose
+                                                        (False, 8, 32768, 5, 48), (True, 8, 32768, 5, 48)])  # BASELINE configs[3]: 32768 platoons x 5 over 8 ranks
+def test_interfrl_exchange_matches_oracle_mean_over_all_platoons(weighted, world, P_total, M, n):
+    """World 2 (unequal shards) and world 8 with configs[3]'s split -- shard_platoons(32768, 8): 4096 platoons x 5 vehicle indices
+    per rank (VERDICT r03 #4c; `n` columns of the [M, theta] slab stand for all of them: the exchange is elementwise)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, P_total, M, n, weighted, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    if world == 8:
+        assert [adist.shard_platoons(P_total, world, r) for r in range(world)] == [(4096 * r, 4096 * (r + 1)) for r in range(8)]
     rs = np.random.RandomState(0)
     g = rs.normal(size=(P_total, M, n)).astype(np.float32)
     w = rs.uniform(0.5, 6.0, size=(P_total, M)).astype(np.float32)
@@ -88,8 +92,9 @@ def test_interfrl_exchange_world2_matches_oracle_mean_over_all_platoons(weighted
     for rank, count, avg, any1, any0 in res:
         assert count == P_total and any1 is True and any0 is False
         for m in range(M):
-            assert np.allclose(avg[m], ref[m][0], rtol=1e-5, atol=1e-6)
-    assert np.array_equal(res[0][2], res[1][2])  # every rank ends with the identical average (bit-equal weights)
+            assert np.allclose(avg[m], ref[m][0], rtol=1e-5, atol=(1e-6 if world == 2 else 2e-5))  # (f32 sums of 32768 terms)
+    for other in res[1:]:
+        assert np.array_equal(res[0][2], other[2])  # every rank ends with the identical average (bit-equal weights)
 
 
 class _Sets:

@@ -5,9 +5,10 @@ workers/trainer.py:472-508), so the bar is float32's own, enforced here rather t
 
   SPLIT_TOL = 2e-5 of each gradient tensor's max against the float64 oracle (or 4 x the float32 ORACLE's own error on the same
   batch where that is larger) -- 5 x tighter than the 1e-4 the exact-f32 kernels are held to (tests/test_gpu_mlp.py GRAD_TOL).
-  Measured (tools/r04_precision_probe.py, profiles/r04_precision_probe.txt): <= 5.6e-6 at 64 ... 4480 rows per set, <= 1.1e-5
-  per tensor at 4096 x 5 (262 144 rows per set), where the exact-f32 per-agent engine + fed_mean sits at <= 1.5e-5 and the
-  float32 NumPy oracle at <= 1.8e-4.
+  Measured (tools/r04_precision_probe.py, profiles/r04_precision_probe.txt): <= 5e-7 at 64 ... 4480 rows per set (asserted at
+  SPLIT_TOL_SMALL = 4e-6; the float32 NumPy oracle sits at 1e-6 there, r03's bf16 pairs sat at 5.6e-6), <= 1.1e-5 per tensor at
+  4096 x 5 (262 144 rows per set; one relu-tie row is worth ~1e-5 there), where the exact-f32 per-agent engine + fed_mean sits at
+  <= 1.5e-5 and the float32 NumPy oracle at <= 1.8e-4.
 
 Covered: conditioned inputs (no relu ties) AND unconditioned inputs with every out-of-tolerance tensor traced to a tie row;
 the exact-f32 per-agent kernel + fed_mean; bit-identical reruns; fp16 overflow and non-finite inputs -> NaN; at 4096 x 5 the
@@ -25,6 +26,7 @@ from tests.test_gpu_mlp import GRAD_TOL, _nets, _perturbed_group, _relerr
 pytestmark = pytest.mark.gpu
 
 SPLIT_TOL = 2e-5
+SPLIT_TOL_SMALL = 4e-6  # conditioned inputs, <= 4480 rows per set
 
 
 def _tie_mask(grp, M, S, s, a, tie=1e-6):
@@ -115,7 +117,7 @@ def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     assert torch.isfinite(g).all()
     errs, worst = _errors_vs_oracle(grp, g, s, a, r, s2, P, M, range(M), losses=losses)
     assert not errs, errs
-    assert worst <= SPLIT_TOL, worst  # (at these sizes the float32-oracle clause is not even needed)
+    assert worst <= SPLIT_TOL_SMALL, worst  # (at these sizes the float32-oracle clause is not needed: fp16 pairs measure 3e-7 ... 5e-7)
 
 
 @pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
