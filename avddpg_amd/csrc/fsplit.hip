@@ -1638,7 +1638,7 @@ constexpr long MFMA_PER_TILE = 2 * (200 + 238 + 200 + 314 + 200)      /* five he
                                + 8 * (2 + 32 + 1 + 2 * 1 * 2)         /* dw actor */
                                + 2 * 8 * (32 + 2 + 8)                 /* dx critic, actor */
                                + 4 * 16;                              /* dxa */
-static_assert(MFMA_PER_TILE == 3696, "update DESIGN.md 3.1d and the count above together");
+static_assert(MFMA_PER_TILE == 3696, "update DESIGN.md 3.4 and the count above together");
 }}
 extern "C" int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int n_sets, unsigned long long* mfma_32x32x16) {
     int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_mfma_count");
