@@ -4,26 +4,30 @@
 // reference widths 256 / 128 / 48 (src/config.py:112-117) -- but with f32-class results: the reference computes in float32
 // (agent/model.py:26-36, 63-83) and single-rounded bf16 operands miss it by 1.7e-2 on the actor gradients (fset.hip).
 //
-// Every matrix product runs on v_mfma_f32_32x32x16_bf16 with BOTH operands carried as exact bf16 pairs x = hi + lo
-// (hi = bf16(x), lo = bf16(x - hi): 2^-17 relative per operand), accumulated in f32:
-//     A . B  ~=  A_hi . B_hi + A_lo . B_hi + A_hi . B_lo          (the dropped lo . lo term is 2^-18 of the product)
+// Every matrix product runs on v_mfma_f32_32x32x16_f16 with BOTH operands carried as fp16 PAIRS x = hi + lo
+// (hi = rn16(x), lo = rn16(x - hi): |x - hi - lo| <= 2^-22 |x|, measured worst 2^-23; since r04 no operand is a bf16 pair --
+// 2^-17 -- any more), accumulated in f32:
+//     A . B  ~=  A_hi . B_hi + A_lo . B_hi + A_hi . B_lo          (the dropped lo . lo term is below the pairs' own residual)
+// fp16's 5-bit exponent is handled by exact power-of-two scales folded into f32 constants (SW, SWC per set and net on the static
+// second-layer operands; S1 = 64 on the first layers; 2^kg per set on the row factor |g3|, from the maximum the backward heads
+// leave: set_gscale), and every conversion that could overflow is watched: *bad -> finalize writes NaN (see F16_OVERFLOW).
 // Three structural facts keep this from costing 3x fset.hip:
 //   * the output layers are one unit wide, so the second-layer gradient is rank one times a mask:
 //         dZ2[row][n] = g3[row] * c3[n] * [z2[row][n] > 0]
-//     The mask (with the sign of g3) is EXACT in bf16: it is what the heads write (as bf16 +-1 / 0, "sm"), c3[n] is folded
+//     The mask (with the sign of g3) is EXACT in fp16: it is what the heads write (as fp16 +-1 / 0, "sm"), c3[n] is folded
 //     into the other operand (dx: W2c[f][n] = c3[n] W2[f][n], split once per call) or applied at the end (dw: finalize), and
 //     |g3[row]| is folded into the first-layer input (dw: relu(W1 (|g| x) + |g| b1) = |g| P1, one MFMA with split operands
 //     like every first layer here) or multiplied onto the f32 result (dx). dw and dx then need TWO MFMAs per product, and the
 //     heads split nothing on their way out.
 //   * second-layer weights are split once per call (prep) and stay in LDS (heads: hi + lo images, 135 / 160 KB, stored in the
 //     k order in which a first-layer accumulator tile IS the next MFMA's B operand: no cross-lane exchange of activations)
-//     or in registers (dx); only the activations are split on the fly (4 VALU per element, in the shadow of the MFMAs).
+//     or in registers (dx); only the activations are split on the fly (4 VALU per pair, in the shadow of the MFMAs).
 //   * the action gradient of the actor loss needs no dZ2 at all: dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row] with
 //     M = W2T[:, action features] . (mask_a * wa), a second product over the action k-steps with the weight fragments the
 //     forward pass has just read.
 // Kernel chain, workspace, partial-sum layouts and the deterministic two-stage reduction are fset.hip's (finalize_* are
-// shared, fset_common.h). Tested against the float64 oracle at the f32 kernels' tolerance (1e-4 of each tensor's max,
-// tests/test_gpu_fsplit.py) -- not the 2 % the bf16 learners are allowed.
+// shared, fset_common.h). Tested against the float64 oracle at 2e-5 of each tensor's max (tests/test_gpu_fsplit.py,
+// test_gpu_configs_full.py: 5 x tighter than the exact-f32 kernels' 1e-4) -- not the 2 % the bf16 learners are allowed.
 #include <type_traits>
 
 #include "fset_common.h"
@@ -50,25 +54,6 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
     }
-}
-
-// ---- exact bf16 pairs -------------------------------------------------------------------------------------------------
-// (a, b) -> packed hi pair and packed lo pair: 2 x (float(hi) by shift / mask, subtract) + 2 conversions
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const f32x2 f = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
-    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-    const f32x2 l = {a - ha, b - hb};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
-}
-__device__ __forceinline__ void split1(float x, bf16& hi, bf16& lo) {
-    hi = (bf16)x;
-    lo = (bf16)(x - (float)hi);
-}
-__device__ __forceinline__ bf16x8 frag(unsigned a, unsigned b, unsigned c, unsigned d) {
-    uint4 o;
-    o.x = a, o.y = b, o.z = c, o.w = d;
-    return __builtin_bit_cast(bf16x8, o);
 }
 
 // fp16 pairs (heads): 11 + 11 significant bits, |x - hi - lo| <= 2^-24 |x| -- an f32 value almost exactly. The heads need

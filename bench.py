@@ -55,8 +55,8 @@ def parse():
     ap.add_argument("--engine", choices=["per_agent", "batched", "fused", "fused3"], default=None,
                     help="interfrl: per_agent = f32 LDS-resident learn kernel per agent + federated sum; batched = one "
                          "bf16 MFMA GEMM chain per weight set over all its rows (default where per_agent does not exist); "
-                         "fused = persistent set learner, bf16 operands (fset.hip); fused3 = the same with every operand an exact "
-                         "bf16 hi+lo pair, f32-class results (fsplit.hip)")
+                         "fused = persistent set learner, bf16 operands (fset.hip); fused3 = the same with every operand an "
+                         "fp16 hi+lo pair, f32-class results (fsplit.hip)")
     ap.add_argument("--hidden", type=int, default=None,
                     help="actor/critic layer1 = layer2 size (BASELINE config 5: 1024; needs --mode interfrl)")
     ap.add_argument("--framework", choices=["decentralized", "centralized"], default="decentralized",
@@ -330,7 +330,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
             flops = flop_per_sample * 64 * n_agents
         roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x5, dw x2, dx x2, dxa persistent kernels + scale, prep, "
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
-                                 "matrix work is ~2.6x the algorithmic FLOPs priced here)" if split3 else
+                                 "matrix work is 2.5x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
                                  ("avd_learn_shared_bf16 (wide.hip, hidden >= 512: fwd_gen x4, fwd_delta, out_bwd x2, dw_gen x2, dx_gen x2 + "
                                   "row / table kernels; FLOPs priced = the chain's algorithmic GEMMs, forward x5 incl. the pass the delta kernel "
@@ -345,29 +345,32 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         if mode == "nofrl":
             roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
-    # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # runs of this same command, gfx950 FETCH_SIZE correction calibrated on known byte counts: tools/pmc_summary.py)
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if stage_ms["learn+update"] > 0 else "pmc_traffic_unfused.json")
-    if os.path.exists(pmc_path) and P == 4096 and L == 5 and mode == "nofrl" and args.chunks == 1 and args.framework == "decentralized":
-        pmc = json.load(open(pmc_path))["kernels"]
-        want = {fused_name: (lk,) if lk == "learn_kernel_l" else (lk, "adam_polyak_ranges"), lk: (lk,),
-                "adam_polyak_kernel": ("adam_polyak_kernel",)}
-        for r in roofs:
-            per_unit = [next((v["hbm_bytes_per_unit"] for k, v in pmc.items() if s in k), None) for s in want[r["kernel"]]]
-            if all(per_unit):
-                r["traffic"] = sum(per_unit) * n_agents
-                r["traffic_note"] = ("HBM-side bytes per step of these kernels, PMC FETCH_SIZE(corrected)+WRITE_SIZE, profiles/"
-                                     + os.path.basename(pmc_path))
-    # the split set learner's chain: HBM-side bytes per learn from the committed PMC passes of `bench.py --mode interfrl`
-    pmc_split = os.path.join(ROOT, "profiles", "pmc_traffic_interfrl_split.json")
-    if split3 and os.path.exists(pmc_split) and P == 4096 and L == 5:
-        pk = json.load(open(pmc_split))["kernels"]
-        per_step = next((v["launches"] for k, v in pk.items() if "dw_kernel" in k and "CriticS" in k), 0)
-        if per_step:
-            chain = [v for k, v in pk.items() if "fsplit" in k or "finalize" in k]
-            roofs[0]["traffic"] = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in chain) / per_step
-            roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE(x2: gfx950 correction)+WRITE_SIZE, "
-                                        "profiles/pmc_traffic_interfrl_split.json (matrix-core bound: reported, not the binding roof)")
+    # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    # tools/pmc_workload.py -- the same trainer step at 4096 x 5 --, both counters calibrated on a 1 GiB elementwise kernel of the
+    # same pass: tools/pmc_traffic.py; measured factors 2.000 / 1.000)
+    def pmc(name):
+        path = os.path.join(ROOT, "profiles", name)
+        return json.load(open(path)) if os.path.exists(path) else None
+
+    if P == 4096 and L == 5 and args.framework == "decentralized" and not args.hidden and args.chunks == 1:
+        if fused and mode == "nofrl" and pmc("r04_pmc_traffic_nofrl.json"):
+            d = pmc("r04_pmc_traffic_nofrl.json")
+            k = next((v for n, v in d["kernels"].items() if "learn_kernel_l" in n), None)
+            if k:
+                for r in roofs:
+                    r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                    r["traffic_note"] = ("HBM-side bytes per launch of learn_kernel_l<fused>, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (factors "
+                                         "calibrated on a 1 GiB elementwise kernel in the same pass), profiles/r04_pmc_traffic_nofrl.json"
+                                         % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
+        if split3 and pmc("r04_pmc_traffic_interfrl.json"):
+            d = pmc("r04_pmc_traffic_interfrl.json")
+            chain = {n: v for n, v in d["kernels"].items() if "fsplit" in n or "finalize" in n}
+            per_learn = next((v["launches"] for n, v in chain.items() if "dxa_kernel" in n), 0)
+            if per_learn:
+                roofs[0]["traffic"] = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in chain.values()) / per_learn
+                roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated in "
+                                            "the same pass), profiles/r04_pmc_traffic_interfrl.json (matrix-core bound: reported, not the binding roof)"
+                                            % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
     for r in roofs:
         r["frac"] = r["achieved"] / r["peak"]
     if fused:
@@ -399,7 +402,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         "unit": "env-steps/s",
         "updates_per_s": updates_per_s,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "dtype": ("f32-class (fp16/bf16 hi+lo operand pairs on the 16-bit matrix cores, f32 accumulate)" if split3 else
+        "dtype": ("f32-class (fp16 hi+lo operand pairs on the 16-bit matrix cores, f32 accumulate)" if split3 else
                   "bf16 (GEMM operands; f32 accumulation, parameters and optimiser)" if batched else "f32"),
         "config": {"workload": f"{P} platoons x {L} vehicles per GPU, DDPG "
                                + ("centralized " if args.framework == "centralized" else "")
@@ -411,10 +414,12 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                    "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": mode,
                    "parallelism": f"platoon shards x{world}" + (f" + one {args.backend} all-reduce(sum) of the [M, theta] gradient slab per step"
                                                                 if rccl else " (no data-path collective)")},
-        "dtype_note": ("every matrix-product operand an exact 16-bit pair hi+lo (fp16 pairs, residual 2^-24, in the forward passes and "
-                       "for every relu mask; bf16 pairs, 2^-18, times exact +-1/0 masks in the weight / input-gradient products), "
-                       "A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, gradients and optimiser; 1e-4 of each gradient "
-                       "tensor's max against the float64 oracle, the f32 kernels' tolerance (tests/test_gpu_fsplit.py)" if split3 else None),
+        "dtype_note": ("every matrix-product operand an fp16 pair hi+lo (hi = rn16(x), lo = rn16(x - hi): worst-case residual 2^-22 |x|, "
+                       "measured worst 2^-23; r03's bf16 pairs -- 2^-17 worst -- are gone), scaled by exact powers of two into fp16's range, "
+                       "times exact +-1/0 relu masks where the algebra has them; A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, "
+                       "gradients and optimiser. Enforced by the GPU tests at 2e-5 of each gradient tensor's max against the float64 oracle "
+                       "(4e-6 at <= 4480 rows; the exact-f32 kernels: 1e-4), incl. two whole sets at 4096 x 5, and by a 2036-update reward-curve "
+                       "test against the float32 noise floor (tests/test_gpu_fsplit.py, tests/test_gpu_configs_full.py)" if split3 else None),
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
                     | (split_extra if split3 else {}),
         "stages_ms": stage_ms,

@@ -8,7 +8,6 @@ python bench.py --framework centralized --no-cpu-baseline --steps 300 --warmup 3
 python bench.py --mode interfrl --hidden 1024 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${T}_bench_config5_hidden1024.json 2>>$OUT/err.txt
 python bench.py --mode interfrl --engine per_agent --no-cpu-baseline --steps 300 --warmup 30 > $OUT/${T}_bench_interfrl_per_agent.json 2>>$OUT/err.txt
 python bench.py --gpus 2 --backend gloo --single-device --platoons 256 --buffer-size 4096 --steps 50 --warmup 10 --no-cpu-baseline --mode interfrl > $OUT/${T}_bench_2ranks_one_gpu_gloo.json 2>>$OUT/err.txt
-bash tools/ab_lib.sh "" 2 400 > $OUT/${T}_fsplit_same_box_ab_vs_r04_precision_build.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline"
 for m in interfrl nofrl; do

@@ -23,7 +23,7 @@ def per_kernel(path, counter):
 
 def calib(agg):
     """the copy kernel: the launches whose counted bytes are the largest non-avd ones (three identical 1 GiB copies)"""
-    cands = {k: v for k, v in agg.items() if "avd::" not in k and "elementwise" in k.lower() and v[1] >= 3}
+    cands = {k: v for k, v in agg.items() if "avd::" not in k and "elementwise" in k.lower() and v[1] == 3}  # launched exactly three times
     if not cands:
         return None, None
     k = max(cands, key=lambda k: cands[k][0] / cands[k][1])

@@ -17,7 +17,7 @@ GIB = 1 << 30
 src = torch.empty(GIB // 4, dtype=torch.float32, device="cuda").normal_()
 dst = torch.empty_like(src)
 for _ in range(3):
-    dst.copy_(src)  # one elementwise copy kernel: reads 1 GiB, writes 1 GiB
+    torch.add(src, 1.0, out=dst)  # ONE vectorized elementwise kernel: reads 1 GiB, writes 1 GiB (a plain copy_ would be a DMA, not a kernel)
 torch.cuda.synchronize()
 del src, dst
 conf = config.Config(num_platoons=4096, pl_size=5, buffer_size=2048, fed_method="interfrl" if mode == "interfrl" else "normal",
