@@ -799,7 +799,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 // lane jl sums the partials of workgroups jl, jl + 32, .. of the set, then a fixed shuffle tree combines the 32 lanes.
 __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
     const int set = blockIdx.x, net = a.net_lo + blockIdx.y, tid = threadIdx.x, jl = tid & 31;
-    const int item = blockIdx.z * 16 + (tid >> 5);
+    const int item = a.item_base + blockIdx.z * 16 + (tid >> 5);
     const bool critic = net;
     const avd_mlp_layout& L = a.L;
     const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
@@ -847,13 +847,15 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
     float U0 = 0.f, U1 = 0.f, V[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = 0.f;
+    const bool have_u = a.partU[net] != nullptr;
     for (int j = jl; j < a.J; j += 32) {
         const long wg = (long)j * a.n_sets + set;
         for (int rh = 0; rh < a.nrh; ++rh) {
-            for (int h = 0; h < 2; ++h) {
-                const float* pu = a.partU[net] + ((((wg * a.nrh + rh) * 2 + h) * KP) + f) * 2;
-                U0 += pu[0], U1 += pu[1];
-            }
+            if (have_u)
+                for (int h = 0; h < 2; ++h) {
+                    const float* pu = a.partU[net] + ((((wg * a.nrh + rh) * 2 + h) * KP) + f) * 2;
+                    U0 += pu[0], U1 += pu[1];
+                }
             const float* pv = a.partV[net] + ((wg * a.nrh + rh) * KP + f) * 16;
 #pragma unroll
             for (int k = 0; k < 9; ++k) V[k] += pv[k];
@@ -862,6 +864,22 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
     U0 = allsum(U0), U1 = allsum(U1);
 #pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = allsum(V[k]);
+    if (!have_u) {
+        // fsplit.hip (r04): the two unmasked per-feature sums are linear images of sums that exist anyway --
+        //   U0 = sum_rows dC[row][f]          = sum_n W2[f][n] db2[n]                    (db2: written by the launch before this one)
+        //   U1 = sum_rows dC[row][f] relu(z1) = sum_k W1[k][f] V[k] + b1[f] V[8]         (relu(z1) = mask (x . W1 + b1); V = sum (dC mask) [x | 1])
+        // so dx_kernel / dxa_kernel spend nothing on them. 32 lanes share the 128-term dot, fixed shuffle tree.
+        const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
+        float u0 = 0.f;
+        for (int n = jl; n < H2; n += 32) u0 = fmaf(th[oW2 + (long)f * H2 + n], g[ob2 + n], u0);
+        U0 = allsum(u0);
+        int oW, ob, ff = f, ld = H1, sin = a.S;
+        if (!critic) oW = L.aW1, ob = L.ab1;
+        else if (f < H1) oW = L.cWs, ob = L.cbs;
+        else oW = L.cWa, ob = L.cba, ff = f - H1, ld = HA, sin = 1;
+        U1 = th[ob + ff] * V[8];
+        for (int k = 0; k < sin; ++k) U1 = fmaf(th[oW + k * ld + ff], V[k] + V[4 + k], U1);
+    }
     if (a.bad && *a.bad) U0 = U1 = V[0] = V[4] = V[8] = __uint_as_float(0x7fc00000u);
     if (jl == 0) {
         int og, obe, omm, omv, oW, ob, ff = f, ld = H1, sin = a.S;
@@ -890,8 +908,20 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     else if (f < H1) og = L.cgs, obe = L.cbes, omm = L.cmms, omv = L.cmvs;
     else og = L.cga, obe = L.cbea, omm = L.cmma, omv = L.cmva, ff = f - H1;
     const float inv1 = (1.0f / sqrtf(st[omv + ff] + BN_EPS)) * th[og + ff], sh1 = th[obe + ff] - st[omm + ff] * inv1;
+    // (the J partials are added in index order -- the bits of the result are a function of the plan -- but their loads are
+    //  independent: eight in flight instead of a chain of J dependent round trips to L2 / HBM: 27 -> ~12 us per launch)
     float G = 0.f;
-    for (int j = 0; j < a.J; ++j) G += a.partG[net][(((long)j * a.n_sets + set) * KG + f) * H2 + n];
+    const float* pg = a.partG[net] + ((long)set * KG + f) * H2 + n;
+    const long stride = (long)a.n_sets * KG * H2;
+    int j = 0;
+    for (; j + 8 <= a.J; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pg[(j + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) G += v[u];
+    }
+    for (; j < a.J; ++j) G += pg[j * stride];
     if (a.c3[net]) G *= a.c3[net][(long)set * VEC + H2 + n];
     if (a.bad && *a.bad) G = __uint_as_float(0x7fc00000u);
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
@@ -902,9 +932,15 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
 // the two losses (the actor loss is the mean of q(s, mu): partLa).
 void launch_finalize(const FinArgs& fa0, hipStream_t st, int net_lo, int n_nets) {
     FinArgs fa = fa0;
-    fa.net_lo = net_lo;
+    fa.net_lo = net_lo, fa.item_base = 0;
     const int K = (net_lo + n_nets > 1) ? Critic::K : Actor::K;
-    hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (H2 + K + 15) / 16), dim3(512), 0, st, fa);
+    if (fa.partU[net_lo]) {
+        hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (H2 + K + 15) / 16), dim3(512), 0, st, fa);
+    } else {  // the feature items read the db2 the column items write: two launches
+        hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, H2 / 16), dim3(512), 0, st, fa);
+        fa.item_base = H2;
+        hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (K + 15) / 16), dim3(512), 0, st, fa);
+    }
     hipLaunchKernelGGL(finalize_w2_kernel, dim3(K, fa.n_sets, n_nets), dim3(H2), 0, st, fa);
 }
 

@@ -60,7 +60,7 @@ struct FinArgs {
     const float* partH[2];   // [0] actor (pass 9), [1] critic (pass 4)
     const float* partHs[2];
     const float* partLa;     // pass 7's part_s (actor loss sums)
-    const float* partU[2];
+    const float* partU[2];   // NULL (fsplit.hip since r04): d beta1 / d gamma1 are derived from partV, db2 and the weights (finalize_small_kernel)
     const float* partV[2];
     const float* partG[2];
     const float* c3[2];      // fsplit.hip: [n_sets][VEC] vectors whose [H2 + n] entry scales column n of partG (dZ2 = g3 c3[n] mask
@@ -70,6 +70,7 @@ struct FinArgs {
     float* losses;  // [n_sets][2] or NULL
     float inv_n;
     int net_lo;     // first net of this launch (0 actor, 1 critic): set by launch_finalize
+    int item_base;  // first item of this launch of finalize_small_kernel (items < H2: output columns; >= H2: first-layer features)
 };
 void launch_finalize(const FinArgs& fa, hipStream_t st, int net_lo = 0, int n_nets = 2);
 int cu_count();  // CUs of the current device (cached per device ordinal)

@@ -1136,7 +1136,6 @@ struct DxArgs {
     const float* g3;
     const float* part_m;  // [grid][8] max |g3| per wave of the head that wrote g3 (set_gscale)
     const f16* sm;
-    float* partU;      // [grid][2 h][KP][2]   sum dC, sum dC * p1 per feature
     float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only
 };
@@ -1178,7 +1177,6 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     const float gv = gsc * VSH, vs = gsc * swc * VSH;
     const f16x8 wf = p.net.wf1h[((long)set * NGT_MAX + ft) * 64 + lane];  // (scaled by S1: p1 = S1 z1, U1 rescaled at the end)
     f32x16 V = zero16;
-    float U0 = 0.f, U1 = 0.f;
     for (int i = tid; i < 2 * 2 * 32 * 32; i += NT) {  // columns 9.. stay zero, column 8 is the ones column (bias)
         const int k = (i >> 5) & 31;
         (&xt[0][0][0])[i] = (f16)(k == 8 ? 1.f : 0.f);
@@ -1245,8 +1243,12 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
                 for (int j = 0; j < 4; ++j) xb[s][j] = lo[j], xb[s][4 + j] = hi[j];
             }
         };
-        auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8], float& A0, float& A1) {
-            float u0 = 0.f, u1 = 0.f;
+        // BN/ReLU backward of the first layer: only the MASKED gradient is needed per element. The two unmasked per-feature sums of
+        // r03 -- sum_rows dC (-> d beta1) and sum_rows dC relu(z1) (-> d gamma1): 3 of this kernel's ~8 VALU per element, and the
+        // kernel is VALU-bound at 40 % of the matrix pipe -- are linear images of sums that exist anyway (r04, finalize_feat_kernel):
+        //     sum_rows dC[row][f]           = sum_n W2[f][n] db2[n]                         (backprop of the row sum through the layer)
+        //     sum_rows dC[row][f] relu(z1)  = sum_k W1[k][f] V[f][k] + b1[f] V[f][8]        (relu(z1) = mask z1, z1 = x . W1 + b1)
+        auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8]) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 gq = *(const float4*)(&g3s[buf][32 * e + 8 * g + 4 * h]);
@@ -1255,15 +1257,11 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * g + j;
-                    const float pr = relu(p1[k]), d = dc[k] * gg[j];
-                    u0 += d;
-                    u1 = fmaf(d, pr, u1);
-                    dm[j] = pr > 0.f ? d : 0.f;
+                    dm[j] = p1[k] > 0.f ? dc[k] * gg[j] : 0.f;
                 }
                 split2h(dm[0], dm[1], vh[2 * g], vl[2 * g]);
                 split2h(dm[2], dm[3], vh[2 * g + 1], vl[2 * g + 1]);
             }
-            A0 += u0, A1 += u1;
         };
         f16x8 smf[8], xb0[2], xb1[2];
         unsigned vh0[8], vl0[8], vh1[8], vl1[8];
@@ -1281,12 +1279,12 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) dc1 = mfmah(smf[s], wch[s], dc1), dc1 = mfmah(smf[s], wcl[s], dc1);
         const f32x16 p11 = mfmah(xf[1], wf, zero16);
-        backward(0, dc0, p10, vh0, vl0, U0, U1);
+        backward(0, dc0, p10, vh0, vl0);
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1297,7 +1295,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
             V = mfmah(fragh(vh0[4 * s], vh0[4 * s + 1], vh0[4 * s + 2], vh0[4 * s + 3]), xb0[s], V);
             V = mfmah(fragh(vl0[4 * s], vl0[4 * s + 1], vl0[4 * s + 2], vl0[4 * s + 3]), xb0[s], V);
         }
-        backward(1, dc1, p11, vh1, vl1, U0, U1);
+        backward(1, dc1, p11, vh1, vl1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             V = mfmah(fragh(vh1[4 * s], vh1[4 * s + 1], vh1[4 * s + 2], vh1[4 * s + 3]), xb1[s], V);
@@ -1314,8 +1312,6 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = dacc[i];
 #endif
     const float ivs = 1.f / vs;  // (powers of two: exact)
-    float* pu = p.partU + (((long)blockIdx.x * 2 + h) * KP + 32 * ft + r) * 2;
-    pu[0] = U0 * ivs, pu[1] = U1 * (ivs / S1);
     if (r < 16) {
         float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft) * 16 + r;
 #pragma unroll
@@ -1343,7 +1339,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     constexpr int LDZ = 136;
     __shared__ __attribute__((aligned(16))) f16 simg[8][32 * LDZ];     // per wave: its unit's 32 sm rows
     __shared__ __attribute__((aligned(16))) float ga[8][2][2][32];  // per wave, per buffer: |g3| gv and a of its 32 rows
-    __shared__ float comb[8][64][4];
+    __shared__ float comb[8][64][2];
     __shared__ float gred[8];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int rh = w & 1, ftl = (w >> 1) & 1, par = w >> 2;
@@ -1361,7 +1357,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
     const float gv = gsc * VSH, vs = gsc * swc * VSH;  // the scaled domain of dx_kernel (nothing here needs it for range: one scale for both kernels)
     const float* th = p.net.th + (long)set * p.net.th_stride;
     const float wa = f < HA ? th[p.L_cWa + f] : 0.f, ba = f < HA ? th[p.L_cba + f] : 0.f;
-    float U0 = 0.f, U1 = 0.f, Sa = 0.f, Sb = 0.f;
+    float Sa = 0.f, Sb = 0.f;
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;
     // two register sets of prefetched operands, used alternately (k = par, par + 2, ..). (Plain variables through macros: as arrays
     // handed to lambdas by reference the two sets ended up in scratch memory and -- promoted by the compiler -- in 64 KB of LDS.)
@@ -1391,22 +1387,19 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
             const f16x8 af = *(const f16x8*)(arow + 16 * s);
             dc = mfmah(af, wch[s], dc), dc = mfmah(af, wcl[s], dc);
         }
-        float u0 = 0.f, u1 = 0.f, sa = 0.f, sb = 0.f;
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 gq = *(const float4*)(&ga[w][buf][0][8 * q + 4 * h]), aq = *(const float4*)(&ga[w][buf][1][8 * q + 4 * h]);
             const float gg[4] = {gq.x, gq.y, gq.z, gq.w}, av[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float pr = relu(fmaf(av[j], wa, ba)), d = dc[4 * q + j] * gg[j];
-                u0 += d;
-                u1 = fmaf(d, pr, u1);
-                const float m = pr > 0.f ? d : 0.f;
+                const float m = fmaf(av[j], wa, ba) > 0.f ? dc[4 * q + j] * gg[j] : 0.f;  // (the unmasked sums: finalize_feat_kernel, see dx_kernel)
                 sa = fmaf(m, av[j], sa);
                 sb += m;
             }
         }
-        U0 += u0, U1 += u1, Sa += sa, Sb += sb;
+        Sa += sa, Sb += sb;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the image is rewritten by this wave's next unit)
         __builtin_amdgcn_wave_barrier();
     };
@@ -1425,29 +1418,26 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 #undef DXA_FETCH
 #undef DXA_PUT
     // combine: the two lane halves (16 rows each) and the four (rh, par) waves of a feature tile, fixed order; one writer per feature
-    comb[w][lane][0] = U0, comb[w][lane][1] = U1, comb[w][lane][2] = Sa, comb[w][lane][3] = Sb;
+    comb[w][lane][0] = Sa, comb[w][lane][1] = Sb;
     __syncthreads();
     if (rh == 0 && par == 0 && h == 0) {
         const int ws[4] = {w, w + 1, w + 4, w + 5};  // (rh 0, par 0), (rh 1, par 0), (rh 0, par 1), (rh 1, par 1)
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        float t[2] = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) t[c] += comb[ws[i]][r][c] + comb[ws[i]][32 + r][c];
+            for (int c = 0; c < 2; ++c) t[c] += comb[ws[i]][r][c] + comb[ws[i]][32 + r][c];
         const float ivs = 1.f / vs;  // (powers of two: exact)
-        float* pu0 = p.partU + (((long)blockIdx.x * 2 + 0) * KP + 32 * ft + r) * 2;
-        float* pu1 = p.partU + (((long)blockIdx.x * 2 + 1) * KP + 32 * ft + r) * 2;
-        pu0[0] = t[0] * ivs, pu0[1] = t[1] * ivs, pu1[0] = 0.f, pu1[1] = 0.f;
         float* pv = p.partV + ((long)blockIdx.x * KP + 32 * ft + r) * 16;  // [feature][16]: 0 = sum (dC mask) a, 4 = its lo part (none), 8 = sum (dC mask)
 #pragma unroll
-        for (int c = 0; c < 9; ++c) pv[c] = c == 0 ? t[2] * ivs : (c == 8 ? t[3] * ivs : 0.f);
+        for (int c = 0; c < 9; ++c) pv[c] = c == 0 ? t[0] * ivs : (c == 8 ? t[1] * ivs : 0.f);
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Plan {
     int grid, J;
-    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partM[2], partU[2],
+    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partM[2],
         partV[2], partG[2], bad, total;
 };
 static Plan make_plan(int n_agents, int n_sets) {
@@ -1480,7 +1470,6 @@ static Plan make_plan(int n_agents, int n_sets) {
         const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
         pl.partH[i] = take(4 * (size_t)pl.grid * 8 * H2);
         pl.partM[i] = take(4 * (size_t)pl.grid * 8);
-        pl.partU[i] = take(4 * (size_t)pl.grid * 2 * KP * 2);
         pl.partV[i] = take(4 * (size_t)pl.grid * KP * 16);
         pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
     }
@@ -1562,7 +1551,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.nrh = 1, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
     fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]), fa.bad = bad;
     for (int i = 0; i < 2; ++i)
-        fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
+        fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = nullptr, fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
     if (phases & PH_CRITIC) {
         if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
@@ -1583,12 +1572,13 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
         dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]), dw.part_m = F(pl.partM[1]);
         hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
-        dx.net = net[1], dx.partU = F(pl.partU[1]), dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
+        dx.net = net[1], dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
         hipLaunchKernelGGL((dx_kernel<S, CriticS>), grid, block, 0, st, dx);
         dx.L_cWa = L.cWa, dx.L_cba = L.cba;
         hipLaunchKernelGGL((dxa_kernel<S>), grid, block, 0, st, dx);
-        // 8: the critic block of the slab (+ both losses: the actor loss is the mean of q(s, mu), summed by HEAD_BOTH)
-        launch_finalize(fa, st, 1, 1);
+        // 8: the critic block of the slab (+ both losses: the actor loss is the mean of q(s, mu), summed by HEAD_BOTH) -- when the
+        // caller asked for this phase alone; the single call finalizes both blocks together at its end (three launches, not six)
+        if (phases == PH_CRITIC) launch_finalize(fa, st, 1, 1);
     }
     if (phases & PH_ACTOR) {
         // 9-11: actor gradients
@@ -1596,10 +1586,11 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
         dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]), dw.part_m = F(pl.partM[0]);
         hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
-        dx.net = net[0], dx.partU = F(pl.partU[0]), dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]), dx.L_cWa = dx.L_cba = 0;
+        dx.net = net[0], dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]), dx.L_cWa = dx.L_cba = 0;
         hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
-        // 12: the actor block of the slab
-        launch_finalize(fa, st, 0, 1);
+        // 12: the actor block of the slab (the single call: both blocks)
+        if (phases == PH_ACTOR) launch_finalize(fa, st, 0, 1);
+        else launch_finalize(fa, st, 0, 2);
     }
     return check_launch("avd_learn_set_split");
 }

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/bench_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd $R
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/err_default.txt
-AVD_LEARN_KERNEL=fast python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_default_learn_kernel_t.json 2>/dev/null
+AVDDPG_HIP_LIB=$R/avddpg_amd/lib/libavddpg_hip_diag.so AVD_LEARN_KERNEL=fast python bench.py --allow-diagnostics --no-cpu-baseline > $OUT/${TAG}_bench_default_learn_kernel_t.json 2>/dev/null
 python bench.py --no-fused --no-cpu-baseline > $OUT/${TAG}_bench_unfused.json 2>/dev/null
 python bench.py --mode interfrl --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
 python bench.py --mode interfrl --engine batched --no-cpu-baseline > $OUT/${TAG}_bench_interfrl_batched.json 2>/dev/null

@@ -14,7 +14,7 @@ python bench.py --mode interfrl --no-cpu-baseline --steps 2000 --warmup 200 > $O
 python bench.py --mode nofrl --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/${TAG}_bench_nofrl_sustained_2000.json 2>/dev/null
 # nofrl variants
 python bench.py --mode nofrl $N > $OUT/${TAG}_bench_nofrl.json 2>/dev/null
-AVD_LEARN_KERNEL=fast python bench.py --mode nofrl $N > $OUT/${TAG}_bench_nofrl_learn_kernel_t.json 2>/dev/null
+AVDDPG_HIP_LIB=$R/avddpg_amd/lib/libavddpg_hip_diag.so AVD_LEARN_KERNEL=fast python bench.py --allow-diagnostics --mode nofrl $N > $OUT/${TAG}_bench_nofrl_learn_kernel_t.json 2>/dev/null
 python bench.py --mode nofrl --no-fused $N > $OUT/${TAG}_bench_nofrl_unfused.json 2>/dev/null
 # interfrl engines
 python bench.py --mode interfrl --engine per_agent $N > $OUT/${TAG}_bench_interfrl_per_agent.json 2>/dev/null
