@@ -99,7 +99,7 @@ def _errors_vs_oracle(grp, g, s, a, r, s2, P, M, sets, B=64, losses=None, loss_t
     return errs, worst
 
 
-@pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5)])
+@pytest.mark.parametrize("S,P,M", [(4, 6, 2), (3, 5, 3), (4, 1, 1), (4, 70, 5), (4, 300, 1)])  # (300, 1): every CU's workgroup on ONE set, 1-2 tiles each
 def test_split_set_learner_matches_oracle_at_the_f32_tolerance(S, P, M):
     """The mean over a set's P agents of their 64-row batch gradients == the gradient of the P*64-row batch (inference-mode
     BN: rows are independent). Every gradient tensor within max(SPLIT_TOL = 2e-5, 4 x the float32 oracle's own error) of the

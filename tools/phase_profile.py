@@ -13,7 +13,7 @@ import torch
 
 from avddpg_amd import _hip
 
-_hip.LIB_PATH = os.path.join(ROOT, "avddpg_amd", "lib", "libavddpg_hip_diag.so")
+_hip.LIB_PATH = os.path.join(ROOT, "avddpg_amd", "lib", "libavddpg_hip_phase.so")  # tools/build_phase_lib.sh
 from avddpg_amd import config, vec
 
 NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fwd", 3: "actor out layer",
