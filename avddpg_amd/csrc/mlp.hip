@@ -78,7 +78,10 @@ __device__ __forceinline__ GLds carve(float* p, const avd_mlp_layout& L) {
 // first layer of a branch: out[r][col0+k] = relu(sum_j X[r*K+j]*W[j*H+k] + b[k]) and the BN coefficients of column k,
 // on the matrix cores: 16 x 16 output tiles (row tile, column tile) dealt over the waves, the K <= 64 inputs in MFMA steps
 // of 4 (indices past K are clamped and their operands zeroed). A tile's weight operands are all requested up front.
-__device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
+// ST = compile-time bound on the MFMA steps (K <= 4 ST): with 16 (any K <= 64) a K = 20 layer -- the centralized framework's state
+// input at L = 5 -- issued 16 weight loads and 16 LDS reads per tile for 5 MFMAs (r04: ST = 5 and ST = 2 copies).
+template <int ST>
+__device__ __attribute__((noinline)) void l1_fwd_t(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
                                        const glb_f* __restrict__ g, const glb_f* __restrict__ be,
                                        const glb_f* __restrict__ mm, const glb_f* __restrict__ mv, int H, lds_f* out,
                                        int ld, int col0, lds_f* inv, lds_f* sh) {
@@ -92,11 +95,11 @@ __device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const gl
     // a wave's items are the column tiles t = wave, wave + 4, ..; each serves the four row tiles with ONE set of weight
     // operands, and the next column tile's are requested before the current one is used
     const int ctiles = H >> 4;
-    float wn[16], bn_ = 0.f;
-    auto load_w = [&](int t, float(&w)[16], float& bc) {
+    float wn[ST], bn_ = 0.f;
+    auto load_w = [&](int t, float(&w)[ST], float& bc) {
         const int col = 16 * min(t, ctiles - 1) + lr;
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
+        for (int st = 0; st < ST; ++st) {
             const int j = 4 * st + lg;
             w[st] = W[min(j, K - 1) * H + col] * (j < K ? 1.f : 0.f);
         }
@@ -104,9 +107,9 @@ __device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const gl
     };
     load_w(wave, wn, bn_);
     for (int t = wave; t < ctiles; t += 4) {
-        float wv[16];
+        float wv[ST];
 #pragma unroll
-        for (int st = 0; st < 16; ++st) wv[st] = wn[st];
+        for (int st = 0; st < ST; ++st) wv[st] = wn[st];
         const float bc = bn_;
         load_w(t + 4, wn, bn_);
         const int col = 16 * t + lr;
@@ -115,12 +118,20 @@ __device__ __attribute__((noinline)) void l1_fwd(const lds_f* X, int K, const gl
             const lds_f* xr = X + (16 * m + lr) * K;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int st = 0; st < 16; ++st)
+            for (int st = 0; st < ST; ++st)
                 if (st < steps) acc = MFMA16(xr[min(4 * st + lg, K - 1)], wv[st], acc);  // (clamped x meets a zero weight)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) out[(16 * m + 4 * lg + reg) * ld + col0 + col] = fmaxf(acc[reg] + bc, 0.f);
         }
     }
+}
+
+__device__ __forceinline__ void l1_fwd(const lds_f* X, int K, const glb_f* __restrict__ W, const glb_f* __restrict__ b,
+                                       const glb_f* __restrict__ g, const glb_f* __restrict__ be, const glb_f* __restrict__ mm,
+                                       const glb_f* __restrict__ mv, int H, lds_f* out, int ld, int col0, lds_f* inv, lds_f* sh) {
+    if (K <= 8) l1_fwd_t<2>(X, K, W, b, g, be, mm, mv, H, out, ld, col0, inv, sh);
+    else if (K <= 20) l1_fwd_t<5>(X, K, W, b, g, be, mm, mv, H, out, ld, col0, inv, sh);
+    else l1_fwd_t<16>(X, K, W, b, g, be, mm, mv, H, out, ld, col0, inv, sh);
 }
 
 // BN coefficient tables of the layer in front of the output layer

@@ -497,6 +497,10 @@ def main():
 
     if args.mode:
         modes = [args.mode]
+    elif args.framework != "decentralized":
+        # the centralized framework has no federated method (src/config.py:26-27: fed_enabled needs the decentralized one): one model
+        # per platoon, the fused learn + Adam + Polyak kernel
+        modes = ["nofrl"]
     else:
         modes = [PRIMARY_MODE] + ([] if args.no_secondary or args.hidden or args.framework != "decentralized" else
                                   ["interfrl" if PRIMARY_MODE == "nofrl" else "nofrl"])
