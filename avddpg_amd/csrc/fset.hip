@@ -817,25 +817,29 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
         const int oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3, ob2 = critic ? L.cb2 : L.ab2;
         const int KG = critic ? Critic::KG : Actor::KG;
         float T1 = 0.f, S2 = 0.f, D = 0.f, Lc = 0.f, La = 0.f;
+        const bool t1g = a.t1_from_g[net] != 0;
         for (int j = jl; j < a.J; j += 32) {
             const long wg = (long)j * a.n_sets + set;
             for (int w = 0; w < 8; ++w) {
-                T1 += a.partH[net][(wg * 8 + w) * H2 + n];
+                if (!t1g) T1 += a.partH[net][(wg * 8 + w) * H2 + n];
                 D += a.partHs[net][(wg * 8 + w) * 2];
                 if (critic && n == 0) Lc += a.partHs[1][(wg * 8 + w) * 2 + 1], La += a.partLa[(wg * 8 + w) * 2 + 1];
             }
             S2 += a.partG[net][(wg * KG + K) * H2 + n];  // dw_kernel's constant-one feature: sum over rows of dZ2 = db2
         }
         T1 = allsum(T1), S2 = allsum(S2), D = allsum(D);
+        if (t1g && jl == 0) a.s2raw[(long)set * H2 + n] = S2;  // (before c3: sum_rows g3 mask[n])
         if (a.c3[net]) S2 *= a.c3[net][(long)set * VEC + H2 + n];  // fsplit: the column factor c3[n] of dZ2 is applied here
         if (critic && n == 0) Lc = allsum(Lc), La = allsum(La);
         if (a.bad && *a.bad) T1 = S2 = D = Lc = La = __uint_as_float(0x7fc00000u);  // non-finite input: NaN out, like the f32 engines
         if (jl == 0) {
             const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
             const float sh2 = th[obe2 + n] - mm2 * inv2, w3 = th[oW3 + n];
-            g[oW3 + n] = inv2 * T1 + sh2 * D;
+            if (!t1g) {  // (else: finalize_t1_kernel, once the weight-gradient partials have been summed)
+                g[oW3 + n] = inv2 * T1 + sh2 * D;
+                g[og2 + n] = w3 * rs2 * (T1 - mm2 * D);
+            }
             g[obe2 + n] = w3 * D;
-            g[og2 + n] = w3 * rs2 * (T1 - mm2 * D);
             g[ob2 + n] = S2;
             if (n == 0) g[ob3] = D;
             if (critic && n == 0 && a.losses) a.losses[2 * set] = Lc * a.inv_n, a.losses[2 * set + 1] = -La * a.inv_n;
@@ -922,10 +926,42 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
         for (int u = 0; u < 8; ++u) G += v[u];
     }
     for (; j < a.J; ++j) G += pg[j * stride];
+    const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
+    if (a.t1_from_g[net]) a.t1p[((long)set * Critic::K + f) * H2 + n] = inv1 * th[oW2 + (long)f * H2 + n] * G;  // W2'[f][n] G[f][n]
     if (a.c3[net]) G *= a.c3[net][(long)set * VEC + H2 + n];
     if (a.bad && *a.bad) G = __uint_as_float(0x7fc00000u);
-    const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
     g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
+}
+// T1-dependent outputs of a net whose T1 comes from the weight-gradient partials (FinArgs::t1_from_g): one block per set, one
+// thread per output column, the K products in index order with eight loads in flight
+__global__ __launch_bounds__(128) void finalize_t1_kernel(const FinArgs a, int net) {
+    const int set = blockIdx.x, n = threadIdx.x;
+    const bool critic = net;
+    const avd_mlp_layout& L = a.L;
+    const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const float* st = a.stats + (long)set * L.stats_size;
+    float* g = a.grads + (long)set * L.theta_size + (critic ? L.actor_size : 0);
+    const int K = critic ? Critic::K : Actor::K;
+    const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
+    const int oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
+    const float* tp = a.t1p + (long)set * Critic::K * H2 + n;
+    float T1 = 0.f;
+    int f = 0;
+    for (; f + 8 <= K; f += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tp[(long)(f + u) * H2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) T1 += v[u];
+    }
+    for (; f < K; ++f) T1 += tp[(long)f * H2];
+    T1 = fmaf(a.c3[net][(long)set * VEC + n], a.s2raw[(long)set * H2 + n], T1);  // + b2'[n] S2[n]  (vec[n] = b2')
+    const float D = g[ob3];
+    if (a.bad && *a.bad) T1 = __uint_as_float(0x7fc00000u);
+    const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
+    const float sh2 = th[obe2 + n] - mm2 * inv2, w3 = th[oW3 + n];
+    g[oW3 + n] = inv2 * T1 + sh2 * D;
+    g[og2 + n] = w3 * rs2 * (T1 - mm2 * D);
 }
 
 // nets [net_lo, net_lo + n_nets): both (default), or one block of the slab (fsplit.hip's two phases). The critic launch also writes
@@ -942,6 +978,8 @@ void launch_finalize(const FinArgs& fa0, hipStream_t st, int net_lo, int n_nets)
         hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (K + 15) / 16), dim3(512), 0, st, fa);
     }
     hipLaunchKernelGGL(finalize_w2_kernel, dim3(K, fa.n_sets, n_nets), dim3(H2), 0, st, fa);
+    for (int net = net_lo; net < net_lo + n_nets; ++net)
+        if (fa.t1_from_g[net]) hipLaunchKernelGGL(finalize_t1_kernel, dim3(fa.n_sets), dim3(H2), 0, st, fa, net);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -1084,6 +1122,7 @@ static int run(const avd_mlp_layout& L, int n_agents, int n_sets, const float* t
         fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = F(pl.partU[i]), fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]);
     fa.nrh = 2, fa.c3[0] = fa.c3[1] = nullptr, fa.bad = (const int*)(ws + pl.bad);
+    fa.t1_from_g[0] = fa.t1_from_g[1] = 0, fa.t1p = nullptr, fa.s2raw = nullptr;
     launch_finalize(fa, st);
     return check_launch("avd_learn_set_fused_bf16");
 }

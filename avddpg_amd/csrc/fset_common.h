@@ -71,6 +71,13 @@ struct FinArgs {
     float inv_n;
     int net_lo;     // first net of this launch (0 actor, 1 critic): set by launch_finalize
     int item_base;  // first item of this launch of finalize_small_kernel (items < H2: output columns; >= H2: first-layer features)
+    // fsplit.hip (r04), per net: T1[n] = sum_rows g3 relu(z2)[n] (-> dW3, d gamma2) is NOT accumulated by a head kernel but derived from
+    // the weight-gradient partials: relu(z2) = mask (P1 . W2' + b2'), so T1[n] = sum_f W2'[f][n] G[f][n] + b2'[n] S2[n] with
+    // G = P1^T (g3 mask) (dw_kernel's raw sums), S2 = its constant-one row, W2' = inv1 (.) W2, b2' = vec[n]. finalize_w2_kernel leaves
+    // the products in t1p [n_sets][Critic::K][H2], finalize_small_kernel S2 in s2raw [n_sets][H2], finalize_t1_kernel adds them up.
+    int t1_from_g[2];
+    float* t1p;
+    float* s2raw;
 };
 void launch_finalize(const FinArgs& fa, hipStream_t st, int net_lo = 0, int n_nets = 2);
 int cu_count();  // CUs of the current device (cached per device ordinal)

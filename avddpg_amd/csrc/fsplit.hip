@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
 }
 
 // ---- head: first layer -> second-layer GEMM (three MFMAs per product) -> output layer [-> its backward] -------------------
-enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4, HEAD_BOTH = 5 };
+enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4, HEAD_BOTH = 5, OUT_TANH_SAVE = 6 };
 struct HeadArgs {
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
     NetP net;
@@ -392,6 +392,7 @@ struct HeadArgs {
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float* part_s2;    // HEAD_BOTH: the same sums of the critic(s, mu) branch (the actor loss)
     float* part_m;     // backward modes: [grid][8 waves] max |g3| over the wave's rows (dw / dx scale their fp16 operands by it)
+    float* tz;         // OUT_TANH_SAVE: tanh(z) per row [n_agents][64] (the actor's backward seed needs 1 - t^2: actor_seed_kernel)
     float gamma, high, inv_n;
     int* bad;          // set when an activation would overflow fp16 (S1 P1 >= 65520): finalize then writes NaN gradients
 };
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     constexpr int NW = head_waves(MODE), NTH = 64 * NW;
     constexpr bool BOTH = (MODE == HEAD_BOTH);
     constexpr bool AG = (MODE == HEAD_CONST || BOTH), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR || BOTH);
+    constexpr bool PARTIALS = (MODE >= HEAD_CRITIC && MODE != OUT_TANH_SAVE);  // the modes that leave per-wave partial sums
     static_assert(!BOTH || NET::critic, "HEAD_BOTH is a critic mode");
     __shared__ __attribute__((aligned(16))) f16 wimg[2][H2 * LD];
     __shared__ __attribute__((aligned(16))) float b2s[H2];
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         if (BOTH) nb = p.act2[ri];
         if (MODE == OUT_TD) ny = p.r[ri];
         if (BWD) ny = p.yin[ri];
-        if (MODE >= HEAD_CRITIC && p.aw) nw = p.aw[agent];
+        if (PARTIALS && p.aw) nw = p.aw[agent];
     };
     const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
     const f16* wlo0 = &wimg[1][r * LD + 8 * h];
@@ -556,6 +558,24 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 }
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {  // 16-byte row-major pieces: the row's two lanes cover 32 contiguous bytes
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
+                uint4 o;
+                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
+                *(uint4*)(dst + 32 * t + 16 * gg) = o;
+            }
+        };
+        auto mask_t = [&](const f32x16& a, int t, f16* dst) {  // the unsigned mask of tile t alone (a = relu(z2))
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 4 * g + 2 * e;
+                    pk[g][e] = (a[i] > 0.f ? 0x3c00u : 0u) | (a[i + 1] > 0.f ? 0x3c000000u : 0u);
+                }
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
                 uint4 o;
@@ -797,6 +817,14 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         if (MODE == OUT_TANH) {
             const float o = tanhf(z) * p.high;
             if (h == 0) p.out[ri] = o;
+        } else if (MODE == OUT_TANH_SAVE) {
+            // mu = actor(s) AND what the actor's backward pass needs from this forward pass: the relu mask of z2 (fp16 1 / 0,
+            // UNSIGNED: the seed's sign is not known yet -- it rides on the row factor in dw / dx) and tanh(z). With them
+            // r03's HEAD_ACTOR launch -- the same 200 MFMAs per 32 rows once more, 239 us -- is not needed at all (r04).
+            const float t = tanhf(z);
+            if (h == 0) p.out[ri] = t * p.high, p.tz[ri] = t;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) mask_t(acc[tt], tt, p.sm + ri * H2 + 8 * h);
         } else if (MODE == OUT_TD) {
             if (h == 0) p.out[ri] = ty + p.gamma * z;
         } else {
@@ -825,7 +853,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = hacc[i];
 #endif
     if (watch >= 0x7f800000u) atomicOr(p.bad, 1);
-    if (MODE >= HEAD_CRITIC) {
+    if (PARTIALS) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
         // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
         if (BWD) {
@@ -866,6 +894,34 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     }
 }
 
+// ---- the actor's backward seed (r04: what is left of r03's HEAD_ACTOR launch) --------------------------------------------------
+// g3[row] = d mu[row] * high * (1 - tanh(z)^2) (workers/trainer.py:502-506 through agent/model.py:34-36), from the d q / d mu the
+// critic head left and the tanh(z) the mu pass stored; per wave max |g3| (set_gscale) and sum g3 (-> d b3) in head_kernel's layout.
+struct SeedArgs {
+    int n_agents, n_sets;
+    const float *dmu, *tz;
+    float high;
+    float *g3, *part_m, *part_s;
+};
+__global__ __launch_bounds__(NT) void actor_seed_kernel(const SeedArgs p) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
+    float gmax = 0.f, D = 0.f;
+    for (int pi = j0 + w * J; pi < P; pi += 8 * J) {  // wave w: tiles j0 + w J, + 8 J, .. of the workgroup's set; lane = row
+        const long ri = (long)(pi * p.n_sets + set) * TILE + lane;
+        const float t = p.tz[ri], g = p.dmu[ri] * p.high * (1.f - t * t);
+        p.g3[ri] = g;
+        gmax = fmaxf(gmax, fabsf(g));
+        D += g;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o)), D += __shfl_xor(D, o);
+    if (lane == 0) {
+        p.part_m[(long)blockIdx.x * 8 + w] = gmax;
+        p.part_s[((long)blockIdx.x * 8 + w) * 2] = D, p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = 0.f;
+    }
+}
+
 // ---- the row factor's scale --------------------------------------------------------------------------------------------------
 // dw and dx carry |g3[row]| inside fp16 operands; g3 is 2 (q - y) / N or d mu * high * (1 - t^2): anything from 1e-12 to 1e-3. The
 // backward heads leave max |g3| per wave (part_m); every workgroup of dw / dx reduces its set's J x 8 values to the power of two
@@ -894,8 +950,9 @@ struct DwArgs {
     const float* x;    // states [n_agents][64][S]
     const float* act;  // the critic's action input [n_agents][64]
     const float* g3;   // [n_agents][64]
-    const float* part_m;  // [grid][8] max |g3| per wave of the head that wrote g3 (set_gscale)
-    const f16* sm;     // [n_agents][64][128] fp16 +-1 / 0
+    const float* part_m;  // [grid][8] max |g3| per wave of the kernel that wrote g3 (set_gscale)
+    const f16* sm;     // [n_agents][64][128] fp16 +-1 / 0 (critic: sign(g3) inside, HEAD_BOTH) or 1 / 0 (actor: OUT_TANH_SAVE; the sign of
+                       // g3 then goes onto the A operand: one v_xor per packed pair, from a per-row sign table in LDS)
     float* partG;      // [grid][KG][128] (row K: the constant-one feature = sum over rows of g3 * mask -> db2 / c3)
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
 };
@@ -912,6 +969,8 @@ template <int S, class NET>
 __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     constexpr int KG = NET::KG, LDZ = 160;
     constexpr int XC = NET::critic ? 2 : 1;  // column tiles of a wave's extra piece
+    constexpr bool SGN = !NET::critic;       // unsigned masks: the sign of g3 rides on the A operand
+    __shared__ __attribute__((aligned(16))) unsigned short sgn16[2][TILE];  // 0x8000 where g3[row] < 0: two rows = one packed-pair sign word
     __shared__ __attribute__((aligned(16))) f16 smimg[2][TILE * LDZ];  // (40 KB: reused for the extra pieces' partial sums)
     __shared__ __attribute__((aligned(16))) f16x8 fq[2][TILE * 2];      // scaled input fragments [row][lane half] of the states
     __shared__ __attribute__((aligned(16))) f16x8 fa[2][TILE * 2];      // ... of the action (critic)
@@ -954,6 +1013,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
             const float g = fabsf(sg) * gsc;  // in [0, 1)
             fq[buf][tid] = make_xg(g * sx[0], g * sx[1], g * sx[2], g * sx[3], g, fh);
             if (NET::critic) fa[buf][tid] = make_xg(g * sa, 0.f, 0.f, 0.f, g, fh);
+            if (SGN && fh == 0) sgn16[buf][frow] = sg < 0.f ? 0x8000 : 0;
         }
     };
     const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -976,14 +1036,22 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
                 for (int j = 0; j < 4; ++j) bfr[c][4 * hf + j] = t[j];
             }
     };
-    auto split16 = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8]) {
+    // pair m of a unit's 16 rows = registers 2m, 2m + 1 = rows acc_row(2m, h), + 1 of row half e: sign word 16 e + 4 (m >> 1) + 2 h + (m & 1)
+    auto split16e = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8], int buf, int e) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
+        if (SGN) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const uint2 sw = *(const uint2*)((const unsigned*)sgn16[buf] + 16 * e + 4 * qd + 2 * h);
+                qh[2 * qd] ^= sw.x, ql[2 * qd] ^= sw.x, qh[2 * qd + 1] ^= sw.y, ql[2 * qd + 1] ^= sw.y;
+            }
+        }
     };
     auto compute = [&](int buf) {
         unsigned ah[8], al[8], bh[8], bl[8];
         // stage 0: first layer + split of row half 0 (exposed)
-        split16(mfmah(fq[buf][r * 2 + h], wf0, zero16), ah, al);
+        split16e(mfmah(fq[buf][r * 2 + h], wf0, zero16), ah, al, buf, 0);
         __builtin_amdgcn_sched_barrier(0);
         // stage 1: MFMAs of row half 0 | first layer + split of row half 1
         {
@@ -997,7 +1065,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) G0[c] = mfmah(hi, bfr[c], G0[c]), G0[c] = mfmah(lo, bfr[c], G0[c]);
             }
-            split16(p1, bh, bl);
+            split16e(p1, bh, bl, buf, 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -1005,7 +1073,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SGN ? 4 : 3, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1023,7 +1091,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) G0[c] = mfmah(hi, bfr[c], G0[c]), G0[c] = mfmah(lo, bfr[c], G0[c]);
             }
-            split16(px, ah, al);
+            split16e(px, ah, al, buf, xrh);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -1031,7 +1099,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SGN ? 4 : 3, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1134,8 +1202,9 @@ struct DxArgs {
     const float* act;  // dxa_kernel: the per-row action input [n_agents][64]
     int L_cWa, L_cba;  // dxa_kernel: offsets of the critic's action-layer weights / bias inside net.th
     const float* g3;
-    const float* part_m;  // [grid][8] max |g3| per wave of the head that wrote g3 (set_gscale)
+    const float* part_m;  // [grid][8] max |g3| per wave of the kernel that wrote g3 (set_gscale)
     const f16* sm;
+    int unsigned_mask;  // actor: sm holds 1 / 0 (OUT_TANH_SAVE), the row factor keeps the sign of g3; critic: sm holds sign(g3) inside
     float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only
 };
@@ -1192,7 +1261,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     auto stage = [&](int buf) {
         uint4* dst = (uint4*)(smimg[buf] + srow * LDZ + 16 * sch);
         dst[0] = d0, dst[1] = d1;
-        if (tid < TILE) g3s[buf][tid] = fabsf(gn) * gv;
+        if (tid < TILE) g3s[buf][tid] = (p.unsigned_mask ? gn : fabsf(gn)) * gv;
     };
     f16x8 xfn0 = {}, xfn1 = {};  // the rows' input fragments [x_hi | x_lo] (h = 0) / [x_hi | 1 1 0 0] (h = 1), both row halves (two
                                  // variables, not an array: LLVM merges the two image copies below into one indexed by the wave number
@@ -1437,7 +1506,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Plan {
     int grid, J;
-    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, xfs, xfs2, partH[2], partHs[3], partM[2],
+    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, sma, tz, t1p, s2raw, xfs, xfs2, partH[2], partHs[3], partM[2],
         partV[2], partG[2], bad, total;
 };
 static Plan make_plan(int n_agents, int n_sets) {
@@ -1464,7 +1533,10 @@ static Plan make_plan(int n_agents, int n_sets) {
     pl.wap = take(4 * (size_t)n_sets * 48);
     const size_t rows = (size_t)n_agents * TILE;
     pl.a2 = take(4 * rows), pl.y = take(4 * rows), pl.mu = take(4 * rows), pl.dmu = take(4 * rows), pl.g3 = take(4 * rows);
-    pl.sm = take(sizeof(f16) * rows * H2);
+    pl.sm = take(sizeof(f16) * rows * H2);   // the critic's signed masks (HEAD_BOTH)
+    pl.sma = take(sizeof(f16) * rows * H2);  // the actor's unsigned masks (OUT_TANH_SAVE: written before the critic's are used)
+    pl.tz = take(4 * rows);
+    pl.t1p = take(4 * (size_t)n_sets * CriticS::K * H2), pl.s2raw = take(4 * (size_t)n_sets * H2);
     pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows);
     for (int i = 0; i < 2; ++i) {
         const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
@@ -1522,12 +1594,12 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     int* bad = (int*)(ws + pl.bad);
     float *a2 = (float*)(ws + pl.a2), *y = (float*)(ws + pl.y), *mu = (float*)(ws + pl.mu), *dmu = (float*)(ws + pl.dmu);
     float* g3 = (float*)(ws + pl.g3);
-    f16* sm = (f16*)(ws + pl.sm);
+    f16 *sm = (f16*)(ws + pl.sm), *sma = (f16*)(ws + pl.sma);
     auto F = [&](size_t off) { return (float*)(ws + off); };
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
-    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr;
+    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr, h.tz = F(pl.tz);
     int head_threads = NT;
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
                     float* part_s) {
@@ -1543,7 +1615,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     dw.stamp = d_stamp;
 #endif
     DxArgs dx;
-    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xfh = xfs, dx.stamp = nullptr, dx.L_cWa = dx.L_cba = 0;
+    dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xfh = xfs, dx.stamp = nullptr, dx.L_cWa = dx.L_cba = 0, dx.unsigned_mask = 0;
 #ifdef AVD_STAMP
     dx.stamp = d_stamp;
 #endif
@@ -1553,6 +1625,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     for (int i = 0; i < 2; ++i)
         fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = nullptr, fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
+    fa.t1_from_g[0] = 1, fa.t1_from_g[1] = 0, fa.t1p = F(pl.t1p), fa.s2raw = F(pl.s2raw);  // the actor's T1: from its weight-gradient partials
     if (phases & PH_CRITIC) {
         if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
             return check_launch("avd_learn_set_split: memset");
@@ -1564,8 +1637,10 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         // 1-2: targets
         head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
         head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
-        // 3: mu
-        head(head_kernel<S, ActorS, OUT_TANH>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+        // 3: mu -- and the actor's relu masks + tanh(z) for its backward pass (no second actor forward: r03's HEAD_ACTOR)
+        h.sm = sma;
+        head(head_kernel<S, ActorS, OUT_TANH_SAVE>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+        h.sm = sm;
         // 4-7: critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH)
         h.act2 = mu, h.part_s2 = F(pl.partHs[2]), h.part_m = F(pl.partM[1]);
         head_threads = 64 * head_waves(HEAD_BOTH);
@@ -1581,12 +1656,15 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         if (phases == PH_CRITIC) launch_finalize(fa, st, 1, 1);
     }
     if (phases & PH_ACTOR) {
-        // 9-11: actor gradients
-        h.act2 = nullptr, h.part_s2 = nullptr, h.part_m = F(pl.partM[0]);
-        head(head_kernel<S, ActorS, HEAD_ACTOR>, 0, xfs, nullptr, nullptr, dmu, nullptr, F(pl.partH[0]), F(pl.partHs[0]));
+        // 9-11: actor gradients: the seed from d mu and the stored tanh(z), then dw / dx on the stored (unsigned) masks
+        SeedArgs sd;
+        sd.n_agents = n_agents, sd.n_sets = n_sets, sd.dmu = dmu, sd.tz = F(pl.tz), sd.high = high, sd.g3 = g3, sd.part_m = F(pl.partM[0]),
+        sd.part_s = F(pl.partHs[0]);
+        hipLaunchKernelGGL(actor_seed_kernel, grid, block, 0, st, sd);
+        dw.sm = sma, dx.sm = sma;
         dw.net = net[0], dw.act = nullptr, dw.partG = F(pl.partG[0]), dw.part_m = F(pl.partM[0]);
         hipLaunchKernelGGL((dw_kernel<S, ActorS>), grid, block, 0, st, dw);
-        dx.net = net[0], dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]), dx.L_cWa = dx.L_cba = 0;
+        dx.net = net[0], dx.partV = F(pl.partV[0]), dx.act = nullptr, dx.part_m = F(pl.partM[0]), dx.L_cWa = dx.L_cba = 0, dx.unsigned_mask = 1;
         hipLaunchKernelGGL((dx_kernel<S, ActorS>), grid, block, 0, st, dx);
         // 12: the actor block of the slab (the single call: both blocks)
         if (phases == PH_ACTOR) launch_finalize(fa, st, 0, 1);
@@ -1604,17 +1682,17 @@ using namespace avd;
 // the kernels' loop structure -- every product of two f32-class operands is three MFMAs on 16-bit pairs (two where one operand is
 // an exact +-1 / 0 mask), first layers ride on the matrix cores too:
 //   head, per 32-row unit: first layer NFT + second layer 3 x 4 column tiles x NKS k-steps
-//     OUT_TANH (actor) 8 + 192 = 200, OUT_TD (critic) 10 + 228 = 238, HEAD_ACTOR 200,
+//     OUT_TANH / OUT_TANH_SAVE (actor) 8 + 192 = 200, OUT_TD (critic) 10 + 228 = 238 (r03's HEAD_ACTOR, 200 more, is gone),
 //     HEAD_BOTH 8 + 192 (state part, once) + (2 + 36) (branch A) + (4 + 36) (branch B1) + 36 (B2: M) = 314
 //   dw, per tile: 8 waves x (2 first-layer + 2 row halves x 2 k-steps x 4 column tiles x 2) + the extra pieces 8 x (1 + 2 x XC x 2)
 //   dx, per tile: 8 waves x (2 x 16 (dC) + 2 (first layer) + 2 x 4 (V));  dxa, per tile: 4 units x 16
 namespace avd { namespace fsplit {
-constexpr long MFMA_PER_TILE = 2 * (200 + 238 + 200 + 314 + 200)      /* five head launches, two 32-row units per tile */
+constexpr long MFMA_PER_TILE = 2 * (200 + 238 + 200 + 314)            /* four head launches, two 32-row units per tile */
                                + 8 * (2 + 32 + 1 + 2 * 2 * 2)         /* dw critic */
                                + 8 * (2 + 32 + 1 + 2 * 1 * 2)         /* dw actor */
                                + 2 * 8 * (32 + 2 + 8)                 /* dx critic, actor */
                                + 4 * 16;                              /* dxa */
-static_assert(MFMA_PER_TILE == 3696, "update DESIGN.md 3.4 and the count above together");
+static_assert(MFMA_PER_TILE == 3296, "update DESIGN.md 3.4 and the count above together");
 }}
 extern "C" int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int n_sets, unsigned long long* mfma_32x32x16) {
     int rc = fsplit::check_shape(lay, n_agents, n_sets, "avd_learn_set_split_mfma_count");
