@@ -828,7 +828,7 @@ __global__ __launch_bounds__(512) void finalize_small_kernel(const FinArgs a) {
             S2 += a.partG[net][(wg * KG + K) * H2 + n];  // dw_kernel's constant-one feature: sum over rows of dZ2 = db2
         }
         T1 = allsum(T1), S2 = allsum(S2), D = allsum(D);
-        if (t1g && jl == 0) a.s2raw[(long)set * H2 + n] = S2;  // (before c3: sum_rows g3 mask[n])
+        if (t1g && jl == 0) a.s2raw[((long)net * a.n_sets + set) * H2 + n] = S2;  // (before c3: sum_rows g3 mask[n])
         if (a.c3[net]) S2 *= a.c3[net][(long)set * VEC + H2 + n];  // fsplit: the column factor c3[n] of dZ2 is applied here
         if (critic && n == 0) Lc = allsum(Lc), La = allsum(La);
         if (a.bad && *a.bad) T1 = S2 = D = Lc = La = __uint_as_float(0x7fc00000u);  // non-finite input: NaN out, like the f32 engines
@@ -927,15 +927,16 @@ __global__ __launch_bounds__(128) void finalize_w2_kernel(const FinArgs a) {
     }
     for (; j < a.J; ++j) G += pg[j * stride];
     const int oW2 = critic ? L.cW2 : L.aW2, ob2 = critic ? L.cb2 : L.ab2;
-    if (a.t1_from_g[net]) a.t1p[((long)set * Critic::K + f) * H2 + n] = inv1 * th[oW2 + (long)f * H2 + n] * G;  // W2'[f][n] G[f][n]
+    if (a.t1_from_g[net]) a.t1p[(((long)net * a.n_sets + set) * Critic::K + f) * H2 + n] = inv1 * th[oW2 + (long)f * H2 + n] * G;  // W2'[f][n] G[f][n]
     if (a.c3[net]) G *= a.c3[net][(long)set * VEC + H2 + n];
     if (a.bad && *a.bad) G = __uint_as_float(0x7fc00000u);
     g[oW2 + (long)f * H2 + n] = inv1 * G + sh1 * g[ob2 + n];
 }
 // T1-dependent outputs of a net whose T1 comes from the weight-gradient partials (FinArgs::t1_from_g): one block per set, one
 // thread per output column, the K products in index order with eight loads in flight
-__global__ __launch_bounds__(128) void finalize_t1_kernel(const FinArgs a, int net) {
-    const int set = blockIdx.x, n = threadIdx.x;
+__global__ __launch_bounds__(128) void finalize_t1_kernel(const FinArgs a) {
+    const int set = blockIdx.x, net = a.net_lo + blockIdx.y, n = threadIdx.x;
+    if (!a.t1_from_g[net]) return;
     const bool critic = net;
     const avd_mlp_layout& L = a.L;
     const float* th = a.theta + (long)set * L.theta_size + (critic ? L.actor_size : 0);
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(128) void finalize_t1_kernel(const FinArgs a, int n
     const int K = critic ? Critic::K : Actor::K;
     const int og2 = critic ? L.cg3 : L.ag2, obe2 = critic ? L.cbe3 : L.abe2, omm2 = critic ? L.cmm3 : L.amm2, omv2 = critic ? L.cmv3 : L.amv2;
     const int oW3 = critic ? L.cW3 : L.aW3, ob3 = critic ? L.cb3 : L.ab3;
-    const float* tp = a.t1p + (long)set * Critic::K * H2 + n;
+    const float* tp = a.t1p + ((long)net * a.n_sets + set) * Critic::K * H2 + n;
     float T1 = 0.f;
     int f = 0;
     for (; f + 8 <= K; f += 8) {
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(128) void finalize_t1_kernel(const FinArgs a, int n
         for (int u = 0; u < 8; ++u) T1 += v[u];
     }
     for (; f < K; ++f) T1 += tp[(long)f * H2];
-    T1 = fmaf(a.c3[net][(long)set * VEC + n], a.s2raw[(long)set * H2 + n], T1);  // + b2'[n] S2[n]  (vec[n] = b2')
+    T1 = fmaf(a.c3[net][(long)set * VEC + n], a.s2raw[((long)net * a.n_sets + set) * H2 + n], T1);  // + b2'[n] S2[n]  (vec[n] = b2')
     const float D = g[ob3];
     if (a.bad && *a.bad) T1 = __uint_as_float(0x7fc00000u);
     const float rs2 = 1.0f / sqrtf(st[omv2 + n] + BN_EPS), inv2 = rs2 * th[og2 + n], mm2 = st[omm2 + n];
@@ -978,8 +979,9 @@ void launch_finalize(const FinArgs& fa0, hipStream_t st, int net_lo, int n_nets)
         hipLaunchKernelGGL(finalize_small_kernel, dim3(fa.n_sets, n_nets, (K + 15) / 16), dim3(512), 0, st, fa);
     }
     hipLaunchKernelGGL(finalize_w2_kernel, dim3(K, fa.n_sets, n_nets), dim3(H2), 0, st, fa);
-    for (int net = net_lo; net < net_lo + n_nets; ++net)
-        if (fa.t1_from_g[net]) hipLaunchKernelGGL(finalize_t1_kernel, dim3(fa.n_sets), dim3(H2), 0, st, fa, net);
+    bool any = false;
+    for (int net = net_lo; net < net_lo + n_nets; ++net) any = any || fa.t1_from_g[net];
+    if (any) hipLaunchKernelGGL(finalize_t1_kernel, dim3(fa.n_sets, n_nets), dim3(H2), 0, st, fa);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------

@@ -74,7 +74,7 @@ struct FinArgs {
     // fsplit.hip (r04), per net: T1[n] = sum_rows g3 relu(z2)[n] (-> dW3, d gamma2) is NOT accumulated by a head kernel but derived from
     // the weight-gradient partials: relu(z2) = mask (P1 . W2' + b2'), so T1[n] = sum_f W2'[f][n] G[f][n] + b2'[n] S2[n] with
     // G = P1^T (g3 mask) (dw_kernel's raw sums), S2 = its constant-one row, W2' = inv1 (.) W2, b2' = vec[n]. finalize_w2_kernel leaves
-    // the products in t1p [n_sets][Critic::K][H2], finalize_small_kernel S2 in s2raw [n_sets][H2], finalize_t1_kernel adds them up.
+    // the products in t1p [2 nets][n_sets][Critic::K][H2], finalize_small_kernel S2 in s2raw [2][n_sets][H2], finalize_t1_kernel adds them up.
     int t1_from_g[2];
     float* t1p;
     float* s2raw;

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     constexpr bool BOTH = (MODE == HEAD_BOTH);
     constexpr bool AG = (MODE == HEAD_CONST || BOTH), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR || BOTH);
     constexpr bool PARTIALS = (MODE >= HEAD_CRITIC && MODE != OUT_TANH_SAVE);  // the modes that leave per-wave partial sums
+    constexpr bool T1H = BWD && !BOTH;  // T1 = sum_rows g3 relu(z2) accumulated here (HEAD_BOTH: derived from dw's partials, FinArgs::t1_from_g)
     static_assert(!BOTH || NET::critic, "HEAD_BOTH is a critic mode");
     __shared__ __attribute__((aligned(16))) f16 wimg[2][H2 * LD];
     __shared__ __attribute__((aligned(16))) float b2s[H2];
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #else
 #define HSTAMP(i)
 #endif
-    float T1[BWD ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f, gmax = 0.f;
+    float T1[T1H ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f, gmax = 0.f;
     // fp16 overflow watch. An activation S1 P1 >= 65520 converts to the pair (hi, lo) = (+inf, -inf), and whatever the weights,
     // w_hi inf + w_lo inf - w_hi inf is NaN in EVERY second-layer accumulator of that batch row (0 inf is NaN too): one
     // accumulator per row and sweep is looked at (bit test: the file is built with -fno-honor-nans), |bits| max-accumulated.
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         watch = watch > u ? watch : u;
     };
 #pragma unroll
-    for (int t = 0; t < (BWD ? 4 : 1); ++t)
+    for (int t = 0; t < (T1H ? 4 : 1); ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) T1[t][i] = 0.f;
     __syncthreads();
@@ -552,8 +553,10 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 4 * g + 2 * e;
-                    T1[BWD ? t : 0][i] = fmaf(g3i, BOTH ? relu(a[i]) : a[i], T1[BWD ? t : 0][i]);
-                    T1[BWD ? t : 0][i + 1] = fmaf(g3i, BOTH ? relu(a[i + 1]) : a[i + 1], T1[BWD ? t : 0][i + 1]);
+                    if (T1H) {
+                        T1[T1H ? t : 0][i] = fmaf(g3i, a[i], T1[T1H ? t : 0][i]);
+                        T1[T1H ? t : 0][i + 1] = fmaf(g3i, a[i + 1], T1[T1H ? t : 0][i + 1]);
+                    }
                     pk[g][e] = (a[i] > 0.f ? s16 : 0u) | (a[i + 1] > 0.f ? s16 << 16 : 0u);
                 }
 #pragma unroll
@@ -752,8 +755,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     bwd_t(acc[t], t, g3a * isc, g3a < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
-                    // (pin the update HERE: the optimiser otherwise sinks it below branch B and keeps relu(z2) alive across it)
-                    pin16(T1[BWD ? t : 0]);
+
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -856,13 +858,13 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     if (PARTIALS) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
         // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
-        if (BWD) {
+        if (T1H) {
             float* pt = p.part + ((long)blockIdx.x * 8 + w) * H2;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float v = T1[t][i];
+                    float v = T1[T1H ? t : 0][i];
 #pragma unroll
                     for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
                     if (r == 0) {
@@ -1536,7 +1538,7 @@ static Plan make_plan(int n_agents, int n_sets) {
     pl.sm = take(sizeof(f16) * rows * H2);   // the critic's signed masks (HEAD_BOTH)
     pl.sma = take(sizeof(f16) * rows * H2);  // the actor's unsigned masks (OUT_TANH_SAVE: written before the critic's are used)
     pl.tz = take(4 * rows);
-    pl.t1p = take(4 * (size_t)n_sets * CriticS::K * H2), pl.s2raw = take(4 * (size_t)n_sets * H2);
+    pl.t1p = take(2 * 4 * (size_t)n_sets * CriticS::K * H2), pl.s2raw = take(2 * 4 * (size_t)n_sets * H2);  // (per net)
     pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows);
     for (int i = 0; i < 2; ++i) {
         const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
@@ -1625,7 +1627,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     for (int i = 0; i < 2; ++i)
         fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = nullptr, fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
-    fa.t1_from_g[0] = 1, fa.t1_from_g[1] = 0, fa.t1p = F(pl.t1p), fa.s2raw = F(pl.s2raw);  // the actor's T1: from its weight-gradient partials
+    fa.t1_from_g[0] = fa.t1_from_g[1] = 1, fa.t1p = F(pl.t1p), fa.s2raw = F(pl.s2raw);  // T1 of both nets: from the weight-gradient partials
     if (phases & PH_CRITIC) {
         if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
             return check_launch("avd_learn_set_split: memset");
