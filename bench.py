@@ -328,9 +328,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x5, dw x2, dx x2, dxa persistent kernels + scale, prep, "
+        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x4, actor seed, dw x2, dx x2, dxa persistent kernels + scale, prep, "
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
-                                 "matrix work is 2.5x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
+                                 "matrix work is 2.2x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
                                  ("avd_learn_shared_bf16 (wide.hip, hidden >= 512: fwd_gen x4, fwd_delta, out_bwd x2, dw_gen x2, dx_gen x2 + "
                                   "row / table kernels; FLOPs priced = the chain's algorithmic GEMMs, forward x5 incl. the pass the delta kernel "
