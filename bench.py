@@ -107,7 +107,9 @@ def cpu_baseline(seconds, pl_size, mode="nofrl"):
             "updates_per_s": (tr.updates - u0) / dt,
             "sample": f"{P} platoons x {pl_size} vehicles (={P * pl_size} agents), {mode}, {n} training steps after a "
                       f"65-step replay warm-up, {dt:.1f} s on 1 thread; the per-platoon cost of the reference loop "
-                      "does not depend on the number of platoons"}
+                      "does not depend on the number of platoons",
+            "see_also": "profiles/r04_cpu_baseline_config1.txt (tools/cpu_baseline_config1.py): SURVEY 8(d)'s line -- BASELINE configs[0], 1 platoon x 3 "
+                        "vehicles, 5000 steps on one thread: 352 env-steps/s; 256 independent single-thread copies on all host cores: 7.1 k"}
 
 
 def _cpu_worker(seconds, pl_size, q, mode="nofrl"):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # LDS activity / bank conflicts of the config-5 kernels and of the gemm-like probe (same tile, same reads)
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/lds; rm -rf $OUT; mkdir -p $OUT
+[ -x $R/tools/probes/lds_dma_bw ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/tools/probes/lds_dma_bw.hip -o $R/tools/probes/lds_dma_bw  # (the binary is not tracked)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT --kernel-trace --output-format csv -d $OUT/c5 -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --mode interfrl --hidden 1024 > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT --kernel-trace --output-format csv -d $OUT/probe -o run -- $R/tools/probes/lds_dma_bw > /dev/null 2>&1

@@ -25,4 +25,6 @@ done
 cd $R
 bash tools/fsplit_pmc.sh > $OUT/${T}_fsplit_kernels_and_sq_counters.txt 2>/dev/null
 python tools/cpu_baseline_config1.py > $OUT/${T}_cpu_baseline_config1.txt 2>&1
+(python tools/determinism_engines.py 3000; python tools/determinism_engines.py 1500 10) > $OUT/${T}_determinism_of_repeated_learns.txt 2>&1
+python tools/fsplit_time.py 1000 > $OUT/${T}_fsplit_time_1000_learns.txt 2>&1
 ls -la $OUT
