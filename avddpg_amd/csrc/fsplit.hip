@@ -170,7 +170,7 @@ struct NetP {
     const f16x8* wf1h; // [sets][NGT_MAX][64] first-layer weight fragments per feature tile and lane, fp16 pairs scaled by S1 (feature K:
                        // the constant one, relu(0 x + 1): its row of dw_kernel's G is db2)
     const float* vec;  // [sets][VEC]: b2'[128] = b2 + sh1 . W2, c3[128] = inv2 * w3, d3 = b3 + sh2 . w3, SW, SWC
-    const unsigned* wap;  // [sets][2 hi/lo][2 h][3 k-steps][4] packed fp16 pairs of S1 * wa, the critic's action-layer weights (HEAD_CONST)
+    const unsigned* wap;  // [sets][2 hi/lo][2 h][3 k-steps][4] packed fp16 pairs of S1 * wa, the critic's action-layer weights (HEAD_BOTH's sweep B2)
 };
 
 // ---- pack: split first-layer input fragments of every batch row, once per learn call (+ the finiteness test) ----------
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
     }
     a.wf1h[net][((long)set * NGT_MAX + ft) * 64 + lane] = make_wh(w[0], w[1], w[2], w[3], b, S1, h);
     if (net == 1 && ft == 0 && lane < 48) {
-        // HEAD_CONST's B operand of M = W2T[:, action] . (mask_a * wa): element jj of lane half hh of action k-step ks is action
+        // HEAD_BOTH's B operand of M = W2T[:, action] . (mask_a * wa): element jj of lane half hh of action k-step ks is action
         // feature fa = 16 ks + 8 (jj >> 2) + 4 hh + (jj & 3); entry [hl][hh][ks][m] packs elements jj = 2 m, 2 m + 1
         const int hl = lane / 24, hh = (lane / 12) & 1, ks = (lane / 4) % 3, m = lane & 3;
         unsigned v = 0;
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(64) void prep1_kernel(const PrepArgs a) {
 }
 
 // ---- head: first layer -> second-layer GEMM (three MFMAs per product) -> output layer [-> its backward] -------------------
-enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_CRITIC = 2, HEAD_CONST = 3, HEAD_ACTOR = 4, HEAD_BOTH = 5, OUT_TANH_SAVE = 6 };
+// (2..4 were r03's HEAD_CRITIC / HEAD_CONST / HEAD_ACTOR: two-launch critic heads and the second actor forward, gone in r04)
+enum HeadMode { OUT_TANH = 0, OUT_TD = 1, HEAD_BOTH = 5, OUT_TANH_SAVE = 6 };
 struct HeadArgs {
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
     NetP net;
@@ -382,13 +383,12 @@ struct HeadArgs {
     const float* act;  // [n_agents][64] the critic's action input (a, a' or mu)
     const float* act2; // HEAD_BOTH: mu (act = a)
     const float* r;    // OUT_TD: rewards [n_agents][64]
-    const float* yin;  // HEAD_CRITIC / HEAD_BOTH: TD targets; HEAD_ACTOR: dmu
+    const float* yin;  // HEAD_BOTH: TD targets
     const float* aw;   // per-agent factor on the loss seeds (weighted federated mean) or NULL
     float* out;        // OUT_*: per-row result
-    f16* sm;           // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: sign(g3) * [z2 > 0] as fp16 +-1 / 0 (EXACT), [n_agents][64][128]
-    float* g3;         // HEAD_CRITIC / HEAD_BOTH / HEAD_ACTOR: the row factor of dZ2 [n_agents][64]
-    float* dmu;        // HEAD_CONST / HEAD_BOTH: dLa/dmu per row [n_agents][64]
-    float* part;       // backward modes: [grid][8 waves][128] sums T1 = sum_rows g3 * p2 per output column
+    f16* sm;           // HEAD_BOTH: sign(g3) * [z2 > 0] as fp16 +-1 / 0 (EXACT); OUT_TANH_SAVE: [z2 > 0] as 1 / 0; [n_agents][64][128]
+    float* g3;         // HEAD_BOTH: the row factor of dZ2 [n_agents][64]
+    float* dmu;        // HEAD_BOTH: dLa/dmu per row [n_agents][64]
     float* part_s;     // HEAD_*: [grid][8 waves][2] sums of the seeds and of the loss terms
     float* part_s2;    // HEAD_BOTH: the same sums of the critic(s, mu) branch (the actor loss)
     float* part_m;     // backward modes: [grid][8 waves] max |g3| over the wave's rows (dw / dx scale their fp16 operands by it)
@@ -401,34 +401,30 @@ struct HeadArgs {
 // on the matrix cores (lane = batch row, registers = features), relu, hi / lo split of the 16 values (VALU), and per k-step
 // and 32-column tile three MFMAs (A = weight fragments from LDS, B = the split activations as they stand in the registers).
 //
-// Modes: OUT_TANH (actor, mu or a'), OUT_TD (target critic -> y), HEAD_ACTOR (actor backward seeds), and for the critic either
-// HEAD_CRITIC + HEAD_CONST as two launches or HEAD_BOTH: critic(s, a) and critic(s, mu) see the same states through the
-// same weights, so 8 of their 10 first-layer tiles and 192 of their 228 second-layer MFMAs per 32 rows are the SAME work --
-// one pass over the state tiles, then the action tiles twice: branch A (input a: TD seed, masks, T1) from a copy of the
-// accumulators, branch B (input mu: the action gradient through M) in place.
+// Modes: OUT_TANH (target actor: a'), OUT_TANH_SAVE (actor: mu, + the relu masks and tanh(z) its backward pass needs), OUT_TD (target
+// critic -> y) and HEAD_BOTH: critic(s, a) and critic(s, mu) see the same states through the same weights, so 8 of their 10
+// first-layer tiles and 192 of their 228 second-layer MFMAs per 32 rows are the SAME work -- one pass over the state tiles, then
+// three sweeps over the action k-steps on the one accumulator set: A (input a: TD seed, signed masks), B1 (input mu, by
+// linearity), B2 (the action gradient through M).
 // (r04, tried: the forward-only modes with 64 rows per wave -- both row halves against every weight fragment pair, six MFMAs per
 // two LDS reads instead of three, 128 accumulator registers: OUT_TANH 190.9 us against 190, OUT_TD 220.8 against 223 on the same
 // box. Halving the LDS bytes per MFMA buys nothing: the heads are not LDS-bound. Not kept.)
-// waves per workgroup (every mode: 8 = two per SIMD at <= 256 registers)
-__host__ __device__ constexpr int head_waves(int mode) { return 8; }
 #ifndef HEAD_FAST
 #define HEAD_FAST 5
 #define HEAD_SLOW 3
 #endif
 
 template <int S, class NET, int MODE>
-__global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadArgs p) {
+__global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
     constexpr int K = NET::K, NKS = NET::NKS, NFT = NET::NFT, LD = NET::LD;  // LD/2 = 4 (mod 8) dwords: conflict-free b128
-    constexpr int NW = head_waves(MODE), NTH = 64 * NW;
+    constexpr int NTH = NT;  // 8 waves: two per SIMD at <= 256 registers
     constexpr bool BOTH = (MODE == HEAD_BOTH);
-    constexpr bool AG = (MODE == HEAD_CONST || BOTH), BWD = (MODE == HEAD_CRITIC || MODE == HEAD_ACTOR || BOTH);
-    constexpr bool PARTIALS = (MODE >= HEAD_CRITIC && MODE != OUT_TANH_SAVE);  // the modes that leave per-wave partial sums
-    constexpr bool T1H = BWD && !BOTH;  // T1 = sum_rows g3 relu(z2) accumulated here (HEAD_BOTH: derived from dw's partials, FinArgs::t1_from_g)
+    // (T1 = sum_rows g3 relu(z2) is not accumulated here: finalize derives it from dw_kernel's partials, FinArgs::t1_from_g)
     static_assert(!BOTH || NET::critic, "HEAD_BOTH is a critic mode");
     __shared__ __attribute__((aligned(16))) f16 wimg[2][H2 * LD];
     __shared__ __attribute__((aligned(16))) float b2s[H2];
     __shared__ __attribute__((aligned(16))) float c3s[H2];
-    __shared__ __attribute__((aligned(16))) unsigned waps[AG ? 48 : 4];
+    __shared__ __attribute__((aligned(16))) unsigned waps[BOTH ? 48 : 4];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, q = w >> 1, rh = w & 1;
     const int set = blockIdx.x % p.n_sets, j0 = blockIdx.x / p.n_sets, J = gridDim.x / p.n_sets, P = p.n_agents / p.n_sets;
     for (int i = tid; i < 2 * H2 * (K / 8); i += NTH) {
@@ -440,7 +436,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     // acc = SW S1 z2: the scales of the fp16 operands are folded into the f32 tables (bias in, output weights out)
     const float SW = vec[2 * H2 + 1], sc = SW * S1, isc = 1.f / sc;
     if (tid < H2) b2s[tid] = vec[tid] * sc, c3s[tid] = vec[H2 + tid] * isc;
-    if (AG && tid < 48) waps[tid] = p.net.wap[(long)set * 48 + tid];
+    if (BOTH && tid < 48) waps[tid] = p.net.wap[(long)set * 48 + tid];
     const float d3 = vec[2 * H2];
     const f16x8* wf1 = p.net.wf1h + (long)set * NGT_MAX * 64 + lane;  // + 64 ft
     const f32x16 zero16 = {};
@@ -451,7 +447,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
 #else
 #define HSTAMP(i)
 #endif
-    float T1[T1H ? 4 : 1][16], Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f, gmax = 0.f;
+    float Dacc = 0.f, Lacc = 0.f, Dacc2 = 0.f, Lacc2 = 0.f, gmax = 0.f;
     // fp16 overflow watch. An activation S1 P1 >= 65520 converts to the pair (hi, lo) = (+inf, -inf), and whatever the weights,
     // w_hi inf + w_lo inf - w_hi inf is NaN in EVERY second-layer accumulator of that batch row (0 inf is NaN too): one
     // accumulator per row and sweep is looked at (bit test: the file is built with -fno-honor-nans), |bits| max-accumulated.
@@ -462,10 +458,6 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         u &= 0x7fffffffu;
         watch = watch > u ? watch : u;
     };
-#pragma unroll
-    for (int t = 0; t < (T1H ? 4 : 1); ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T1[t][i] = 0.f;
     __syncthreads();
 
     const int ntile = j0 < P ? (P - j0 + J - 1) / J : 0;  // tiles of this workgroup: j0, j0 + J, ..
@@ -479,8 +471,8 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         if (NET::critic) na = p.act[ri];
         if (BOTH) nb = p.act2[ri];
         if (MODE == OUT_TD) ny = p.r[ri];
-        if (BWD) ny = p.yin[ri];
-        if (PARTIALS && p.aw) nw = p.aw[agent];
+        if (BOTH) ny = p.yin[ri];
+        if (BOTH && p.aw) nw = p.aw[agent];
     };
     const f16* whi0 = &wimg[0][r * LD + 8 * h];  // + 32 t LD + 16 ks
     const f16* wlo0 = &wimg[1][r * LD + 8 * h];
@@ -491,9 +483,9 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
     // and waves 4..7 20.4 k until the old ones were done, then finished alone at 61 % of the matrix pipe (s_memtime stamps, r03;
     // s_setprio does not change it). The tiles are therefore dealt FAST : SLOW per wave pair in periods of 2 (FAST + SLOW) tiles
     // -- a static map, so the grouping of the partial sums (the bits of the result) stays a function of the plan.
-    constexpr int FAST = NW == 8 ? HEAD_FAST : 1, SLOW = NW == 8 ? HEAD_SLOW : 1, PERIOD = 2 * (FAST + SLOW);
+    constexpr int FAST = HEAD_FAST, SLOW = HEAD_SLOW, PERIOD = 2 * (FAST + SLOW);
     const int qs = __builtin_amdgcn_readfirstlane(q);  // (scalar tile arithmetic)
-    const int cnt = (qs < 2 || NW != 8) ? FAST : SLOW, start = NW != 8 ? qs : (qs < 2 ? qs * FAST : 2 * FAST + (qs - 2) * SLOW);
+    const int cnt = qs < 2 ? FAST : SLOW, start = qs < 2 ? qs * FAST : 2 * FAST + (qs - 2) * SLOW;
     int k = start, pos = 0;  // the wave pair's current tile and its place in the pair's group of cnt
     auto next_tile = [&](int kk, int pp) { return pp + 1 == cnt ? kk + PERIOD - cnt + 1 : kk + 1; };
     if (k < ntile) fetch_in(k);
@@ -503,7 +495,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         const f16x8 xs = nx, xa = make_xh(na, 0.f, 0.f, 0.f, h), xb = BOTH ? make_xh(nb, 0.f, 0.f, 0.f, h) : xa;
         const float ty = ny, tw = nw;
         if (next_tile(k, pos) < ntile) fetch_in(next_tile(k, pos));
-        f32x16 acc[4], M[(AG && !BOTH) ? 4 : 1];
+        f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -511,8 +503,6 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 const float4 b = *(const float4*)(b2s + 32 * t + 8 * g + 4 * h);
                 acc[t][4 * g] = b.x, acc[t][4 * g + 1] = b.y, acc[t][4 * g + 2] = b.z, acc[t][4 * g + 3] = b.w;
             }
-#pragma unroll
-        for (int t = 0; t < ((AG && !BOTH) ? 4 : 1); ++t) M[t] = zero16;
         // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
         unsigned ph[8], pl[8];
         auto split16 = [&](const f32x16& p1) {
@@ -546,17 +536,14 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             }
             return zp;
         };
-        auto bwd_t = [&](const f32x16& a, int t, float g3i, unsigned s16, f16* dst) {  // T1 and the signed mask of tile t (a = z2 or relu(z2))
+        // the relu mask of tile t as fp16 (a = z2 or relu(z2)): s16 = 0x3c00 (+1: unsigned, OUT_TANH_SAVE) or the seed's sign, 0x3c00 / 0xbc00
+        auto mask_t = [&](const f32x16& a, int t, unsigned s16, f16* dst) {
             unsigned pk[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 4 * g + 2 * e;
-                    if (T1H) {
-                        T1[T1H ? t : 0][i] = fmaf(g3i, a[i], T1[T1H ? t : 0][i]);
-                        T1[T1H ? t : 0][i + 1] = fmaf(g3i, a[i + 1], T1[T1H ? t : 0][i + 1]);
-                    }
                     pk[g][e] = (a[i] > 0.f ? s16 : 0u) | (a[i + 1] > 0.f ? s16 << 16 : 0u);
                 }
 #pragma unroll
@@ -568,57 +555,12 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 *(uint4*)(dst + 32 * t + 16 * gg) = o;
             }
         };
-        auto mask_t = [&](const f32x16& a, int t, f16* dst) {  // the unsigned mask of tile t alone (a = relu(z2))
-            unsigned pk[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int i = 4 * g + 2 * e;
-                    pk[g][e] = (a[i] > 0.f ? 0x3c00u : 0u) | (a[i + 1] > 0.f ? 0x3c000000u : 0u);
-                }
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][0], pk[2 * gg + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gg][1], pk[2 * gg + 1][1], false, false);
-                uint4 o;
-                o.x = s0[0], o.y = s1[0], o.z = s0[1], o.w = s1[1];
-                *(uint4*)(dst + 32 * t + 16 * gg) = o;
-            }
-        };
-        auto dmu_t = [&](const f32x16& a, const f32x16& m, int t) {  // this lane's part of sum_n c3[n] [z2 > 0] M[n]
-            float sum = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 c = *(const float4*)(c3s + 32 * t + 8 * g + 4 * h);
-                const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sum += a[4 * g + j] > 0.f ? cc[j] * m[4 * g + j] : 0.f;
-            }
-            return sum;
-        };
         auto out_z = [&](f32x16 (&ac)[4]) {  // relu in place, output layer: z = d3 + sum_n c3[n] relu(z2[n])
             float zp = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) zp += zdot_t(ac[t], t);
             zp += __shfl_xor(zp, 32);
             return d3 + zp;
-        };
-        auto epi_bwd = [&](f32x16 (&ac)[4], float g3) {  // row factor, masks and T1 of a backward pass
-            if (h == 0) p.g3[ri] = g3;
-            // T1 sums g3 * relu(z2) = (g3 / (SW S1)) * relu(acc); the mask carries the sign of g3 as fp16 -1 / +1
-            gmax = fmaxf(gmax, fabsf(g3));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bwd_t(ac[t], t, g3 * isc, g3 < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
-        };
-        auto epi_dmu = [&](f32x16 (&ac)[4], float g3) {
-            // dmu[row] = g3 sum_n c3[n] [z2 > 0] M[n][row]: the lane holds 64 columns of its row, its partner the others
-            // (the accumulators hold SW S1 M -- SW from the weights, S1 from the scaled wa -- and c3s carries 1 / (SW S1))
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) sum += dmu_t(ac[t], M[AG ? t : 0], t);
-            sum += __shfl_xor(sum, 32);
-            if (h == 0) p.dmu[ri] = g3 * sum;
         };
         // ---- the tiles ---------------------------------------------------------------------------------------------------
         split16(mfmah(wf1[0], xs, zero16));
@@ -639,7 +581,6 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         auto tile = [&](auto si_c, f32x16 (&ac)[4]) {
             constexpr int si = decltype(si_c)::value;
             constexpr int ft = si;                          // feature tile
-            constexpr bool with_m = AG && !BOTH && ft >= 8;  // (HEAD_BOTH streams its action tiles after the sequence)
             // the first layer of the next tile of the sequence
             f32x16 p1n = zero16;
             if constexpr (si + 1 < NSEQ) {
@@ -652,23 +593,6 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 if (ks >= NKS) continue;  // (the critic's last tile holds only 16 features)
                 const f16x8 bhi = fragh(ph[4 * s], ph[4 * s + 1], ph[4 * s + 2], ph[4 * s + 3]);
                 const f16x8 blo = fragh(pl[4 * s], pl[4 * s + 1], pl[4 * s + 2], pl[4 * s + 3]);
-                f16x8 mhi = {}, mlo = {};
-                if constexpr (with_m) {
-                    // action features: B operand of M = mask_a * wa (hi, lo), from the packed constants and the relu'd hi
-                    // pairs (a half is non-zero exactly where the activation is positive)
-                    const int kk = ks - 16;
-                    const uint4 ch = *(const uint4*)(waps + (0 * 2 + h) * 12 + 4 * kk), cl = *(const uint4*)(waps + (1 * 2 + h) * 12 + 4 * kk);
-                    const unsigned chv[4] = {ch.x, ch.y, ch.z, ch.w}, clv[4] = {cl.x, cl.y, cl.z, cl.w};
-                    unsigned mh[4], ml[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                        const u16x2 v = __builtin_bit_cast(u16x2, ph[4 * s + m]), one = {1, 1}, z2 = {0, 0};
-                        const unsigned mask = __builtin_bit_cast(unsigned, (u16x2)(z2 - __builtin_elementwise_min(v, one)));
-                        mh[m] = chv[m] & mask, ml[m] = clv[m] & mask;
-                    }
-                    mhi = fragh(mh[0], mh[1], mh[2], mh[3]), mlo = fragh(ml[0], ml[1], ml[2], ml[3]);
-                }
 #pragma unroll
                 for (int th = 0; th < 2; ++th) {
                     const int g = 2 * ks + th;
@@ -680,11 +604,6 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                         ac[t] = mfmah(whi, bhi, ac[t]);
                         ac[t] = mfmah(wlo, bhi, ac[t]);
                         ac[t] = mfmah(whi, blo, ac[t]);
-                        if constexpr (with_m) {
-                            M[t] = mfmah(whi, mhi, M[t]);
-                            M[t] = mfmah(wlo, mhi, M[t]);
-                            M[t] = mfmah(whi, mlo, M[t]);
-                        }
                     }
                 }
             }
@@ -696,7 +615,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             for (int gi = 0; gi < 4; ++gi) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int i = 0; i < (with_m ? 12 : 6); ++i) {
+                for (int i = 0; i < 6; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 }
@@ -754,8 +673,7 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
                 gmax = fmaxf(gmax, fabsf(g3a));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    bwd_t(acc[t], t, g3a * isc, g3a < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
-
+                    mask_t(acc[t], t, g3a < 0.f ? 0xbc00u : 0x3c00u, p.sm + ri * H2 + 8 * h);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -826,23 +744,9 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
             const float t = tanhf(z);
             if (h == 0) p.out[ri] = t * p.high, p.tz[ri] = t;
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) mask_t(acc[tt], tt, p.sm + ri * H2 + 8 * h);
-        } else if (MODE == OUT_TD) {
+            for (int tt = 0; tt < 4; ++tt) mask_t(acc[tt], tt, 0x3c00u, p.sm + ri * H2 + 8 * h);
+        } else {  // OUT_TD
             if (h == 0) p.out[ri] = ty + p.gamma * z;
-        } else {
-            float g3, loss;
-            if (MODE == HEAD_CRITIC) {
-                const float diff = z - ty;
-                g3 = 2.f * diff * p.inv_n * tw, loss = diff * diff;
-            } else if (MODE == HEAD_CONST) {
-                g3 = -p.inv_n * tw, loss = z;
-            } else {
-                const float t = tanhf(z);
-                g3 = ty * p.high * (1.f - t * t), loss = 0.f;
-            }
-            if (AG) epi_dmu(acc, g3);
-            else epi_bwd(acc, g3);
-            if (h == 0) Dacc += g3, Lacc += loss;
         }
         HSTAMP(2);  // epilogue
 #ifdef AVD_STAMP
@@ -855,43 +759,20 @@ __global__ __launch_bounds__(64 * head_waves(MODE)) void head_kernel(const HeadA
         for (int i = 0; i < 4; ++i) p.stamp[w * 8 + i] = hacc[i];
 #endif
     if (watch >= 0x7f800000u) atomicOr(p.bad, 1);
-    if (PARTIALS) {
+    if (BOTH) {
         // one partial per wave: sums over the 32 row lanes of each half (fixed shuffle tree), one writer per half
-        // (the partial buffers have 8 wave slots per workgroup: a 4-wave mode zeroes the other four)
-        if (T1H) {
-            float* pt = p.part + ((long)blockIdx.x * 8 + w) * H2;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = T1[T1H ? t : 0][i];
-#pragma unroll
-                    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
-                    if (r == 0) {
-                        pt[32 * t + acc_row(i, h)] = v;
-                        if (NW == 4) pt[4 * H2 + 32 * t + acc_row(i, h)] = 0.f;
-                    }
-                }
-        }
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
-            Dacc += __shfl_xor(Dacc, o);
-            Lacc += __shfl_xor(Lacc, o);
-            if (BOTH) Dacc2 += __shfl_xor(Dacc2, o), Lacc2 += __shfl_xor(Lacc2, o);
+            Dacc += __shfl_xor(Dacc, o), Lacc += __shfl_xor(Lacc, o);
+            Dacc2 += __shfl_xor(Dacc2, o), Lacc2 += __shfl_xor(Lacc2, o);
         }
-        if (BWD) {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
-            if (lane == 0) p.part_m[(long)blockIdx.x * 8 + w] = gmax;
-        }
+        for (int o = 1; o < 64; o <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
         if (lane == 0) {
-            p.part_s[((long)blockIdx.x * 8 + w) * 2] = Dacc;
-            p.part_s[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc;
-            if (BOTH) p.part_s2[((long)blockIdx.x * 8 + w) * 2] = Dacc2, p.part_s2[((long)blockIdx.x * 8 + w) * 2 + 1] = Lacc2;
-            if (NW == 4) {
-                p.part_s[((long)blockIdx.x * 8 + w + 4) * 2] = 0.f, p.part_s[((long)blockIdx.x * 8 + w + 4) * 2 + 1] = 0.f;
-                if (BOTH) p.part_s2[((long)blockIdx.x * 8 + w + 4) * 2] = 0.f, p.part_s2[((long)blockIdx.x * 8 + w + 4) * 2 + 1] = 0.f;
-            }
+            const long slot = (long)blockIdx.x * 8 + w;
+            p.part_m[slot] = gmax;
+            p.part_s[slot * 2] = Dacc, p.part_s[slot * 2 + 1] = Lacc;
+            p.part_s2[slot * 2] = Dacc2, p.part_s2[slot * 2 + 1] = Lacc2;
         }
     }
 }
@@ -1508,7 +1389,7 @@ __global__ __launch_bounds__(NT) void dxa_kernel(const DxArgs p) {
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct Plan {
     int grid, J;
-    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, sma, tz, t1p, s2raw, xfs, xfs2, partH[2], partHs[3], partM[2],
+    size_t Whi[4], Wlo[4], Wchi[2], Wclo[2], wf1h[4], vec[4], wap, a2, y, mu, dmu, g3, sm, sma, tz, t1p, s2raw, xfs, xfs2, partHs[3], partM[2],
         partV[2], partG[2], bad, total;
 };
 static Plan make_plan(int n_agents, int n_sets) {
@@ -1542,7 +1423,6 @@ static Plan make_plan(int n_agents, int n_sets) {
     pl.xfs = take(32 * rows), pl.xfs2 = take(32 * rows);
     for (int i = 0; i < 2; ++i) {
         const int KP = i ? CriticS::KP : ActorS::KP, KG = i ? CriticS::KG : ActorS::KG;
-        pl.partH[i] = take(4 * (size_t)pl.grid * 8 * H2);
         pl.partM[i] = take(4 * (size_t)pl.grid * 8);
         pl.partV[i] = take(4 * (size_t)pl.grid * KP * 16);
         pl.partG[i] = take(4 * (size_t)pl.grid * KG * H2);
@@ -1602,12 +1482,9 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
     h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr, h.tz = F(pl.tz);
-    int head_threads = NT;
-    auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part,
-                    float* part_s) {
-        h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part = part, h.part_s = part_s;
-        hipLaunchKernelGGL(kern, grid, dim3(head_threads), 0, st, h);
-        head_threads = NT;
+    auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part_s) {
+        h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part_s = part_s;
+        hipLaunchKernelGGL(kern, grid, block, 0, st, h);
     };
     DwArgs dw;
     dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr;
@@ -1625,7 +1502,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     fa.L = L, fa.n_sets = n_sets, fa.J = pl.J, fa.S = S, fa.nrh = 1, fa.theta = theta, fa.stats = stats, fa.grads = grads, fa.losses = losses;
     fa.inv_n = inv_n, fa.partLa = F(pl.partHs[2]), fa.bad = bad;
     for (int i = 0; i < 2; ++i)
-        fa.partH[i] = F(pl.partH[i]), fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = nullptr, fa.partV[i] = F(pl.partV[i]),
+        fa.partH[i] = nullptr, fa.partHs[i] = F(pl.partHs[i]), fa.partU[i] = nullptr, fa.partV[i] = F(pl.partV[i]),
         fa.partG[i] = F(pl.partG[i]), fa.c3[i] = F(pl.vec[i]);
     fa.t1_from_g[0] = fa.t1_from_g[1] = 1, fa.t1p = F(pl.t1p), fa.s2raw = F(pl.s2raw);  // T1 of both nets: from the weight-gradient partials
     if (phases & PH_CRITIC) {
@@ -1637,16 +1514,15 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, true, nrows, xfs, bad);
         hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, false, nrows, xfs2, bad);
         // 1-2: targets
-        head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr, nullptr);
-        head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr, nullptr);
+        head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr);
+        head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr);
         // 3: mu -- and the actor's relu masks + tanh(z) for its backward pass (no second actor forward: r03's HEAD_ACTOR)
         h.sm = sma;
-        head(head_kernel<S, ActorS, OUT_TANH_SAVE>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr, nullptr);
+        head(head_kernel<S, ActorS, OUT_TANH_SAVE>, 0, xfs, nullptr, nullptr, nullptr, mu, nullptr);
         h.sm = sm;
         // 4-7: critic loss and gradients; critic(s, mu) and the action gradient ride in the same launch (HEAD_BOTH)
         h.act2 = mu, h.part_s2 = F(pl.partHs[2]), h.part_m = F(pl.partM[1]);
-        head_threads = 64 * head_waves(HEAD_BOTH);
-        head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partH[1]), F(pl.partHs[1]));
+        head(head_kernel<S, CriticS, HEAD_BOTH>, 1, xfs, a, nullptr, y, nullptr, F(pl.partHs[1]));
         dw.net = net[1], dw.act = a, dw.partG = F(pl.partG[1]), dw.part_m = F(pl.partM[1]);
         hipLaunchKernelGGL((dw_kernel<S, CriticS>), grid, block, 0, st, dw);
         dx.net = net[1], dx.partV = F(pl.partV[1]), dx.act = a, dx.part_m = F(pl.partM[1]);
