@@ -679,6 +679,17 @@ struct UpdArgs {
     float* act_out;
 };
 
+// cen.hip: learn_kernel_c, the centralized framework's shapes (H1 / H2 / Ha = 320 / 160 / 64, (S, A) = (12, 3) or (20, 5)): gradients
+// out (avd_learn_f32's contract) and the whole update (avd_learn_update_f32's: learn chunks and their Adam + Polyak passes on two streams)
+bool cen_supports(const avd_mlp_layout* lay);
+int cen_launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats, const float* theta_t,
+               const float* stats_t, const float* s, const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
+               float* losses, void* stream);
+int cen_launch_update(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats, float* theta_out, float* theta_t,
+                      float* stats_t, float* m, float* v, const int32_t* step, const float* s, const float* a, const float* r,
+                      const float* s2, float gamma, float high, float actor_lr, float critic_lr, double tau, float* grads, float* losses,
+                      void* stream);
+
 // lean.hip: learn_kernel_l (two workgroups per CU; layer-1 activations recomputed on the fly). Same contract as
 // fast::launch in mlp.hip; the reference widths 256/128/48 with S in {3, 4} only.
 int lean_launch(const avd_mlp_layout* lay, bool fused, int n_agents, int set_mod, const float* theta, const float* stats,

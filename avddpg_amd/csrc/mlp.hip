@@ -475,6 +475,7 @@ __global__ __launch_bounds__(NTHREADS) void learn_kernel_g(avd_mlp_layout L, int
             l1_grads(LDSP(l.sX), S, LDSP(l.bufA), ldA, 0, H1, GLBP(ga + L.aW1), GLBP(ga + L.ab1));
             PH(19);
         }
+        lds_barrier();  // (the next pass's first layer overwrites bufA while slower waves may still read dz1 from it)
     }
 }
 
@@ -1634,6 +1635,9 @@ extern "C" int avd_learn_f32(const avd_mlp_layout* lay, int n_agents, int set_mo
                                                     (float*)stats_t, s, a, r, s2, gamma, high, grads, losses, none,
                                                     stream);
     }
+    // the centralized framework's shapes (S = 4 L, A = L, widths x 1.2) at L = 3 / 5: their own eight-wave kernel (cen.hip)
+    if (cen_supports(lay) && !AVD_DIAG_ENV("LEARN_GENERAL"))
+        return cen_launch(lay, n_agents, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, stream);
     const size_t lds = sizeof(float) * gen::lds_floats(*lay);
     if (lds > 160 * 1024) {
         set_error("avd_learn_f32: S=%d A=%d H1=%d H2=%d Ha=%d need %zu B of LDS per 64-row tile (> 160 KiB)", lay->S,
@@ -1716,6 +1720,14 @@ static int learn_update_impl(const avd_mlp_layout* lay, int n_agents, const floa
             return AVD_E_LAUNCH;
         }
         const UpdArgs updg = {theta_out, m, v, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau), nullptr, 0, nullptr};
+        if (cen_supports(lay) && !AVD_DIAG_ENV("LEARN_GENERAL")) {
+            // the centralized shapes: chunked learn + whole-row Adam / Polyak passes on two streams (cen.hip)
+            rc = cen_launch_update(lay, n_agents, theta, stats, theta_out, theta_t, stats_t, m, v, step, s, a, r, s2, gamma, high, actor_lr,
+                                   critic_lr, tau, grads_scratch, losses, stream);
+            if (rc || !next_action) return rc;
+            return launch_rows(lay, 0, n_agents, 0, theta_out, stats, next_state, x_stride, nullptr, high, next_action, stream,
+                               "avd_learn_update_act_f32(actor)");
+        }
         hipLaunchKernelGGL(gen::learn_kernel_g<true>, dim3(n_agents), dim3(NTHREADS), lds, (hipStream_t)stream, *lay, 0, theta,
                            stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads_scratch, losses, updg);
         rc = check_launch("avd_learn_update_f32 (general)");

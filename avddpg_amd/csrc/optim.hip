@@ -98,6 +98,57 @@ __global__ __launch_bounds__(256) void adam_polyak_ranges_kernel(int theta_size,
     }
 }
 
+// The same update of WHOLE slab rows, theta_in -> theta_out, as a small persistent grid: workgroup b walks rows b, b + gridDim.x, ..
+// with AR_UNR float4 groups of each of the five arrays in flight per thread. Made to run BESIDE a compute kernel that holds every CU's
+// LDS (cen.hip: the centralized learn kernel's chunks): a few hundred long-lived workgroups -- one or two per CU, ~100 registers -- keep
+// HBM busy without flooding each CU's wave slots and memory queue the way the row-per-blockIdx.y grid above does.
+constexpr int AR_UNR = 4;
+__global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, int actor_size, int n_sets,
+                                                               const float4* __restrict__ theta_in, float4* __restrict__ theta_out,
+                                                               float4* __restrict__ theta_t, float4* __restrict__ m,
+                                                               float4* __restrict__ v, const float4* __restrict__ grads,
+                                                               const int32_t* __restrict__ step, float actor_lr, float critic_lr,
+                                                               float tau, float omt) {
+#pragma clang fp contract(off)
+    const int n4 = theta_size / 4;
+    for (int set = blockIdx.x; set < n_sets; set += gridDim.x) {
+        const int t = step[set];
+        const float b1p = (float)pow((double)ADAM_B1, (double)t);
+        const float b2p = (float)pow((double)ADAM_B2, (double)t);
+        const float root = sqrtf(1.0f - b2p);
+        const float alpha_a = (actor_lr * root) / (1.0f - b1p);
+        const float alpha_c = (critic_lr * root) / (1.0f - b1p);
+        const long base = (long)set * n4;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * AR_UNR) {
+            float4 w[AR_UNR], wt[AR_UNR], mm[AR_UNR], vv[AR_UNR], g[AR_UNR];
+#pragma unroll
+            for (int u = 0; u < AR_UNR; ++u) {
+                const int i = min(i0 + 256 * u, n4 - 1);
+                w[u] = theta_in[base + i], wt[u] = theta_t[base + i], mm[u] = m[base + i], vv[u] = v[base + i], g[u] = grads[base + i];
+            }
+#pragma unroll
+            for (int u = 0; u < AR_UNR; ++u) {
+                const int i = i0 + 256 * u;
+                if (i >= n4) break;
+                const float alpha = (i * 4 < actor_size) ? alpha_a : alpha_c;
+                float* wp = &w[u].x;
+                float* tp = &wt[u].x;
+                float* mp = &mm[u].x;
+                float* vp = &vv[u].x;
+                const float* gp = &g[u].x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    mp[k] = mp[k] + (gp[k] - mp[k]) * (1.0f - ADAM_B1);
+                    vp[k] = vp[k] + (gp[k] * gp[k] - vp[k]) * (1.0f - ADAM_B2);
+                    wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
+                    tp[k] = wp[k] * tau + tp[k] * omt;
+                }
+                theta_out[base + i] = w[u], theta_t[base + i] = wt[u], m[base + i] = mm[u], v[base + i] = vv[u];
+            }
+        }
+    }
+}
+
 __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __restrict__ t, float tau, float omt) {
 #pragma clang fp contract(off)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -214,6 +265,16 @@ int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float
                        (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau),
                        skip_a0, skip_a1, skip_c0, skip_c1);
     return check_launch("avd_learn_update_f32(small tensors)");
+}
+
+int launch_adam_polyak_rows(const avd_mlp_layout* lay, int n_sets, int n_groups, const float* theta_in, float* theta_out, float* theta_t,
+                            float* m, float* v, const float* grads, const int32_t* step, float actor_lr, float critic_lr, double tau,
+                            void* stream) {
+    AVD_REQUIRE(lay->theta_size % 4 == 0 && lay->actor_size % 4 == 0 && n_groups > 0, "launch_adam_polyak_rows: layout not 4-float aligned");
+    hipLaunchKernelGGL(adam_polyak_rows_kernel, dim3(n_groups < n_sets ? n_groups : n_sets), dim3(256), 0, (hipStream_t)stream,
+                       lay->theta_size, lay->actor_size, n_sets, (const float4*)theta_in, (float4*)theta_out, (float4*)theta_t, (float4*)m,
+                       (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, (float)tau, (float)(1.0 - tau));
+    return check_launch("avd_learn_update_f32(update pass)");
 }
 
 extern "C" int avd_polyak_f32(int64_t n, const float* w, float* t, double tau, void* stream) {

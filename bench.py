@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=None,
                     help="actor/critic layer1 = layer2 size (BASELINE config 5: 1024; needs --mode interfrl)")
     ap.add_argument("--framework", choices=["decentralized", "centralized"], default="decentralized",
-                    help="centralized: one model per platoon with S = 4L, A = L, widths x1.2 (SURVEY 8 f-3; general learn kernel)")
+                    help="centralized: one model per platoon with S = 4L, A = L, widths x1.2 (SURVEY 8 f-3; cen.hip / general learn kernel)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
     ap.add_argument("--no-fused", action="store_true",
@@ -311,7 +311,13 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     # learn_kernel_l<fused> updates the small tensors itself (one launch); learn_kernel_t leaves them to a second kernel
     fused_name = lk + "<fused>" + ("" if lk == "learn_kernel_l" else " + adam_polyak_ranges_kernel")
     if args.framework != "decentralized":
-        lk, fused_name = "gen::learn_kernel_g", "gen::learn_kernel_g<fused> + adam_polyak_ranges_kernel"
+        # widths x 1.2 at L = 3 / 5: cen.hip (eight-wave kernel; the update as chunked learn kernels in the caller's stream and their
+        # whole-row Adam + Polyak passes on a side stream); any other centralized shape: the general kernel
+        lay_ = vt.agents.lay  # (padded widths)
+        if (lay_.H1, lay_.H2, lay_.Ha) == (320, 160, 64) and (lay_.S, lay_.A) in ((12, 3), (20, 5)):
+            lk, fused_name = "cen::learn_kernel_c", "cen::learn_kernel_c x16 chunks || adam_polyak_rows_kernel (two streams)"
+        else:
+            lk, fused_name = "gen::learn_kernel_g", "gen::learn_kernel_g<fused> + adam_polyak_ranges_kernel"
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
@@ -429,6 +435,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
                       "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
                      if (fused and getattr(vt, "_act_ready", False)) else
+                     ("avd_learn_update_f32 -> cen.hip: the agents in chunks of 256; chunk c's learn kernel (cen::learn_kernel_c, in the "
+                      "caller's stream) is followed by its whole-row Adam + Polyak pass (adam_polyak_rows_kernel, a side stream) under chunk "
+                      "c + 1's learn kernel") if (fused and lk == "cen::learn_kernel_c") else
                      f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
                      (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
                       "summed kernel durations and overlap") if (mode == "nofrl" and args.chunks > 1) else

@@ -352,6 +352,81 @@ def test_centralized_shapes_forward_and_learn(L):
         assert np.all(gh[v, lay.ag1 + 307:lay.ag1 + 320] == 0) and np.all(gh[v, lay.abe2 + 153:lay.abe2 + 160] == 0)
 
 
+def _central_batches(n_agents, S, A, seed):
+    rs = np.random.RandomState(seed)
+    s = rs.normal(0, 1.5, size=(n_agents, 64, S)).astype(np.float32)
+    a = rs.uniform(-2.5, 2.5, size=(n_agents, 64, A)).astype(np.float32)
+    r = -np.abs(rs.normal(0, 0.3, size=(n_agents, 64))).astype(np.float32)
+    s2 = rs.normal(0, 1.5, size=(n_agents, 64, S)).astype(np.float32)
+    return t(s), t(a), t(r), t(s2)
+
+
+@pytest.mark.parametrize("L", [3, 5])
+def test_centralized_kernel_agrees_with_the_general_kernel(L, monkeypatch):
+    """cen::learn_kernel_c (csrc/cen.hip: the centralized shapes' own eight-wave kernel, the shipped path of avd_learn_f32 at
+    S = 4 L, A = L, widths x 1.2) against gen::learn_kernel_g (mlp.hip) on the same inputs -- the diagnostic build's
+    AVD_LEARN_GENERAL=1 routes the same call to the general kernel. Same algorithm, different summation orders: every gradient tensor
+    within 3e-6 of its max (both sit ~1e-6 from the float64 oracle, test_centralized_shapes_forward_and_learn), losses within 1e-6."""
+    need_gpu()
+    from avddpg_amd import _hip
+
+    n_agents, S, A = 7, 4 * L, L
+    batches = _central_batches(n_agents, S, A, seed=50 + L)
+    got = {}
+    for which in ("cen", "gen"):
+        conf, grp = _perturbed_group(n_agents, S=S, A=A, hidd_mult=1.2, seed=43)
+        losses = torch.zeros(n_agents, 2, device="cuda")
+        if which == "gen":
+            monkeypatch.setenv("AVD_LEARN_GENERAL", "1")
+            with _hip.diag_library():
+                g = grp.learn(*batches, 0, losses=losses)
+                torch.cuda.synchronize()
+            monkeypatch.delenv("AVD_LEARN_GENERAL")
+        else:
+            g = grp.learn(*batches, 0, losses=losses)
+        got[which] = (g.cpu().numpy(), losses.cpu().numpy(), grp)
+    (gc, lc, grp), (gg, lg, _) = got["cen"], got["gen"]
+    assert not np.array_equal(gc, gg)  # (two kernels did run)
+    assert np.allclose(lc, lg, rtol=1e-6, atol=1e-7)
+    for v in range(n_agents):
+        for x, y in zip(sum(grp.grads_as_lists(torch.from_numpy(gc[v])), []), sum(grp.grads_as_lists(torch.from_numpy(gg[v])), [])):
+            assert _relerr(np.asarray(x), np.asarray(y)) <= 3e-6
+    # shared weight sets (set_mod > 0: several agents read one set) take the same kernel: agent v reads set v % 2
+    conf, grp = _perturbed_group(2, S=S, A=A, hidd_mult=1.2, seed=43)
+    b6 = _central_batches(6, S, A, seed=60)
+    g6 = grp.learn(*b6, 2)
+    for v in (0, 2, 4):  # alone in a launch of one agent, set_mod = 0, the same batch reads set 0 as well
+        g1 = grp.learn(*[x[v:v + 1].contiguous() for x in b6], 0)
+        assert torch.equal(g1[0], g6[v])
+    assert not torch.equal(g6[0], g6[1])
+
+
+def test_centralized_update_in_chunks_on_two_streams_is_learn_then_adam_bit_for_bit():
+    """avd_learn_update_f32 at the centralized shapes cuts the agents into chunks of 256: chunk c's learn kernel in the caller's stream,
+    its whole-row Adam + Polyak pass on a side stream under chunk c + 1's learn kernel (csrc/cen.hip cen_launch_update). 700 models =
+    three chunks (the last one ragged): weights, targets, BN statistics' soft update and moments are exactly those of avd_learn_f32 +
+    avd_adam_polyak_f32, three updates in a row (theta ping-pong), and a repeat of the whole sequence gives the same bits (the
+    two-stream schedule does not leak into the result)."""
+    need_gpu()
+    n_agents, S, A = 700, 20, 5
+    runs = []
+    for mode in ("update", "update", "separate"):
+        conf, grp = _perturbed_group(n_agents, S=S, A=A, hidd_mult=1.2, seed=47)
+        losses = torch.zeros(n_agents, 2, device="cuda")
+        scratch = torch.empty(n_agents, grp.lay.theta_size, device="cuda")
+        for k in range(3):
+            b = _central_batches(n_agents, S, A, seed=70 + k)
+            if mode == "update":
+                grp.learn_update(*b, scratch, losses=losses)
+            else:
+                grp.apply(grp.learn(*b, 0, losses=losses))
+        torch.cuda.synchronize()
+        runs.append([x.clone() for x in (grp.theta, grp.theta_t, grp.stats_t, grp.m, grp.v, losses)])
+    for x, y, z in zip(*runs):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert not torch.equal(runs[0][0], _perturbed_group(n_agents, S=S, A=A, hidd_mult=1.2, seed=47)[1].theta)
+
+
 def test_learn_update_next_action_epilogue_and_conditional_actor():
     """avd_learn_update_act_f32: next_action = actor(next_state) with the updated weights, bit-identical to the actor
     launch on the updated slab; avd_actor_forward_cond_f32 runs only when its device flag is non-zero."""

@@ -13,7 +13,7 @@ import torch
 
 from avddpg_amd import _hip
 
-_hip.LIB_PATH = os.path.join(ROOT, "avddpg_amd", "lib", "libavddpg_hip_phase.so")  # tools/build_phase_lib.sh
+_hip.LIB_PATH = os.environ.get("AVD_PHASE_LIB", os.path.join(ROOT, "avddpg_amd", "lib", "libavddpg_hip_phase.so"))  # tools/build_phase_lib.sh
 from avddpg_amd import config, vec
 
 NAMES = {0: "stage batch", 1: "actor L1 (VALU) + bn coefs", 2: "actor L2 GEMM fwd", 3: "actor out layer",
@@ -27,7 +27,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 FUSED = len(sys.argv) > 2 and sys.argv[2] in ("fused", "lean-fused")
 LEAN = len(sys.argv) > 2 and sys.argv[2].startswith("lean")  # learn_kernel_l (lean.hip); else learn_kernel_t
 os.environ["AVD_LEARN_KERNEL"] = "lean" if LEAN else "fast"
-CENTRAL = len(sys.argv) > 2 and sys.argv[2] == "centralized"  # general kernel at S = 20, A = 5, widths x1.2
+CENTRAL = len(sys.argv) > 2 and sys.argv[2].startswith("centralized")  # S = 20, A = 5, widths x1.2: cen::learn_kernel_c
+FUSED = FUSED or (len(sys.argv) > 2 and sys.argv[2].endswith("-fused"))
+if len(sys.argv) > 2 and "general" in sys.argv[2]:  # "centralized-general[-fused]": gen::learn_kernel_g on the same shape
+    os.environ["AVD_LEARN_GENERAL"] = "1"
 conf = config.Config()
 S, A = (20, 5) if CENTRAL else (4, 1)
 grp = vec.AgentGroup(n, S, A, conf, hidd_mult=1.2 if CENTRAL else 1.0)
@@ -35,6 +38,8 @@ f = lambda *s: torch.randn(*s, device="cuda")
 s, a, r, s2 = f(n, 64, S), f(n, 64, A), f(n, 64), f(n, 64, S)
 lib = _hip.lib()
 dbg = lib.avd_debug_phase_cycles_lean if LEAN else lib.avd_debug_phase_cycles
+if CENTRAL and "general" not in sys.argv[2]:
+    dbg = lib.avd_debug_phase_cycles_cen
 dbg.argtypes = [ctypes.c_void_p, ctypes.c_int]
 gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
 run = (lambda: grp.learn_update(s, a, r, s2, gscr)) if FUSED else (lambda: grp.learn(s, a, r, s2, 0))
@@ -52,7 +57,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 dbg(buf, 0)
-tot = sum(buf[:30])
+tot = sum(buf[:24])
 if buf[31]:  # learn_kernel_l stamps its lifetime with both counters: the clock the chip held while it ran
     print(f"in-kernel clock = {100e6 * buf[30] / buf[31] / 1e9:.3f} GHz (sum of s_memtime / sum of s_memrealtime x 100 MHz over all workgroups)")
     print(f"workgroup lifetime = {buf[30] / (3 * n):.0f} cyc/tile = {buf[31] / (3 * n) / 100:.1f} us/tile "
@@ -65,5 +70,8 @@ if LEAN:
                   10: "-", 11: "-", 17: "actor dW2 + dX (+update)", 18: "-", 19: "-"})
 if CENTRAL:  # the general kernel stamps its first-layer pieces under these ids (and they are NOT part of phases 1 / 4)
     NAMES.update({20: "stage state batch", 21: "actor first layer", 22: "critic first layer (state)", 23: "critic first layer (action)"})
-for i in range(24):
+if CENTRAL and "general" not in sys.argv[2]:
+    NAMES.update({24: "  fwd GEMMs: to the end of k-block 0", 25: "  fwd GEMMs: k-blocks 1 .. NB/2", 26: "  fwd GEMMs: k-blocks NB/2+1 .. NB-1",
+                  27: "  fwd GEMMs: epilogue"})
+for i in range(28 if CENTRAL else 24):
     print(f"{i:2d} {NAMES[i]:38s} {buf[i] / (3 * n):9.0f} cyc/tile  {100 * buf[i] / tot:5.1f}%")
