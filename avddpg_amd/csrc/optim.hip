@@ -101,8 +101,14 @@ __global__ __launch_bounds__(256) void adam_polyak_ranges_kernel(int theta_size,
 // The same update of WHOLE slab rows, theta_in -> theta_out, as a small persistent grid: workgroup b walks rows b, b + gridDim.x, ..
 // with AR_UNR float4 groups of each of the five arrays in flight per thread. Made to run BESIDE a compute kernel that holds every CU's
 // LDS (cen.hip: the centralized learn kernel's chunks): a few hundred long-lived workgroups -- one or two per CU, ~100 registers -- keep
-// HBM busy without flooding each CU's wave slots and memory queue the way the row-per-blockIdx.y grid above does.
-constexpr int AR_UNR = 4;
+// HBM busy without flooding each CU's wave slots and memory queue the way the row-per-blockIdx.y grid above does. Every access is
+// non-temporal: the rows stream through once, and without the hint they evict the weights the learn workgroups keep re-reading
+// (4096 x 5 centralized, same box: 7.29 -> 6.68 ms per step).
+#ifndef AR_UNR_N
+#define AR_UNR_N 4
+#endif
+constexpr int AR_UNR = AR_UNR_N;
+typedef float v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, int actor_size, int n_sets,
                                                                const float4* __restrict__ theta_in, float4* __restrict__ theta_out,
                                                                float4* __restrict__ theta_t, float4* __restrict__ m,
@@ -124,7 +130,9 @@ __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, i
 #pragma unroll
             for (int u = 0; u < AR_UNR; ++u) {
                 const int i = min(i0 + 256 * u, n4 - 1);
-                w[u] = theta_in[base + i], wt[u] = theta_t[base + i], mm[u] = m[base + i], vv[u] = v[base + i], g[u] = grads[base + i];
+#define NTL(p) ({ const v4f t_ = __builtin_nontemporal_load((const v4f*)(p)); make_float4(t_[0], t_[1], t_[2], t_[3]); })
+                w[u] = NTL(theta_in + base + i), wt[u] = NTL(theta_t + base + i), mm[u] = NTL(m + base + i), vv[u] = NTL(v + base + i);
+                g[u] = NTL(grads + base + i);
             }
 #pragma unroll
             for (int u = 0; u < AR_UNR; ++u) {
@@ -143,7 +151,8 @@ __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, i
                     wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
                     tp[k] = wp[k] * tau + tp[k] * omt;
                 }
-                theta_out[base + i] = w[u], theta_t[base + i] = wt[u], m[base + i] = mm[u], v[base + i] = vv[u];
+#define NTS(val_, p) __builtin_nontemporal_store((v4f){(val_).x, (val_).y, (val_).z, (val_).w}, (v4f*)(p))
+                NTS(w[u], theta_out + base + i), NTS(wt[u], theta_t + base + i), NTS(mm[u], m + base + i), NTS(vv[u], v + base + i);
             }
         }
     }

@@ -4,7 +4,7 @@ passes relative to the first launch (do they overlap?). usage: cen_trace.py <ker
 import csv
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "learn_kernel_c" in r["Kernel_Name"] or "adam_polyak_ranges" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "learn_kernel_c" in r["Kernel_Name"] or "adam_polyak_r" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 rows = rows[-n:]  # the last update(s)
