@@ -118,97 +118,86 @@ __device__ __forceinline__ void coefs_b(const float* __restrict__ g, const float
 }
 
 // hidden layer forward: out[r][n] = relu(sum_k bn(X[r][k]) W[k][n] + b[n]), X [64][LDA] and out [64][LDB] in LDS, W global [K][160].
-// Wave w: rows 16 (w & 3) .., columns 80 (w >> 2) .. + 80 as five 16-column tiles: tiles 0..3 hold columns 4 lr + t of the wave's
-// first 64 (one 16-byte load per weight row feeds four tiles, one 16-byte LDS write stores four), tile 4 columns 64 + lr. The weights
-// of a 16-deep k-block (four rows per lane) are requested three blocks before the MFMAs that use them.
-// (r04, tried: 96 + 64 columns for the older / younger wave of a SIMD -- oldest-first arbitration leaves waves 4..7 behind, 5 k of
-// 44 k cycles per call are spent waiting for them -- costs 12 registers, i.e. a co-resident update wave, and gains nothing: the
-// steady state is ~1.9 k cycles per k-block for 1.28 k of MFMA either way; a ring of 6 or 8 blocks does not change it either.)
+// Wave w: rows 32 (w & 1) .. + 32 (two row tiles against every weight operand) and one of four column groups, 160 = 48 + 48 + 32 + 32:
+// waves 0..3 (the older wave of each SIMD) take the 48-column groups, waves 4..7 the 32-column ones -- 24 : 16 MFMAs per k-block, the
+// younger wave's 16 fit into the older one's load / operand stage. Tile t of a wave holds columns c0 + NTL lr + t: one 12- or 8-byte
+// load per weight row, one such LDS write per output row. The weights of a 16-deep k-block (four rows per lane) are requested three
+// blocks before the MFMAs that use them; the LDS operand of a block is READ one block ahead and turned into the MFMA operand
+// (x inv + sh) at the head of its own MFMA stage.
+// Fully unrolled, two pinned stages per k-block: [weight loads three blocks ahead + the next block's LDS reads] | [MFMAs]. Without the
+// sched_barriers hipcc sinks every load down to its first use (one load in flight: the ring prefetches nothing), and as a loop over
+// groups of RING blocks it drains the ring on the back-edge (mlp.hip fast::gemm_fwd).
+// (r04, the first plan: 16 rows x 80 columns per wave, five tiles. 44 k cycles per actor call for 25.6 k of MFMA, ~1.6 k per k-block
+// in the steady state; a ring of 6 or 8 blocks changed nothing, 96 + 64 columns for the older / younger wave neither; with the weight
+// loads ablated the loop ran at 1.283 k per k-block, the matrix pipe's rate -- the cost was every weight being fetched by the four
+// waves that shared its columns. 32 rows per wave halve the loads per MFMA: 33 k cycles per call, and 13 registers fewer.)
 #ifndef CEN_RING
 #define CEN_RING 4
 #endif
 template <int K, int NTL>
-__device__ __forceinline__ void gemm_fwd_part(const float* X, const float* inv, const float* sh, const float* __restrict__ W,
-                                              const float* __restrict__ b, float* out) {
-    static_assert(NTL >= 4 && NTL <= 6, "96 + 64 or 80 + 80 columns");
-    constexpr int NX = NTL - 4;  // tiles beyond the four of the 16-byte load
+__device__ __forceinline__ void gemm_fwd_rows32(const float* X, const float* inv, const float* sh, const float* __restrict__ W,
+                                                const float* __restrict__ b, float* out) {
+    static_assert(NTL == 3 || NTL == 2, "48- or 32-column groups");
     const int wave = tidx() >> 6, lane = tidx() & 63, lr = lane & 15, lg = lane >> 4;
-    const int rt = wave & 3, c0 = NTL == 6 ? 0 : (NTL == 4 ? 96 : 80 * (wave >> 2));
-    PHX_T0();
+    const int rh = wave & 1, c0 = (NTL == 3 ? 0 : 96) + 16 * NTL * ((wave >> 1) & 1);
     constexpr int NB = K / 16, RING = CEN_RING;
-    f32x4 acc[NTL];
+    f32x4 acc[2][NTL];
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wp = W + (long)(4 * lg) * H2 + c0;  // row 16 blk + 4 lg + jj
-    f32x4 rq[RING][4];
-    float rs[NX ? RING : 1][4][NX ? NX : 1];
-#define CEN_FWD_ISSUE(blk, d)                                                       \
-    {                                                                               \
-        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                          \
-            const float* p_ = wp + (long)(16 * (blk) + jj) * H2;                    \
-            rq[d][jj] = *(const f32x4*)(p_ + 4 * lr);                               \
-            if constexpr (NX == 2) *(f32x2*)rs[d][jj] = *(const f32x2*)(p_ + 64 + 2 * lr); \
-            if constexpr (NX == 1) rs[d][jj][0] = p_[64 + lr];                      \
-        }                                                                           \
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (long)(4 * lg) * H2 + c0 + NTL * lr;  // row 16 blk + 4 lg + jj
+    float rq[RING][4][NTL];
+#define CEN_FWD_ISSUE(blk, d)                                                                   \
+    {                                                                                           \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                      \
+            const float* p_ = wp + (long)(16 * (blk) + jj) * H2;                                \
+            *(f32x2*)rq[d][jj] = *(const f32x2*)p_;                                             \
+            if constexpr (NTL == 3) rq[d][jj][2] = p_[2];                                       \
+        }                                                                                       \
     }
 #pragma unroll
     for (int d = 0; d < RING - 1; ++d) CEN_FWD_ISSUE(d, d);
-    const float* xr = X + (16 * rt + lr) * LDA + 4 * lg;
-    // the LDS operand of a block is READ one block ahead and turned into the MFMA operand (x inv + sh) at the head of its own MFMA
-    // stage: the read's latency hides behind the previous block's MFMAs
-    f32x4 rx[2], ri[2], rh[2];
-#define CEN_FWD_READ(blk) rx[(blk) & 1] = *(const f32x4*)(xr + 16 * (blk)), ri[(blk) & 1] = *(const f32x4*)(inv + 16 * (blk) + 4 * lg), \
-                          rh[(blk) & 1] = *(const f32x4*)(sh + 16 * (blk) + 4 * lg)
+    const float* xr = X + (32 * rh + lr) * LDA + 4 * lg;
+    f32x4 rx[2][2], ri[2], rh_[2];
+#define CEN_FWD_READ(blk)                                                                                                      \
+    rx[(blk) & 1][0] = *(const f32x4*)(xr + 16 * (blk)), rx[(blk) & 1][1] = *(const f32x4*)(xr + 16 * LDA + 16 * (blk)),      \
+    ri[(blk) & 1] = *(const f32x4*)(inv + 16 * (blk) + 4 * lg), rh_[(blk) & 1] = *(const f32x4*)(sh + 16 * (blk) + 4 * lg)
     CEN_FWD_READ(0);
-    // Fully unrolled, two pinned stages per k-block: [weight loads three blocks ahead + the next block's LDS reads] | [MFMAs].
-    // Without the sched_barriers hipcc sinks every load down to its first use (one load in flight: the ring prefetches nothing), and
-    // as a loop over groups of RING blocks it drains the ring on the back-edge (mlp.hip fast::gemm_fwd).
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         if (blk + RING - 1 < NB) CEN_FWD_ISSUE(blk + RING - 1, (blk + RING - 1) % RING);
         if (blk + 1 < NB) CEN_FWD_READ(blk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const f32x4 av = rx[blk & 1] * ri[blk & 1] + rh[blk & 1];
+        const f32x4 a0 = rx[blk & 1][0] * ri[blk & 1] + rh_[blk & 1], a1 = rx[blk & 1][1] * ri[blk & 1] + rh_[blk & 1];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[jj], rq[blk % RING][jj][t], acc[t]);
-#pragma unroll
-            for (int x = 0; x < NX; ++x) acc[4 + x] = MFMA16(av[jj], rs[blk % RING][jj][x], acc[4 + x]);
-        }
+            for (int t = 0; t < NTL; ++t) {
+                acc[0][t] = MFMA16(a0[jj], rq[blk % RING][jj][t], acc[0][t]);
+                acc[1][t] = MFMA16(a1[jj], rq[blk % RING][jj][t], acc[1][t]);
+            }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef AVD_PHASE_TIMING
-        if (blk == 0) { asm volatile("s_nop 0" ::"v"(acc[3])); PHX(24); }      // block 0 done: ring fill latency
-        if (blk == NB / 2) { asm volatile("s_nop 0" ::"v"(acc[3])); PHX(25); } // first half of the steady state
-        if (blk == NB - 1) { asm volatile("s_nop 0" ::"v"(acc[3])); PHX(26); } // second half
-#endif
     }
 #undef CEN_FWD_READ
 #undef CEN_FWD_ISSUE
-    const f32x4 bq = *(const f32x4*)(b + c0 + 4 * lr);
-    float bs[2] = {0.f, 0.f};
+    float bc[NTL];
 #pragma unroll
-    for (int x = 0; x < NX; ++x) bs[x] = b[c0 + 64 + NX * lr + x];
+    for (int t = 0; t < NTL; ++t) bc[t] = b[c0 + NTL * lr + t];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        float* o = out + (16 * rt + 4 * lg + reg) * LDB + c0;
-        f32x4 v;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][reg] + bq[t], 0.f);
-        *(f32x4*)(o + 4 * lr) = v;
-        if constexpr (NX == 2) {
-            f32x2 u;
-            u[0] = fmaxf(acc[4][reg] + bs[0], 0.f), u[1] = fmaxf(acc[5][reg] + bs[1], 0.f);
-            *(f32x2*)(o + 64 + 2 * lr) = u;
+        for (int reg = 0; reg < 4; ++reg) {
+            float* o = out + (32 * rh + 16 * m + 4 * lg + reg) * LDB + c0 + NTL * lr;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) o[t] = fmaxf(acc[m][t][reg] + bc[t], 0.f);
         }
-        if constexpr (NX == 1) o[64 + lr] = fmaxf(acc[4][reg] + bs[0], 0.f);
-    }
-    PHX(27);  // epilogue (the barrier after it is in the caller's phase minus these four)
 }
 template <int K>
 __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, const float* __restrict__ W,
                                          const float* __restrict__ b, float* out) {
-    gemm_fwd_part<K, 5>(X, inv, sh, W, b, out);
+    if ((tidx() >> 6) < 4) gemm_fwd_rows32<K, 3>(X, inv, sh, W, b, out);
+    else gemm_fwd_rows32<K, 2>(X, inv, sh, W, b, out);
 }
 
 // narrow GEMM: out[r][a] = sum_k x(r, k) W[k wk + a wa] (+ bias[a]), a < A <= 16; x = X[r ldx + k] inv[k] + sh[k] (BN = false: x = X).
