@@ -48,7 +48,8 @@ try:
 except Exception as e:  # noqa
     print("per-agent check skipped:", e)
 
-# centralized framework (general kernel gen::learn_kernel_g: S = 4 L, A = L, widths x 1.2), 2048 models
+# centralized framework (cen::learn_kernel_c: S = 4 L, A = L, widths x 1.2), 2048 models: the learn kernel, and the whole update
+# (chunks of 256 on the caller's stream, their Adam + Polyak passes on a side stream) restarted from the same state every time
 try:
     L = 5
     cg = vec.AgentGroup(2048, 4 * L, L, conf, seed=5, hidd_mult=1.2)
@@ -61,6 +62,19 @@ try:
         d = ((out - ref).abs().max() / ref.abs().max()).item()
         worst = max(worst, d)
         bad += d > 1e-6
-    print(f"{'centralized f32 (mlp.hip), 2048 models':40s}: worst deviation {worst:.2e}; repeats off: {bad}")
+    print(f"{'centralized f32 (cen.hip), 2048 models':40s}: worst deviation {worst:.2e}; repeats off: {bad}")
+    state0 = [x.clone() for x in (cg.theta, cg.theta_t, cg.stats_t, cg.m, cg.v, cg.step)]
+    scratch = torch.empty(2048, cg.lay.theta_size, device="cuda")
+    ref, bad, reps = None, 0, max(20, N // 20)
+    for _ in range(reps):
+        for dst, src in zip((cg.theta, cg.theta_t, cg.stats_t, cg.m, cg.v, cg.step), state0):
+            dst.copy_(src)
+        cg.learn_update(cs, ca, cr, cs2, scratch)
+        cg.learn_update(cs2, ca, cr, cs, scratch)
+        got = torch.cat([cg.theta.flatten(), cg.theta_t.flatten(), cg.stats_t.flatten(), cg.m.flatten(), cg.v.flatten()])
+        if ref is None:
+            ref = got.clone()
+        bad += not torch.equal(got, ref)
+    print(f"{'centralized update, 8 chunks x 2 streams':40s}: {reps} restarts of two updates, bitwise different from the first: {bad}")
 except Exception as e:  # noqa
     print("centralized check skipped:", repr(e))

@@ -22,7 +22,12 @@ for m in interfrl nofrl; do
   python3 $R/tools/pmc_traffic.py "$(f FETCH_SIZE)" "$(f WRITE_SIZE)" $OUT/${T}_pmc_traffic_$m.json > $OUT/${T}_pmc_traffic_$m.txt 2>&1
   rm -rf $OUT/stats_$m $OUT/mfma_$m $OUT/pmc_${m}_FETCH_SIZE $OUT/pmc_${m}_WRITE_SIZE
 done
+rocprofv3 --kernel-trace --output-format csv -d $OUT/cen_trace -o run -- python3 $R/bench.py --framework centralized --no-cpu-baseline --steps 10 --warmup 5 > /dev/null 2>&1
+c=$(find $OUT/cen_trace -name "*kernel_trace.csv" | head -1); [ -n "$c" ] && python3 $R/tools/cen_trace.py "$c" 33 > $OUT/${T}_centralized_update_timeline.txt 2>&1
+rm -rf $OUT/cen_trace
 cd $R
+[ -f avddpg_amd/lib/libavddpg_hip_phase.so ] || bash tools/build_phase_lib.sh > /dev/null 2>&1
+(echo "# python tools/phase_profile.py 4096 centralized  (tools/build_phase_lib.sh library: cen::learn_kernel_c, gradients out, 4096 models S = 20, A = 5; shader cycles of wave 0 per model)"; python tools/phase_profile.py 4096 centralized 2>&1 | grep -v "amdgpu.ids\| 0 cyc/tile") > $OUT/${T}_phase_profile_centralized.txt
 bash tools/fsplit_pmc.sh > $OUT/${T}_fsplit_kernels_and_sq_counters.txt 2>/dev/null
 python tools/cpu_baseline_config1.py > $OUT/${T}_cpu_baseline_config1.txt 2>&1
 (python tools/determinism_engines.py 3000; python tools/determinism_engines.py 1500 10) > $OUT/${T}_determinism_of_repeated_learns.txt 2>&1
