@@ -379,6 +379,17 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                 roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated in "
                                             "the same pass), profiles/r04_pmc_traffic_interfrl.json (matrix-core bound: reported, not the binding roof)"
                                             % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
+    if P == 4096 and L == 5 and args.framework == "centralized" and fused and lk == "cen::learn_kernel_c" and pmc("r04_pmc_traffic_centralized.json"):
+        d = pmc("r04_pmc_traffic_centralized.json")
+        ks = [v for n, v in d["kernels"].items() if "learn_kernel_c" in n or "adam_polyak_rows" in n]
+        if len(ks) == 2:  # per step: 16 chunks of each kernel (the profiled launches are chunks of 256 models)
+            per_step = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in ks) * ((n_agents + 255) // 256)
+            for r in roofs:
+                r["traffic"] = per_step
+                r["traffic_note"] = ("HBM-side bytes per step = 16 x (learn chunk + update pass), PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated on a "
+                                     "1 GiB elementwise kernel in the same pass; kernels serialised by the counter pass), profiles/r04_pmc_traffic_centralized.json: "
+                                     "2.0 x the 15.8 GB priced here -- the gradients' round trip (+1 MB per model) and five re-reads of the online W2 "
+                                     "matrices that miss L2 (+1.2 MB)" % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
     for r in roofs:
         r["frac"] = r["achieved"] / r["peak"]
     if fused:

@@ -25,6 +25,11 @@ done
 rocprofv3 --kernel-trace --output-format csv -d $OUT/cen_trace -o run -- python3 $R/bench.py --framework centralized --no-cpu-baseline --steps 10 --warmup 5 > /dev/null 2>&1
 c=$(find $OUT/cen_trace -name "*kernel_trace.csv" | head -1); [ -n "$c" ] && python3 $R/tools/cen_trace.py "$c" 33 > $OUT/${T}_centralized_update_timeline.txt 2>&1
 rm -rf $OUT/cen_trace
+for cn in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $cn --kernel-trace --output-format csv -d $OUT/pmc_centralized_$cn -o run -- python3 $R/tools/pmc_workload.py centralized 3 > /dev/null 2>&1
+done
+python3 $R/tools/pmc_traffic.py "$(find $OUT/pmc_centralized_FETCH_SIZE -name "*counter_collection.csv" | head -1)" "$(find $OUT/pmc_centralized_WRITE_SIZE -name "*counter_collection.csv" | head -1)" $OUT/${T}_pmc_traffic_centralized.json > $OUT/${T}_pmc_traffic_centralized.txt 2>&1
+rm -rf $OUT/pmc_centralized_FETCH_SIZE $OUT/pmc_centralized_WRITE_SIZE
 cd $R
 [ -f avddpg_amd/lib/libavddpg_hip_phase.so ] || bash tools/build_phase_lib.sh > /dev/null 2>&1
 (echo "# python tools/phase_profile.py 4096 centralized  (tools/build_phase_lib.sh library: cen::learn_kernel_c, gradients out, 4096 models S = 20, A = 5; shader cycles of wave 0 per model)"; python tools/phase_profile.py 4096 centralized 2>&1 | grep -v "amdgpu.ids\| 0 cyc/tile") > $OUT/${T}_phase_profile_centralized.txt

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The PMC traffic passes of tools/make_profiles_r04.sh alone (FETCH_SIZE and WRITE_SIZE in separate runs, calibrated on the 1 GiB
-# elementwise kernel of the same pass).
+# elementwise kernel of the same pass). usage: pmc_only.sh [modes: interfrl nofrl centralized]
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=r04; OUT=$R/gpurun_out/profiles_$T; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for m in interfrl nofrl; do
+for m in ${@:-interfrl nofrl centralized}; do
   for cn in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $cn --kernel-trace --output-format csv -d $OUT/pmc_${m}_$cn -o run -- python3 $R/tools/pmc_workload.py $m 3 > /dev/null 2>&1
   done

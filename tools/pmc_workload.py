@@ -2,7 +2,7 @@
 """The program profiled by the PMC passes of tools/make_profiles_r04.sh: (1) a stream copy of KNOWN size -- 1 GiB read, 1 GiB written,
 16 bytes per lane -- whose FETCH_SIZE / WRITE_SIZE calibrate the counters IN THE SAME PASS (MI355X_MICROARCH.md, HBM: FETCH_SIZE
 reports 1/2 of wide coalesced reads on gfx950; VERDICT r03 weak #8 asked for a calibration that calibrates), then (2) a few steps of
-one bench workload at 4096 x 5. usage: pmc_workload.py interfrl|nofrl [steps]"""
+one bench workload at 4096 x 5. usage: pmc_workload.py interfrl|nofrl|centralized [steps]"""
 import os
 import sys
 
@@ -21,8 +21,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 del src, dst
 conf = config.Config(num_platoons=4096, pl_size=5, buffer_size=2048, fed_method="interfrl" if mode == "interfrl" else "normal",
-                     weighted_average_enabled=False)
-vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1, fused_update=(mode == "nofrl"),
+                     weighted_average_enabled=False, framework="centralized" if mode == "centralized" else "decentralized")
+vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1, fused_update=(mode != "interfrl"),
                         shared_engine="fused3" if mode == "interfrl" else None)
 vt.replay.ring.normal_(0.0, 1.0)
 vt.replay.buffer_counter = conf.buffer_size
