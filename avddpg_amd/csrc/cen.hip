@@ -134,18 +134,30 @@ __device__ __forceinline__ void coefs_b(const float* __restrict__ g, const float
 #ifndef CEN_RING
 #define CEN_RING 4
 #endif
-template <int K, int NTL>
+// FIRST / SNAP split the reduction for an input whose leading SNAP k-blocks do not change between two calls (the critic's state
+// features in passes 1 and 2: same states, same weights): a call with SNAP > 0 stores its accumulators as they stand before block
+// SNAP (row-major [64][160] at `snap`, global), a call with FIRST > 0 starts from them and runs blocks FIRST.. only -- the same
+// additions in the same order as a full run, bit for bit; one sixth of the GEMM and of the W2 read.
+template <int K, int NTL, int FIRST, int SNAP>
 __device__ __forceinline__ void gemm_fwd_rows32(const float* X, const float* inv, const float* sh, const float* __restrict__ W,
-                                                const float* __restrict__ b, float* out) {
+                                                const float* __restrict__ b, float* out, float* __restrict__ snap) {
     static_assert(NTL == 3 || NTL == 2, "48- or 32-column groups");
+    static_assert(FIRST < K / 16 && SNAP < K / 16 && !(FIRST && SNAP), "resume / snapshot points");
     const int wave = tidx() >> 6, lane = tidx() & 63, lr = lane & 15, lg = lane >> 4;
     const int rh = wave & 1, c0 = (NTL == 3 ? 0 : 96) + 16 * NTL * ((wave >> 1) & 1);
     constexpr int NB = K / 16, RING = CEN_RING;
     f32x4 acc[2][NTL];
+    float* sp = snap + (32 * rh + 4 * lg) * H2 + c0 + NTL * lr;  // the lane's accumulator elements: rows + 16 m + reg, columns + t
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTL; ++t) {
+            acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (FIRST > 0) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[m][t][reg] = sp[(16 * m + reg) * H2 + t];
+            }
+        }
     const float* wp = W + (long)(4 * lg) * H2 + c0 + NTL * lr;  // row 16 blk + 4 lg + jj
     float rq[RING][4][NTL];
 #define CEN_FWD_ISSUE(blk, d)                                                                   \
@@ -157,15 +169,26 @@ __device__ __forceinline__ void gemm_fwd_rows32(const float* X, const float* inv
         }                                                                                       \
     }
 #pragma unroll
-    for (int d = 0; d < RING - 1; ++d) CEN_FWD_ISSUE(d, d);
+    for (int d = 0; d < RING - 1; ++d)
+        if (FIRST + d < NB) CEN_FWD_ISSUE(FIRST + d, (FIRST + d) % RING);
     const float* xr = X + (32 * rh + lr) * LDA + 4 * lg;
     f32x4 rx[2][2], ri[2], rh_[2];
 #define CEN_FWD_READ(blk)                                                                                                      \
     rx[(blk) & 1][0] = *(const f32x4*)(xr + 16 * (blk)), rx[(blk) & 1][1] = *(const f32x4*)(xr + 16 * LDA + 16 * (blk)),      \
     ri[(blk) & 1] = *(const f32x4*)(inv + 16 * (blk) + 4 * lg), rh_[(blk) & 1] = *(const f32x4*)(sh + 16 * (blk) + 4 * lg)
-    CEN_FWD_READ(0);
+    CEN_FWD_READ(FIRST);
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
+    for (int blk = FIRST; blk < NB; ++blk) {
+        if constexpr (SNAP > 0) {
+            if (blk == SNAP && snap) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) sp[(16 * m + reg) * H2 + t] = acc[m][t][reg];
+            }
+        }
         if (blk + RING - 1 < NB) CEN_FWD_ISSUE(blk + RING - 1, (blk + RING - 1) % RING);
         if (blk + 1 < NB) CEN_FWD_READ(blk + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -193,11 +216,11 @@ __device__ __forceinline__ void gemm_fwd_rows32(const float* X, const float* inv
             for (int t = 0; t < NTL; ++t) o[t] = fmaxf(acc[m][t][reg] + bc[t], 0.f);
         }
 }
-template <int K>
+template <int K, int FIRST = 0, int SNAP = 0>
 __device__ __forceinline__ void gemm_fwd(const float* X, const float* inv, const float* sh, const float* __restrict__ W,
-                                         const float* __restrict__ b, float* out) {
-    if ((tidx() >> 6) < 4) gemm_fwd_rows32<K, 3>(X, inv, sh, W, b, out);
-    else gemm_fwd_rows32<K, 2>(X, inv, sh, W, b, out);
+                                         const float* __restrict__ b, float* out, float* __restrict__ snap = nullptr) {
+    if ((tidx() >> 6) < 4) gemm_fwd_rows32<K, 3, FIRST, SNAP>(X, inv, sh, W, b, out, snap);
+    else gemm_fwd_rows32<K, 2, FIRST, SNAP>(X, inv, sh, W, b, out, snap);
 }
 
 // narrow GEMM: out[r][a] = sum_k x(r, k) W[k wk + a wa] (+ bias[a]), a < A <= 16; x = X[r ldx + k] inv[k] + sh[k] (BN = false: x = X).
@@ -533,6 +556,11 @@ __global__ __launch_bounds__(NT) void learn_kernel_c(avd_mlp_layout L_arg, int s
             lds_barrier();
         }
         PH(20);
+        // Scratch in the agent's own gradient row: its ACTOR block is written by pass 3 only, so until then [0, 64 x 160) floats hold the
+        // online actor's layer-2 activations of pass 2 (pass 3 needs them again: same weights, same states) and the next 64 x 160 the
+        // critic's layer-2 accumulators after the state blocks (passes 1 and 2 run it on the same states with the same weights).
+        float* const keep_p2 = ga;
+        float* const keep_cs = ga + TILE * H2;
         if (it != 1) {  // ---- actor forward (agent/model.py:26-36)
             const float* th = n.th;
             L1W<S> qa;
@@ -541,37 +569,56 @@ __global__ __launch_bounds__(NT) void learn_kernel_c(avd_mlp_layout L_arg, int s
             coefs_b(th + L.ag2, th + L.abe2, n.st + L.amm2, n.st + L.amv2, invB, shB, rsB, mmB);
             l1_mma<S>(qa, sX, H1, bufA);
             PH(21);
-            lds_barrier();
-            PH(1);
-            gemm_fwd<H1>(bufA, invA, shA, th + L.aW2, th + L.ab2, bufB);
-            lds_barrier();
-            PH(2);
-            narrow_gemm<H2, A, true, true>(bufB, LDB, invB, shB, th + L.aW3, A, 1, th + L.ab3, sQ, sD);  // (sD: free until this pass's loss)
-            lds_barrier();
-            for (int i = tid; i < TILE * A; i += NT) {
-                const float t = tanhf(sQ[i] + sD[i]);
-                sT[i] = t, sA1[i] = t * high;
+            if (it == 3) {
+                // pass 2 has computed exactly this layer: its activations come back from the scratch (41 KB against 205 KB of W2 and
+                // 3200 MFMAs), the tanh values are still in sT
+                __syncthreads();  // (vmcnt(0) in every wave: pass 2's copy is complete, whichever wave wrote it)
+                for (int i = tid; i < TILE * (H2 / 4); i += NT) {
+                    const int r = i / (H2 / 4), c4 = i - r * (H2 / 4);
+                    *(f32x4*)(bufB + r * LDB + 4 * c4) = *(const f32x4*)(keep_p2 + r * H2 + 4 * c4);
+                }
+                lds_barrier();
+                PH(2);
+            } else {
+                lds_barrier();
+                PH(1);
+                gemm_fwd<H1>(bufA, invA, shA, th + L.aW2, th + L.ab2, bufB);
+                lds_barrier();
+                PH(2);
+                narrow_gemm<H2, A, true, true>(bufB, LDB, invB, shB, th + L.aW3, A, 1, th + L.ab3, sQ, sD);  // (sD: free until this pass's loss)
+                if (it == 2) {
+                    for (int i = tid; i < TILE * (H2 / 4); i += NT) {
+                        const int r = i / (H2 / 4), c4 = i - r * (H2 / 4);
+                        *(f32x4*)(keep_p2 + r * H2 + 4 * c4) = *(const f32x4*)(bufB + r * LDB + 4 * c4);
+                    }
+                }
+                lds_barrier();
+                for (int i = tid; i < TILE * A; i += NT) {
+                    const float t = tanhf(sQ[i] + sD[i]);
+                    sT[i] = t, sA1[i] = t * high;
+                }
+                lds_barrier();
+                PH(3);
             }
-            lds_barrier();
-            PH(3);
         }
         if (it != 3) {  // ---- critic forward (agent/model.py:63-83)
             const float* th = n.th + L.actor_size;
             const float* act = (it == 1) ? sAct : sA1;
             L1W<S> qs;
             L1W<A> qx;
-            l1_load<S>(qs, th + L.cWs, th + L.cbs, H1);
+            if (it != 2) l1_load<S>(qs, th + L.cWs, th + L.cbs, H1);
             l1_load<A>(qx, th + L.cWa, th + L.cba, HA);
-            bn_table(th + L.cgs, th + L.cbes, n.st + L.cmms, n.st + L.cmvs, H1, invA, shA);
+            if (it != 2) bn_table(th + L.cgs, th + L.cbes, n.st + L.cmms, n.st + L.cmvs, H1, invA, shA);
             bn_table(th + L.cga, th + L.cbea, n.st + L.cmma, n.st + L.cmva, HA, invA + H1, shA + H1);
             coefs_b(th + L.cg3, th + L.cbe3, n.st + L.cmm3, n.st + L.cmv3, invB, shB, rsB, mmB);
-            l1_mma<S>(qs, sX, H1, bufA);
+            if (it != 2) l1_mma<S>(qs, sX, H1, bufA);  // (pass 2: the state blocks' sums come from pass 1's snapshot, nothing else reads them)
             PH(22);
             l1_mma<A>(qx, act, HA, bufA + H1);
             PH(23);
             lds_barrier();
             PH(4);
-            gemm_fwd<KC>(bufA, invA, shA, th + L.cW2, th + L.cb2, bufB);
+            if (it == 2) gemm_fwd<KC, H1 / 16, 0>(bufA, invA, shA, th + L.cW2, th + L.cb2, bufB, keep_cs);
+            else gemm_fwd<KC, 0, H1 / 16>(bufA, invA, shA, th + L.cW2, th + L.cb2, bufB, it == 1 ? keep_cs : nullptr);
             lds_barrier();
             PH(5);
             narrow_gemm<H2, A, true, true>(bufB, LDB, invB, shB, th + L.cW3, A, 1, th + L.cb3, sQ, sD);
