@@ -1,18 +1,20 @@
-// Learn kernel of the centralized framework (src/environment.py:35-52, 234-236, 281; config.py:26, 95; agent/model.py
-// hidd_mult): one actor / critic per platoon with S = 4 L states, A = L actions and the reference widths x 1.2 (307 / 153 / 57, held
-// zero-padded as 320 / 160 / 64 -- params.py), exact f32 on the matrix cores (v_mfma_f32_16x16x4_f32). Same four-pass plan and the same
-// results as gen::learn_kernel_g (mlp.hip), which stays the kernel of every other shape; what is different here (r04):
+// Learn kernel and update pipeline of the centralized framework (src/environment.py:35-52, 234-236, 281; config.py:26, 95;
+// agent/model.py hidd_mult): one actor / critic per platoon with S = 4 L states, A = L actions and the reference widths x 1.2
+// (307 / 153 / 57, held zero-padded as 320 / 160 / 64 -- params.py), exact f32 on the matrix cores (v_mfma_f32_16x16x4_f32). Same
+// four-pass plan and LDS layout as gen::learn_kernel_g (mlp.hip), which stays the kernel of every other shape; what is different (r04):
 //   * the dimensions are compile-time constants: register arrays have their real sizes (the general kernel holds 512 registers and
 //     620 bytes of scratch per lane), loops have no tails;
-//   * EIGHT waves per workgroup = two per SIMD (LDS still holds one agent's activations, 158 KB: one workgroup per CU): while one wave
-//     of a SIMD waits for weights, runs the VALU of an epilogue (the fused Adam + Polyak update of W2: ~60 instructions per element)
-//     or sits in a barrier, the other one issues MFMAs. The general kernel has one wave per SIMD and overlaps nothing;
-//   * tile plans for eight waves at N = 160: forward 16 rows x 80 columns per wave (five accumulators, weights four k-blocks ahead),
-//     weight gradient 32 x 32 items (50 / 60 of them), input gradient 16-column tiles (20 / 24);
+//   * EIGHT waves per workgroup = two per SIMD (LDS still holds one model's activations, 158 KB: one workgroup per CU);
+//   * tile plans for eight waves at N = 160: forward 32 rows x 48 / 32 columns per wave (weights three k-blocks ahead in a register
+//     ring, stages pinned), weight gradient 32 x 32 items (50 / 60 of them), input gradient 16-column tiles (20 / 24);
 //   * the output layer's backward pass on the matrix cores (d y = D W3^T and d W3 = y^T D are A-wide GEMMs: 24 MFMAs per 16 columns
 //     instead of a 64 x 8 FMA loop per column on 160 threads), with the BN / relu backward, d gamma, d beta and the bias gradient of
-//     the layer below in its epilogue (no separate column-sum pass).
-// Every sum has a fixed order: results are a function of the inputs only.
+//     the layer below in its epilogue (no separate column-sum pass);
+//   * what two passes compute twice is computed once: pass 3 takes the actor's layer-2 activations of pass 2 back from a scratch in
+//     the model's own gradient row, the critic's pass 2 resumes from pass 1's accumulators after the state blocks;
+//   * the update (avd_learn_update_f32) is a pipeline of two streams: learn kernels over chunks of 256 models in the caller's stream,
+//     each chunk's Adam + Polyak pass (optim.hip adam_polyak_rows_kernel) on a side stream under the next chunk's learn kernel.
+// Every sum has a fixed order: results are a function of the inputs only. 4096 models at L = 5: 9.5 -> ~6 ms per step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -535,19 +537,19 @@ __global__ __launch_bounds__(NT) void learn_kernel_c(avd_mlp_layout L_arg, int s
     // pass 0: targets (y); 1: critic loss + gradient; 2: actor -> critic, gradient wrt the actions; 3: actor gradient
 #pragma nounroll
     for (int it = 0; it < 4; ++it) {
-    const avd_mlp_layout& L = *(const avd_mlp_layout*)((const char*)Lk + opaque_zero());
-    float* const smem = smem0 + opaque_zero();
-    float *bufA = smem + O::bufA, *bufB = smem + O::bufB, *invA = smem + O::invA, *shA = smem + O::shA, *invB = smem + O::invB,
-          *shB = smem + O::shB, *rsB = smem + O::rsB, *mmB = smem + O::mmB, *db = smem + O::db, *sX = smem + O::sX, *sR = smem + O::sR,
-          *sAct = smem + O::sAct, *sY = smem + O::sY, *sQ = smem + O::sQ, *sD = smem + O::sD, *sA1 = smem + O::sA1, *sT = smem + O::sT,
-          *sDa = smem + O::sDa, *red = smem + O::red;
-    const int tid = tidx();
-    const int set = set_mod > 0 ? agent % set_mod : agent;
-    const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
-    const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
-    float* ga = grads + (long)agent * L.theta_size;
-    float* gc = ga + L.actor_size;
-    constexpr float invn = 1.0f / (float)(TILE * A);
+        const avd_mlp_layout& L = *(const avd_mlp_layout*)((const char*)Lk + opaque_zero());
+        float* const smem = smem0 + opaque_zero();
+        float *bufA = smem + O::bufA, *bufB = smem + O::bufB, *invA = smem + O::invA, *shA = smem + O::shA, *invB = smem + O::invB,
+              *shB = smem + O::shB, *rsB = smem + O::rsB, *mmB = smem + O::mmB, *db = smem + O::db, *sX = smem + O::sX, *sR = smem + O::sR,
+              *sAct = smem + O::sAct, *sY = smem + O::sY, *sQ = smem + O::sQ, *sD = smem + O::sD, *sA1 = smem + O::sA1, *sT = smem + O::sT,
+              *sDa = smem + O::sDa, *red = smem + O::red;
+        const int tid = tidx();
+        const int set = set_mod > 0 ? agent % set_mod : agent;
+        const Net net = {theta + (long)set * L.theta_size, stats + (long)set * L.stats_size};
+        const Net tgt = {theta_t + (long)set * L.theta_size, stats_t + (long)set * L.stats_size};
+        float* ga = grads + (long)agent * L.theta_size;
+        float* gc = ga + L.actor_size;
+        constexpr float invn = 1.0f / (float)(TILE * A);
         const Net n = (it == 0) ? tgt : net;
         if (it < 2) {  // state batch of this pass: s2 for the targets, s afterwards
             lds_barrier();
@@ -744,6 +746,7 @@ struct Side {
     hipStream_t st = nullptr;
     hipEvent_t learned[MAX_CHUNKS] = {}, join = nullptr;
     bool ready = false;
+    std::mutex enqueue;  // one caller at a time records / waits on the device's events (two host threads must not interleave them)
 };
 static Side* side_stream() {
     static Side sides[64];
@@ -779,7 +782,8 @@ namespace avd {
 
 bool cen_supports(const avd_mlp_layout* lay) {
     return lay->B == TILE && lay->H1 == cen::H1 && lay->H2 == cen::H2 && lay->Ha == cen::HA &&
-           ((lay->S == 20 && lay->A == 5) || (lay->S == 12 && lay->A == 3));
+           ((lay->S == 20 && lay->A == 5) || (lay->S == 12 && lay->A == 3)) &&
+           lay->ab3 >= 2 * TILE * cen::H2;  // (the kernel parks 2 x 64 x 160 floats at the head of the gradient row's actor block)
 }
 
 int cen_launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats, const float* theta_t,
@@ -811,6 +815,8 @@ int cen_launch_update(const avd_mlp_layout* lay, int n_agents, const float* thet
     if (const char* e = AVD_DIAG_ENV("CEN_GROUPS")) groups = atoi(e);
     if ((n_agents + chunk - 1) / chunk > cen::MAX_CHUNKS) chunk = (n_agents + cen::MAX_CHUNKS - 1) / cen::MAX_CHUNKS;
     cen::Side* sd = n_agents > chunk ? cen::side_stream() : nullptr;
+    std::unique_lock<std::mutex> lock;
+    if (sd) lock = std::unique_lock<std::mutex>(sd->enqueue);
     int c = 0;
     for (int lo = 0; lo < n_agents; lo += chunk, ++c) {
         const cen::Span sp = {lo, n_agents - lo < chunk ? n_agents - lo : chunk};
