@@ -201,9 +201,12 @@ int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, flo
  *   grads_scratch [n_agents][theta_size] workspace: receives only the gradients of the small tensors (biases, BN
  *              gamma/beta, first/last layers, ~6 % of the slab), consumed at the end of the same launch (learn_kernel_l)
  *              or by a second, range-restricted launch (learn_kernel_t);
- *   losses [n_agents][2] or NULL.  Same result as the two separate calls. Any shape avd_learn_f32 serves (the reference
- *   widths take learn_kernel_l / learn_kernel_t, everything else -- centralized framework, other widths -- the general
- *   kernel's fused form); B = 64. */
+ *   losses [n_agents][2] or NULL.  Same result as the two separate calls, bit for bit. Any shape avd_learn_f32 serves; B = 64.
+ *   By shape: the reference widths take learn_kernel_l / learn_kernel_t (update applied where each gradient is produced); the
+ *   centralized framework at L = 3 / 5 (S = 4 L, A = L, widths 320 / 160 / 64) runs as a PIPELINE -- learn kernels over chunks of
+ *   256 agents in `stream`, each chunk's whole-row Adam + Polyak pass on a library-owned side stream under the next chunk's learn
+ *   kernel, forked off and joined back into `stream` by events (work queued on `stream` afterwards sees every result; the call is
+ *   capturable); there grads_scratch receives ALL gradients. Every other shape: the general kernel's fused form. */
 int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,
                          float* theta_out, float* theta_t, float* stats_t, float* m, float* v, const int32_t* step,
                          const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
