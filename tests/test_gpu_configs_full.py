@@ -66,6 +66,46 @@ def test_config3_trainer_4096x10_learns_like_the_oracle_and_fused_equals_two_ker
     _free(a, b)
 
 
+def test_centralized_trainer_4096x5_pipeline_of_16_chunks_equals_the_two_kernel_path_and_tracks_the_oracle():
+    """The centralized framework (SURVEY f-3) at BASELINE configs[1]'s size: 4096 models of S = 20 / A = 5 (widths x 1.2). The fused
+    update runs as 16 chunks of 256 models -- learn kernels on the caller's stream, their Adam + Polyak passes on a side stream
+    (csrc/cen.hip) -- the other trainer does learn -> gradient slab -> Adam / Polyak in two launches: 69 steps = 5 updates of every
+    model on the same Philox streams end in bit-identical weights / targets / BN statistics / moments, three models' gradients of the
+    last step sit at the float64 oracle on the batch they sampled, and the models did take 4096 different updates."""
+    need_gpu()
+    P, L, steps = 4096, 5, 69
+    mk = lambda fused: trainer.VecTrainer(config.Config(num_platoons=P, pl_size=L, buffer_size=128, framework="centralized"), rng="device",
+                                          auto_reset=True, seed=3, fused_update=fused)
+    a, b = mk(True), mk(False)
+    assert a.n_agents == b.n_agents == P and a.agents.n_sets == P and not a.shared
+    assert (a.agents.lay.S, a.agents.lay.A, a.agents.lay.H1, a.agents.lay.H2, a.agents.lay.Ha) == (20, 5, 320, 160, 64)
+    for vt in (a, b):
+        vt.reset_episode()
+    for i in range(steps - 1):
+        a.step()
+        b.step()
+    spots = (0, 255 + 256 * 7, P - 1)  # first model / the last of a middle chunk / the last model
+    pre = {v: _nets(b.agents, v, np.float64) for v in spots}
+    pre32 = {v: _nets(b.agents, v, np.float32) for v in spots}
+    a.step()
+    b.step()
+    torch.cuda.synchronize()
+    for v in spots:
+        batch = (b.replay.s[v].cpu().numpy(), b.replay.a[v].cpu().numpy(), b.replay.r[v].cpu().numpy()[:, None],
+                 b.replay.s2[v].cpu().numpy())
+        cg, ag, _ = omlp.learn(batch, *pre[v])
+        cg32, ag32, _ = omlp.learn(tuple(x.astype(np.float32) for x in batch), *pre32[v])
+        gcg, gag = b.agents.grads_as_lists(b.grads[v])
+        for got, ref, r32 in zip(gcg + gag, cg + ag, cg32 + ag32):
+            assert _relerr(got, ref) <= max(GRAD_TOL, 4 * _relerr(r32, ref)), v
+    for name in ("theta", "theta_t", "stats_t", "m", "v"):
+        assert torch.equal(getattr(a.agents, name), getattr(b.agents, name)), name
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.replay.ring, b.replay.ring) and torch.equal(a.losses, b.losses)
+    assert torch.isfinite(a.agents.theta).all() and int(a.agents.step.min()) == int(a.agents.step.max()) == steps - 64
+    assert not torch.equal(a.agents.theta[0], a.agents.theta[1])
+    _free(a, b)
+
+
 def test_config3_learn_kernels_lane_independent_at_40960_agents():
     """Lane independence + determinism of Trainer.learn at configs[2]'s grid (40960 workgroups): a duplicated agent gives
     the same bits wherever it sits; two launches agree bit for bit."""
