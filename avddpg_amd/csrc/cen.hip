@@ -29,6 +29,9 @@ int launch_adam_polyak_rows(const avd_mlp_layout* lay, int n_sets, int n_groups,
                             void* stream);
 
 namespace avd {
+namespace fset {
+int cu_count();  // fset.hip: CUs of the current device (cached per device ordinal)
+}
 namespace cen {
 
 constexpr int NT = 512, NW = NT / 64;
@@ -809,9 +812,12 @@ int cen_launch_update(const avd_mlp_layout* lay, int n_agents, const float* thet
     hipStream_t main = (hipStream_t)stream;
     const float tauf = (float)tau, omt = (float)(1.0 - tau);
     const long ts = lay->theta_size;
-    int chunk = 256;  // one workgroup per CU and chunk (measured: 6.8 ms per step at 4096 agents, 7.3 at 512, 11.4 at 128)
+    // one learn workgroup per CU and chunk, one update workgroup per CU (MI355X, 256 CUs, 4096 agents: 6.8 ms per step with 256 / 256,
+    // 7.3 with chunks of 512, 11.4 with 128; 128 or 192 update workgroups: 8.1, 384 / 512: 6.6 against 6.3)
+    const int cus = fset::cu_count() > 0 ? fset::cu_count() : 256;
+    int chunk = cus;
     if (const char* e = AVD_DIAG_ENV("CEN_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : n_agents;
-    int groups = 256;  // update-pass workgroups (optim.hip adam_polyak_rows_kernel)
+    int groups = cus;  // update-pass workgroups (optim.hip adam_polyak_rows_kernel)
     if (const char* e = AVD_DIAG_ENV("CEN_GROUPS")) groups = atoi(e);
     if ((n_agents + chunk - 1) / chunk > cen::MAX_CHUNKS) chunk = (n_agents + cen::MAX_CHUNKS - 1) / cen::MAX_CHUNKS;
     cen::Side* sd = n_agents > chunk ? cen::side_stream() : nullptr;

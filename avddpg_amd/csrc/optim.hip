@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void adam_polyak_ranges_kernel(int theta_size,
 #endif
 constexpr int AR_UNR = AR_UNR_N;
 typedef float v4f __attribute__((ext_vector_type(4)));
+#define NTL(p) ({ const v4f t_ = __builtin_nontemporal_load((const v4f*)(p)); make_float4(t_[0], t_[1], t_[2], t_[3]); })
+#define NTS(val_, p) __builtin_nontemporal_store((v4f){(val_).x, (val_).y, (val_).z, (val_).w}, (v4f*)(p))
 __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, int actor_size, int n_sets,
                                                                const float4* __restrict__ theta_in, float4* __restrict__ theta_out,
                                                                float4* __restrict__ theta_t, float4* __restrict__ m,
@@ -130,7 +132,6 @@ __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, i
 #pragma unroll
             for (int u = 0; u < AR_UNR; ++u) {
                 const int i = min(i0 + 256 * u, n4 - 1);
-#define NTL(p) ({ const v4f t_ = __builtin_nontemporal_load((const v4f*)(p)); make_float4(t_[0], t_[1], t_[2], t_[3]); })
                 w[u] = NTL(theta_in + base + i), wt[u] = NTL(theta_t + base + i), mm[u] = NTL(m + base + i), vv[u] = NTL(v + base + i);
                 g[u] = NTL(grads + base + i);
             }
@@ -151,12 +152,14 @@ __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, i
                     wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
                     tp[k] = wp[k] * tau + tp[k] * omt;
                 }
-#define NTS(val_, p) __builtin_nontemporal_store((v4f){(val_).x, (val_).y, (val_).z, (val_).w}, (v4f*)(p))
                 NTS(w[u], theta_out + base + i), NTS(wt[u], theta_t + base + i), NTS(mm[u], m + base + i), NTS(vv[u], v + base + i);
             }
         }
     }
 }
+
+#undef NTL
+#undef NTS
 
 __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __restrict__ t, float tau, float omt) {
 #pragma clang fp contract(off)
