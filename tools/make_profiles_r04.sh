@@ -30,6 +30,9 @@ for cn in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $R/tools/pmc_traffic.py "$(find $OUT/pmc_centralized_FETCH_SIZE -name "*counter_collection.csv" | head -1)" "$(find $OUT/pmc_centralized_WRITE_SIZE -name "*counter_collection.csv" | head -1)" $OUT/${T}_pmc_traffic_centralized.json > $OUT/${T}_pmc_traffic_centralized.txt 2>&1
 rm -rf $OUT/pmc_centralized_FETCH_SIZE $OUT/pmc_centralized_WRITE_SIZE
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/mfma_cen -o run -- python3 $R/bench.py --framework centralized --no-cpu-baseline --steps 6 --warmup 4 > /dev/null 2>&1
+c=$(find $OUT/mfma_cen -name "*counter_collection.csv" | head -1); [ -n "$c" ] && python3 $R/tools/pmc_avg.py "$c" MfmaUtil $OUT/${T}_mfma_util_centralized.json > /dev/null 2>&1
+rm -rf $OUT/mfma_cen
 cd $R
 [ -f avddpg_amd/lib/libavddpg_hip_phase.so ] || bash tools/build_phase_lib.sh > /dev/null 2>&1
 (echo "# python tools/phase_profile.py 4096 centralized  (tools/build_phase_lib.sh library: cen::learn_kernel_c, gradients out, 4096 models S = 20, A = 5; shader cycles of wave 0 per model)"; python tools/phase_profile.py 4096 centralized 2>&1 | grep -v "amdgpu.ids\| 0 cyc/tile") > $OUT/${T}_phase_profile_centralized.txt
