@@ -23,10 +23,6 @@
 #include "../../include/avddpg_hip.h"
 #include "learn_common.h"
 
-// optim.hip: the same update of everything outside two skip ranges of each row
-int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float* theta_in, float* theta_out, float* theta_t, float* m,
-                              float* v, const float* grads, const int32_t* step, float actor_lr, float critic_lr, double tau, int skip_a0,
-                              int skip_a1, int skip_c0, int skip_c1, void* stream);
 // optim.hip: Adam + Polyak of whole slab rows, theta_in -> theta_out, by a persistent grid of n_groups workgroups
 int launch_adam_polyak_rows(const avd_mlp_layout* lay, int n_sets, int n_groups, const float* theta_in, float* theta_out, float* theta_t,
                             float* m, float* v, const float* grads, const int32_t* step, float actor_lr, float critic_lr, double tau,
@@ -733,24 +729,10 @@ static int launch_t(const avd_mlp_layout* lay, Span sp, int set_mod, const float
     return check_launch(STATS ? "avd_learn_update_f32 (centralized)" : "avd_learn_f32 (centralized)");
 }
 
-}  // namespace cen
-// cen2.hip: the same contracts (gradients out / fused update of the W2 matrices) with four waves per workgroup and two workgroups per CU
-int cen2_launch(const avd_mlp_layout* lay, bool fused, int n_agents, int set_mod, const float* theta, const float* stats, float* theta_t,
-                float* stats_t, const float* s, const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
-                float* losses, const UpdArgs& upd, void* stream);
-namespace cen {
 template <bool STATS>
 static int launch_shape(const avd_mlp_layout* lay, Span sp, int set_mod, const float* theta, const float* stats, float* theta_t,
                         float* stats_t, const float* s, const float* a, const float* r, const float* s2, float gamma, float high,
                         float* grads, float* losses, float tau, float omt, hipStream_t stream) {
-    if (AVD_DIAG_ENV("CEN2_PIPE")) {  // experiment: the two-workgroups-per-CU kernel as the learn kernel of the chunked pipeline
-        const long lo = sp.lo, ts = lay->theta_size, ss = lay->stats_size, wo = set_mod > 0 ? 0 : lo;
-        UpdArgs u = {};
-        u.tau = tau, u.omt = STATS ? omt : 0.f;
-        return cen2_launch(lay, false, sp.n, set_mod, theta + wo * ts, stats + wo * ss, theta_t + wo * ts, stats_t + wo * ss,
-                           s + lo * TILE * lay->S, a + lo * TILE * lay->A, r + lo * TILE, s2 + lo * TILE * lay->S, gamma, high, grads + lo * ts,
-                           losses ? losses + lo * 2 : nullptr, u, stream);
-    }
     if (lay->S == 20 && lay->A == 5)
         return launch_t<20, 5, STATS>(lay, sp, set_mod, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, tau, omt, stream);
     if (lay->S == 12 && lay->A == 3)
@@ -810,9 +792,6 @@ bool cen_supports(const avd_mlp_layout* lay) {
 int cen_launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats, const float* theta_t,
                const float* stats_t, const float* s, const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
                float* losses, void* stream) {
-    if (AVD_DIAG_ENV("CEN2"))
-        return cen2_launch(lay, false, n_agents, set_mod, theta, stats, (float*)theta_t, (float*)stats_t, s, a, r, s2, gamma, high, grads,
-                           losses, UpdArgs{}, stream);
     return cen::launch_shape<false>(lay, cen::Span{0, n_agents}, set_mod, theta, stats, (float*)theta_t, (float*)stats_t, s, a, r, s2, gamma,
                                     high, grads, losses, 0.f, 0.f, (hipStream_t)stream);
 }
@@ -832,14 +811,6 @@ int cen_launch_update(const avd_mlp_layout* lay, int n_agents, const float* thet
                       void* stream) {
     hipStream_t main = (hipStream_t)stream;
     const float tauf = (float)tau, omt = (float)(1.0 - tau);
-    if (AVD_DIAG_ENV("CEN2")) {  // one launch, the W2 matrices updated where their gradients are produced; the small tensors behind it
-        const UpdArgs upd = {theta_out, m, v, step, actor_lr, critic_lr, tauf, omt, nullptr, 0, nullptr};
-        int rc = cen2_launch(lay, true, n_agents, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, upd, stream);
-        if (rc) return rc;
-        const int a0 = lay->aW2, a1 = lay->aW2 + lay->H1 * lay->H2, c0 = lay->actor_size + lay->cW2, c1 = c0 + (lay->H1 + lay->Ha) * lay->H2;
-        return ::launch_adam_polyak_ranges(lay, n_agents, theta, theta_out, theta_t, m, v, grads, step, actor_lr, critic_lr, tau, a0, a1, c0,
-                                           c1, stream);
-    }
     const long ts = lay->theta_size;
     // one learn workgroup per CU and chunk, one update workgroup per CU (MI355X, 256 CUs, 4096 agents: 6.8 ms per step with 256 / 256,
     // 7.3 with chunks of 512, 11.4 with 128; 128 or 192 update workgroups: 8.1, 384 / 512: 6.6 against 6.3)

@@ -39,7 +39,7 @@ s, a, r, s2 = f(n, 64, S), f(n, 64, A), f(n, 64), f(n, 64, S)
 lib = _hip.lib()
 dbg = lib.avd_debug_phase_cycles_lean if LEAN else lib.avd_debug_phase_cycles
 if CENTRAL and "general" not in sys.argv[2]:
-    dbg = lib.avd_debug_phase_cycles_cen2 if os.environ.get("AVD_CEN2") else lib.avd_debug_phase_cycles_cen
+    dbg = lib.avd_debug_phase_cycles_cen
 dbg.argtypes = [ctypes.c_void_p, ctypes.c_int]
 gscr = torch.zeros(n, grp.lay.theta_size, device='cuda')
 run = (lambda: grp.learn_update(s, a, r, s2, gscr)) if FUSED else (lambda: grp.learn(s, a, r, s2, 0))
