@@ -55,6 +55,7 @@ _PROTOS = {
     "avd_mlp_layout_init": [_LP, _i, _i, _i, _i, _i, _i],
     "avd_env_step_f32": [_P, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "avd_env_reset_f32": [_P, _i, _i, _P, _P, _P, _P, _P, _i, _u64, _u64, _P, _P],
+    "avd_episode_end_f32": [_P, _i, _i, _i, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _P, _i, _u64, _u64, _P],
     "avd_ou_step_f32": [_i, _P, _P, _f, _f, _f, _f, _u64, _u64, _P],
     "avd_policy_f32": [_i, _P, _P, _f, _f, _P, _P],
     "avd_normal_f32": [_i, _P, _f, _u64, _u64, _P],
@@ -72,6 +73,7 @@ _PROTOS = {
     "avd_learn_f32": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P],
     "avd_learn_update_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _d, _P, _P, _P],
     "avd_learn_update_act_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _d, _P, _P, _P, _i, _P, _P],
+    "avd_learn_update_plan": [_LP, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "avd_adam_polyak_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
     "avd_polyak_f32": [_i64, _P, _P, _d, _P],
     "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],
@@ -85,7 +87,8 @@ _PROTOS = {
     "avd_learn_set_split_mfma_count": [_LP, _i, _i, C.POINTER(C.c_ulonglong)],
     "avd_learn_set_split_critic": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
     "avd_learn_set_split_actor": [_LP, _i, _i, _P, _P, _P, _f, _P, _P, C.c_size_t, _P],
-    "avd_learn_set_split_bf16x3": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
+    "avd_learn_set_split_bf16x3": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],  # deprecated alias
+    "avd_learn_set_split_f16x3": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
     "avd_actor_forward_shared_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],
     "avd_actor_forward_shared_bf16": [_LP, _i, _i, _P, _P, _P, _f, _P, _P, C.c_size_t, _P],
     "avd_gemm_bt_bf16": [_i, _i, _i, _P, C.c_long, _P, C.c_long, _P, C.c_long, _P],
@@ -101,14 +104,18 @@ def _load(path):
                        "avddpg_amd has no CPU fallback")
     l = C.CDLL(path)
     for name, args in _PROTOS.items():
-        fn = getattr(l, name)
+        fn = getattr(l, name, None)
+        if fn is None:
+            continue  # an older build (A/B tooling loads one through AVDDPG_HIP_LIB): call() raises when the name is used
         fn.argtypes = args
         fn.restype = C.c_int
     l.avd_last_error.restype = C.c_char_p
     l.avd_last_error.argtypes = []
-    for name in ("avd_version", "avd_diagnostics_enabled"):
-        getattr(l, name).restype = C.c_int
-        getattr(l, name).argtypes = []
+    l.avd_version.restype, l.avd_version.argtypes = C.c_int, []
+    if getattr(l, "avd_diagnostics_enabled", None) is None:  # pre-r04 library: no diagnostic build existed
+        l.avd_diagnostics_enabled = lambda: 0
+    else:
+        l.avd_diagnostics_enabled.restype, l.avd_diagnostics_enabled.argtypes = C.c_int, []
     return l
 
 
@@ -144,7 +151,10 @@ class diag_library:
 
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise AvdError(f"{name} is not exported by the loaded library (an older build?)")
+    rc = fn(*args)
     if rc != 0:
         raise AvdError(f"{name} failed ({rc}): {lib().avd_last_error().decode()}")
 

@@ -15,6 +15,7 @@
 //   * the update (avd_learn_update_f32) is a pipeline of two streams: learn kernels over chunks of 256 models in the caller's stream,
 //     each chunk's Adam + Polyak pass (optim.hip adam_polyak_rows_kernel) on a side stream under the next chunk's learn kernel.
 // Every sum has a fixed order: results are a function of the inputs only. 4096 models at L = 5: 9.5 -> ~6 ms per step.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -711,14 +712,14 @@ static int launch_t(const avd_mlp_layout* lay, Span sp, int set_mod, const float
     constexpr size_t lds = sizeof(float) * Lds<S, A>::total;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    static bool attr[64] = {};
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
+    static std::atomic<bool> attr[64];  // (zero-initialised; a race sets the same attribute twice: harmless)
+    if (dev < 0 || dev >= 64 || !attr[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)learn_kernel_c<S, A, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("cen_launch: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
             return AVD_E_LAUNCH;
         }
-        attr[dev] = true;
+        if (dev >= 0 && dev < 64) attr[dev].store(true, std::memory_order_release);
     }
     // (a span is addressed by offsetting the per-agent arrays; shared sets -- set_mod > 0 -- only ever come with lo == 0)
     const long lo = sp.lo, ts = lay->theta_size, ss = lay->stats_size;
@@ -751,11 +752,12 @@ struct Side {
     bool ready = false;
     std::mutex enqueue;  // one caller at a time records / waits on the device's events (two host threads must not interleave them)
 };
-static Side* side_stream() {
+static Side* side_stream(hipStream_t of) {
     static Side sides[64];
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    // the device the CALLER'S stream lives on (the null stream: the current device)
+    if ((of ? hipStreamGetDevice(of, &dev) : hipGetDevice(&dev)) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     Side& sd = sides[dev];
     if (!sd.ready) {
@@ -772,7 +774,7 @@ static Side* side_stream() {
 
 #ifdef AVD_PHASE_TIMING
 }  // namespace avd
-extern "C" int avd_debug_phase_cycles_cen(unsigned long long* h_out, int reset) {
+extern "C" __attribute__((visibility("default"))) int avd_debug_phase_cycles_cen(unsigned long long* h_out, int reset) {
     if (h_out) (void)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
     if (reset) {
         unsigned long long z[32] = {0};
@@ -796,6 +798,20 @@ int cen_launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float
                                     high, grads, losses, 0.f, 0.f, (hipStream_t)stream);
 }
 
+// How cen_launch_update cuts n_agents models into chunks: one learn workgroup per CU and chunk, at most MAX_CHUNKS chunks (the chunk
+// grows beyond the CU count instead), one update workgroup per CU (MI355X, 256 CUs, 4096 agents: 6.8 ms per step with 256 / 256, 7.3
+// with chunks of 512, 11.4 with 128; 128 or 192 update workgroups: 8.1, 384 / 512: 6.6 against 6.3). Exported as
+// avd_learn_update_plan so that a caller can describe the pipeline it measured.
+void cen_update_plan(int n_agents, int* chunk_out, int* groups_out) {
+    const int cus = fset::cu_count() > 0 ? fset::cu_count() : 256;
+    int chunk = cus;
+    if (const char* e = AVD_DIAG_ENV("CEN_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : n_agents;
+    int groups = cus;  // update-pass workgroups (optim.hip adam_polyak_rows_kernel)
+    if (const char* e = AVD_DIAG_ENV("CEN_GROUPS")) groups = atoi(e);
+    if ((n_agents + chunk - 1) / chunk > cen::MAX_CHUNKS) chunk = (n_agents + cen::MAX_CHUNKS - 1) / cen::MAX_CHUNKS;
+    *chunk_out = chunk, *groups_out = groups;
+}
+
 // avd_learn_update_f32 for the centralized shapes: learn + Adam + Polyak of every agent, theta -> theta_out.
 // The update of an agent's 0.5 MB of weights moves 4 MB through one CU's memory pipeline -- applied where the gradients are
 // produced (the general kernel's fused form; this kernel's first version: 283 k of 984 k cycles per agent at 12 B / clk / CU, with one
@@ -814,33 +830,45 @@ int cen_launch_update(const avd_mlp_layout* lay, int n_agents, const float* thet
     const long ts = lay->theta_size;
     // one learn workgroup per CU and chunk, one update workgroup per CU (MI355X, 256 CUs, 4096 agents: 6.8 ms per step with 256 / 256,
     // 7.3 with chunks of 512, 11.4 with 128; 128 or 192 update workgroups: 8.1, 384 / 512: 6.6 against 6.3)
-    const int cus = fset::cu_count() > 0 ? fset::cu_count() : 256;
-    int chunk = cus;
-    if (const char* e = AVD_DIAG_ENV("CEN_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : n_agents;
-    int groups = cus;  // update-pass workgroups (optim.hip adam_polyak_rows_kernel)
-    if (const char* e = AVD_DIAG_ENV("CEN_GROUPS")) groups = atoi(e);
-    if ((n_agents + chunk - 1) / chunk > cen::MAX_CHUNKS) chunk = (n_agents + cen::MAX_CHUNKS - 1) / cen::MAX_CHUNKS;
-    cen::Side* sd = n_agents > chunk ? cen::side_stream() : nullptr;
+    int chunk = 0, groups = 0;
+    cen_update_plan(n_agents, &chunk, &groups);
+    cen::Side* sd = n_agents > chunk ? cen::side_stream(main) : nullptr;
     std::unique_lock<std::mutex> lock;
     if (sd) lock = std::unique_lock<std::mutex>(sd->enqueue);
+    bool forked = false;
+    // every return after the first fork joins the side stream back into the caller's stream: in eager mode nothing the caller
+    // enqueues next can race with update passes still queued there, and a hipGraph capture is not left with an unjoined fork
+    auto join = [&]() -> bool {
+        if (!forked) return true;
+        forked = false;
+        return hipEventRecord(sd->join, sd->st) == hipSuccess && hipStreamWaitEvent(main, sd->join, 0) == hipSuccess;
+    };
     int c = 0;
     for (int lo = 0; lo < n_agents; lo += chunk, ++c) {
         const cen::Span sp = {lo, n_agents - lo < chunk ? n_agents - lo : chunk};
         int rc = cen::launch_shape<true>(lay, sp, 0, theta, stats, theta_t, stats_t, s, a, r, s2, gamma, high, grads, losses, tauf, omt, main);
-        if (rc) return rc;
+        if (rc) {
+            (void)join();
+            return rc;
+        }
         hipStream_t ust = main;
         if (sd) {
-            if (hipEventRecord(sd->learned[c], main) != hipSuccess || hipStreamWaitEvent(sd->st, sd->learned[c], 0) != hipSuccess)
+            if (hipEventRecord(sd->learned[c], main) != hipSuccess || hipStreamWaitEvent(sd->st, sd->learned[c], 0) != hipSuccess) {
+                (void)join();
                 return check_launch("avd_learn_update_f32 (centralized): fork");
+            }
+            forked = true;
             ust = sd->st;
         }
         const long o = (long)sp.lo * ts;
         rc = ::launch_adam_polyak_rows(lay, sp.n, groups, theta + o, theta_out + o, theta_t + o, m + o, v + o, grads + o, step + sp.lo, actor_lr,
                                        critic_lr, tau, ust);
-        if (rc) return rc;
+        if (rc) {
+            (void)join();
+            return rc;
+        }
     }
-    if (sd && (hipEventRecord(sd->join, sd->st) != hipSuccess || hipStreamWaitEvent(main, sd->join, 0) != hipSuccess))
-        return check_launch("avd_learn_update_f32 (centralized): join");
+    if (!join()) return check_launch("avd_learn_update_f32 (centralized): join");
     return AVD_OK;
 }
 

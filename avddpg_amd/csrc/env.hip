@@ -108,6 +108,43 @@ __global__ __launch_bounds__(ENV_THREADS) void env_step_kernel(const avd_env_con
     if (any_done && __syncthreads_or(block_any) && tid == 0) *any_done = 1;
 }
 
+// Fresh state of vehicle (p, i) (Vehicle.reset, environment.py:520-559; Platoon.reset :284-301) -- the draws only; the caller
+// chains a_lead = predecessor's fresh x[2] (:291-294).
+__device__ __forceinline__ void reset_draws(const avd_env_consts* cst, int mode, const float* draws, const float* front_accel,
+                                            uint64_t seed, uint64_t counter, int p, int i, long v, float& d0, float& d1,
+                                            float& d2, float& fa) {
+#pragma clang fp contract(off)
+    if (mode == 1) {  // evaluator constants (environment.py:534-539)
+        d0 = cst->reset_ep_eval, d1 = cst->reset_ev_eval, d2 = cst->reset_a_eval;
+    } else if (mode == 2) {  // rand_states=False (:552-555)
+        d0 = cst->reset_ep_max, d1 = cst->reset_max_ev, d2 = cst->reset_max_a;
+    } else if (draws) {  // host-RNG parity mode
+        d0 = draws[v * 3 + 0], d1 = draws[v * 3 + 1], d2 = draws[v * 3 + 2];
+    } else {  // device Philox (:547-549; util.py:67-70)
+        const u32x4 ra = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_A);
+        const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
+        if (cst->uniform_reset) {
+            d0 = uniform_pm1(ra.x) * cst->reset_ep_max;
+            d1 = uniform_pm1(ra.y) * cst->reset_max_ev;
+            d2 = uniform_pm1(rb.x) * cst->reset_max_a;
+        } else {
+            float n1;
+            const float n0 = box_muller(ra.x, ra.y, &n1);
+            d0 = n0 * cst->reset_ep_max;
+            d1 = n1 * cst->reset_max_ev;
+            d2 = box_muller(rb.x, rb.y, nullptr) * cst->reset_max_a;
+        }
+    }
+    if (i == 0) {
+        if (front_accel) {
+            fa = front_accel[p];
+        } else {
+            const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
+            fa = (cst->uniform_reset ? uniform_pm1(rb.z) : box_muller(rb.z, rb.w, nullptr)) * cst->leader_reset_a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(ENV_THREADS) void env_reset_kernel(const avd_env_consts* __restrict__ cst, int P, int L,
                                                                 float4* __restrict__ x, float* __restrict__ prev_a,
                                                                 float* __restrict__ cum_accel,
@@ -126,37 +163,7 @@ __global__ __launch_bounds__(ENV_THREADS) void env_reset_kernel(const avd_env_co
     const bool active = (lp < pb) && (p < P);
     const long v = (long)p * L + i;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, fa = 0.f;
-    if (active) {
-        if (mode == 1) {  // evaluator constants (environment.py:534-539)
-            d0 = cst->reset_ep_eval, d1 = cst->reset_ev_eval, d2 = cst->reset_a_eval;
-        } else if (mode == 2) {  // rand_states=False (:552-555)
-            d0 = cst->reset_ep_max, d1 = cst->reset_max_ev, d2 = cst->reset_max_a;
-        } else if (draws) {  // host-RNG parity mode
-            d0 = draws[v * 3 + 0], d1 = draws[v * 3 + 1], d2 = draws[v * 3 + 2];
-        } else {  // device Philox (:547-549; util.py:67-70)
-            const u32x4 ra = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_A);
-            const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
-            if (cst->uniform_reset) {
-                d0 = uniform_pm1(ra.x) * cst->reset_ep_max;
-                d1 = uniform_pm1(ra.y) * cst->reset_max_ev;
-                d2 = uniform_pm1(rb.x) * cst->reset_max_a;
-            } else {
-                float n1;
-                const float n0 = box_muller(ra.x, ra.y, &n1);
-                d0 = n0 * cst->reset_ep_max;
-                d1 = n1 * cst->reset_max_ev;
-                d2 = box_muller(rb.x, rb.y, nullptr) * cst->reset_max_a;
-            }
-        }
-        if (i == 0) {
-            if (front_accel) {
-                fa = front_accel[p];
-            } else {
-                const u32x4 rb = philox_at(seed, counter, (uint32_t)v, STREAM_RESET_B);
-                fa = (cst->uniform_reset ? uniform_pm1(rb.z) : box_muller(rb.z, rb.w, nullptr)) * cst->leader_reset_a;
-            }
-        }
-    }
+    if (active) reset_draws(cst, mode, draws, front_accel, seed, counter, p, i, v, d0, d1, d2, fa);
     x2s[tid] = d2;
     __syncthreads();
     if (active) {
@@ -165,6 +172,69 @@ __global__ __launch_bounds__(ENV_THREADS) void env_reset_kernel(const avd_env_co
         prev_a[v] = d2;  // prev_x = x (:557)
         if (cum_accel) cum_accel[v] = 0.f;
     }
+}
+
+// Per-platoon episode end (vectorised-environment form of workers/trainer.py:232-273; device-RNG throughput mode). The reference
+// ends the episode of ALL platoons when any one is terminal (:268-269) -- with thousands of platoons that cuts every episode to
+// the first terminal among them. Here each platoon runs its own episode: after a step, a platoon whose step was terminal
+// (done[p]) or whose episode has reached `limit` steps (config.py:89) closes its episode -- its M float32 episodic reward
+// counters (:249, 321) go into the platoon's statistics (sum over finished episodes of the platoon-mean episodic reward, of the
+// episode lengths, and the episode count: what trainer.py:510-517 appends per episode, kept as sums so that nothing leaves the
+// device per step), the counters restart from 0 and the platoon gets fresh reset states (Platoon.reset, same draws as
+// env_reset_kernel at (seed, counter, vehicle)). *any_reset is set to 1 when any platoon was reset (the caller's "states changed
+// under the actor outputs" flag). One thread per vehicle, whole platoons per block.
+__global__ __launch_bounds__(ENV_THREADS) void episode_end_kernel(const avd_env_consts* __restrict__ cst, int P, int L, int M,
+                                                                  float4* __restrict__ x, float* __restrict__ prev_a,
+                                                                  float* __restrict__ cum_accel,
+                                                                  const uint8_t* __restrict__ done, int32_t* __restrict__ ep_len,
+                                                                  float* __restrict__ ep_reward, int limit,
+                                                                  float* __restrict__ ret_sum, float* __restrict__ len_sum,
+                                                                  int32_t* __restrict__ ep_cnt, int32_t* __restrict__ any_reset,
+                                                                  int mode, uint64_t seed, uint64_t counter) {
+#pragma clang fp contract(off)
+    __shared__ float x2s[ENV_THREADS];
+    __shared__ float rs[ENV_THREADS];
+    const int tid = threadIdx.x;
+    const int pb = ENV_THREADS / L;
+    const int lp = tid / L;
+    const int i = tid - lp * L;
+    const int p = blockIdx.x * pb + lp;
+    const bool active = (lp < pb) && (p < P);
+    const long v = (long)p * L + i;
+    int len = 0;
+    bool end = false;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, fa = 0.f, er = 0.f;
+    if (active) {
+        len = ep_len[p] + 1;
+        end = (done[p] != 0) || (len >= limit);
+        if (end) {
+            reset_draws(cst, mode, nullptr, nullptr, seed, counter, p, i, v, d0, d1, d2, fa);
+            if (i < M) er = ep_reward[(long)p * M + i];
+        }
+    }
+    x2s[tid] = d2;
+    rs[tid] = er;
+    const int block_any = __syncthreads_or(end ? 1 : 0);  // also orders the ep_len reads above before the write below
+    if (active && end) {
+        const float a_lead = (i == 0) ? fa : x2s[tid - 1];
+        x[v] = make_float4(d0, d1, d2, a_lead);
+        prev_a[v] = d2;
+        if (cum_accel) cum_accel[v] = 0.f;
+        if (i < M) ep_reward[(long)p * M + i] = 0.f;
+    }
+    if (active && i == 0) {
+        if (end) {
+            float s = 0.f;
+            for (int k = 0; k < M; ++k) s = s + rs[tid + k];  // vehicle order
+            ret_sum[p] = ret_sum[p] + s / (float)M;
+            len_sum[p] = len_sum[p] + (float)len;
+            ep_cnt[p] = ep_cnt[p] + 1;
+            ep_len[p] = 0;
+        } else {
+            ep_len[p] = len;
+        }
+    }
+    if (any_reset && block_any && tid == 0) *any_reset = 1;  // every writer stores the same value
 }
 
 // ---- one launch per training step: OU noise -> policy clip -> leader exog -> platoon step -> replay add (+ reward sums) -----
@@ -346,6 +416,21 @@ extern "C" int avd_env_reset_f32(const avd_env_consts* d_consts, int P, int L, f
     hipLaunchKernelGGL(env_reset_kernel, dim3(grid), dim3(ENV_THREADS), 0, (hipStream_t)stream, d_consts, P, L,
                        (float4*)x, prev_a, cum_accel, draws, front_accel, mode, seed, counter, cond);
     return check_launch("avd_env_reset_f32");
+}
+
+extern "C" int avd_episode_end_f32(const avd_env_consts* d_consts, int P, int L, int M, float* x, float* prev_a, float* cum_accel,
+                                   const uint8_t* done, int32_t* ep_len, float* ep_reward, int limit, float* ret_sum,
+                                   float* len_sum, int32_t* ep_cnt, int32_t* any_reset, int mode, uint64_t seed,
+                                   uint64_t counter, void* stream) {
+    AVD_REQUIRE(P > 0 && L > 0 && L <= AVD_MAX_L && M >= 1 && M <= L, "avd_episode_end_f32: P=%d L=%d M=%d", P, L, M);
+    AVD_REQUIRE(d_consts && x && prev_a && done && ep_len && ep_reward && ret_sum && len_sum && ep_cnt,
+                "avd_episode_end_f32: null pointer");
+    AVD_REQUIRE(limit >= 1 && mode >= 0 && mode <= 2, "avd_episode_end_f32: limit=%d mode=%d", limit, mode);
+    const int pb = ENV_THREADS / L;
+    hipLaunchKernelGGL(episode_end_kernel, dim3((P + pb - 1) / pb), dim3(ENV_THREADS), 0, (hipStream_t)stream, d_consts, P, L, M,
+                       (float4*)x, prev_a, cum_accel, done, ep_len, ep_reward, limit, ret_sum, len_sum, ep_cnt, any_reset, mode,
+                       seed, counter);
+    return check_launch("avd_episode_end_f32");
 }
 
 extern "C" int avd_ou_step_f32(int n, float* ou_state, const float* normals, float theta, float mean, float dt,

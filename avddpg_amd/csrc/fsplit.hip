@@ -1445,7 +1445,7 @@ static int check_shape(const avd_mlp_layout* L, int n_agents, int n_sets, const 
     return AVD_OK;
 }
 
-// The chain in two phases over one workspace (avd_learn_set_split_critic / _actor; avd_learn_set_split_bf16x3 = both):
+// The chain in two phases over one workspace (avd_learn_set_split_critic / _actor; avd_learn_set_split_f16x3 = both):
 //   CRITIC: operand preparation, targets, mu, critic loss + gradients + the action gradient d q / d mu, finalize of the critic block
 //   ACTOR : actor gradients from the d mu the critic phase left in the workspace, finalize of the actor block
 // so that a multi-GPU caller can put the critic block's all-reduce on a side stream while the actor phase still runs
@@ -1608,12 +1608,21 @@ static int split_entry(int phases, const char* who, const avd_mlp_layout* lay, i
                           (unsigned char*)workspace, pl, (hipStream_t)stream);
 }
 
+extern "C" int avd_learn_set_split_f16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                                          const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                                          const float* s2, const float* agent_weight, float gamma, float high, float* grads,
+                                          float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+    return split_entry(fsplit::PH_BOTH, "avd_learn_set_split_f16x3", lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2,
+                       agent_weight, gamma, high, grads, losses, workspace, workspace_bytes, stream);
+}
+
+// deprecated alias (r03's name: the operand pairs were bf16 then; every pair has been fp16 since r04)
 extern "C" int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                           const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
                                           const float* s2, const float* agent_weight, float gamma, float high, float* grads,
                                           float* losses, void* workspace, size_t workspace_bytes, void* stream) {
-    return split_entry(fsplit::PH_BOTH, "avd_learn_set_split_bf16x3", lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2,
-                       agent_weight, gamma, high, grads, losses, workspace, workspace_bytes, stream);
+    return avd_learn_set_split_f16x3(lay, n_agents, n_sets, theta, stats, theta_t, stats_t, s, a, r, s2, agent_weight, gamma, high, grads,
+                                     losses, workspace, workspace_bytes, stream);
 }
 
 extern "C" int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,

@@ -903,7 +903,7 @@ static int launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const fl
 
 #ifdef AVD_PHASE_TIMING
 }  // namespace avd
-extern "C" int avd_debug_phase_cycles_lean(unsigned long long* h_out, int reset) {
+extern "C" __attribute__((visibility("default"))) int avd_debug_phase_cycles_lean(unsigned long long* h_out, int reset) {
     if (h_out) (void)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
     if (reset) {
         unsigned long long z[32] = {0};

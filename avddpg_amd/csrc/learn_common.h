@@ -682,6 +682,7 @@ struct UpdArgs {
 // cen.hip: learn_kernel_c, the centralized framework's shapes (H1 / H2 / Ha = 320 / 160 / 64, (S, A) = (12, 3) or (20, 5)): gradients
 // out (avd_learn_f32's contract) and the whole update (avd_learn_update_f32's: learn chunks and their Adam + Polyak passes on two streams)
 bool cen_supports(const avd_mlp_layout* lay);
+void cen_update_plan(int n_agents, int* chunk_out, int* groups_out);
 int cen_launch(const avd_mlp_layout* lay, int n_agents, int set_mod, const float* theta, const float* stats, const float* theta_t,
                const float* stats_t, const float* s, const float* a, const float* r, const float* s2, float gamma, float high, float* grads,
                float* losses, void* stream);

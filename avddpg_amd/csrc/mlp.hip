@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(NTHREADS) void actor_rows_shared_kernel(avd_mlp_lay
 
 #ifdef AVD_PHASE_TIMING
 }  // namespace avd
-extern "C" int avd_debug_phase_cycles(unsigned long long* h_out, int reset) {
+extern "C" __attribute__((visibility("default"))) int avd_debug_phase_cycles(unsigned long long* h_out, int reset) {
     if (h_out) (void)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(avd::g_phase_cycles), sizeof(unsigned long long) * 32);
     if (reset) {
         unsigned long long z[32] = {0};
@@ -1674,6 +1674,17 @@ extern "C" int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, con
                                     double tau, float* grads_scratch, float* losses, void* stream) {
     return learn_update_impl(lay, n_agents, theta, stats, theta_out, theta_t, stats_t, m, v, step, s, a, r, s2, gamma, high,
                              actor_lr, critic_lr, tau, grads_scratch, losses, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int avd_learn_update_plan(const avd_mlp_layout* lay, int n_agents, int* chunk_agents, int* n_chunks, int* update_groups) {
+    AVD_REQUIRE(lay && n_agents > 0 && chunk_agents && n_chunks && update_groups, "avd_learn_update_plan: null / n_agents=%d", n_agents);
+    if (cen_supports(lay) && !AVD_DIAG_ENV("LEARN_GENERAL")) {
+        cen_update_plan(n_agents, chunk_agents, update_groups);
+        *n_chunks = (n_agents + *chunk_agents - 1) / *chunk_agents;
+    } else {  // one launch over all agents, the update applied inside it
+        *chunk_agents = n_agents, *n_chunks = 1, *update_groups = 0;
+    }
+    return AVD_OK;
 }
 
 extern "C" int avd_learn_update_act_f32(const avd_mlp_layout* lay, int n_agents, const float* theta, const float* stats,

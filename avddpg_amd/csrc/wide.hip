@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <atomic>
 
 namespace avd {
 namespace wide {
@@ -420,12 +421,22 @@ template <class Epi>
 static int launch_gemm(const GemmP& p, const Epi& e, int n_sets, hipStream_t st, const char* who) {
     constexpr size_t lds128 = 2 * (BM + BN) * BK * sizeof(bf16), lds256 = NSTG * (TM + 256) * TK * sizeof(bf16),
                      lds256x128 = NSTG * (TM + 128) * TK * sizeof(bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-        (void)hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256x128);
-        attr_set = true;
+    // the > 64 KB dynamic-LDS opt-in, once per DEVICE of this process and per epilogue (the attribute belongs to the device's copy of
+    // the function); a failure is reported, not swallowed. (Two host threads racing here both set the same attribute: harmless.)
+    static std::atomic<unsigned long long> attr_done{0};  // bit = device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t err = hipFuncSetAttribute((const void*)gemm_bt_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute((const void*)gemm_bt256_kernel<Epi, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256x128);
+        if (err != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(dynamic LDS %zu B) on device %d: %s", who, lds256, dev, hipGetErrorString(err));
+            return AVD_E_LAUNCH;
+        }
+        if (dev >= 0 && dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
     static const char* force = AVD_DIAG_ENV("GEMM_TILE");  // diagnostics: "128", "256x128", "256"
     int tile = (p.M >= 2 * TM && p.Nc >= 2 * 256) ? 256 : 128;  // large problems: 256^2 tiles

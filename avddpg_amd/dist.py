@@ -53,6 +53,69 @@ def exchange_fed_sums(out_sum, wsum, n_local, group, total=None):
     return total_platoons(n_local, group, out_sum.device) if total is None else float(total)
 
 
+def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, actor_phase, timers=None):
+    """The interfrl exchange of a learn call that runs in two phases (avd_learn_set_split_critic / _actor): the CRITIC block
+    set_grads[:, actor_size:] is final when this is called and is all-reduced (as the local sum: x `scale`) while
+    ``actor_phase()`` -- which must leave the actor block set_grads[:, :actor_size] final -- computes; the actor block (with the
+    [M] weight sums of a weighted mean riding in the same buffer) follows; both are divided by `total` / the reduced weight sums
+    and written back. Same elementwise sums as exchange_fed_sums on the whole slab (workers/trainer.py:400-431 averages the
+    critic and the actor gradient lists independently; src/server/federated.py:47-63).
+
+    Collective ORDER: critic block first, actor block second, both issued from this one host thread with async_op=True -- the
+    same sequence on every rank whatever the ranks' timing, which is what a NCCL / RCCL communicator requires (collectives of
+    one communicator must be issued in the same order everywhere); waited for in that order too. On CUDA tensors the critic
+    block's scaling and collective are queued on bufs["stream"] (a side stream) behind bufs["ready"], so they run under the
+    actor phase on the caller's stream; on CPU tensors (gloo tests) the same calls run without streams.
+    bufs: dict(crit=[M, T - A] buffer, act=flat [M * A + M] buffer[, stream, ready])."""
+    import torch.distributed as dist
+
+    M, A = set_grads.shape[0], actor_size
+    cuda = set_grads.is_cuda
+    crit, actbuf = bufs["crit"], bufs["act"]
+    ev = None
+    if cuda:
+        main, side = torch.cuda.current_stream(), bufs["stream"]
+        bufs["ready"].record(main)
+        if timers is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        with torch.cuda.stream(side):
+            side.wait_event(bufs["ready"])
+            torch.mul(set_grads[:, A:], scale, out=crit)  # local (weighted) mean -> local (weighted) sum
+            if ev:
+                ev[0].record()
+            # async_op: the host returns at once on every backend, so the actor phase is launched while the collective is in
+            # flight (a blocking call would hold the host until a host-staged backend has finished: nothing would overlap)
+            work_c = dist.all_reduce(crit, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    else:
+        torch.mul(set_grads[:, A:], scale, out=crit)
+        work_c = dist.all_reduce(crit, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    actor_phase()
+    act = actbuf[:M * A].view(M, A)
+    torch.mul(set_grads[:, :A], scale, out=act)
+    if wsum is not None:
+        actbuf[M * A:M * A + M].copy_(wsum)
+    n = M * A + (M if wsum is not None else 0)
+    if ev:
+        ev[2].record()
+    work_a = dist.all_reduce(actbuf[:n], op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if cuda:
+        with torch.cuda.stream(side):
+            work_c.wait()
+            if ev:
+                ev[1].record()
+        work_a.wait()
+        if ev:
+            ev[3].record()
+            timers.setdefault("allreduce", []).extend([(ev[0], ev[1]), (ev[2], ev[3])])
+        main.wait_stream(side)
+    else:
+        work_c.wait()
+        work_a.wait()
+    div = float(total) if wsum is None else actbuf[M * A:M * A + M].view(M, 1)
+    set_grads[:, A:].copy_(crit.div_(div))
+    set_grads[:, :A].copy_(act.div_(div))
+
+
 def broadcast_agents(agents, group, src=0):
     """Every rank starts from rank `src`'s initial weights: the reference starts every agent from agent (0,0)'s weights
     and the targets from their online nets (workers/trainer.py:121-131), and the shared-set / interfrl arithmetic

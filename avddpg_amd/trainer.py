@@ -68,7 +68,11 @@ class VecTrainer:
                  replay_ring=None, overlap_allreduce=None):
         """group: torch.distributed process group whose ranks each hold ``conf.num_platoons`` platoons
         (interfrl gradients are all-reduced over it). auto_reset: end episodes on the device (no host
-        sync per step); needs rng='device'.
+        sync per step); needs rng='device'. True: the reference's rule -- any terminal platoon (or the step limit) ends
+        the episode of ALL platoons (workers/trainer.py:268-269). "platoon": every platoon runs its own episodes
+        (vec.VecPlatoon.episode_end: closed on its own terminal step or at its own step limit, episodic rewards kept as
+        per-platoon running sums in ``env.ep_stats``) -- the vectorised-environment form for thousands of platoons, where
+        the any-terminal rule cuts every episode to the first terminal among them.
         seed: this rank's env / noise / replay stream seed (give every rank its own). init_seed: seed of the initial
         weights, ``conf.random_seed`` by default -- rank-INVARIANT: every agent on every rank starts from the same
         weights (workers/trainer.py:121-131); with a group they are broadcast from rank 0 as well."""
@@ -139,6 +143,8 @@ class VecTrainer:
         self.fed_weights = None
         self.exog_calls = 0
         self.seed = seed
+        if auto_reset not in (False, True, "platoon"):
+            raise ValueError(f"auto_reset={auto_reset!r}: False, True (any-terminal, all platoons) or 'platoon'")
         self.auto_reset = auto_reset
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
@@ -160,9 +166,17 @@ class VecTrainer:
         # the per-agent weight-set regime is asserted, i.e. the per_agent engine)
         self.act_mfma = (self.shared and self.shared_engine in ("fused", "fused3")
                          and (lay.H1, lay.H2, lay.A) == (256, 128, 1) and lay.S in (3, 4))
-        self.overlap_allreduce = (group is not None and self.shared and self.shared_engine == "fused3") if overlap_allreduce is None \
-            else bool(overlap_allreduce)
-        if self.overlap_allreduce and not (group is not None and self.shared and self.shared_engine == "fused3"):
+        # overlapped exchange (two-phase learn call, critic block all-reduced on a side stream under the actor phase): on by
+        # default only where the backend is stream-asynchronous (RCCL: the collective is enqueued, the host goes on launching
+        # the actor phase). gloo stages through the host -- the overlap buys nothing there and is opt-in (tests use it to check
+        # that the two collectives give the bits of the single one).
+        can_overlap = group is not None and self.shared and self.shared_engine == "fused3"
+        if overlap_allreduce is None:
+            import torch.distributed as _td
+            self.overlap_allreduce = can_overlap and _td.get_backend(group) == "nccl"
+        else:
+            self.overlap_allreduce = bool(overlap_allreduce)
+        if self.overlap_allreduce and not can_overlap:
             raise ValueError("overlap_allreduce needs a process group and shared_engine='fused3' (the two-phase learn call)")
         self._side = None  # side stream + buffers of the overlapped exchange, made on first use
         self._step_parity = 0
@@ -366,7 +380,7 @@ class VecTrainer:
         streams join, and both blocks are divided by the global platoon count / weight. The same elementwise sums as
         exchange_fed_sums on the whole slab (workers/trainer.py:400-431 averages the critic and the actor gradient lists
         independently; src/server/federated.py:47-63)."""
-        import torch.distributed as dist
+        from .dist import exchange_two_phase
 
         P, M = self.P, self.M
         lay = self.agents.lay
@@ -375,28 +389,12 @@ class VecTrainer:
             f32 = dict(dtype=torch.float32, device=self.device)
             self._side = dict(stream=torch.cuda.Stream(device=self.device), ready=torch.cuda.Event(),
                               crit=torch.empty(M, T - A, **f32), act=torch.empty(M * A + M, **f32))
-        sd = self._side
-        main = torch.cuda.current_stream()
         scale = float(P) if wsum is None else wsum.view(M, 1)
-        self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw, split=True,
-                                    phase="critic")
-        sd["ready"].record(main)
-        with torch.cuda.stream(sd["stream"]):
-            sd["stream"].wait_event(sd["ready"])
-            torch.mul(self.set_grads[:, A:], scale, out=sd["crit"])  # local (weighted) mean -> local (weighted) sum
-            self._timed("allreduce", dist.all_reduce, sd["crit"], op=dist.ReduceOp.SUM, group=self.group)
-        self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw, split=True,
-                                    phase="actor")
-        act = sd["act"][:M * A].view(M, A)
-        torch.mul(self.set_grads[:, :A], scale, out=act)
-        if wsum is not None:
-            sd["act"][M * A:].copy_(wsum)
-        n = M * A + (M if wsum is not None else 0)
-        self._timed("allreduce", dist.all_reduce, sd["act"][:n], op=dist.ReduceOp.SUM, group=self.group)
-        main.wait_stream(sd["stream"])
-        div = self.total_platoons if wsum is None else sd["act"][M * A:].view(M, 1)
-        self.set_grads[:, A:].copy_(sd["crit"].div_(div))
-        self.set_grads[:, :A].copy_(act.div_(div))
+        learn = lambda phase: self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses,
+                                                          agent_weight=aw, split=True, phase=phase)
+        learn("critic")
+        exchange_two_phase(self.set_grads, A, scale, wsum, self.total_platoons, self.group, self._side,
+                           lambda: learn("actor"), timers=self.timers)
 
     def _update(self, ep, i, fed):
         conf, P, M = self.conf, self.P, self.M
@@ -458,6 +456,10 @@ class VecTrainer:
         self._train(ep, i)
         self.env_steps += self.P
         self.ep_step += 1
+        if self.auto_reset == "platoon":
+            # per-platoon episodes: no global episode counter; the schedule predicates see episode 0 and the running step
+            self.env.episode_end(self.ep_reward, self.M, self.conf.steps_per_episode, any_reset=self.env.any_done)
+            return None
         if self.auto_reset:
             # any platoon terminal ends the episode for ALL platoons (:268-269); so does the step limit
             if self.ep_step >= self.conf.steps_per_episode:

@@ -66,6 +66,7 @@ class VecPlatoon:
         self.any_done = self._any_flags[0:1]
         self.reset_count = 0
         self.step_count = 0
+        self.ep_len = self.ep_stats = None  # per-platoon episodes (episode_end), made on first use
         if rng == "host":
             # constructor draws of P reference Platoon objects: 2 + 3L each (environment.py:24,32,385)
             self._host_ctor_draws()
@@ -138,6 +139,33 @@ class VecPlatoon:
         self._upload_reset(draws, fa, cond)
         self.reset_count += 1
         return self.observations()
+
+    def episode_end(self, ep_reward, M, limit, any_reset=None):
+        """Per-platoon episode end (avd_episode_end_f32; device-RNG mode): call once after every step. Platoons whose step was
+        terminal or whose episode reached ``limit`` steps are closed -- their ``ep_reward`` counters [P, M] go into
+        ``self.ep_stats`` (running sums over closed episodes: platoon-mean episodic reward, length, count), and they restart
+        from fresh reset states. ``any_reset`` (int32[1]) is set when any platoon was closed."""
+        if self.rng != "device":
+            raise ValueError("per-platoon episode ends need rng='device'")
+        if self.ep_len is None:
+            z = lambda dt: torch.zeros(self.P, dtype=dt, device=self.device)
+            self.ep_len = z(torch.int32)
+            self.ep_stats = dict(ret_sum=z(torch.float32), len_sum=z(torch.float32), count=z(torch.int32))
+        st = self.ep_stats
+        call("avd_episode_end_f32", ptr(self.d_consts), self.P, self.L, M, ptr(self.x), ptr(self.prev_a), ptr(self.cum_accel),
+             ptr(self.done), ptr(self.ep_len), ptr(ep_reward), int(limit), ptr(st["ret_sum"]), ptr(st["len_sum"]),
+             ptr(st["count"]), ptr(any_reset), self._mode(), self.seed, self.reset_count, stream_handle())
+        self.reset_count += 1
+
+    def pop_episode_stats(self):
+        """(mean platoon-mean episodic reward, mean episode length, episodes closed) since the last call; clears the sums.
+        Host synchronisation: call it at reporting points, not per step."""
+        st = self.ep_stats
+        n = int(st["count"].sum())
+        ret, ln = float(st["ret_sum"].double().sum()), float(st["len_sum"].double().sum())
+        for t in st.values():
+            t.zero_()
+        return (ret / n if n else float("nan")), (ln / n if n else float("nan")), n
 
     def step(self, actions, leader_exog):
         """actions [P, L] float32 (device), leader_exog [P]. Returns (obs, reward, done) device tensors;
@@ -352,7 +380,7 @@ class AgentGroup:
         m): s, s2 [n_agents, B, S], a [n_agents, B(, 1)], r [n_agents, B].
         agent_weight [n_agents] (optional): w_p * P / sum(w) per agent = the weighted federated mean.
         split=False: bf16 GEMM operands (csrc/fset.hip, avd_learn_set_fused_bf16);
-        split=True: every operand an fp16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_bf16x3).
+        split=True: every operand an fp16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_f16x3).
         phase (split only): None = the whole call; "critic" / "actor" = its two halves over the same workspace
         (avd_learn_set_split_critic / _actor: the critic block of ``grads`` is final after the first, the actor block after the
         second; same stream, same ``grads``, nothing else in between -- VecTrainer overlaps the critic block's all-reduce).
@@ -361,7 +389,7 @@ class AgentGroup:
         self._check_agent_major(s, a, r, s2, n_agents, agent_weight)
         if grads is None:
             grads = torch.empty(self.n_sets, self.lay.theta_size, dtype=torch.float32, device=self.device)
-        wsf, fn, attr = (("avd_learn_set_split_workspace", "avd_learn_set_split_bf16x3", "_fsplit_ws") if split else
+        wsf, fn, attr = (("avd_learn_set_split_workspace", "avd_learn_set_split_f16x3", "_fsplit_ws") if split else
                          ("avd_learn_set_fused_workspace", "avd_learn_set_fused_bf16", "_fset_ws"))
         need = ctypes.c_size_t(0)
         call(wsf, self._layp, n_agents, self.n_sets, ctypes.byref(need))

@@ -68,6 +68,14 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test: every rank uses GPU 0 (a 1-GPU box cannot host one rank per GPU)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="interfrl, N > 1: one all-reduce of the whole [M, theta] slab between learn and Adam instead of the critic "
+                         "block's all-reduce overlapped with the actor phase (the default on RCCL)")
+    ap.add_argument("--no-collective-ab", action="store_true",
+                    help="interfrl, N > 1: do not also time the OTHER collective form (by default the line carries both under "
+                         "collective.forms so that one multi-GPU run attributes its own communication cost)")
+    ap.add_argument("--init-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the process-group rendezvous + first collective may take before the rank gives up (non-zero exit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
@@ -234,7 +242,8 @@ def build_trainer(args, mode, engine, rank, group, ring=None):
     return trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
                               seed=1 + rank, pipeline_chunks=args.chunks,
                               fused_update=(mode == "nofrl" and not args.no_fused),
-                              shared_engine=engine if mode == "interfrl" else None, replay_ring=ring)
+                              shared_engine=engine if mode == "interfrl" else None, replay_ring=ring,
+                              overlap_allreduce=False if (args.no_overlap and mode == "interfrl" and group is not None) else None)
 
 
 def run_workload(args, mode, engine, rank, world, group, vt=None):
@@ -262,30 +271,48 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         vt.timers = ev if record else None
         vt.step()
 
-    ev = {}
-    for _ in range(args.warmup):
-        one_step(False)
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_run(warmup, steps):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; max over ranks. Returns
+        (seconds, per-step summed launch durations of each stage)."""
+        nonlocal ev
+        ev = {}
+        for _ in range(warmup):
+            one_step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, {n: sum(a.elapsed_time(b) for a, b in ev.get(n, [])) / steps for n in names}
+
+    ev = {}
+    elapsed, stage_ms = timed_run(args.warmup, args.steps)
+    # N > 1, split engine: time the OTHER collective form too (same trainer, same state), so that one multi-GPU run shows what the
+    # overlap hides: forms.single = one all-reduce of the whole slab between learn and Adam; forms.overlapped = critic block on a side
+    # stream under the actor phase + actor block on the main stream. `value` is the form the trainer chose (overlapped on RCCL).
+    forms = None
+    if world > 1 and mode == "interfrl" and split3 and not args.no_collective_ab:
+        chosen = "overlapped" if vt.overlap_allreduce else "single"
+        forms = {chosen: {"ms_per_step": 1e3 * elapsed / args.steps, "stages_ms": stage_ms}}
+        vt.overlap_allreduce = not vt.overlap_allreduce
+        alt_steps = max(1, min(args.steps, 500))
+        e2, st2 = timed_run(min(args.warmup, 50), alt_steps)
+        forms["single" if chosen == "overlapped" else "overlapped"] = {"ms_per_step": 1e3 * e2 / alt_steps, "stages_ms": st2, "steps": alt_steps}
+        vt.overlap_allreduce = not vt.overlap_allreduce
 
     # per step: summed launch durations of each stage (learn/update: all agent slices of the step)
-    stage_ms = {n: sum(a.elapsed_time(b) for a, b in ev.get(n, [])) / args.steps for n in names}
     n_agents = P * vt.M  # models: L per platoon (decentralized), 1 (centralized)
     env_steps_per_s = world * P * args.steps / elapsed
     updates_per_s = world * n_agents * args.steps / elapsed
@@ -336,7 +363,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         learn_s = stage_ms["learn"] / 1e3
         if fset:  # the algorithmic count of SURVEY 8(d) (0.751 MFLOP per sample), like the f32 kernels
             flops = flop_per_sample * 64 * n_agents
-        roofs.append({"kernel": ("avd_learn_set_split_bf16x3 (fsplit.hip: head x4, actor seed, dw x2, dx x2, dxa persistent kernels + scale, prep, "
+        roofs.append({"kernel": ("avd_learn_set_split_f16x3 (fsplit.hip: head x4, actor seed, dw x2, dx x2, dxa persistent kernels + scale, prep, "
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
                                  "matrix work is 2.2x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
@@ -452,7 +479,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                      f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
                      (f"learn || Adam+Polyak over {args.chunks} agent slices on 2 HIP streams; stage times are "
                       "summed kernel durations and overlap") if (mode == "nofrl" and args.chunks > 1) else
-                     ("split-operand fused shared-set learner (avd_learn_set_split_bf16x3) + Adam/Polyak on the sets" if split3 else
+                     ("split-operand fused shared-set learner (avd_learn_set_split_f16x3) + Adam/Polyak on the sets" if split3 else
                       "fused shared-set learner (avd_learn_set_fused_bf16: second-layer weights resident in registers, first layers on "
                       "the matrix cores, per-workgroup gradient partials) + Adam/Polyak on the sets" if fset else
                       "batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
@@ -462,6 +489,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         out["rccl_ranks"] = world if args.backend == "nccl" else 0
         out["collective_backend"] = args.backend
         out["collective"] = {"per_step_ms": stage_ms["allreduce"], "overlapped": bool(getattr(vt, "overlap_allreduce", False)),
+                             "overlap_is_real": bool(getattr(vt, "overlap_allreduce", False)) and args.backend == "nccl",
+                             "forms": forms,
+                             "hidden_ms": ((forms["single"]["ms_per_step"] - forms["overlapped"]["ms_per_step"]) if forms else None),
                              "bytes_per_step": 4 * vt.M * vt.agents.lay.theta_size,
                              "note": ("two all-reduce(sum) per step: the critic block [M, 41 412] on a side stream under the actor phase of the learn "
                                       "call, the actor block [M, 35 076] on the main stream; per_step_ms = their summed durations on their own streams "
@@ -496,25 +526,52 @@ def main():
     if diag_build and not args.allow_diagnostics:
         sys.exit(f"bench.py: {_hip.LIB_PATH} is a diagnostic build (-DAVD_DIAG); pass --allow-diagnostics to measure it anyway")
     dev = 0 if args.single_device else local_rank
+    # fail fast, non-zero and with a reason (the parent of self-spawned ranks then stops the others): fewer GPUs than ranks
+    # (device_count() does not initialise the GPU), a rendezvous / first collective that does not complete in --init-timeout
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (not args.single_device and n_dev < world):
+        sys.exit(f"bench.py: --gpus {world} needs {world} visible GPUs, torch.cuda.device_count() = {n_dev} "
+                 "(one rank per GPU; --single-device puts every rank on GPU 0 for plumbing tests only)")
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
+        import datetime
+        import threading
+
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+        def give_up():
+            sys.stderr.write(f"bench.py: rank {rank}: process-group init + first collective over {args.backend} did not complete "
+                             f"within --init-timeout {args.init_timeout:.0f} s (MASTER_ADDR={os.environ.get('MASTER_ADDR')} "
+                             f"MASTER_PORT={os.environ.get('MASTER_PORT')}); giving up\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+        watchdog = threading.Timer(args.init_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        timeout = datetime.timedelta(seconds=max(30.0, args.init_timeout))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=timeout)
+            hello = torch.ones(1, device="cuda")
+            dist.all_reduce(hello)  # RCCL builds its communicator on the first collective: do it here, under the watchdog
+            torch.cuda.synchronize()
+            if int(hello.item()) != world:
+                sys.exit(f"bench.py: first all-reduce over RCCL returned {hello.item()} on rank {rank}, expected {world}")
         else:
             # (gloo's C++ side prints a connection banner to stdout: keep rank 0's stdout to the ONE JSON line)
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                dist.init_process_group(args.backend)
+                dist.init_process_group(args.backend, timeout=timeout)
                 dist.barrier()
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
+        watchdog.cancel()
         group = dist.group.WORLD
 
     if args.mode:

@@ -25,6 +25,8 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table. */
+#pragma GCC visibility push(default)
 #endif
 
 #define AVD_MAX_L 16 /* vehicles per platoon supported by the env kernels */
@@ -112,6 +114,21 @@ int avd_env_step_f32(const avd_env_consts* d_consts, int P, int L, const float* 
 int avd_env_reset_f32(const avd_env_consts* d_consts, int P, int L, float* x, float* prev_a, float* cum_accel,
                       const float* draws, const float* front_accel, int mode, uint64_t seed, uint64_t counter,
                       const int32_t* cond, void* stream);
+
+/* Per-platoon episode end -- the vectorised-environment form of the episode loop (workers/trainer.py:232-273) for the
+ * device-RNG throughput mode. The reference closes the episode of ALL platoons when any is terminal (:268-269; that form is
+ * avd_env_reset_f32 with `cond`). Here, called once after every step, each platoon closes its OWN episode when its step was
+ * terminal (done[p], src/environment.py:237-241) or its episode has reached `limit` steps (src/config.py:89):
+ *   ep_len    [P] int32  steps of the running episode (+1 per call; 0 after a close)
+ *   ep_reward [P*M] f32  the episodic reward counters of :249, 321 (M = L decentralized, 1 centralized); zeroed on close
+ *   ret_sum / len_sum [P] f32, ep_cnt [P] int32: per platoon, over its closed episodes, the sum of the platoon-mean episodic
+ *             reward (what :510-517 appends per episode), of the episode lengths, and the episode count -- running sums the
+ *             caller reads and clears whenever it reports a curve point; nothing leaves the device per step
+ *   any_reset int32 or NULL: set to 1 when any platoon was closed (states changed under already-computed actor outputs)
+ * A closed platoon gets fresh states exactly like avd_env_reset_f32 (mode, seed, counter; device Philox draws). */
+int avd_episode_end_f32(const avd_env_consts* d_consts, int P, int L, int M, float* x, float* prev_a, float* cum_accel,
+                        const uint8_t* done, int32_t* ep_len, float* ep_reward, int limit, float* ret_sum, float* len_sum,
+                        int32_t* ep_cnt, int32_t* any_reset, int mode, uint64_t seed, uint64_t counter, void* stream);
 
 /* Aux read-outs used by the evaluator/renderer (environment.py:243-251, 477, 500-503), from the
  * PRE-step state that produced them: jerk = (x2 - prev_a)/T is computed by the caller from the
@@ -213,6 +230,11 @@ int avd_learn_update_f32(const avd_mlp_layout* lay, int n_agents, const float* t
                          float actor_lr, float critic_lr, double tau, float* grads_scratch, float* losses,
                          void* stream);
 
+/* How avd_learn_update_f32 will cut `n_agents` models of this shape into launches on the current device: the centralized
+ * pipeline's chunk size (one learn workgroup per CU and chunk, at most 32 chunks), chunk count and the workgroups of its
+ * Adam + Polyak pass; every other shape: one launch (chunk = n_agents, 1 chunk, 0). For callers that describe what they measured. */
+int avd_learn_update_plan(const avd_mlp_layout* lay, int n_agents, int* chunk_agents, int* n_chunks, int* update_groups);
+
 /* avd_learn_update_f32 plus the agents' NEXT actions (workers/trainer.py:287-289 of the following step, before noise
  * and clipping): next_action[v] = actor(next_state[v * x_stride ..]) with the UPDATED weights, evaluated by the
  * workgroup that has just written them (A = 1). Bit-identical to avd_actor_forward_f32 on theta_out afterwards. */
@@ -310,8 +332,8 @@ int avd_learn_set_fused_bf16(const avd_mlp_layout* lay, int n_agents, int n_sets
  * deterministic reduction, but every matrix-product operand is carried as an fp16 PAIR hi + lo (|x - hi - lo| <= 2^-22 |x|,
  * measured worst 2^-23; static operands and row factors scaled by exact powers of two into fp16's range) and each product runs
  * as A_hi B_hi + A_lo B_hi + A_hi B_lo on v_mfma_f32_32x32x16_f16 with f32 accumulation -- two MFMAs where one operand is the
- * exact relu mask: dZ2 = g3[row] c3[n] [z2 > 0] is rank one times a mask (the output layers are one unit wide). (The name keeps
- * r03's "bf16x3"; since r04 no operand is a bf16 pair any more.) The reference computes Trainer.learn in float32
+ * exact relu mask: dZ2 = g3[row] c3[n] [z2 > 0] is rank one times a mask (the output layers are one unit wide). (avd_learn_set_split_bf16x3,
+ * r03's name from when the pairs were bf16, remains as a deprecated alias of avd_learn_set_split_f16x3.) The reference computes Trainer.learn in float32
  * (agent/model.py:26-36, 63-83; workers/trainer.py:472-508): this entry point is tested at 2e-5 of each gradient tensor's max
  * against the float64 oracle (tests/test_gpu_fsplit.py: measured <= 1.1e-5 at 4096 x 5; the exact-f32 kernels are asserted at
  * 1e-4), which the single-rounded bf16 operands of avd_learn_set_fused_bf16 miss by three orders of magnitude on the actor
@@ -326,7 +348,7 @@ int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int 
  *                               of every set of `grads` (zeroes the slab first) and both losses;
  *   avd_learn_set_split_actor   the actor gradients from what the critic phase left in the workspace; writes the ACTOR block.
  * critic, then actor, on the same stream with the same workspace and nothing else touching it in between, is bit-identical to
- * avd_learn_set_split_bf16x3 (tested). Between the two the critic block is final: a multi-GPU caller starts its all-reduce on a
+ * avd_learn_set_split_f16x3 (tested). Between the two the critic block is final: a multi-GPU caller starts its all-reduce on a
  * side stream there (avddpg_amd/trainer.py) and only the actor block's exchange stays on the critical path. */
 int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
@@ -335,6 +357,12 @@ int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_se
 int avd_learn_set_split_actor(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                               const float* s, float high, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 int avd_learn_set_split_workspace(const avd_mlp_layout* lay, int n_agents, int n_sets, size_t* bytes);
+int avd_learn_set_split_f16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
+                               const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
+                               const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Deprecated alias of avd_learn_set_split_f16x3 (same arguments, same results). */
 int avd_learn_set_split_bf16x3(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
                                const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
@@ -355,6 +383,7 @@ int avd_gemm_bt_bf16(int M, int Nc, int K, const void* A, long lda, const void* 
                      void* stream);
 
 #ifdef __cplusplus
+#pragma GCC visibility pop
 }
 #endif
 #endif /* AVDDPG_HIP_H */

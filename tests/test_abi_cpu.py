@@ -27,6 +27,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(names) - {"avd_last_error", "avd_version", "avd_diagnostics_enabled"} == set(_hip._PROTOS)
 
 
+def test_dynamic_symbol_table_is_exactly_the_declared_c_abi():
+    """built with -fvisibility=hidden + a linker version script, the library's dynamic symbol table holds the
+    `avd_*` entry points of include/avddpg_hip.h and nothing else -- no mangled C++ helper, launcher or kernel handle."""
+    import subprocess
+
+    for path in (_hip.LIB_PATH, _hip.DIAG_LIB_PATH):
+        if not os.path.exists(path):
+            continue
+        nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)
+        syms = sorted(line.split()[-1] for line in nm.stdout.splitlines() if line.strip())
+        assert syms and all(s.startswith("avd_") for s in syms), [s for s in syms if not s.startswith("avd_")]
+        extra = set(syms) - set(_declared())
+        assert all(s.startswith("avd_debug_") for s in extra), extra  # (phase-timing read-outs of diagnostic builds only)
+        if path == _hip.LIB_PATH:
+            assert set(syms) == set(_declared())
+    # the f16x3 name is the real one; r03's bf16x3 stays as an alias with the same prototype
+    assert _hip._PROTOS["avd_learn_set_split_bf16x3"] == _hip._PROTOS["avd_learn_set_split_f16x3"]
+
+
 def test_shipped_library_reads_no_environment_switch():
     """every diagnostic switch (kernel / tile choices, work-skipping ablations) is compiled in only under
     -DAVD_DIAG (`make diag` -> libavddpg_hip_diag.so). The product library holds no "AVD_" string at all, does not import

@@ -172,3 +172,74 @@ def test_bench_self_spawns_its_ranks_as_children_without_a_launcher():
     src = open(os.path.join(root, "bench.py")).read()
     main_src = src[src.index("def main():"):]
     assert main_src.index("spawn_ranks(args)") < main_src.index("import torch")
+
+
+def _two_phase_worker(rank, world, port, weighted, q):
+    """exchange_two_phase on CPU tensors over gloo with dist.all_reduce wrapped by a recorder: the 'fake process group that records
+    calls' of VERDICT r04 #3c is the real gloo group seen through the recorder, so the data path is exercised as well."""
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M, A, T, P = 5, 24, 56, 3 + rank  # unequal shards
+        g = torch.Generator().manual_seed(7 + rank)
+        slab = torch.randn(M, T, generator=g)
+        w = torch.rand(P, M, generator=g) + 0.5 if weighted else None
+        wsum = w.sum(dim=0) if weighted else None
+        scale = float(P) if wsum is None else wsum.view(M, 1)
+        total = adist.total_platoons(P, dist.group.WORLD)
+        # the single-collective form on a copy (exchange_fed_sums) = what the two-phase form must reproduce bit for bit
+        one = slab.clone()
+        ws1 = None if wsum is None else wsum.clone()
+        one.mul_(scale if wsum is None else ws1.view(M, 1))
+        tot = adist.exchange_fed_sums(one, ws1, P, dist.group.WORLD, total=total)
+        one.div_(tot if ws1 is None else ws1.view(M, 1))
+        calls, real = [], dist.all_reduce
+
+        def recorder(t, *a, **kw):
+            calls.append((int(t.numel()), bool(kw.get("async_op", False)), time.monotonic()))
+            return real(t, *a, **kw)
+
+        two = slab.clone()
+        bufs = dict(crit=torch.empty(M, T - A), act=torch.empty(M * A + M))
+        actor_started = []
+
+        def actor_phase():  # ranks take DIFFERENT time between the two collectives: the order of issue must not depend on it
+            actor_started.append(time.monotonic())
+            time.sleep(0.4 * rank)
+
+        dist.all_reduce = recorder
+        try:
+            adist.exchange_two_phase(two, A, scale, None if wsum is None else wsum.clone(), total, dist.group.WORLD, bufs, actor_phase)
+        finally:
+            dist.all_reduce = real
+        q.put((rank, [(n, a) for n, a, _ in calls], calls[0][2] <= actor_started[0] <= calls[1][2], torch.equal(one, two), two.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_two_phase_exchange_issues_its_collectives_in_the_same_order_on_every_rank(weighted):
+    """VERDICT r04 #3c: the overlapped exchange (avddpg_amd/dist.py exchange_two_phase; workers/trainer.py:400-431 over platoon
+    shards) issues critic block, then actor block (+ the [M] weight sums), both async, on EVERY rank and independently of how long
+    a rank's actor phase takes -- what a NCCL / RCCL communicator needs -- and gives the bits of the single-collective form."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_phase_worker, args=(r, world, port, weighted, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    M, A, T = 5, 24, 56
+    want = [(M * (T - A), True), (M * A + (M if weighted else 0), True)]
+    for rank, calls, crit_before_actor, same_bits, _ in res:
+        assert calls == want, (rank, calls)
+        assert crit_before_actor  # the critic block's collective is in flight before the actor phase starts
+        assert same_bits
+    assert np.array_equal(res[0][4], res[1][4])  # every rank ends with the identical average

@@ -240,7 +240,7 @@ SPLIT_TOL = 2e-5  # tests/test_gpu_fsplit.py
 @pytest.mark.parametrize("L", [5, 10])
 def test_split_engine_trainer_at_full_size_tracks_the_exact_engine_and_the_oracle(L):
     """BASELINE configs[1] (4096 x 5) and configs[2] (4096 x 10) through VecTrainer with the engine the bench line runs
-    (interfrl, one weight set per vehicle index, shared_engine='fused3' = avd_learn_set_split_bf16x3) -- VERDICT r03 #6. Two
+    (interfrl, one weight set per vehicle index, shared_engine='fused3' = avd_learn_set_split_f16x3) -- VERDICT r03 #6. Two
     trainers on the same device Philox streams, 'fused3' and the exact-f32 'per_agent' engine (learn_kernel_l per agent +
     fed_sum), 70 steps = 6 federated updates of every set:
       * before the first update (65th add) the two differ only by the acting kernel's f32 summation order: 2e-6; afterwards
@@ -356,7 +356,7 @@ def test_split_engine_reward_curves_at_scale_stay_inside_the_float32_noise_floor
     three times on identical streams:
         E  the exact-f32 engine           (per_agent: learn_kernel_l per agent + fed_sum)
         F  the exact-f32 engine, with its other learn kernel (learn_kernel_t: the same exact f32 products, another summation order)
-        S  the split-operand engine       (fused3: avd_learn_set_split_bf16x3)
+        S  the split-operand engine       (fused3: avd_learn_set_split_f16x3)
     |E - F| is what float32 arithmetic itself leaves undetermined after 2036 Adam updates (Adam turns a gradient component's
     sign into a step of lr: differences of 1e-7 in a gradient near zero become 1e-5 in a weight) -- the floor of the metric.
     Asserted: S ends every episode at the same step as E; every agent's episodic reward within max(1e-3, 1.5 x floor) of E's,

@@ -177,6 +177,67 @@ def test_reset_device_rng_distribution_and_chain():
     assert np.abs(xu[..., 0]).max() <= 1.5 and np.abs(xu[..., 2]).max() <= 0.05 and abs(xu[..., 0].std() - 1.5 / np.sqrt(3)) < 0.03
 
 
+@pytest.mark.parametrize("L,M", [(5, 5), (3, 3), (5, 1), (10, 10)])
+def test_per_platoon_episode_end_closes_only_the_platoons_that_ended(L, M):
+    """avd_episode_end_f32 (the vectorised-environment form of workers/trainer.py:232-273): a platoon closes its episode when
+    its step was terminal or its episode reached the limit -- float32 counters into the per-platoon statistics in vehicle order
+    (trainer.py:510-517), counters and length restart, fresh states identical to what a full reset at the same (seed, counter)
+    gives that platoon (bit-exact); every other platoon is left alone with its length advanced by one."""
+    need_gpu()
+    conf, _ = conf_and_ep()
+    P, limit = 301, 12
+    rs = np.random.RandomState(11)
+    env = vec.VecPlatoon(P, L, conf, rng="device", seed=5)
+    env.reset()
+    ref = vec.VecPlatoon(P, L, conf, rng="device", seed=5)
+    ref.reset()  # reset_count 1 on both from here on
+    x0, pa0 = env.x.clone(), env.prev_a.clone()
+    done = rs.uniform(size=P) < 0.2
+    ep_len = rs.randint(0, limit, size=P).astype(np.int32)  # len + 1 >= limit closes too
+    env.done.copy_(t(done.astype(np.uint8), torch.uint8))
+    env.episode_end(torch.zeros(P, M, device="cuda"), M, limit)  # first call creates the statistics; redo with chosen contents
+    env.x.copy_(x0), env.prev_a.copy_(pa0)
+    env.ep_len.copy_(t(ep_len, torch.int32))
+    for v in env.ep_stats.values():
+        v.zero_()
+    ret0 = rs.normal(size=P).astype(np.float32)
+    env.ep_stats["ret_sum"].copy_(t(ret0))
+    er = rs.normal(-20, 5, size=(P, M)).astype(np.float32)
+    ep_reward = t(er)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert env.reset_count == 2
+    env.episode_end(ep_reward, M, limit, any_reset=flag)
+    ref.reset_count = 2
+    ref.reset()  # the same (seed, counter): what a closed platoon must now hold
+    end = done | (ep_len + 1 >= limit)
+    assert end.any() and (~end).any() and int(flag.item()) == 1
+    x, pa = env.x.cpu().numpy(), env.prev_a.cpu().numpy()
+    assert np.array_equal(x[end], ref.x.cpu().numpy()[end]) and np.array_equal(pa[end], ref.prev_a.cpu().numpy()[end])
+    assert np.array_equal(x[~end], x0.cpu().numpy()[~end]) and np.array_equal(pa[~end], pa0.cpu().numpy()[~end])
+    got_len = env.ep_len.cpu().numpy()
+    assert np.array_equal(got_len, np.where(end, 0, ep_len + 1))
+    want_ret = ret0.copy()
+    for p in np.nonzero(end)[0]:
+        s_ = np.float32(0)
+        for m in range(M):
+            s_ = np.float32(s_ + er[p, m])
+        want_ret[p] = np.float32(want_ret[p] + np.float32(s_ / np.float32(M)))
+    assert np.array_equal(env.ep_stats["ret_sum"].cpu().numpy(), want_ret)
+    assert np.array_equal(env.ep_stats["count"].cpu().numpy(), end.astype(np.int32))
+    assert np.array_equal(env.ep_stats["len_sum"].cpu().numpy(), np.where(end, ep_len + 1, 0).astype(np.float32))
+    got_er = ep_reward.cpu().numpy()
+    assert np.all(got_er[end] == 0) and np.array_equal(got_er[~end], er[~end])
+    mean_ret, mean_len, n = env.pop_episode_stats()
+    assert n == int(end.sum()) and abs(mean_len - (ep_len + 1)[end].mean()) < 1e-4 and int(env.ep_stats["count"].sum()) == 0
+    # nothing ends: no flag, no state change
+    env.done.zero_()
+    env.ep_len.zero_()
+    flag.zero_()
+    before = env.x.clone()
+    env.episode_end(ep_reward, M, limit, any_reset=flag)
+    assert int(flag.item()) == 0 and torch.equal(before, env.x) and int(env.ep_len.min()) == 1
+
+
 def test_ou_noise_matches_reference_sequence():
     need_gpu()
     g = np.load(os.path.join(G, "g4_ou.npz"))

@@ -1,4 +1,4 @@
-"""GPU parity of the split-operand fused set learner (csrc/fsplit.hip, avd_learn_set_split_bf16x3): Trainer.learn
+"""GPU parity of the split-operand fused set learner (csrc/fsplit.hip, avd_learn_set_split_f16x3): Trainer.learn
 (workers/trainer.py:472-508) + federated mean (src/server/federated.py:47-63, 99-118) for agents that share their networks,
 with every GEMM operand an exact 16-bit pair hi + lo. The reference multiplies float32 by float32 (agent/model.py:26-36, 63-83;
 workers/trainer.py:472-508), so the bar is float32's own, enforced here rather than quoted from a profile:

@@ -656,3 +656,36 @@ def test_fused_step_launch_is_bitwise_the_seven_separate_kernels(kw):
     assert torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.agents.theta_t, b.agents.theta_t)
     assert a.episode == b.episode >= 3 and int(a.env.any_done.item()) == int(b.env.any_done.item())
     assert a.updates == (75 - 64) * a.n_agents
+
+
+def test_per_platoon_auto_reset_runs_every_platoon_in_its_own_episodes():
+    """auto_reset="platoon" (vec.VecPlatoon.episode_end): platoons close their own episodes (own terminal step or own step limit)
+    and the episodic rewards arrive as per-platoon running sums; the fused nofrl update's "next action from the epilogue" must be
+    recomputed for the steps after a reset (same trajectory as the unfused update, bit for bit)."""
+    P, L, steps, limit = 96, 3, 150, 20
+    runs = []
+    for fused in (False, True):
+        conf = config.Config(num_platoons=P, pl_size=L, buffer_size=256, episode_sim_time=limit * 0.1)
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset="platoon", fused_update=fused, seed=3)
+        vt.reset_episode()
+        seen = torch.zeros(P, dtype=torch.int32, device="cuda")
+        for k in range(steps):
+            vt.step()
+            seen = torch.maximum(seen, vt.env.ep_len)
+        torch.cuda.synchronize()
+        runs.append(vt)
+        assert int(seen.max()) <= limit - 1 and int(vt.env.ep_len.min()) >= 0
+        cnt = vt.env.ep_stats["count"].cpu().numpy()
+        lens = vt.env.ep_stats["len_sum"].cpu().numpy()
+        assert cnt.min() >= steps // limit and np.all(lens + vt.env.ep_len.cpu().numpy() == steps)  # every step belongs to an episode
+        ret = vt.env.ep_stats["ret_sum"].cpu().numpy()
+        assert np.all(ret < 0) and np.all(np.isfinite(ret))
+        # rewards are in (-0.5 * steps, 0): the closed episodes' platoon-mean sums + the running counters account for every step
+        total = ret + vt.ep_reward.cpu().numpy().mean(axis=1)
+        assert np.all(total > -0.5 * steps - 1e-3) and np.all(total < 0)
+        mean_ret, mean_len, n = vt.env.pop_episode_stats()
+        assert n == int(cnt.sum()) and 1 <= mean_len <= limit and mean_ret < 0
+    a, b = runs
+    assert torch.equal(a.env.x, b.env.x) and torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.actions, b.actions)
+    with pytest.raises(ValueError, match="auto_reset"):
+        trainer.VecTrainer(config.Config(num_platoons=2, pl_size=2), rng="device", auto_reset="vehicle")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: avd_learn_set_split_bf16x3 (csrc/fsplit.hip) -- per-tensor error against the exact-f32 per-agent kernel +
+"""Diagnostic: avd_learn_set_split_f16x3 (csrc/fsplit.hip) -- per-tensor error against the exact-f32 per-agent kernel +
 federated mean (and the bf16 set learner beside it) on perturbed weights, then timing at bench size.
 usage: fsplit_check.py [P] [M] [iters]"""
 import os

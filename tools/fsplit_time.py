@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time avd_learn_set_split_bf16x3 alone at 4096 x 5 (per-launch HIP events over `reps` back-to-back learns after a warm-up) and
+"""Time avd_learn_set_split_f16x3 alone at 4096 x 5 (per-launch HIP events over `reps` back-to-back learns after a warm-up) and
 print its per-tensor distance from the exact-f32 engine. usage: fsplit_time.py [reps] [L]"""
 import os
 import sys

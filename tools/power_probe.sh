@@ -3,7 +3,7 @@
 # (b) while nofrl's learn kernel runs, (c) while a register-resident MFMA loop runs (tools/probes/mfma_dep), (d) idle.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 smi() { rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Graphics" | sed 's/GPU\[0\]\t\t: //' | tr '\n' ' '; echo; }
-echo "== (a) split set learner (avd_learn_set_split_bf16x3), 4096 x 5, 3000 learns back to back"
+echo "== (a) split set learner (avd_learn_set_split_f16x3), 4096 x 5, 3000 learns back to back"
 python $R/tools/fsplit_time.py 4096 5 3000 > /tmp/pp.log 2>&1 &
 PID=$!; sleep 4; for i in 1 2 3; do smi; sleep 1; done; wait $PID; tail -1 /tmp/pp.log
 echo "== (b) nofrl step (learn_kernel_l), 4096 x 5"

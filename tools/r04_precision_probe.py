@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round-4 measurement behind the split-operand learner's test tolerances (tests/test_gpu_fsplit.py, test_gpu_configs_full.py):
-  part A  unconditioned inputs at the parity-test sizes: per-tensor error of avd_learn_set_split_bf16x3 and of the float32 oracle
+  part A  unconditioned inputs at the parity-test sizes: per-tensor error of avd_learn_set_split_f16x3 and of the float32 oracle
           against the float64 oracle;
   part B  4096 x 5 (BASELINE configs[1]): the same for two whole sets (262 144 rows each);
   part C  VecTrainer 4096 x 5 interfrl on device Philox streams, fused3 vs per_agent: episodic rewards and weights after N steps.
