@@ -837,6 +837,8 @@ struct DwArgs {
     const f16* sm;     // [n_agents][64][128] fp16 +-1 / 0 (critic: sign(g3) inside, HEAD_BOTH) or 1 / 0 (actor: OUT_TANH_SAVE; the sign of
                        // g3 then goes onto the A operand: one v_xor per packed pair, from a per-row sign table in LDS)
     float* partG;      // [grid][KG][128] (row K: the constant-one feature = sum over rows of g3 * mask -> db2 / c3)
+    int abl;           // diagnostic build only (AVD_FSPLIT_ABL; 0 in the product): timing ablations with WRONG results -- 1: every tile
+                       // fetch reads the workgroup's first tile (no HBM traffic), 2: no workgroup barrier in the tile loop
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only: [8 waves][8] accumulated s_memtime deltas of workgroup 16
 };
 // Wave w owns feature tile w (both row halves, all four column tiles: 64 accumulator registers). The tiles past the eight
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     const int srow = tid >> 3, sch = tid & 7, frow = tid >> 1, fh = tid & 1;
     uint4 a0 = {}, a1 = {}, b0 = {}, b1 = {};
     float sx[4] = {0.f, 0.f, 0.f, 0.f}, sg = 0.f, sa = 0.f;
-    auto smsrc = [&](int pl) { return (const uint4*)(p.sm + ((long)(pl * p.n_sets + set) * TILE + srow) * H2 + 16 * sch); };
+    auto smsrc = [&](int pl) { return (const uint4*)(p.sm + ((long)(((p.abl & 1) ? j0 : pl) * p.n_sets + set) * TILE + srow) * H2 + 16 * sch); };
     auto fetch_x = [&](int pl) {
         if (pl >= P || tid >= 2 * TILE) return;
         const long ri = (long)(pl * p.n_sets + set) * TILE + frow;
@@ -1028,7 +1030,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
         STAMP(1);
         stage(pi + J, 1, b0, b1);
         STAMP(2);
-        __syncthreads();
+        if (!(p.abl & 2)) __syncthreads();
         STAMP(3);
         if (pi + J < P) {
             // tile pi + J from buffer 1; set b takes tile pi + 3J; set a (tile pi + 2J) goes to buffer 0
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
             STAMP(1);
             stage(pi + 2 * J, 0, a0, a1);
             STAMP(2);
-            __syncthreads();
+            if (!(p.abl & 2)) __syncthreads();
             STAMP(3);
         }
     }
@@ -1089,6 +1091,7 @@ struct DxArgs {
     const f16* sm;
     int unsigned_mask;  // actor: sm holds 1 / 0 (OUT_TANH_SAVE), the row factor keeps the sign of g3; critic: sm holds sign(g3) inside
     float* partV;      // [grid][KP][16]       sum_rows (dC * mask) * [x_hi | x_lo | 1] per feature
+    int abl;           // diagnostic build only (see DwArgs)
     unsigned long long* stamp;  // diagnostic build (-DAVD_STAMP) only
 };
 // Wave w = state feature tile w (8 tiles), both row halves. Resident: fp16 hi and lo of the tile's rows of SWC W2c as B fragments
@@ -1137,6 +1140,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     uint4 d0 = {}, d1 = {};
     float gn = 0.f;
     auto fetch = [&](int agent) {
+        if (p.abl & 1) agent = j0 * p.n_sets + set;
         const uint4* src = (const uint4*)(p.sm + ((long)agent * TILE + srow) * H2 + 16 * sch);
         d0 = src[0], d1 = src[1];
         if (tid < TILE) gn = p.g3[(long)agent * TILE + tid];
@@ -1256,7 +1260,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         DXSTAMP(1);
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
         DXSTAMP(2);
-        __syncthreads();
+        if (!(p.abl & 2)) __syncthreads();
         DXSTAMP(3);
     }
 #ifdef AVD_STAMP
@@ -1487,7 +1491,8 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
         hipLaunchKernelGGL(kern, grid, block, 0, st, h);
     };
     DwArgs dw;
-    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr;
+    dw.n_agents = n_agents, dw.n_sets = n_sets, dw.sm = sm, dw.g3 = g3, dw.x = s, dw.stamp = nullptr, dw.abl = 0;
+    if (const char* e = AVD_DIAG_ENV("FSPLIT_ABL")) dw.abl = atoi(e);
 #ifdef AVD_STAMP
     static unsigned long long* d_stamp = nullptr;
     if (!d_stamp) (void)hipMalloc(&d_stamp, 128 * 8);
@@ -1495,6 +1500,7 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
 #endif
     DxArgs dx;
     dx.n_agents = n_agents, dx.n_sets = n_sets, dx.sm = sm, dx.g3 = g3, dx.xfh = xfs, dx.stamp = nullptr, dx.L_cWa = dx.L_cba = 0, dx.unsigned_mask = 0;
+    dx.abl = dw.abl;
 #ifdef AVD_STAMP
     dx.stamp = d_stamp;
 #endif

@@ -29,11 +29,12 @@ SPLIT_TOL = 2e-5
 SPLIT_TOL_SMALL = 4e-6  # conditioned inputs, <= 4480 rows per set
 
 
-def _tie_mask(grp, M, S, s, a, tie=1e-6):
+def _tie_mask(grp, M, S, s, a, tie=1e-6, sets=None):
     """[agents, 64] bool: batch rows with a pre-activation closer to 0 than `tie` x its layer's largest, in any layer that is
-    differentiated (actor(s), critic(s, a), critic(s, mu)) -- evaluated in float64 with agent v's set v % M."""
+    differentiated (actor(s), critic(s, a), critic(s, mu)) -- evaluated in float64 with agent v's set v % M (only the agents of
+    `sets` when given; the others stay False)."""
     bad = np.zeros(s.shape[:2], bool)
-    for k in range(M):
+    for k in (range(M) if sets is None else sets):
         an, cn, _, _ = _nets(grp, k, np.float64)
         sel = np.arange(k, s.shape[0], M)
         x = s[sel].reshape(-1, s.shape[2])[:, :S].astype(np.float64)
