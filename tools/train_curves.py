@@ -249,12 +249,13 @@ def compare_with_fixture(got, fx, window=40):
     return out
 
 
-def write_reference_csvs(out_dir, r, tag):
-    """ep_reward / avg_ep_reward files in the reference's schema (workers/trainer.py:598-611; avddpg_amd/artifacts.py)."""
-    from avddpg_amd import artifacts
+def write_reference_csvs(out_dir, seed, r):
+    """ep_reward__seed<N>.csv / avg_ep_reward__seed<N>.csv in the reference's schema (workers/trainer.py:552-568, 598-611; column
+    names src/env/env.py:5-11; file names src/config.py:135-138) through the package's own writer (avddpg_amd/artifacts.py)."""
+    from avddpg_amd import artifacts, config
 
     os.makedirs(out_dir, exist_ok=True)
-    artifacts.write_reward_csvs(out_dir, r["conf"], r["ep_lists"], r["avg_lists"], suffix=tag)
+    return artifacts.generate_csvs(out_dir, config.Config(num_platoons=1, pl_size=3, random_seed=seed), r["ep_lists"], r["avg_lists"])
 
 
 def cmd_gpu(args):
@@ -273,6 +274,8 @@ def cmd_gpu(args):
                         evals=np.stack([got[s]["evals"] for s in seeds]))
     with open(os.path.join(args.out, "config1_summary.json"), "w") as f:
         json.dump(cmp_, f, indent=1)
+    for s_ in seeds:
+        write_reference_csvs(os.path.join(args.out, "config1_reference_schema"), s_, got[s_])
     # the curves themselves as text: episode, then per seed oracle / gpu platoon-mean episodic reward
     with open(os.path.join(args.out, "config1_platoon_mean_episodic_reward.csv"), "w") as f:
         f.write("episode," + ",".join(f"oracle_seed{s},gpu_seed{s}" for s in seeds) + "\n")
@@ -304,7 +307,7 @@ def _evaluator_scores(conf, vt, platoons=(0,)):
     return out
 
 
-def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset="platoon", eval_platoons=(0,), **kw):
+def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset="platoon", eval_platoons=(0,), hook=None, **kw):
     """One long run of VecTrainer (device RNG). auto_reset="platoon": per-platoon episodes, curve points = means over the episodes
     closed in each reporting window (env.pop_episode_stats). auto_reset="parity": the reference's loop -- every platoon reset
     together, the episode of ALL platoons ends at the first terminal one (workers/trainer.py:246-249, 268-269), host sync per
@@ -315,6 +318,8 @@ def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset
 
     parity = auto_reset == "parity"
     vt = trainer.VecTrainer(conf, rng="device", auto_reset=False if parity else auto_reset, **kw)
+    if hook is not None:
+        hook(vt)
     vt.reset_episode()
     rows, t0 = [], time.perf_counter()
     ev = _evaluator_scores(conf, vt, eval_platoons)
@@ -376,6 +381,31 @@ def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset
     return summary
 
 
+def use_torch_f32_engine(vt):
+    """Swap VecTrainer's shared-set learner AND its acting path for the plain-PyTorch float32 reference (tools/torch_set_learn.py):
+    the f32 trainer a bf16 engine's curve is compared with at widths where no exact-f32 HIP engine exists (hidden 1024)."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch_set_learn as tsl
+
+    P, M = vt.P, vt.M
+
+    def learn(s, a, r, s2, weights=None):
+        if weights is not None:
+            raise ValueError("torch f32 engine: unweighted federated mean only")
+        if getattr(vt, "set_grads", None) is None:
+            vt.set_grads = torch.zeros(M, vt.agents.lay.theta_size, dtype=torch.float32, device=vt.device)
+            vt.set_losses = torch.zeros(M, 2, dtype=torch.float32, device=vt.device)
+        tsl.learn_sets(vt.agents, s, a, r, s2, P * M, grads=vt.set_grads, losses=vt.set_losses)
+
+    vt._learn_batched = learn
+    vt.agents.actor_shared = lambda sm, n: tsl.act_sets(vt.agents, sm.transpose(0, 1).reshape(n, -1), n,
+                                                        torch.empty(n, device=vt.device)).view(P, M).transpose(0, 1).contiguous()
+    vt.shared_engine_note = "torch-f32"
+    return vt
+
+
 def cmd_big(args):
     from avddpg_amd import config
 
@@ -395,8 +425,20 @@ def cmd_big(args):
         out["nofrl"] = big_run(f"nofrl_{args.nofrl_platoons}x{args.pl_size}_per_platoon_episodes", conf, args.nofrl_steps, args.out,
                                report=args.report, eval_every=args.eval_every, auto_reset="platoon", fused_update=True,
                                eval_platoons=tuple(range(min(8, args.nofrl_platoons))))
-    with open(os.path.join(args.out, "big_summary.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    if "wide" in runs:
+        # BASELINE configs[4]'s width (hidden 1024): the bf16 layer-wise engine (csrc/wide.hip) against the float32 PyTorch reference
+        # trainer on the same Philox streams (tie the 6 % gradient tolerance of the bf16 operands to an outcome)
+        mk = lambda: config.Config(num_platoons=args.wide_platoons, fed_method="interfrl", actor_layer1_size=1024, actor_layer2_size=1024,
+                                   critic_layer1_size=1024, critic_layer2_size=1024, **base)
+        kw = dict(report=args.report, eval_every=args.eval_every, auto_reset="platoon", shared_engine="batched")
+        out["wide_bf16"] = big_run(f"interfrl_{args.wide_platoons}x{args.pl_size}_hidden1024_bf16_engine", mk(), args.wide_steps, args.out, **kw)
+        out["wide_f32"] = big_run(f"interfrl_{args.wide_platoons}x{args.pl_size}_hidden1024_torch_f32_reference", mk(), args.wide_steps, args.out,
+                                  hook=use_torch_f32_engine, **kw)
+    path = os.path.join(args.out, "big_summary.json")  # (runs of earlier calls stay in the file)
+    merged = json.load(open(path)) if os.path.exists(path) else {}
+    merged.update(out)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1)
     print(json.dumps(out))
 
 
@@ -424,6 +466,8 @@ def main():
     b.add_argument("--parity-steps", type=int, default=20000)
     b.add_argument("--nofrl-platoons", type=int, default=512)
     b.add_argument("--nofrl-steps", type=int, default=50100)
+    b.add_argument("--wide-platoons", type=int, default=256)
+    b.add_argument("--wide-steps", type=int, default=30000)
     b.add_argument("--report", type=int, default=1000)
     b.add_argument("--eval-every", type=int, default=5000)
     b.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_training_curves"))
