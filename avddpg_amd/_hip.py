@@ -75,6 +75,7 @@ _PROTOS = {
     "avd_learn_update_act_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _f, _d, _P, _P, _P, _i, _P, _P],
     "avd_learn_update_plan": [_LP, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "avd_adam_polyak_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
+    "avd_adam_polyak_guarded_f32": [_LP, _i, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P, _P],
     "avd_polyak_f32": [_i64, _P, _P, _d, _P],
     "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],
     "avd_fed_finalize_f32": [_i, _i, _P, _f, _P, _P],

@@ -175,10 +175,23 @@ struct NetP {
 
 // ---- pack: split first-layer input fragments of every batch row, once per learn call (+ the finiteness test) ----------
 // outh: fp16 pairs (heads, dx_kernel); extra: the per-row scalar that travels with x (a: an fp16 fragment too; r: only tested)
+// One launch packs both inputs of a learn call: blockIdx.y = 0 -> (s, a: the action travels as an fp16 fragment too), 1 -> (s2, r: only
+// tested for finiteness).
+struct PackArgs {
+    const float* x[2];
+    const float* extra[2];
+    f16x8* outh[2];
+    long rows;
+    int* bad;
+};
 template <int S>
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float* extra, bool extra_is_action, long rows, f16x8* outh, int* bad) {
+__global__ __launch_bounds__(256) void pack_x_kernel(const PackArgs a) {
+    const int which = blockIdx.y;
+    const float* x = a.x[which];
+    const float* extra = a.extra[which];
+    const bool extra_is_action = which == 0;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * rows) return;
+    if (i >= 2 * a.rows) return;
     float v[4];
     load_x<S>(x, i >> 1, v);
     bool nf = not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
@@ -187,8 +200,8 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float* x, const float
         const float e = extra[i >> 1];  // a (an fp16 input fragment of the critic too) or r
         nf = nf || not_finite(e) || (extra_is_action && fabsf(e) >= F16_OVERFLOW);
     }
-    if (nf) atomicOr(bad, 1);
-    outh[i] = make_xh(v[0], v[1], v[2], v[3], (int)(i & 1));
+    if (nf) atomicOr(a.bad, 1);
+    a.outh[which][i] = make_xh(v[0], v[1], v[2], v[3], (int)(i & 1));
 }
 
 // ---- operand preparation ---------------------------------------------------------------------------------------------
@@ -1514,11 +1527,15 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     if (phases & PH_CRITIC) {
         if (hipMemsetAsync(ws + pl.bad, 0, sizeof(int) + sizeof(unsigned) * 4 * (size_t)n_sets * 2, st) != hipSuccess)
             return check_launch("avd_learn_set_split: memset");
+        // (r05, measured and not kept: the preparation chain -- three small dependent launches over 1.5 MB of weights, ~30 us -- on a side
+        //  stream beside the input packing, forked and joined by events: 1969-1978 us per learn against 1957-1961 serial on the same
+        //  box; the fork / join costs more than the overlap of two sub-30-us stages returns)
         hipLaunchKernelGGL(scale_kernel, dim3(4, n_sets, SCALE_SLICES), dim3(256), 0, st, pa);
         hipLaunchKernelGGL(prep_kernel, dim3(H2, 4, n_sets), dim3(320), 0, st, pa);
         hipLaunchKernelGGL(prep1_kernel, dim3(NGT_MAX, 4, n_sets), dim3(64), 0, st, pa);
-        hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s, a, true, nrows, xfs, bad);
-        hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256)), dim3(256), 0, st, s2, r, false, nrows, xfs2, bad);
+        PackArgs pk;
+        pk.x[0] = s, pk.extra[0] = a, pk.outh[0] = xfs, pk.x[1] = s2, pk.extra[1] = r, pk.outh[1] = xfs2, pk.rows = nrows, pk.bad = bad;
+        hipLaunchKernelGGL(pack_x_kernel<S>, dim3((unsigned)((2 * nrows + 255) / 256), 2), dim3(256), 0, st, pk);
         // 1-2: targets
         head(head_kernel<S, ActorS, OUT_TANH>, 2, xfs2, nullptr, nullptr, nullptr, a2, nullptr);
         head(head_kernel<S, CriticS, OUT_TD>, 3, xfs2, a2, r, nullptr, y, nullptr);

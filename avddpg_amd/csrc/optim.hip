@@ -11,15 +11,32 @@ namespace avd {
 
 constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-7f;
 
-// grid: (blocks over theta_size/4, n_sets)
+// A set whose gradient slab is not finite at the head of its actor block or of its critic block (the set learners of fset.hip /
+// fsplit.hip turn a non-finite input or an fp16 overflow into an ALL-NaN block: finalize_*) -- the guarded update leaves such a set
+// untouched.
+__device__ __forceinline__ bool slab_is_nan(const float* g, int actor_size) {
+    const unsigned a = __float_as_uint(g[0]) & 0x7fffffffu, c = __float_as_uint(g[actor_size]) & 0x7fffffffu;
+    return a > 0x7f800000u || c > 0x7f800000u;
+}
+
+// grid: (blocks over theta_size/4, n_sets). GUARD: avd_adam_polyak_guarded_f32 -- a set with a NaN gradient slab takes no step at all
+// (weights, moments, targets untouched), its Adam iteration count (already advanced by the caller) is put back and *skipped counts it.
+template <bool GUARD>
 __global__ __launch_bounds__(256) void adam_polyak_kernel(int theta_size, int actor_size, float4* __restrict__ theta,
                                                           float4* __restrict__ theta_t, float4* __restrict__ m,
                                                           float4* __restrict__ v, const float4* __restrict__ grads,
-                                                          const int32_t* __restrict__ step, float actor_lr,
-                                                          float critic_lr, float tau, float omt) {
+                                                          int32_t* __restrict__ step, float actor_lr,
+                                                          float critic_lr, float tau, float omt, int32_t* __restrict__ skipped) {
 #pragma clang fp contract(off)
     const int set = blockIdx.y;
     const int t = step[set];
+    if (GUARD && slab_is_nan((const float*)grads + (long)set * theta_size, actor_size)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            step[set] = t - 1;  // (every thread of the set returns here: nobody uses the count)
+            if (skipped) atomicAdd(skipped, 1);
+        }
+        return;
+    }
     // beta^t as float32(pow) like the oracle / TF (math_ops.pow on float32 scalars)
     const float b1p = (float)pow((double)ADAM_B1, (double)t);
     const float b2p = (float)pow((double)ADAM_B2, (double)t);
@@ -166,6 +183,16 @@ __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __rest
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         t[i] = w[i] * tau + t[i] * omt;
 }
+// the BN statistics' soft update of the guarded form: set by set, skipping the sets adam_polyak_kernel<true> skips
+__global__ void polyak_guarded_kernel(int stats_size, const float* __restrict__ w, float* __restrict__ t, float tau, float omt,
+                                      const float* __restrict__ grads, int theta_size, int actor_size) {
+#pragma clang fp contract(off)
+    const int set = blockIdx.y;
+    if (slab_is_nan(grads + (long)set * theta_size, actor_size)) return;
+    const long base = (long)set * stats_size;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stats_size; i += gridDim.x * blockDim.x)
+        t[base + i] = w[base + i] * tau + t[base + i] * omt;
+}
 
 // out[o][j] = sum_i w[row(o,i)] * g[row(o,i)][j], reproducible: a workgroup owns 64 float4 columns of one output row and
 // splits the members i over 4 phases (thread = column + 64 * phase, members phase, phase + 4, ...), 8 loads in flight per
@@ -238,30 +265,53 @@ __global__ void fed_scatter_kernel(int so, int si, int i_begin, int n, const flo
 
 using namespace avd;
 
-extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
-                                   float* stats_t, float* m, float* v, const float* grads, const int32_t* step,
-                                   float actor_lr, float critic_lr, double tau, void* stream) {
-    AVD_REQUIRE(lay && n_sets > 0, "avd_adam_polyak_f32: n_sets=%d", n_sets);
-    AVD_REQUIRE(theta && stats && theta_t && stats_t && m && v && grads && step, "avd_adam_polyak_f32: null pointer");
-    AVD_REQUIRE(lay->theta_size % 4 == 0 && lay->actor_size % 4 == 0 && lay->stats_size % 4 == 0,
-                "avd_adam_polyak_f32: layout not 4-float aligned");
+static int adam_polyak_launch(const char* who, bool guard, const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
+                              float* stats_t, float* m, float* v, const float* grads, int32_t* step, float actor_lr, float critic_lr,
+                              double tau, int32_t* skipped, void* stream) {
+    AVD_REQUIRE(lay && n_sets > 0, "%s: n_sets=%d", who, n_sets);
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && m && v && grads && step, "%s: null pointer", who);
+    AVD_REQUIRE(lay->theta_size % 4 == 0 && lay->actor_size % 4 == 0 && lay->stats_size % 4 == 0, "%s: layout not 4-float aligned", who);
     const float tauf = (float)tau, omt = (float)(1.0 - tau);  // Python doubles rounded to f32 (ddpgagent.py:47,53)
     const int n4 = lay->theta_size / 4;
     int gx = (n4 + 255) / 256;
     if (n_sets >= 256 && gx > 8) gx = 8;  // many sets: fewer, longer-lived blocks per set
     if (const char* e = AVD_DIAG_ENV("ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh)
-    hipLaunchKernelGGL(adam_polyak_kernel, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size,
-                       lay->actor_size, (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v,
-                       (const float4*)grads, step, actor_lr, critic_lr, tauf, omt);
-    int rc = check_launch("avd_adam_polyak_f32");
+    if (guard)
+        hipLaunchKernelGGL(adam_polyak_kernel<true>, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size, lay->actor_size,
+                           (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, tauf,
+                           omt, skipped);
+    else
+        hipLaunchKernelGGL(adam_polyak_kernel<false>, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size, lay->actor_size,
+                           (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, tauf,
+                           omt, (int32_t*)nullptr);
+    int rc = check_launch(who);
     if (rc) return rc;
     // BN moving stats take part in the soft update too (ddpgagent.py:44-53 iterates .weights)
+    if (guard) {
+        hipLaunchKernelGGL(polyak_guarded_kernel, dim3((unsigned)((lay->stats_size + 255) / 256), n_sets), dim3(256), 0, (hipStream_t)stream,
+                           lay->stats_size, stats, stats_t, tauf, omt, grads, lay->theta_size, lay->actor_size);
+        return check_launch(who);
+    }
     const long ns = (long)n_sets * lay->stats_size;
     long blocks = (ns + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(polyak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ns, stats, stats_t,
                        tauf, omt);
-    return check_launch("avd_adam_polyak_f32(stats)");
+    return check_launch(who);
+}
+
+extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
+                                   float* stats_t, float* m, float* v, const float* grads, const int32_t* step,
+                                   float actor_lr, float critic_lr, double tau, void* stream) {
+    return adam_polyak_launch("avd_adam_polyak_f32", false, lay, n_sets, theta, stats, theta_t, stats_t, m, v, grads, (int32_t*)step, actor_lr,
+                              critic_lr, tau, nullptr, stream);
+}
+
+extern "C" int avd_adam_polyak_guarded_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
+                                           float* stats_t, float* m, float* v, const float* grads, int32_t* step, float actor_lr,
+                                           float critic_lr, double tau, int32_t* skipped, void* stream) {
+    return adam_polyak_launch("avd_adam_polyak_guarded_f32", true, lay, n_sets, theta, stats, theta_t, stats_t, m, v, grads, step, actor_lr,
+                              critic_lr, tau, skipped, stream);
 }
 
 int launch_adam_polyak_ranges(const avd_mlp_layout* lay, int n_sets, const float* theta_in, float* theta_out,

@@ -336,7 +336,9 @@ class VecTrainer:
                     self.fed_weights = (ep, self._weights_for_fed(ep))
                 weights = self.fed_weights[1]
             self._timed("learn", self._learn_batched, s, a, r, s2, weights)
-            self._timed("update", self.agents.apply, self.set_grads)
+            # the 16-bit set learners answer a non-finite input / an fp16 overflow with an all-NaN slab: the guarded update then
+            # leaves that weight set untouched and counts the event (nonfinite_updates()) instead of poisoning it for good
+            self._timed("update", self.agents.apply, self.set_grads, guarded=self.shared_engine in ("fused", "fused3"))
             return
         self._timed("learn", self.agents.learn, s, a, r, s2, self.set_mod, grads=self.grads, losses=self.losses)
         self._timed("update", self._update, ep, i, fed)
@@ -474,6 +476,12 @@ class VecTrainer:
             return None
         from .dist import any_terminal
         return any_terminal(self.env.any_done, self.group)
+
+    def nonfinite_updates(self):
+        """Weight-set updates skipped because the set learner returned a NaN gradient slab (host synchronisation: call it at
+        reporting points). 0 unless a state, action or reward was non-finite or beyond fp16's range."""
+        n = getattr(self.agents, "nonfinite_skipped", None)
+        return 0 if n is None else int(n.item())
 
     def update_reward_list(self, ep):
         """trainer.py:510-517 (float32 counters, trailing mean over reward_averaging_window)."""

@@ -447,10 +447,19 @@ class AgentGroup:
              ptr(states_set_major), self.high, ptr(out), ptr(ws), ws.numel(), stream_handle())
         return out
 
-    def apply(self, grads):
-        """critic Adam, actor Adam, then Polyak (workers/trainer.py:348-356) for every weight set."""
+    def apply(self, grads, guarded=False):
+        """critic Adam, actor Adam, then Polyak (workers/trainer.py:348-356) for every weight set. guarded: a set whose gradient
+        slab is NaN (what the 16-bit set learners write for a non-finite input or an fp16 overflow) takes no step at all and is
+        counted in ``self.nonfinite_skipped`` (device int32; no host synchronisation) -- avd_adam_polyak_guarded_f32."""
         c = self.config
         self.step += 1
+        if guarded:
+            if getattr(self, "nonfinite_skipped", None) is None:
+                self.nonfinite_skipped = torch.zeros(1, dtype=torch.int32, device=self.device)
+            call("avd_adam_polyak_guarded_f32", self._layp, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(self.theta_t),
+                 ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
+                 float(c.tau), ptr(self.nonfinite_skipped), stream_handle())
+            return
         call("avd_adam_polyak_f32", self._layp, self.n_sets, ptr(self.theta), ptr(self.stats), ptr(self.theta_t),
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())

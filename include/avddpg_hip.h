@@ -208,6 +208,17 @@ int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, flo
                         float* stats_t, float* m, float* v, const float* grads, const int32_t* step, float actor_lr,
                         float critic_lr, double tau, void* stream);
 
+/* avd_adam_polyak_f32 behind a finiteness guard, for gradient slabs that come from the 16-bit set learners
+ * (avd_learn_set_split_f16x3 / avd_learn_set_fused_bf16 turn a non-finite input, or a value fp16 cannot hold, into an ALL-NaN block of
+ * the slab -- loud, but one such batch fed to Adam would poison the shared weight set for good, and through the all-reduce every rank's):
+ * a set whose slab starts with a NaN in its actor block or in its critic block takes NO step -- weights, moments, targets and target
+ * statistics untouched, step[set] (advanced by the caller, as for avd_adam_polyak_f32) put back by one, *skipped (optional, device
+ * int32) incremented. Every other set: bit-identical to avd_adam_polyak_f32. (The reference's float32 Trainer.learn has no such range
+ * limit, workers/trainer.py:472-508; states are bounded by max_ep / max_ev = 20, src/config.py:56-57, far below the limits.) */
+int avd_adam_polyak_guarded_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t, float* stats_t,
+                                float* m, float* v, const float* grads, int32_t* step, float actor_lr, float critic_lr, double tau,
+                                int32_t* skipped, void* stream);
+
 /* Fused form of avd_learn_f32 + avd_adam_polyak_f32 for one weight set per agent (reference nofrl:
  * workers/trainer.py:325-356 learn, apply_gradients x2, update_target per agent): Adam and the soft update are
  * applied where each gradient is produced, so no gradient slab is written or read back.

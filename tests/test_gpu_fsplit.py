@@ -425,3 +425,48 @@ def test_split_set_learner_fp16_scaling_is_robust_to_weight_and_state_magnitudes
                 assert np.abs(x - z).max() <= SPLIT_TOL * scale, (k, name, np.abs(x - z).max() / scale)
             else:
                 assert np.abs(x).max() == 0.0, (k, name)
+
+
+def test_guarded_update_skips_a_set_whose_slab_is_nan_and_is_bitwise_the_plain_update_otherwise():
+    """the split engine answers an fp16 overflow / a non-finite input with an all-NaN slab; fed to Adam that would poison the
+    shared weight set for good. avd_adam_polyak_guarded_f32 leaves such a set untouched (weights, moments, targets, step counter),
+    counts it, and is bit-identical to avd_adam_polyak_f32 for every finite set."""
+    need_gpu()
+    M, P, S = 3, 4, 4
+    conf, grp = _perturbed_group(M, S=S, seed=81)
+    conf2, ref = _perturbed_group(M, S=S, seed=81)
+    n = P * M
+    s, a, r, s2 = _batch(np.random.RandomState(82), n, S)
+    g = grp.learn_set_split(t(s), t(a), t(r), t(s2), n).clone()
+    assert torch.isfinite(g).all()
+    g_bad = g.clone()
+    g_bad[1] = float("nan")  # what finalize writes for a set when the learner's `bad` flag is up
+    before = [x.clone() for x in (grp.theta, grp.theta_t, grp.stats_t, grp.m, grp.v)]
+    grp.apply(g_bad, guarded=True)
+    ref.apply(g)
+    torch.cuda.synchronize()
+    assert int(grp.nonfinite_skipped.item()) == 1 and grp.step.tolist() == [1, 0, 1] and ref.step.tolist() == [1, 1, 1]
+    for x, b, y in zip((grp.theta, grp.theta_t, grp.stats_t, grp.m, grp.v), before, (ref.theta, ref.theta_t, ref.stats_t, ref.m, ref.v)):
+        assert torch.equal(x[1], b[1])                                        # the NaN set: untouched
+        assert torch.equal(x[0], y[0]) and torch.equal(x[2], y[2])            # the others: the plain update, bit for bit
+        assert torch.isfinite(x).all()
+    # a NaN at the head of the CRITIC block alone is caught too (the two-phase call finalizes the blocks separately)
+    g_c = g.clone()
+    g_c[0, grp.lay.actor_size:] = float("nan")
+    th0 = grp.theta[0].clone()
+    grp.apply(g_c, guarded=True)
+    assert int(grp.nonfinite_skipped.item()) == 2 and torch.equal(grp.theta[0], th0) and grp.step.tolist() == [1, 1, 2]
+    # end to end: an overflowing state in one platoon's batch -> NaN slab from the learner -> the trainer's guarded update counts it
+    from avddpg_amd import trainer as tr
+    vt = tr.VecTrainer(config.Config(num_platoons=8, pl_size=3, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False),
+                       rng="device", auto_reset=True, seed=5, shared_engine="fused3")
+    vt.reset_episode()
+    for _ in range(66):
+        vt.step()
+    assert vt.nonfinite_updates() == 0 and vt.updates > 0
+    vt.replay.ring[0, :, 0] = 7e4  # every stored state of agent 0 beyond fp16's range
+    th = vt.agents.theta.clone()
+    vt.step()
+    torch.cuda.synchronize()
+    assert vt.nonfinite_updates() >= 1 and torch.isfinite(vt.agents.theta).all()
+    assert torch.equal(vt.agents.theta[0], th[0])  # agent 0 = vehicle 0's set: skipped
