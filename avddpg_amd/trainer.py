@@ -166,16 +166,13 @@ class VecTrainer:
         # the per-agent weight-set regime is asserted, i.e. the per_agent engine)
         self.act_mfma = (self.shared and self.shared_engine in ("fused", "fused3")
                          and (lay.H1, lay.H2, lay.A) == (256, 128, 1) and lay.S in (3, 4))
-        # overlapped exchange (two-phase learn call, critic block all-reduced on a side stream under the actor phase): on by
-        # default only where the backend is stream-asynchronous (RCCL: the collective is enqueued, the host goes on launching
-        # the actor phase). gloo stages through the host -- the overlap buys nothing there and is opt-in (tests use it to check
-        # that the two collectives give the bits of the single one).
+        # overlapped exchange (two-phase learn call, critic block all-reduced on a side stream under the actor phase): OPT-IN. Measured
+        # on a real RCCL communicator (one rank, r05: bench.py --one-rank-rccl) the overlapped form is SLOWER -- 2.31 ms per step against
+        # 2.18, its collectives 0.53 ms against 0.014: the learn call's persistent kernels hold every CU (one workgroup each, 135-160 KB of
+        # LDS), so RCCL's kernel does not run beside the actor phase but between its launches, and the fork / join costs on top. The
+        # single all-reduce of the slab between learn and Adam is the default on every backend; bench.py times both forms at N > 1.
         can_overlap = group is not None and self.shared and self.shared_engine == "fused3"
-        if overlap_allreduce is None:
-            import torch.distributed as _td
-            self.overlap_allreduce = can_overlap and _td.get_backend(group) == "nccl"
-        else:
-            self.overlap_allreduce = bool(overlap_allreduce)
+        self.overlap_allreduce = False if overlap_allreduce is None else bool(overlap_allreduce)
         if self.overlap_allreduce and not can_overlap:
             raise ValueError("overlap_allreduce needs a process group and shared_engine='fused3' (the two-phase learn call)")
         self._side = None  # side stream + buffers of the overlapped exchange, made on first use

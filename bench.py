@@ -68,14 +68,19 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test: every rank uses GPU 0 (a 1-GPU box cannot host one rank per GPU)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="interfrl, N > 1: one all-reduce of the whole [M, theta] slab between learn and Adam instead of the critic "
-                         "block's all-reduce overlapped with the actor phase (the default on RCCL)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="interfrl, N > 1: the critic block's all-reduce on a side stream under the actor phase of the learn call + the actor "
+                         "block's on the main stream, instead of ONE all-reduce of the whole [M, theta] slab between learn and Adam (the "
+                         "default: on a one-rank RCCL communicator the overlapped form measured slower, DESIGN.md section 6)")
+    ap.add_argument("--no-overlap", action="store_true", help="(the default since r05; accepted for older command lines)")
     ap.add_argument("--no-collective-ab", action="store_true",
                     help="interfrl, N > 1: do not also time the OTHER collective form (by default the line carries both under "
                          "collective.forms so that one multi-GPU run attributes its own communication cost)")
     ap.add_argument("--init-timeout", type=float, default=240.0,
                     help="N > 1: seconds the process-group rendezvous + first collective may take before the rank gives up (non-zero exit)")
+    ap.add_argument("--one-rank-rccl", action="store_true",
+                    help="N = 1 only: run interfrl through a real RCCL communicator of ONE rank (every collective of the N > 1 path is "
+                         "issued -- what a collective costs on the device with no wire behind it; not the default measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
@@ -185,6 +190,28 @@ def refuse_diagnostics(args):
     return ov
 
 
+class stdout_to_stderr:
+    """Keep rank 0's stdout to the ONE JSON line: gloo prints a connection banner and RCCL a version banner through C stdio while a
+    communicator is built (the latter sits in libc's buffer and would surface AFTER the JSON line at exit). Inside the block fd 1 is
+    fd 2; on exit libc's buffers are flushed (into stderr) before fd 1 is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one, which has not
     touched the GPU (no torch import, no HIP call) and only waits. Each child is this script with RANK / LOCAL_RANK /
@@ -243,7 +270,7 @@ def build_trainer(args, mode, engine, rank, group, ring=None):
                               seed=1 + rank, pipeline_chunks=args.chunks,
                               fused_update=(mode == "nofrl" and not args.no_fused),
                               shared_engine=engine if mode == "interfrl" else None, replay_ring=ring,
-                              overlap_allreduce=False if (args.no_overlap and mode == "interfrl" and group is not None) else None)
+                              overlap_allreduce=True if (args.overlap and mode == "interfrl" and group is not None and engine == "fused3") else None)
 
 
 def run_workload(args, mode, engine, rank, world, group, vt=None):
@@ -303,7 +330,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     # overlap hides: forms.single = one all-reduce of the whole slab between learn and Adam; forms.overlapped = critic block on a side
     # stream under the actor phase + actor block on the main stream. `value` is the form the trainer chose (overlapped on RCCL).
     forms = None
-    if world > 1 and mode == "interfrl" and split3 and not args.no_collective_ab:
+    if (world > 1 or group is not None) and mode == "interfrl" and split3 and not args.no_collective_ab:
         chosen = "overlapped" if vt.overlap_allreduce else "single"
         forms = {chosen: {"ms_per_step": 1e3 * elapsed / args.steps, "stages_ms": stage_ms}}
         vt.overlap_allreduce = not vt.overlap_allreduce
@@ -441,7 +468,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                                 "dense fp16 MFMA holds 2.3 PFLOP/s under that cap with one operand static, 1.30-1.35 PFLOP/s with both "
                                 "operands fresh from LDS on every MFMA, ~1.35 with the heads' VALU + LDS mix in either MFMA shape "
                                 "(profiles/r03_power_*.txt, r04_mfma_shape_probe.txt)"}
-    rccl = mode == "interfrl" and world > 1
+    rccl = mode == "interfrl" and (world > 1 or group is not None)
 
     out = {
         "value": env_steps_per_s,
@@ -534,6 +561,16 @@ def main():
                  "(one rank per GPU; --single-device puts every rank on GPU 0 for plumbing tests only)")
     torch.cuda.set_device(dev)
     group = None
+    if world == 1 and args.one_rank_rccl:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port or 29517))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+            hello = torch.ones(1, device="cuda")
+            dist.all_reduce(hello)
+            torch.cuda.synchronize()
+        group = dist.group.WORLD
     if world > 1:
         import datetime
         import threading
@@ -552,25 +589,17 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         timeout = datetime.timedelta(seconds=max(30.0, args.init_timeout))
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=timeout)
-            hello = torch.ones(1, device="cuda")
-            dist.all_reduce(hello)  # RCCL builds its communicator on the first collective: do it here, under the watchdog
-            torch.cuda.synchronize()
-            if int(hello.item()) != world:
-                sys.exit(f"bench.py: first all-reduce over RCCL returned {hello.item()} on rank {rank}, expected {world}")
-        else:
-            # (gloo's C++ side prints a connection banner to stdout: keep rank 0's stdout to the ONE JSON line)
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=timeout)
+                hello = torch.ones(1, device="cuda")
+                dist.all_reduce(hello)  # RCCL builds its communicator on the first collective: do it here, under the watchdog
+                torch.cuda.synchronize()
+                if int(hello.item()) != world:
+                    sys.exit(f"bench.py: first all-reduce over RCCL returned {hello.item()} on rank {rank}, expected {world}")
+            else:
                 dist.init_process_group(args.backend, timeout=timeout)
                 dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
         watchdog.cancel()
         group = dist.group.WORLD
 
@@ -627,9 +656,10 @@ def main():
                 except Exception as e:  # never let the side figure break the bench line
                     out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or group is not None:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        with stdout_to_stderr():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
