@@ -369,7 +369,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         # whole-row Adam + Polyak passes on a side stream); any other centralized shape: the general kernel
         lay_ = vt.agents.lay  # (padded widths)
         if (lay_.H1, lay_.H2, lay_.Ha) == (320, 160, 64) and (lay_.S, lay_.A) in ((12, 3), (20, 5)):
-            lk, fused_name = "cen::learn_kernel_c", "cen::learn_kernel_c x16 chunks || adam_polyak_rows_kernel (two streams)"
+            lk, fused_name = "cen::learn_kernel_c", "cen::learn_kernel_c in chunks || adam_polyak_rows_kernel (two streams)"
         else:
             lk, fused_name = "gen::learn_kernel_g", "gen::learn_kernel_g<fused> + adam_polyak_ranges_kernel"
     if fused:
@@ -408,42 +408,72 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
             roofs.append({"kernel": "adam_polyak_kernel", "bound": "hbm", "achieved": adam_bytes * n_agents / upd_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "_t": upd_s})
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    # tools/pmc_workload.py -- the same trainer step at 4096 x 5 --, both counters calibrated on a 1 GiB elementwise kernel of the
-    # same pass: tools/pmc_traffic.py; measured factors 2.000 / 1.000)
+    # tools/pmc_workload.py -- the same trainer step at 4096 x L, widths as here --, both counters calibrated on a 1 GiB elementwise
+    # kernel of the same pass: tools/pmc_traffic.py; measured factors 2.000 / 1.000). One file per (workload, L, hidden); a line whose
+    # shape has no committed pass carries traffic = null.
     def pmc(name):
-        path = os.path.join(ROOT, "profiles", name)
-        return json.load(open(path)) if os.path.exists(path) else None
+        for rnd in ("r05", "r04"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+            if os.path.exists(path):
+                return json.load(open(path)), f"profiles/{rnd}_{name}"
+        return None, None
 
-    if P == 4096 and L == 5 and args.framework == "decentralized" and not args.hidden and args.chunks == 1:
-        if fused and mode == "nofrl" and pmc("r04_pmc_traffic_nofrl.json"):
-            d = pmc("r04_pmc_traffic_nofrl.json")
-            k = next((v for n, v in d["kernels"].items() if "learn_kernel_l" in n), None)
+    def chain_bytes(d, belongs, once_per_learn):
+        """bytes per learn of the kernels `belongs` selects, from a profile of several learns (count = launches of `once_per_learn`)"""
+        ks = {n: v for n, v in d["kernels"].items() if belongs(n)}
+        n_learn = next((v["launches"] for n, v in ks.items() if once_per_learn in n), 0)
+        if not n_learn:
+            return None
+        return sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks.values()) / n_learn
+
+    shape_tag = ("" if L == 5 else f"_L{L}") + (f"_h{args.hidden}" if args.hidden else "")
+    if P == 4096 and args.framework == "decentralized" and args.chunks == 1:
+        cal = lambda d: (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"])
+        if fused and mode == "nofrl" and not args.hidden:
+            d, src = pmc(f"pmc_traffic_nofrl{shape_tag}.json")
+            k = d and next((v for n, v in d["kernels"].items() if "learn_kernel_l" in n), None)
             if k:
                 for r in roofs:
                     r["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
                     r["traffic_note"] = ("HBM-side bytes per launch of learn_kernel_l<fused>, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (factors "
-                                         "calibrated on a 1 GiB elementwise kernel in the same pass), profiles/r04_pmc_traffic_nofrl.json"
-                                         % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
-        if split3 and pmc("r04_pmc_traffic_interfrl.json"):
-            d = pmc("r04_pmc_traffic_interfrl.json")
-            chain = {n: v for n, v in d["kernels"].items() if "fsplit" in n or "finalize" in n}
-            per_learn = next((v["launches"] for n, v in chain.items() if "dxa_kernel" in n), 0)
-            if per_learn:
-                roofs[0]["traffic"] = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in chain.values()) / per_learn
+                                         "calibrated on a 1 GiB elementwise kernel in the same pass), %s" % (*cal(d), src))
+        if mode == "interfrl" and split3:
+            d, src = pmc(f"pmc_traffic_interfrl{shape_tag}.json")
+            t_ = d and chain_bytes(d, lambda n: "fsplit" in n or "finalize" in n, "dxa_kernel")
+            if t_:
+                roofs[0]["traffic"] = t_
                 roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated in "
-                                            "the same pass), profiles/r04_pmc_traffic_interfrl.json (matrix-core bound: reported, not the binding roof)"
-                                            % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
-    if P == 4096 and L == 5 and args.framework == "centralized" and fused and lk == "cen::learn_kernel_c" and pmc("r04_pmc_traffic_centralized.json"):
-        d = pmc("r04_pmc_traffic_centralized.json")
+                                            "the same pass), %s (matrix-core bound: reported, not the binding roof)" % (*cal(d), src))
+        if mode == "interfrl" and batched and not fset and args.hidden:
+            d, src = pmc(f"pmc_traffic_interfrl{shape_tag}.json")
+            t_ = d and chain_bytes(d, lambda n: "fw::" in n or "wide::" in n, "losses_kernel")
+            if t_:
+                roofs[0]["traffic"] = t_
+                roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the wide.hip chain, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f "
+                                            "(calibrated in the same pass), %s" % (*cal(d), src))
+    # the centralized pipeline as the library will cut it on THIS device (avd_learn_update_plan: chunk = one learn workgroup per CU,
+    # at most 32 chunks), not literals of the profiled box
+    plan = None
+    if args.framework == "centralized" and fused and lk == "cen::learn_kernel_c":
+        import ctypes
+        ch, nch, grp_ = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _hip.call("avd_learn_update_plan", ctypes.byref(vt.agents.lay), n_agents, ctypes.byref(ch), ctypes.byref(nch), ctypes.byref(grp_))
+        plan = {"chunk_agents": ch.value, "chunks": nch.value, "update_workgroups": grp_.value}
+        fused_name = f"cen::learn_kernel_c x{nch.value} chunks of {ch.value} || adam_polyak_rows_kernel ({grp_.value} workgroups, side stream)"
+        for r in roofs:
+            r["kernel"] = fused_name
+    if P == 4096 and L == 5 and plan and pmc("pmc_traffic_centralized.json")[0]:
+        d, src = pmc("pmc_traffic_centralized.json")
         ks = [v for n, v in d["kernels"].items() if "learn_kernel_c" in n or "adam_polyak_rows" in n]
-        if len(ks) == 2:  # per step: 16 chunks of each kernel (the profiled launches are chunks of 256 models)
-            per_step = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in ks) * ((n_agents + 255) // 256)
+        if len(ks) == 2 and plan["chunk_agents"] == 256:  # (the profiled launches are chunks of 256 models: valid for that plan only)
+            per_step = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in ks) * plan["chunks"]
+            alg = adam_bytes * n_agents
             for r in roofs:
                 r["traffic"] = per_step
-                r["traffic_note"] = ("HBM-side bytes per step = 16 x (learn chunk + update pass), PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated on a "
-                                     "1 GiB elementwise kernel in the same pass; kernels serialised by the counter pass), profiles/r04_pmc_traffic_centralized.json: "
-                                     "2.0 x the 15.8 GB priced here -- the gradients' round trip (+1 MB per model) and five re-reads of the online W2 "
-                                     "matrices that miss L2 (+1.2 MB)" % (d["calibration"]["fetch_factor"], d["calibration"]["write_factor"]))
+                r["traffic_note"] = ("HBM-side bytes per step = %d x (learn chunk + update pass), PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated on a "
+                                     "1 GiB elementwise kernel in the same pass; kernels serialised by the counter pass), %s: "
+                                     "%.1f x the %.1f GB priced here -- the gradients' round trip through HBM and re-reads of the online W2 matrices that miss L2"
+                                     % (plan["chunks"], d["calibration"]["fetch_factor"], d["calibration"]["write_factor"], src, per_step / alg, alg / 1e9))
     for r in roofs:
         r["frac"] = r["achieved"] / r["peak"]
     if fused:
@@ -500,7 +530,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
                       "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
                      if (fused and getattr(vt, "_act_ready", False)) else
-                     ("avd_learn_update_f32 -> cen.hip: the agents in chunks of 256; chunk c's learn kernel (cen::learn_kernel_c, in the "
+                     (f"avd_learn_update_f32 -> cen.hip: the agents in {plan['chunks'] if plan else '?'} chunks of {plan['chunk_agents'] if plan else '?'}; chunk c's learn kernel (cen::learn_kernel_c, in the "
                       "caller's stream) is followed by its whole-row Adam + Polyak pass (adam_polyak_rows_kernel, a side stream) under chunk "
                       "c + 1's learn kernel") if (fused and lk == "cen::learn_kernel_c") else
                      f"fused learn+Adam+Polyak kernel (avd_learn_update_f32 -> {lk})" if fused else
@@ -512,6 +542,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                       "batched shared-set learner (avd_learn_shared_bf16) + Adam/Polyak on the sets" if batched else "serial")),
         "kernels": [r for r in (roof_learn, roof_upd) if r],
     }
+    if plan:
+        out["update_plan"] = plan
     if rccl:
         out["rccl_ranks"] = world if args.backend == "nccl" else 0
         out["collective_backend"] = args.backend

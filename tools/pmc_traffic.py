@@ -23,7 +23,7 @@ def per_kernel(path, counter):
 
 def calib(agg):
     """the copy kernel: the launches whose counted bytes are the largest non-avd ones (three identical 1 GiB copies)"""
-    cands = {k: v for k, v in agg.items() if "avd::" not in k and "elementwise" in k.lower() and v[1] == 3}  # launched exactly three times
+    cands = {k: v for k, v in agg.items() if "avd::" not in k and "fw::" not in k and "elementwise" in k.lower() and v[1] == 3}  # launched exactly three times
     if not cands:
         return None, None
     k = max(cands, key=lambda k: cands[k][0] / cands[k][1])
@@ -39,7 +39,7 @@ res = {"calibration": {"copy_kernel": kf, "fetch_factor": cf, "write_factor": cw
        "kernels": {}}
 cf_, cw_ = (cf or 2.0), (cw or 1.0)
 for k in sorted(f, key=lambda k: -f[k][0]):
-    if "avd::" not in k:
+    if "avd::" not in k and "fw::" not in k:  # (fw:: = the persistent kernels of csrc/wide.hip)
         continue
     name = k.split("(")[0].replace("void ", "")
     res["kernels"][name] = {"launches": f[k][1], "fetch_bytes_per_launch": cf_ * f[k][0] / f[k][1],
