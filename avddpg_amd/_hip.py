@@ -133,20 +133,21 @@ class diag_library:
     -DAVD_DIAG) while it is active. Only that build reads the AVD_* environment switches (kernel variants for cross-checks
     and A/B runs); the shipped library reads none. Test / tool infrastructure: nothing in the package enters it."""
     _cached = None
+    _stack = []
 
     def __enter__(self):
-        global _lib
+        global _lib, LIB_PATH
         if diag_library._cached is None:
             diag_library._cached = _load(DIAG_LIB_PATH)
             if not diag_library._cached.avd_diagnostics_enabled():
                 raise AvdError(f"{DIAG_LIB_PATH} is not a diagnostic build")
-        self._saved = lib()
-        _lib = diag_library._cached
+        diag_library._stack.append((lib(), LIB_PATH))  # (nests: every exit restores what its own enter found)
+        _lib, LIB_PATH = diag_library._cached, DIAG_LIB_PATH
         return _lib
 
     def __exit__(self, *exc):
-        global _lib
-        _lib = self._saved
+        global _lib, LIB_PATH
+        _lib, LIB_PATH = diag_library._stack.pop()
         return False
 
 

@@ -121,8 +121,8 @@ def cpu_baseline(seconds, pl_size, mode="nofrl"):
             "sample": f"{P} platoons x {pl_size} vehicles (={P * pl_size} agents), {mode}, {n} training steps after a "
                       f"65-step replay warm-up, {dt:.1f} s on 1 thread; the per-platoon cost of the reference loop "
                       "does not depend on the number of platoons",
-            "see_also": "profiles/r04_cpu_baseline_config1.txt (tools/cpu_baseline_config1.py): SURVEY 8(d)'s line -- BASELINE configs[0], 1 platoon x 3 "
-                        "vehicles, 5000 steps on one thread: 352 env-steps/s; 256 independent single-thread copies on all host cores: 7.1 k"}
+            "see_also": "profiles/r05_cpu_baseline_config1.txt (tools/cpu_baseline_config1.py): SURVEY 8(d)'s line -- BASELINE configs[0], 1 platoon x 3 "
+                        "vehicles, 5000 steps on one thread: 362 env-steps/s; 256 independent single-thread copies on all host cores: 7.2 k"}
 
 
 def _cpu_worker(seconds, pl_size, q, mode="nofrl"):
@@ -522,7 +522,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                        "times exact +-1/0 relu masks where the algebra has them; A_hi B_hi + A_lo B_hi + A_hi B_lo, f32 accumulation, parameters, "
                        "gradients and optimiser. Enforced by the GPU tests at 2e-5 of each gradient tensor's max against the float64 oracle "
                        "(4e-6 at <= 4480 rows; the exact-f32 kernels: 1e-4), incl. two whole sets at 4096 x 5, and by a 2036-update reward-curve "
-                       "test against the float32 noise floor (tests/test_gpu_fsplit.py, tests/test_gpu_configs_full.py)" if split3 else None),
+                       "test against the float32 noise floor (tests/test_gpu_fsplit.py, tests/test_gpu_configs_full.py); that it TRAINS: 50 k "
+                       "updates per set at this shape take the evaluator score from -248 to -4 (DESIGN.md 5.1, profiles/r05_training_curves/)" if split3 else None),
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
                     | (split_extra if split3 else {}),
         "stages_ms": stage_ms,

@@ -358,6 +358,7 @@ def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     finite = bool(torch.isfinite(vt.agents.theta).all())
+    skipped = vt.nonfinite_updates()
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"{name}_curve.csv"), "w") as f:
         f.write("step,updates_per_set,episodes_closed,mean_episodic_reward,mean_episode_length,reward_per_step,evaluator_score\n")
@@ -369,7 +370,7 @@ def big_run(name, conf, steps, out_dir, report=1000, eval_every=5000, auto_reset
     pts = [r for r in rows if r["episodes"]]
     summary = dict(name=name, platoons=conf.num_platoons, pl_size=conf.pl_size, fed_method=conf.fed_method, engine=getattr(vt, "shared_engine", None),
                    auto_reset=auto_reset, steps=steps, updates_per_set=max(0, steps - first_update + 1), wall_s=wall,
-                   env_steps_per_s=conf.num_platoons * steps / wall, weights_finite=finite,
+                   env_steps_per_s=conf.num_platoons * steps / wall, weights_finite=finite, nonfinite_updates_skipped=skipped,
                    evaluator_first=evs[0][1], evaluator_best=max(e for _, e in evs), evaluator_last=evs[-1][1], evaluator_curve=evs,
                    reward_per_step_first=pts[0]["reward_per_step"], reward_per_step_last=pts[-1]["reward_per_step"],
                    mean_ep_len_first=pts[0]["mean_ep_len"], mean_ep_len_last=pts[-1]["mean_ep_len"],
