@@ -208,3 +208,22 @@ def test_federated_server_keeps_the_reference_class_api():
     assert list(inspect.signature(federated.Server.get_avg_params).parameters) == ["self", "system_params"]
     assert list(inspect.signature(federated.Server.get_weighted_avg_params).parameters) == ["self", "system_params", "weight_sums"]
     assert "oracle" not in open(federated.__file__).read().split('"""', 2)[2]
+
+
+def test_learn_update_plan_describes_the_centralized_pipeline_and_single_launch_shapes():
+    """avd_learn_update_plan (bench.py described the centralized pipeline with literals of the profiled box): chunks of one
+    learn workgroup per CU, at most 32 chunks (the chunk grows instead); every other shape is ONE launch. Without a GPU the CU count
+    falls back to 256."""
+    import ctypes as C
+
+    cen = _hip.make_layout(20, 5, 320, 160, 64, 64)   # centralized L = 5: S = 4 L, A = L, widths x 1.2 padded
+    dec = _hip.make_layout(4, 1, 256, 128, 48, 64)
+    ch, n, g = C.c_int(0), C.c_int(0), C.c_int(0)
+    _hip.call("avd_learn_update_plan", C.byref(cen), 4096, C.byref(ch), C.byref(n), C.byref(g))
+    assert ch.value >= 1 and n.value == (4096 + ch.value - 1) // ch.value and n.value <= 32 and g.value >= 1
+    _hip.call("avd_learn_update_plan", C.byref(cen), 100000, C.byref(ch), C.byref(n), C.byref(g))
+    assert n.value <= 32 and ch.value * n.value >= 100000
+    _hip.call("avd_learn_update_plan", C.byref(dec), 20480, C.byref(ch), C.byref(n), C.byref(g))
+    assert (ch.value, n.value, g.value) == (20480, 1, 0)
+    with pytest.raises(_hip.AvdError):
+        _hip.call("avd_learn_update_plan", C.byref(dec), 0, C.byref(ch), C.byref(n), C.byref(g))
