@@ -37,6 +37,15 @@ def get_cmdl_args(argv, conf):
                     help="interfrl with every step federated (shared weight sets): per_agent = exact f32 kernel per agent + federated "
                          "sum (default); fused3 = split-operand set learner, f32-class results, ~4x faster; fused / batched = bf16 "
                          "operands (not in the reference CLI)")
+    tr.add_argument("--episodes", choices=["reference", "platoon"], default="reference",
+                    help="reference: the episode loop of workers/trainer.py:232-273 on the host (any terminal platoon ends the episode of "
+                         "all; per-episode reward CSVs in the reference's schema). platoon: THROUGHPUT mode (needs --rng device): "
+                         "total_time_steps steps with every platoon running its own episodes on the device (avd_episode_end_f32), no "
+                         "host synchronisation per step; writes curve.csv (episodes closed, mean episodic reward and length per "
+                         "reporting window, evaluator score) instead of the per-episode CSVs (not in the reference CLI)")
+    tr.add_argument("--report_every", type=int, default=10000, help="--episodes platoon: steps per curve point")
+    tr.add_argument("--save_platoons", type=int, default=None,
+                    help="checkpoint the agents of the first N platoons only (default: all with --episodes reference, 4 with platoon)")
     tr.add_argument("--out", type=str, default=".outputs")
     es = sub.add_parser("esim", help="run in evaluation/simulator mode")
     es.add_argument("exp_path", type=str)
@@ -74,10 +83,42 @@ def main(argv=None, conf=None):
         np.random.seed(conf.random_seed)  # rand.set_global_seed (src/rand.py:6-15)
         base = os.path.join(args.out, datetime.datetime.now().strftime("%y%m%d_%H%M%S"))
         os.makedirs(base, exist_ok=True)
-        vt = trainer.VecTrainer(conf, rng=args.rng, auto_reset=False, shared_engine=args.engine)
-        ep, avg = vt.run()
-        artifacts.generate_csvs(base, conf, ep, avg)
-        artifacts.save_agents(base, vt.agents, vt.P, vt.M, shared=vt.shared)
+        if args.episodes == "platoon":
+            if args.rng != "device":
+                raise SystemExit("--episodes platoon needs --rng device")
+            from . import evaluator
+            nofrl = conf.fed_method == conf.nofrl
+            vt = trainer.VecTrainer(conf, rng="device", auto_reset="platoon", shared_engine=args.engine, fused_update=nofrl)
+            vt.reset_episode()
+            rng_state = np.random.get_state()
+
+            def score():  # workers/evaluator.py:145 on platoon 1's actors (the evaluator reseeds the global legacy RNG: put it back)
+                grp = vt.agents
+                if not vt.shared:
+                    import copy
+                    grp = copy.copy(vt.agents)
+                    grp.theta, grp.stats, grp.n_sets = vt.agents.theta[:vt.M], vt.agents.stats[:vt.M], vt.M
+                r = evaluator.run(conf=conf, actors=grp, pl_idx=1, set_mod=vt.M if vt.shared else 0)[0]
+                np.random.set_state(rng_state)
+                return float(r)
+
+            with open(os.path.join(base, "curve.csv"), "w") as f:
+                f.write("step,episodes_closed,mean_episodic_reward,mean_episode_length,evaluator_score\n")
+                f.write(f"0,0,,,{score():.3f}\n")
+                for k in range(1, conf.total_time_steps + 1):
+                    vt.step()
+                    if k % args.report_every == 0 or k == conf.total_time_steps:
+                        r, ln, n = vt.env.pop_episode_stats()
+                        f.write(f"{k},{n},{r:.5f},{ln:.2f},{score():.3f}\n")
+                        f.flush()
+            if vt.nonfinite_updates():
+                print(f"warning: {vt.nonfinite_updates()} weight-set updates were skipped for non-finite gradients", file=sys.stderr)
+        else:
+            vt = trainer.VecTrainer(conf, rng=args.rng, auto_reset=False, shared_engine=args.engine)
+            ep, avg = vt.run()
+            artifacts.generate_csvs(base, conf, ep, avg)
+        n_save = vt.P if args.save_platoons is None and args.episodes == "reference" else min(vt.P, 4 if args.save_platoons is None else args.save_platoons)
+        artifacts.save_agents(base, vt.agents, n_save, vt.M, shared=vt.shared)
         artifacts.config_writer(os.path.join(base, "conf.json"), conf)
         print(base)
     elif args.mode == "esim":
@@ -88,6 +129,8 @@ def main(argv=None, conf=None):
         shape = vec.VecPlatoon(1, conf.pl_size, conf, rng="device")  # device RNG: consumes no np.random draws
         M = shape.num_models
         for p in range(1, conf.num_platoons + 1):
+            if not os.path.exists(os.path.join(args.exp_path, artifacts.FNAME["actor"] % (p, 1) + ".npz")):
+                break  # (a run saved with --save_platoons N holds the first N platoons' agents)
             grp = vec.AgentGroup(M, shape.num_states, shape.num_actions, conf, hidd_mult=shape.hidden_multiplier)
             for m in range(M):
                 grp.set_weights(m, "actor", artifacts.load_actor_weights(args.exp_path, p, m + 1))

@@ -689,3 +689,27 @@ def test_per_platoon_auto_reset_runs_every_platoon_in_its_own_episodes():
     assert torch.equal(a.env.x, b.env.x) and torch.equal(a.agents.theta, b.agents.theta) and torch.equal(a.actions, b.actions)
     with pytest.raises(ValueError, match="auto_reset"):
         trainer.VecTrainer(config.Config(num_platoons=2, pl_size=2), rng="device", auto_reset="vehicle")
+
+
+def test_cli_throughput_mode_with_per_platoon_episodes(tmp_path, capsys):
+    """`python -m avddpg_amd tr --rng device --episodes platoon`: the fast path from the command line -- device RNG, per-platoon
+    episodes, no host synchronisation per step; curve.csv + conf.json + checkpoints of the first platoons, reloadable by `esim`."""
+    import os
+
+    from avddpg_amd import __main__ as cli
+
+    cli.main(["tr", "--pl_num", "32", "--pl_size", "3", "--total_time_steps", "300", "--buffer_size", "500", "--fed_method", "interfrl",
+              "--engine", "fused3", "--rng", "device", "--episodes", "platoon", "--report_every", "100", "--save_platoons", "2",
+              "--out", str(tmp_path)])
+    base = capsys.readouterr().out.strip().splitlines()[-1]
+    rows = open(os.path.join(base, "curve.csv")).read().strip().splitlines()
+    assert rows[0].startswith("step,episodes_closed") and len(rows) == 1 + 1 + 3
+    last = rows[-1].split(",")
+    assert int(last[0]) == 300 and int(last[1]) > 0 and float(last[2]) < 0 and 1 <= float(last[3]) <= 600 and float(last[4]) < 0
+    assert os.path.exists(os.path.join(base, "conf.json")) and os.path.exists(os.path.join(base, "actor2_3.npz"))
+    assert not os.path.exists(os.path.join(base, "actor3_1.npz"))
+    cli.main(["esim", base, "--n_timesteps", "50"])
+    out = capsys.readouterr().out
+    assert "platoon 1:" in out and "platoon 2:" in out and "platoon 3:" not in out
+    with pytest.raises(SystemExit):
+        cli.main(["tr", "--episodes", "platoon", "--out", str(tmp_path)])  # host RNG: refused
