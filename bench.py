@@ -81,6 +81,11 @@ def parse():
     ap.add_argument("--one-rank-rccl", action="store_true",
                     help="N = 1 only: run interfrl through a real RCCL communicator of ONE rank (every collective of the N > 1 path is "
                          "issued -- what a collective costs on the device with no wire behind it; not the default measurement)")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5,
+                    help="untimed steps of the SAME workload run before the --warmup steps until this much wall time has passed (0 = none): "
+                         "a chip coming out of idle (trainer construction, ring fill) runs its first ~0.5 s 3-5 %% slow (clocks and power "
+                         "state), so a short run -- --steps 20 --warmup 5 is 55 ms -- would time the ramp, not the workload; the line "
+                         "records what was added (prewarm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
@@ -324,7 +329,15 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
             dt = float(tt.item())
         return dt, {n: sum(a.elapsed_time(b) for a, b in ev.get(n, [])) / steps for n in names}
 
+    # steady state first: untimed steps until --prewarm-seconds have passed (clock / power ramp out of idle), THEN the W warm-up steps
+    # and the K timed ones
+    prewarm_steps, t_pw = 0, time.perf_counter()
     ev = {}
+    while args.prewarm_seconds > 0 and time.perf_counter() - t_pw < args.prewarm_seconds:
+        for _ in range(16):
+            one_step(False)
+        torch.cuda.synchronize()
+        prewarm_steps += 16
     elapsed, stage_ms = timed_run(args.warmup, args.steps)
     # N > 1, split engine: time the OTHER collective form too (same trainer, same state), so that one multi-GPU run shows what the
     # overlap hides: forms.single = one all-reduce of the whole slab between learn and Adam; forms.overlapped = critic block on a side
@@ -527,6 +540,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]}
                     | (split_extra if split3 else {}),
         "stages_ms": stage_ms,
+        "prewarm": {"steps": prewarm_steps, "seconds": args.prewarm_seconds,
+                    "note": "untimed steps of the same workload before the --warmup steps (steady clocks / power state); not in `steps`, `warmup` or the timed region"},
         "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
                       "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
