@@ -383,7 +383,8 @@ class AgentGroup:
         split=True: every operand an fp16 hi + lo pair, f32-class results (csrc/fsplit.hip, avd_learn_set_split_f16x3).
         phase (split only): None = the whole call; "critic" / "actor" = its two halves over the same workspace
         (avd_learn_set_split_critic / _actor: the critic block of ``grads`` is final after the first, the actor block after the
-        second; same stream, same ``grads``, nothing else in between -- VecTrainer overlaps the critic block's all-reduce).
+        second; same stream, same ``grads``, nothing else in between -- VecTrainer(overlap_allreduce=True) puts the critic block's
+        all-reduce between them on a side stream).
         Returns the mean gradient per set [n_sets, theta_size]."""
         import ctypes
         self._check_agent_major(s, a, r, s2, n_agents, agent_weight)

@@ -359,8 +359,9 @@ int avd_learn_set_split_mfma_count(const avd_mlp_layout* lay, int n_agents, int 
  *                               of every set of `grads` (zeroes the slab first) and both losses;
  *   avd_learn_set_split_actor   the actor gradients from what the critic phase left in the workspace; writes the ACTOR block.
  * critic, then actor, on the same stream with the same workspace and nothing else touching it in between, is bit-identical to
- * avd_learn_set_split_f16x3 (tested). Between the two the critic block is final: a multi-GPU caller starts its all-reduce on a
- * side stream there (avddpg_amd/trainer.py) and only the actor block's exchange stays on the critical path. */
+ * avd_learn_set_split_f16x3 (tested). Between the two the critic block is final: a multi-GPU caller MAY start its all-reduce on a
+ * side stream there (avddpg_amd/dist.py exchange_two_phase; opt-in: measured on a one-rank RCCL communicator the persistent kernels of
+ * the actor phase leave the collective no CU to run beside them). */
 int avd_learn_set_split_critic(const avd_mlp_layout* lay, int n_agents, int n_sets, const float* theta, const float* stats,
                                const float* theta_t, const float* stats_t, const float* s, const float* a, const float* r,
                                const float* s2, const float* agent_weight, float gamma, float high, float* grads, float* losses,
