@@ -24,8 +24,8 @@ Fixtures:
   G8 evaluator rollout (stub) g8_evaluator.npz
   G9 same, centralized        g9_evaluator_centralized.npz
 (g10_curves.npz is NOT made here and is not a reference-derived vector: it holds the ORACLE loop's long-run reward curves and
- evaluator scores at BASELINE configs[0] on 5 seeds -- `python tools/train_curves.py oracle --episodes 1666 --max-steps 250000`,
- about an hour on 5 cores -- which tests/test_gpu_curves.py compares the GPU trainer's curves with. The reference itself cannot
+ evaluator scores at BASELINE configs[0] on 5 seeds over the reference's full schedule (1666 episodes) -- `python tools/train_curves.py
+ oracle --episodes 1666`, 3.6 hours on 5 cores -- which tests/test_gpu_curves.py compares the GPU trainer's curves with. The reference itself cannot
  run here: its trainer imports TensorFlow.)
 """
 import json
