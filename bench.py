@@ -76,8 +76,10 @@ def parse():
     ap.add_argument("--no-collective-ab", action="store_true",
                     help="interfrl, N > 1: do not also time the OTHER collective form (by default the line carries both under "
                          "collective.forms so that one multi-GPU run attributes its own communication cost)")
-    ap.add_argument("--init-timeout", type=float, default=240.0,
-                    help="N > 1: seconds the process-group rendezvous + first collective may take before the rank gives up (non-zero exit)")
+    ap.add_argument("--init-timeout", type=float, default=600.0,
+                    help="N > 1: seconds the process-group rendezvous + first collective may take before the rank gives up (non-zero exit). "
+                         "Generous on purpose: on a fresh box the ranks' first `import torch` / HIP initialisation can finish minutes apart, "
+                         "and the ranks that are ready wait here for the last one")
     ap.add_argument("--one-rank-rccl", action="store_true",
                     help="N = 1 only: run interfrl through a real RCCL communicator of ONE rank (every collective of the N > 1 path is "
                          "issued -- what a collective costs on the device with no wire behind it; not the default measurement)")
@@ -333,7 +335,16 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     # and the K timed ones
     prewarm_steps, t_pw = 0, time.perf_counter()
     ev = {}
-    while args.prewarm_seconds > 0 and time.perf_counter() - t_pw < args.prewarm_seconds:
+    def more_prewarm():
+        go = args.prewarm_seconds > 0 and time.perf_counter() - t_pw < args.prewarm_seconds
+        if world > 1:  # every rank must run the SAME number of steps (interfrl steps hold a collective): continue while any rank wants to
+            import torch.distributed as dist
+            flag = torch.tensor([1 if go else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go = bool(flag.item())
+        return go
+
+    while more_prewarm():
         for _ in range(16):
             one_step(False)
         torch.cuda.synchronize()
