@@ -408,6 +408,8 @@ struct HeadArgs {
     float* tz;         // OUT_TANH_SAVE: tanh(z) per row [n_agents][64] (the actor's backward seed needs 1 - t^2: actor_seed_kernel)
     float gamma, high, inv_n;
     int* bad;          // set when an activation would overflow fp16 (S1 P1 >= 65520): finalize then writes NaN gradients
+    int abl;           // diagnostic build only (AVD_FSPLIT_ABL bit 4; 0 in the product): the relu / hi-lo split VALU of every first-layer tile
+                       // is skipped (raw bits as operands: WRONG results) -- what the heads' time owes to that VALU work
 };
 // Workgroup = 8 waves bound to one weight set; LDS holds the fp16 hi and lo images of its BN-folded, scaled second-layer
 // weights for the workgroup's whole life. Wave w owns rows [32 (w & 1), +32) of every 4th tile. Per feature tile: the first layer of ITS rows
@@ -519,6 +521,11 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
         // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
         unsigned ph[8], pl[8];
         auto split16 = [&](const f32x16& p1) {
+            if (p.abl & 4) {  // (timing ablation: no VALU at all)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) ph[m] = __float_as_uint(p1[2 * m]), pl[m] = __float_as_uint(p1[2 * m + 1]);
+                return;
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), ph[m], pl[m]);
         };
@@ -936,6 +943,11 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     };
     // pair m of a unit's 16 rows = registers 2m, 2m + 1 = rows acc_row(2m, h), + 1 of row half e: sign word 16 e + 4 (m >> 1) + 2 h + (m & 1)
     auto split16e = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8], int buf, int e) {
+        if (p.abl & 4) {  // (timing ablation, diagnostic build: no relu / split VALU: WRONG results)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) qh[m] = __float_as_uint(p1[2 * m]), ql[m] = __float_as_uint(p1[2 * m + 1]);
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) split2h(relu(p1[2 * m]), relu(p1[2 * m + 1]), qh[m], ql[m]);
         if (SGN) {
@@ -1218,6 +1230,11 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         //     sum_rows dC[row][f]           = sum_n W2[f][n] db2[n]                         (backprop of the row sum through the layer)
         //     sum_rows dC[row][f] relu(z1)  = sum_k W1[k][f] V[f][k] + b1[f] V[f][8]        (relu(z1) = mask z1, z1 = x . W1 + b1)
         auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8]) {
+            if (p.abl & 4) {  // (timing ablation, diagnostic build: the BN / ReLU backward + split VALU skipped, raw bits as operands: WRONG results)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) vh[m] = __float_as_uint(dc[2 * m]) ^ __float_as_uint(p1[2 * m]), vl[m] = __float_as_uint(dc[2 * m + 1]);
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 gq = *(const float4*)(&g3s[buf][32 * e + 8 * g + 4 * h]);
@@ -1498,7 +1515,8 @@ static int run(int phases, const avd_mlp_layout& L, int n_agents, int n_sets, co
     const dim3 grid(pl.grid), block(NT);
     HeadArgs h;
     h.n_agents = n_agents, h.n_sets = n_sets, h.gamma = gamma, h.high = high, h.inv_n = inv_n, h.aw = aw, h.sm = sm, h.g3 = g3, h.dmu = dmu;
-    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr, h.tz = F(pl.tz);
+    h.act2 = nullptr, h.part_s2 = nullptr, h.stamp = nullptr, h.bad = bad, h.part_m = nullptr, h.tz = F(pl.tz), h.abl = 0;
+    if (const char* e = AVD_DIAG_ENV("FSPLIT_ABL")) h.abl = atoi(e);
     auto head = [&](auto kern, int ni, const f16x8* x, const float* act, const float* rr, const float* yin, float* out, float* part_s) {
         h.net = net[ni], h.xf = x, h.act = act, h.r = rr, h.yin = yin, h.out = out, h.part_s = part_s;
         hipLaunchKernelGGL(kern, grid, block, 0, st, h);

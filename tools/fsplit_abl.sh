@@ -1,12 +1,12 @@
 #!/bin/bash
 # Timing ablations of the split engine's dw / dx kernels (DIAGNOSTIC library, results wrong by design): AVD_FSPLIT_ABL bit 1 = every
-# tile fetch reads the workgroup's first tile (L2 hits, no HBM traffic), bit 2 = no workgroup barrier in the tile loop.
+# tile fetch reads the workgroup's first tile (L2 hits, no HBM traffic), bit 2 = no workgroup barrier in the tile loop, bit 4 = the relu / split (heads, dw) and BN-ReLU-backward (dx) VALU skipped.
 # Per variant: per-kernel averages under rocprofv3 --kernel-trace --stats of tools/fsplit_time.py (4096 x 5).
 # usage: tools/fsplit_abl.sh [variants...]   (default: 0 1 2 3)   -> gpurun_out/fsplit_abl.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export AVDDPG_HIP_LIB=$R/avddpg_amd/lib/libavddpg_hip_diag.so
-V=${@:-0 1 2 3}
+V=${@:-0 1 2 3 4}
 : > $OUT/fsplit_abl.txt
 for v in $V; do
   export AVD_FSPLIT_ABL=$v
