@@ -72,6 +72,13 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float S1 = 64.f;
 constexpr float F16_OVERFLOW = 65520.f;  // the smallest float that rounds to fp16 infinity
+// timing ablations (AVD_FSPLIT_ABL, results wrong by design) exist in the DIAGNOSTIC build only: in the product the bits are the
+// constant 0 and every branch on them folds away
+#ifdef AVD_DIAG
+#define FSPLIT_ABL(x) (x)
+#else
+#define FSPLIT_ABL(x) 0
+#endif
 __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
     const f32x2 f = {a, b};
     const f16x2 h = __builtin_convertvector(f, f16x2);
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(NT) void head_kernel(const HeadArgs p) {
         // relu + hi / lo split of a first-layer tile [feature][row] (row on the lane): pair m of k-step s = registers 8 s + 2 m, + 1
         unsigned ph[8], pl[8];
         auto split16 = [&](const f32x16& p1) {
-            if (p.abl & 4) {  // (timing ablation: no VALU at all)
+            if (FSPLIT_ABL(p.abl) & 4) {  // (timing ablation: no VALU at all)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ph[m] = __float_as_uint(p1[2 * m]), pl[m] = __float_as_uint(p1[2 * m + 1]);
                 return;
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     const int srow = tid >> 3, sch = tid & 7, frow = tid >> 1, fh = tid & 1;
     uint4 a0 = {}, a1 = {}, b0 = {}, b1 = {};
     float sx[4] = {0.f, 0.f, 0.f, 0.f}, sg = 0.f, sa = 0.f;
-    auto smsrc = [&](int pl) { return (const uint4*)(p.sm + ((long)(((p.abl & 1) ? j0 : pl) * p.n_sets + set) * TILE + srow) * H2 + 16 * sch); };
+    auto smsrc = [&](int pl) { return (const uint4*)(p.sm + ((long)(((FSPLIT_ABL(p.abl) & 1) ? j0 : pl) * p.n_sets + set) * TILE + srow) * H2 + 16 * sch); };
     auto fetch_x = [&](int pl) {
         if (pl >= P || tid >= 2 * TILE) return;
         const long ri = (long)(pl * p.n_sets + set) * TILE + frow;
@@ -943,7 +950,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
     };
     // pair m of a unit's 16 rows = registers 2m, 2m + 1 = rows acc_row(2m, h), + 1 of row half e: sign word 16 e + 4 (m >> 1) + 2 h + (m & 1)
     auto split16e = [&](const f32x16& p1, unsigned (&qh)[8], unsigned (&ql)[8], int buf, int e) {
-        if (p.abl & 4) {  // (timing ablation, diagnostic build: no relu / split VALU: WRONG results)
+        if (FSPLIT_ABL(p.abl) & 4) {  // (timing ablation, diagnostic build: no relu / split VALU: WRONG results)
 #pragma unroll
             for (int m = 0; m < 8; ++m) qh[m] = __float_as_uint(p1[2 * m]), ql[m] = __float_as_uint(p1[2 * m + 1]);
             return;
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
         STAMP(1);
         stage(pi + J, 1, b0, b1);
         STAMP(2);
-        if (!(p.abl & 2)) __syncthreads();
+        if (!(FSPLIT_ABL(p.abl) & 2)) __syncthreads();
         STAMP(3);
         if (pi + J < P) {
             // tile pi + J from buffer 1; set b takes tile pi + 3J; set a (tile pi + 2J) goes to buffer 0
@@ -1066,7 +1073,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
             STAMP(1);
             stage(pi + 2 * J, 0, a0, a1);
             STAMP(2);
-            if (!(p.abl & 2)) __syncthreads();
+            if (!(FSPLIT_ABL(p.abl) & 2)) __syncthreads();
             STAMP(3);
         }
     }
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
     uint4 d0 = {}, d1 = {};
     float gn = 0.f;
     auto fetch = [&](int agent) {
-        if (p.abl & 1) agent = j0 * p.n_sets + set;
+        if (FSPLIT_ABL(p.abl) & 1) agent = j0 * p.n_sets + set;
         const uint4* src = (const uint4*)(p.sm + ((long)agent * TILE + srow) * H2 + 16 * sch);
         d0 = src[0], d1 = src[1];
         if (tid < TILE) gn = p.g3[(long)agent * TILE + tid];
@@ -1230,7 +1237,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         //     sum_rows dC[row][f]           = sum_n W2[f][n] db2[n]                         (backprop of the row sum through the layer)
         //     sum_rows dC[row][f] relu(z1)  = sum_k W1[k][f] V[f][k] + b1[f] V[f][8]        (relu(z1) = mask z1, z1 = x . W1 + b1)
         auto backward = [&](int e, const f32x16& dc, const f32x16& p1, unsigned (&vh)[8], unsigned (&vl)[8]) {
-            if (p.abl & 4) {  // (timing ablation, diagnostic build: the BN / ReLU backward + split VALU skipped, raw bits as operands: WRONG results)
+            if (FSPLIT_ABL(p.abl) & 4) {  // (timing ablation, diagnostic build: the BN / ReLU backward + split VALU skipped, raw bits as operands: WRONG results)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) vh[m] = __float_as_uint(dc[2 * m]) ^ __float_as_uint(p1[2 * m]), vl[m] = __float_as_uint(dc[2 * m + 1]);
                 return;
@@ -1290,7 +1297,7 @@ __global__ __launch_bounds__(NT) void dx_kernel(const DxArgs p) {
         DXSTAMP(1);
         if (more) stage(buf ^ 1), stage_x(buf ^ 1);
         DXSTAMP(2);
-        if (!(p.abl & 2)) __syncthreads();
+        if (!(FSPLIT_ABL(p.abl) & 2)) __syncthreads();
         DXSTAMP(3);
     }
 #ifdef AVD_STAMP
