@@ -74,7 +74,9 @@ constexpr float S1 = 64.f;
 constexpr float F16_OVERFLOW = 65520.f;  // the smallest float that rounds to fp16 infinity
 // timing ablations (AVD_FSPLIT_ABL, results wrong by design) exist in the DIAGNOSTIC build only: in the product the bits are the
 // constant 0 and every branch on them folds away
-#ifdef AVD_DIAG
+#if defined(FSPLIT_ABL_CONST)
+#define FSPLIT_ABL(x) FSPLIT_ABL_CONST  // (A/B builds with the ablation compiled in: tools/fsplit_abl_const.sh)
+#elif defined(AVD_DIAG)
 #define FSPLIT_ABL(x) (x)
 #else
 #define FSPLIT_ABL(x) 0
