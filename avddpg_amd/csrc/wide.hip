@@ -41,6 +41,25 @@ __host__ __device__ constexpr long rup(long x, long m) { return (x + m - 1) / m 
 // ------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64, GT = 256;
 
+// The relu mask as the exact bf16 pair {1, 0} of a packed pair, two packed VALU each (inline asm: written as vector arithmetic hipcc
+// makes two compares, two selects and a v_perm of it):
+//   sign_mask2: of SIGNED bf16 pre-activations: x >> 15 (arithmetic, per half) is -1 / 0, times 0x3F80 plus 0x3F80 is 0 / 0x3F80 (a +0
+//               counts as positive);
+//   relu_mask2: of relu'd bf16 activations (non-negative int16): min(x, 1) is 0 / 1, times 0x3F80.
+// The rank-one backward's producers (the actor's forward pass, the critic(s, mu) delta pass) store the mask image with them.
+__device__ __forceinline__ unsigned sign_mask2(unsigned x) {
+    unsigned t, m;
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(t) : "s"(0x000F000F), "v"(x));
+    asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(m) : "v"(t), "s"(0x3F803F80));
+    return m;
+}
+__device__ __forceinline__ unsigned relu_mask2(unsigned x) {
+    unsigned t, m;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "s"(0x00010001), "v"(x));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m) : "s"(0x3F803F80), "v"(t));
+    return m;
+}
+
 struct GemmP {
     const bf16* A;
     const bf16* B;
@@ -344,6 +363,8 @@ struct EpiDx {
     float *dgamma, *dbeta;         // [NSLICE][sets][setTab] accumulators (or NULL): row tile t adds into slice t % NSLICE
     long setTab, sliceStride;      // (thousands of row tiles adding into one address would serialise)
     int c_off;
+    const float* rsc;              // [sets][setR] or NULL: row factor of the accumulator (rank-one form: A = the relu mask, dy = d[row] acc)
+    long setR;
     template <int MI>
     __device__ void operator()(f32x4 (&acc)[MI][4], int rb, int cb, int set, int, int M, int Nc) const {
         const long tb = (long)set * setTab + c_off;
@@ -360,10 +381,11 @@ struct EpiDx {
                 if (!cok || row >= M) continue;
                 const long o = (long)set * setP + (long)row * ldp + c_off + col;
                 const bf16x4 pv = *(const bf16x4*)(P + o);
+                const float rf = rsc ? rsc[(long)set * setR + row] : 1.0f;
                 bf16x4 dz;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dy = acc[i][j][r], pp = (float)pv[r];
+                    const float dy = acc[i][j][r] * rf, pp = (float)pv[r];
                     sg[r] = fmaf(dy * (pp - mv[r]), rsv[r], sg[r]);
                     sb[r] += dy;
                     dz[r] = (bf16)(pp > 0.f ? dy * iv[r] : 0.f);
@@ -486,8 +508,9 @@ __global__ void bn_tables_kernel(const float* th, const float* st, long set_th, 
 
 // Layer-2 weights W[K][N] (f32, Keras layout) -> WT[N][Kp] = bf16(inv[k] * W[k][n]) (forward B operand) and
 // Wn[K][N] = bf16(W[k][n]) (dX B operand: rows = features, reduction over n). 32x32 LDS transpose tiles.
+// cfn != NULL: Wn[k][n] = bf16(cfn[n] * W[k][n]) -- the output layer's coefficients folded into the input gradient's operand (rank-one form)
 __global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, int N, int Kp, const float* inv, long set_tab,
-                               bf16* WT, long set_wt, bf16* Wn, long set_wn, int perm) {
+                               bf16* WT, long set_wt, bf16* Wn, long set_wn, int perm, const float* cfn) {
     __shared__ float tile[32][33];
     const int set = blockIdx.z, k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const float* W = th + (long)set * set_th + w_off;
@@ -497,7 +520,7 @@ __global__ void prep_w2_kernel(const float* th, long set_th, int w_off, int K, i
         float w = 0.f;
         if (k < K && n < N) w = W[(long)k * N + n];
         tile[r][tx] = w;
-        if (Wn && k < K && n < N) Wn[(long)set * set_wn + (long)k * N + n] = (bf16)w;
+        if (Wn && k < K && n < N) Wn[(long)set * set_wn + (long)k * N + n] = (bf16)(cfn ? w * cfn[(long)set * N + n] : w);
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -527,6 +550,38 @@ __global__ __launch_bounds__(1024) void bias2_kernel(const float* th, long set_t
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum += part[i][c];
         bias[(long)set * set_bias + n] = sum;
+    }
+}
+
+// Rank-one backward, after fw::dw_gen_kernel: the gradient slab holds G[k][n] = inv[k] sum_rows d y1[k] mask[n], `cs` holds
+// S2[n] = sum_rows d mask[n]. With relu(z2) = mask (y1 . (inv (.) W2) + bias2):
+//   u[n] = sum_rows d relu(z2)[n] = sum_k W2[k][n] G[k][n] + bias2[n] S2[n]
+//   dW2[k][n] = cf[n] (G[k][n] + sh[k] S2[n]),   db2[n] = cf[n] S2[n]  (written over S2)
+// One block per 64 columns, 16 k-groups of 64 threads (coalesced rows), LDS reduction -- bias2_kernel's shape.
+__global__ __launch_bounds__(1024) void w2_post_kernel(const float* th, long set_th, int w_off, int K, int N, const float* sh, long set_tab,
+                                                       const float* bias2, const float* cf, float* g, long set_g, float* u, float* cs,
+                                                       long set_u) {
+    __shared__ float part[16][64];
+    const int set = blockIdx.y, c = threadIdx.x & 63, gq = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+    const float* W = th + (long)set * set_th + w_off;
+    float* G = g + (long)set * set_g + w_off;
+    const float s2 = n < N ? cs[(long)set * set_u + n] : 0.f, cfv = n < N ? cf[(long)set * N + n] : 0.f;
+    float acc = 0.f;
+    if (n < N)
+        for (int k = gq; k < K; k += 16) {
+            const long o = (long)k * N + n;
+            const float gv = G[o];
+            acc = fmaf(W[o], gv, acc);
+            G[o] = cfv * fmaf(sh[(long)set * set_tab + k], s2, gv);
+        }
+    part[gq][c] = acc;
+    __syncthreads();  // (every thread has read S2 before thread group 0 overwrites it)
+    if (gq == 0 && n < N) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += part[i][c];
+        u[(long)set * set_u + n] = fmaf(bias2[(long)set * N + n], s2, sum);
+        cs[(long)set * set_u + n] = cfv * s2;
     }
 }
 
@@ -910,15 +965,80 @@ __global__ void prep_wf1_kernel(const float* th, long set_th, int S, int ws_off,
         split_bf(k < H1 ? T[bs_off + k] : 0.f, bh, bl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = h ? wl[j] : wh[j];
-        v[4] = h ? bh : wh[0], v[5] = h ? bl : wh[1], v[6] = h ? zero : wh[2], v[7] = h ? zero : wh[3];
+        // (slot 6 of the upper half repeats bh: the forward's x holds [1 1 0 0] there -- bh + bl --, the weight-gradient kernel's
+        //  rank-one form [dh dh dl 0] with |d| = dh + dl the row's loss seed: dh bh + dh bl + dl bh)
+        v[4] = h ? bh : wh[0], v[5] = h ? bl : wh[1], v[6] = h ? bh : wh[2], v[7] = h ? zero : wh[3];
     } else {
         const int k = 32 * (t - nfs) + f;
         bf16 wh, wl, bh, bl;
         split_bf(k < Ha ? T[wa_off + k] : 0.f, wh, wl);
         split_bf(k < Ha ? T[ba_off + k] : 0.f, bh, bl);
-        v[0] = h ? wl : wh, v[4] = h ? bh : wh, v[5] = h ? bl : zero;  // the state layout with one input
+        v[0] = h ? wl : wh, v[4] = h ? bh : wh, v[5] = h ? bl : zero, v[6] = h ? bh : zero;  // the state layout with one input
     }
     wf1[((long)set * nft + t) * 64 + lane] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank-one backward of the output layer (r06). The output layers are one unit wide, so dZ2[n][c] = d[n] cf[c] [z2[n][c] > 0]
+// with d the row's loss seed and cf = inv3 (.) w3: the matrix is never formed (out_bwd_kernel read one activation matrix and wrote
+// one gradient matrix per backward pass: 2 x 1.08 ms at BASELINE config 5). The forward kernel stores the relu MASK as the exact
+// bf16 image {1, 0}; d[n] is folded into the generated first layer of the weight gradient (|d| scales the row's inputs and bias
+// slots, its sign is XORed into the packed relu'd tile) and multiplies the rows of the input gradient; cf[c] is folded into the
+// input gradient's weight operand (prep_w2_kernel) and applied to dW2 at the end (w2_post_kernel), where u[c] = sum_n d relu(z2)
+// and db2 also come from: relu(z2) = mask (y1 . W2' + bias2), so u[c] = sum_f W2'[f][c] G[f][c] + bias2[c] S2[c] with
+// G = sum_n d y1 mask (the raw weight-gradient sums) and S2[c] = sum_n d[n] mask[n][c] (summed beside them in dw_gen_kernel).
+//
+// One record per 32-row chunk j of a set (j = 0 .. Np / 32: one more than there are chunks), everything dw_gen_kernel wants of
+// the rows besides the mask, in the form it is consumed in -- ONE 2304-byte piece of its stream per chunk:
+//   [   0, 1024)  the chunk's state fragments, lane (r, h) 16 B: x = [xh0..3 | xl0..3] (h = 0), [xh0..3 | dh dh dl 0] (h = 1), x = |d| s
+//   [1024, 2048)  its action fragments (critic; the same slots with the action as input 0)
+//   [2048, 2112)  sign words [h][k-step] x 4: bit 15 / 31 = sign of d of the two rows a packed pair of the relu'd tile holds
+//   [2112, 2240)  d of the 32 rows of chunk j - 1 (the mask chunk that travels in the same stage), f32
+// Rows >= Ns give zero fragments and d = 0 (their mask rows are whatever the forward made of a zero input).
+// ------------------------------------------------------------------------------------------
+constexpr int AUX_REC = 2304, AUX_ACT = 1024, AUX_SGN = 2048, AUX_D = 2112, AUX_PIECE = AUX_REC / 8;
+__global__ __launch_bounds__(64) void aux_pack_kernel(const float* X, long setX, const float* act, long setAct, const float* d, long setD,
+                                                      int Ns, int Np, unsigned char* aux, long setAux, float* dclean) {
+    __shared__ float sd[32];
+    const int set = blockIdx.y, j = blockIdx.x, lane = threadIdx.x, r = lane & 31, h = lane >> 5, nch = Np / FK;
+    const long n = (long)j * FK + r;
+    const bool live = j < nch && n < Ns;
+    const float dv = live ? d[(long)set * setD + n] : 0.f, ad = fabsf(dv);
+    if (h == 0) {
+        sd[r] = dv;
+        if (j < nch) dclean[(long)set * Np + n] = dv;  // the seed with zeros in the padding rows (dx_gen_kernel's row factor)
+    }
+    bf16 dh, dl;
+    split_bf(ad, dh, dl);
+    const bf16 zero = (bf16)0.f;
+    auto frag = [&](const float (&x)[4]) {
+        bf16 hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_bf(x[i], hi[i], lo[i]);
+        bf16x8 v;
+        v[0] = hi[0], v[1] = hi[1], v[2] = hi[2], v[3] = hi[3];
+        v[4] = h ? dh : lo[0], v[5] = h ? dh : lo[1], v[6] = h ? dl : lo[2], v[7] = h ? zero : lo[3];
+        return v;
+    };
+    float xs[4] = {0.f, 0.f, 0.f, 0.f}, xa[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const wide::f32x4 xv = *(const wide::f32x4*)(X + (long)set * setX + n * 4);
+        xs[0] = xv[0] * ad, xs[1] = xv[1] * ad, xs[2] = xv[2] * ad, xs[3] = xv[3] * ad;
+        if (act) xa[0] = act[(long)set * setAct + n] * ad;
+    }
+    unsigned char* rec = aux + (long)set * setAux + (long)j * AUX_REC;
+    ((bf16x8*)rec)[lane] = frag(xs);
+    ((bf16x8*)(rec + AUX_ACT))[lane] = frag(xa);
+    __syncthreads();
+    if (lane < 16) {  // word (hh, ks, q): rows 16 ks + 8 (q >> 1) + 4 hh + 2 (q & 1) + {0, 1} -- dword q of the packed tile of k-step ks
+        const int hh = lane >> 3, ks = (lane >> 2) & 1, q = lane & 3, row0 = 16 * ks + 8 * (q >> 1) + 4 * hh + 2 * (q & 1);
+        ((unsigned*)(rec + AUX_SGN))[lane] = ((__float_as_uint(sd[row0]) >> 31) << 15) | ((__float_as_uint(sd[row0 + 1]) >> 31) << 31);
+    } else if (lane < 48) {
+        const long nn = (long)(j - 1) * FK + (lane - 16);
+        ((float*)(rec + AUX_D))[lane - 16] = (j >= 1 && nn < Ns) ? d[(long)set * setD + nn] : 0.f;
+    } else {
+        ((unsigned*)(rec + AUX_D + 128))[lane - 48] = 0u;
+    }
 }
 
 struct FwdP {
@@ -934,6 +1054,8 @@ struct FwdP {
     bf16* P2;            // [sets][Np][H2] or NULL
     long setP2;
     int store_pre;       // != 0: the stored activations keep their sign (bf16 of z2, not of relu(z2)): fwd_delta_kernel continues from them
+    int mask_out;        // != 0: the relu MASK of the (rounded) activations is stored instead, as the exact bf16 image {1, 0}: the
+                         // rank-one backward's operand (nothing else reads the actor's activations)
     float dz_scale;      // != 0: store dZ2 = (relu(z2) > 0) * dz_scale * rw[row] * cf[col] there INSTEAD of the activations (the
     const float* rw;     // output-layer backward of a pass whose seed is the constant -1/N: critic(s, mu)); rw [sets][Ns] or NULL
     float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
@@ -1150,6 +1272,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         }
                         pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
                         pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
+                        if (p.mask_out) pk[g][0] = wide::relu_mask2(pk[g][0]), pk[g][1] = wide::relu_mask2(pk[g][1]);
                     }
                     if (dst) {
 #pragma unroll
@@ -1270,34 +1393,39 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight gradient of the second layer in the same style: dW2[f][c] = inv[f] sum_n y1[n][f] dZ2[n][c] (+ sh[f] db2[c]) with the
-// first-layer activations y1 GENERATED per 32-row chunk (one MFMA per 32 rows x 32 features from the raw inputs) instead of read
-// from a transposed activation matrix, and dZ2^T [c][n] -- written by out_bwd_kernel with the rows of every group of 16 in the
-// k order of the generated operand -- streamed L2 -> LDS through the four stages. Transposed product D[c][f] = sum_n dZ2T[c][n]
-// y1[n][f]: A = dZ2T fragments (LDS), B = relu'd first-layer tile (lane = feature, registers = rows). A work item = 128
-// features x 512 columns x one eighth of a set's rows (1024 chunks), dealt over the persistent workgroups so that the nine
-// feature blocks of a (set, column block, row range) run side by side on the same stream; f32 atomics at the end of an item.
-// Same ping-pong of the two wave groups as fwd_gen_kernel.
+// Weight gradient of the second layer in the same style, rank-one form (r06):
+//   G[f][c] = inv[f] sum_n (d[n] y1[n][f]) mask[n][c]          dW2 = cf[c] (G + sh[f] S2[c])  (w2_post_kernel)
+// with the first-layer activations y1 GENERATED per 32-row chunk (one MFMA per 32 rows x 32 features from the chunk's prepared
+// fragments, whose inputs and bias slots carry |d|; the sign of d is XORed into the packed relu'd tile) instead of read from a
+// transposed activation matrix, and the relu mask of the second layer -- the exact bf16 image {1, 0}, row-major, stored by the
+// actor's forward kernel in place of its activations and by fw::fwd_delta_kernel beside critic(s, mu) (taking the mask from the
+// sign of the stored activations HERE, 64 packed VALU per step, cost dw_gen 60 %: its prepare phase has no VALU issue slots to
+// spare; a second image from the critic's forward kernel cost that kernel 1.2 ms) -- streamed L2 -> LDS through the four stages
+// and transposed on the way out of LDS. Transposed product
+// D[c][f] = sum_n mask[n][c] (d y1)[n][f]: A = mask fragments (LDS), B = relu'd first-layer tile (lane = feature, registers = rows).
+// A work item = 128 features x 512 columns x one eighth (or less) of a set's rows, dealt over the persistent workgroups so that
+// the feature blocks of a (set, column block, row range) run side by side on the same stream; f32 atomics at the end of an item.
+// S2[c] = sum_n d[n] mask[n][c] rides along: thread t of the item with feature block fb < 8 adds rows 4 fb .. 4 fb + 3 of every
+// chunk for column t (the stream's feature blocks share the rows between them). Same ping-pong of the two wave groups as
+// fwd_gen_kernel.
 struct DwP {
-    const float* X;     // [sets][Ns][4]
-    long setX;
-    const float* act;   // critic: [sets][setAct], else NULL
-    long setAct;
-    const bf16x8* wf1;  // [sets][nft][64] (the same fragments: lane = feature)
+    const unsigned char* aux;  // [sets][Np / 32 + 1][AUX_REC]: aux_pack_kernel's records
+    long setAux;               // bytes per set
+    const bf16x8* wf1;         // [sets][nft][64] (the same fragments: lane = feature)
     int nft, nfs;
-    const bf16* ZT;     // [sets][Np][ldz]: dZ2, row-major (ldz = H2)
+    const bf16* ZT;            // [sets][Np][ldz]: the relu mask {1, 0} of the second layer, row-major (ldz = H2)
     long setZT, ldz;
-    const float *inv, *sh;  // [sets][setTab] first-layer BN tables (feature index)
-    const float* db;        // [sets][H2] column sums of dZ2
+    const float* inv;          // [sets][setTab] first-layer BN table (feature index)
     long setTab;
-    float* dW;              // [sets][setW] + offset of W2: [K][H2]
+    float* dW;                 // [sets][setW] + offset of W2: [K][H2], receives G
     long setW;
+    float* s2;                 // [sets][H2], zeroed by the caller
     int Ns, Np, H2, K, n_sets, nsplit;
 };
 
-// stage = the chunk's 32 rows of dZ2 (512 columns each, row stride 1088 B: the transposed reads below are conflict-free) + the next
-// chunk's raw inputs
-constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + 1024;
+// stage = the chunk's 32 mask rows (512 columns each, row stride 1088 B: the transposed reads below are conflict-free) + the record
+// of the NEXT chunk's fragments
+constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + AUX_REC;
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_gen_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1308,23 +1436,22 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     typedef __attribute__((address_space(3))) void* lptr_t;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto mfma = [](bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
-    auto pack = [&](const f32x16& p1, int ks, bf16x8& b) {
+    // relu + bf16 of half a first-layer tile, the rows' signs on top (one v_xor per pair: a relu'd bf16 is non-negative)
+    auto pack = [&](const f32x16& p1, int ks, const wide::u32x4& sg, bf16x8& b) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        unsigned w[4];
+        wide::u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x2 f = {p1[8 * ks + 2 * i], p1[8 * ks + 2 * i + 1]};
             const bf16x2 v = __builtin_convertvector(f, bf16x2);
             const s16x2 z = {0, 0};
-            w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+            o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z)) ^ sg[i];
         }
-        wide::u32x4 o;
-        o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
         b = __builtin_bit_cast(bf16x8, o);
     };
-    // A fragments (lane = column of dZ2, k = rows) from the row-major chunk by ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x
+    // A fragments (lane = column of the mask, k = rows) from the row-major chunk by ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x
     // 16 columns comes back column-major; lane 4 q + pp of the group addresses row q, columns 4 pp .. 4 pp + 3. Two reads per fragment:
     // element 4 g + j of lane half h is row 8 g + 4 h + j of the k-step -- the k order of the generated operand as it stands.
     const int tq = (lane & 15) >> 2, tp = lane & 3, tmb = 16 * ((lane >> 4) & 1);
@@ -1362,41 +1489,23 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             wf[ft] = (bf16x8){zb, zb, zb, zb, zb, zb, zb, zb};
             if (t0 + ft < p.nft) wf[ft] = p.wf1[((long)set * p.nft + t0 + ft) * 64 + lane];
         }
-        // stream: image rows (= columns of dZ2) [64 w, 64 w + 64) of the column block, 16 per instruction; + the raw inputs of the
-        // NEXT chunk's 32 rows (16 B of state per row, 4 B of action), every wave the same bytes (uniform instruction counts)
-        const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(row_base + 4 * wv) * p.ldz + FC * cb);  // rows 4 w .. 4 w + 3 of a chunk
+        // stream: rows 4 w .. 4 w + 3 of the chunk's mask rows (512 columns = 1 KiB per instruction) + this wave's eighth of the
+        // record that holds the NEXT chunk's fragments (18 lanes x 16 B): 5 wave-instructions per chunk
+        const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(row_base + 4 * wv) * p.ldz + FC * cb);
+        const unsigned char* rec0 = p.aux + (long)set * p.setAux + (long)(row_base / FK) * AUX_REC;  // record of the item's chunk 0
         const unsigned vow = (unsigned)lane * 16u;
-        auto dma = [&](int stg, int kc) {  // chunk kc of the item into stage stg: 4 + 1 (+ 1) wave-instructions
+        auto dma = [&](int stg, int kc) {
             unsigned char* l = smem_raw + stg * DW_STG;
             unsigned vw = vow;
             asm volatile("" : "+v"(vw));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)  // one row (512 columns = 1 KiB) per instruction
+            for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ubw + ((long)kc * FK + i) * p.ldz * 2 + vw), (lptr_t)(l + (4 * wv + i) * DW_ROWB), 16, 0, 0);
-            const int kn = kc + 1 < nk ? kc + 1 : kc;  // (the last chunk carries its own rows again: never used)
-            int n = row_base + kn * FK + (lane & 31);
-            n = n < p.Ns ? n : p.Ns - 1;
-            if constexpr (CRITIC) {
-                if (lane < 32) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FK * DW_ROWB), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(l + FK * DW_ROWB + 512), 4, 0, 0);
-                }
-            } else {  // (no branch: the upper lanes repeat the rows into the spare bytes behind them; -3 %. The critic's actions merged
-                      //  into the same instruction as 16-byte groups cost more in lane-address arithmetic than the instruction: +2.5 %)
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(l + FK * DW_ROWB), 16, 0, 0);
-            }
+            if (lane < AUX_PIECE / 16)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rec0 + (long)(kc + 1) * AUX_REC + AUX_PIECE * wv + vw), (lptr_t)(l + FK * DW_ROWB + AUX_PIECE * wv), 16, 0, 0);
         };
-        constexpr int NDMA = CRITIC ? 6 : 5;
-        // x fragment (A operand of the first layer: lane = row of the chunk) from the raw rows in stage stg = rows of chunk kc + 1
-        auto x_of = [&](int stg, int kc) {  // stage stg carries the raw rows of chunk kc + 1
-            const int n = row_base + (kc + 1) * FK + r;
-            const bool live = kc + 1 < nk && n < p.Ns;
-            const unsigned char* l = smem_raw + stg * DW_STG + FK * DW_ROWB;
-            if (action) return x_frag_action(*(const float*)(l + 512 + r * 4), live, h);
-            const f32x4 xv = *(const f32x4*)(l + r * 16);
-            const float x[4] = {xv[0], xv[1], xv[2], xv[3]};
-            return x_frag_state(x, live, h);
-        };
+        constexpr int NDMA = 5;
+        const int fofs = FK * DW_ROWB + (action ? AUX_ACT : 0) + lane * 16, sofs = FK * DW_ROWB + AUX_SGN + h * 32;
         __syncthreads();  // (the previous item's LDS reads are done)
 #pragma unroll
         for (int c = 0; c < FSTG - 1; ++c) dma(c, c < nk ? c : nk - 1);
@@ -1409,24 +1518,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int ct = 0; ct < 4; ++ct) acc[ft][ct] = zero16;
         bf16x8 bfr[2][2];  // relu'd first layer of the chunk: [feature tile][k-step]
         {
-            // chunk 0's own rows are not in a stage (a stage carries the NEXT chunk's): read them directly
-            const int n = row_base + r;
-            const bool live = n < p.Ns;
-            bf16x8 x0;
-            if (action) {
-                x0 = x_frag_action(live ? p.act[(long)set * p.setAct + n] : 0.f, live, h);
-            } else {
-                float x[4] = {0.f, 0.f, 0.f, 0.f};
-                if (live) {
-                    const f32x4 xv = *(const f32x4*)(p.X + (long)set * p.setX + (long)n * 4);
-                    x[0] = xv[0], x[1] = xv[1], x[2] = xv[2], x[3] = xv[3];
-                }
-                x0 = x_frag_state(x, live, h);
-            }
+            // chunk 0's own fragments are not in a stage (a stage carries the NEXT chunk's): read them from its record
+            const bf16x8 x0 = *(const bf16x8*)(rec0 + (action ? AUX_ACT : 0) + lane * 16);
+            const wide::u32x4 sg0 = *(const wide::u32x4*)(rec0 + AUX_SGN + h * 32), sg1 = *(const wide::u32x4*)(rec0 + AUX_SGN + h * 32 + 16);
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 const f32x16 p1 = mfma(x0, wf[ft], zero16);
-                pack(p1, 0, bfr[ft][0]), pack(p1, 1, bfr[ft][1]);
+                pack(p1, 0, sg0, bfr[ft][0]), pack(p1, 1, sg1, bfr[ft][1]);
             }
         }
         if (grp == 1) {  // one phase behind
@@ -1434,17 +1532,26 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_s_barrier();
         }
         int stg = 0;
-        bf16x8 xn;
-        if constexpr (!CRITIC) xn = x_of(0, 0);
+        float s2acc = 0.f;  // sum_n d[n] mask[n][column tid] over this item's share of the rows
+        const bool s2on = fb < 8;
         auto step = [&](int kt, auto wait_c) {
             constexpr bool WAIT = decltype(wait_c)::value;
             // ================= prepare(kt)
             bf16x8 A[2][4];
             read_frags(stg, 0, A[0]);
             read_frags(stg, 1, A[1]);
-            // x fragment of chunk kt + 1 (its raw rows ride in this stage). Critic: built here, where the VALU is idle (its action
-            // branch between the MFMAs cost 8 %); actor: one multiply phase ahead, in the MFMA shadows (2 % the other way)
-            if constexpr (CRITIC) xn = x_of(stg, kt);
+            const unsigned char* l = smem_raw + stg * DW_STG;
+            // fragment + sign words of chunk kt + 1 (its record rides in this stage)
+            const bf16x8 xn = *(const bf16x8*)(l + fofs);
+            const wide::u32x4 sg0 = *(const wide::u32x4*)(l + sofs), sg1 = *(const wide::u32x4*)(l + sofs + 16);
+            if (s2on) {  // (uniform per workgroup)
+                const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned m = *(const unsigned short*)(l + (4 * fb + i) * DW_ROWB + tid * 2);
+                    s2acc = fmaf(__uint_as_float(m << 16), dv[i], s2acc);
+                }
+            }
             {
                 int kc = kt + FSTG - 1;
                 kc = kc < nk ? kc : nk - 1;  // (tail: harmless re-loads keep the vmcnt arithmetic uniform)
@@ -1462,7 +1569,6 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             bf16x8 bnx[2][2];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) p1n[ft] = mfma(xn, wf[ft], zero16);
-            if constexpr (!CRITIC) xn = x_of((stg + 1) & (FSTG - 1), kt + 1);  // (chunk kt + 1 has landed: the wait before this phase's barrier)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1470,14 +1576,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                     for (int ft = 0; ft < 2; ++ft) acc[ft][ct] = mfma(A[ks][ct], bfr[ft][ks], acc[ft][ct]);
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft) pack(p1n[ft], 0, bnx[ft][0]), pack(p1n[ft], 1, bnx[ft][1]);
+            for (int ft = 0; ft < 2; ++ft) pack(p1n[ft], 0, sg0, bnx[ft][0]), pack(p1n[ft], 1, sg1, bnx[ft][1]);
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) bfr[ft][0] = bnx[ft][0], bfr[ft][1] = bnx[ft][1];
             __builtin_amdgcn_s_setprio(0);
@@ -1495,28 +1600,26 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the stream
-        // ---- dW2[f][c] += inv[f] acc (+ sh[f] db2[c] from the first row range), f32 atomics. The accumulator holds a feature per lane
-        // (rows of dW2, 4 KB apart): added as it stands, every atomic instruction touched 32 cache lines with two floats each, and
-        // the epilogues of an item cost as much as 260 of its 1024 steps (0.23 ms: a fifth of the kernel). Each 32 x 32 tile goes
-        // through a private 4.5 KB of LDS instead and is added with a COLUMN per lane: 2 lines x 32 floats per instruction.
-        __syncthreads();  // (the stages are scratch from here: every wave is past its last fragment / raw-row read)
+        if (s2on) atomicAdd(p.s2 + (long)set * p.H2 + FC * cb + tid, s2acc);
+        // ---- G[f][c] += inv[f] acc, f32 atomics. The accumulator holds a feature per lane (rows of dW2, 4 KB apart): added as it
+        // stands, every atomic instruction touched 32 cache lines with two floats each, and the epilogues of an item cost as much
+        // as 260 of its 1024 steps (0.23 ms: a fifth of the kernel). Each 32 x 32 tile goes through a private 4.5 KB of LDS
+        // instead and is added with a COLUMN per lane: 2 lines x 32 floats per instruction.
+        __syncthreads();  // (the stages are scratch from here: every wave is past its last fragment / record read)
         float* tr = (float*)(smem_raw + wv * (32 * 36 * 4));  // [32 features][36]: 16-byte rows, private to the wave
         const int tc = lane & 31, tf = lane >> 5;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             const int f = 32 * (t0 + ft) + r;
-            const bool fok = f < p.K;
-            const float iv = fok ? p.inv[(long)set * p.setTab + f] : 0.f, sf = (fok && split == 0) ? p.sh[(long)set * p.setTab + f] : 0.f;
-            const float* dbp = p.db + (long)set * p.H2 + FC * cb + 128 * cq + 4 * h;
+            const float iv = f < p.K ? p.inv[(long)set * p.setTab + f] : 0.f;
             float* o = p.dW + (long)set * p.setW + (long)(32 * (t0 + ft) + tf) * p.H2 + FC * cb + 128 * cq + tc;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 dbv = *(const f32x4*)(dbp + 32 * ct + 8 * g);
                     f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(iv, acc[ft][ct][4 * g + j], sf * dbv[j]);
+                    for (int j = 0; j < 4; ++j) v[j] = iv * acc[ft][ct][4 * g + j];
                     *(f32x4*)(tr + r * 36 + 8 * g + 4 * h) = v;
                 }
 #pragma unroll
@@ -1531,7 +1634,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // Input gradient of the second layer + everything behind it, without an activation or gradient matrix of the first layer:
-//   dy[n][f] = sum_c dZ2[n][c] W2[f][c]            (MFMA, K = H2; D[row][feature]: lane = feature, registers = rows)
+//   dy[n][f] = d[n] sum_c mask[n][c] (cf[c] W2[f][c])   (MFMA, K = H2; D[row][feature]: lane = feature, registers = rows; the row
+//                                                        factor d[n] multiplies the accumulator tile in the epilogue: r06, rank-one form)
 //   p[n][f]  = x[n] . W1[:, f] + b1[f]              (regenerated: one MFMA per 32 x 32 tile, same layout)
 //   dgamma1[f] = rs (S1 - mean S2), dbeta1[f] = S2, db1[f] = inv S3, dW1[s][f] = inv S4[s]   with the per-feature sums over rows
 //   S1 = sum dy relu(p), S2 = sum dy, S3 = sum [p > 0] dy, S4[s] = sum x[n][s] [p > 0] dy
@@ -1548,9 +1652,11 @@ struct DxP {
     long setAct;
     const bf16x8* wf1;  // [sets][nft][64]
     int nft, nfs;
-    const bf16* dZ;     // [sets][Np][H2]
+    const bf16* dZ;     // [sets][Np][H2]: the relu mask of the second layer as a bf16 image {1, 0} (rank-one form: dZ2 = d (x) cf (.) mask)
     long setDZ;
-    const bf16* Wn;     // [sets][>= 256 nfb][H2]: bf16(W2), row = feature
+    const float* d;     // [sets][setD]: the rows' loss seeds, zeros in the padding rows (aux_pack_kernel's dclean)
+    long setD;
+    const bf16* Wn;     // [sets][>= 256 nfb][H2]: bf16(cf[c] W2[f][c]), row = feature
     long setWn;
     const float *inv, *rs, *mean;  // [sets][setTab]
     long setTab;
@@ -1633,7 +1739,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         int n = tl * 256 + 64 * (wv & 3) + lane;
         n = n < p.Ns ? n : p.Ns - 1;
         __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + DXL_X + (b * 256 + 64 * (wv & 3)) * 16), 16, 0, 0);
-        if (CRITIC) __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + DXL_A + (b * 256 + 64 * (wv & 3)) * 4), 4, 0, 0);
+        // (the seed comes unclamped: its padding rows hold zeros)
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.d + (long)set * p.setD + tl * 256 + 64 * (wv & 3) + lane), (lptr_t)(smem_raw + DXL_A + (b * 256 + 64 * (wv & 3)) * 4), 4, 0, 0);
     };
     constexpr int NDMA = 4;  // per chunk; the counted waits leave ONE chunk in flight (three stages)
     // the sums of the finished set go to the gradient slab
@@ -1774,9 +1881,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const float x0[4] = {raw_x1(row, 0), raw_x1(row, 1), raw_x1(row, 2), raw_x1(row, 3)};
                 const f32x16 p1 = mfma(x_frag_state(x0, tl * 256 + row < p.Ns, h), wf, zero16);  // [row (registers)][feature (lane)]
                 float md[16];
+                const float* dsc = (const float*)(smem_raw + DXL_A) + xb * 256 + 64 * rq + 32 * rt + 4 * h;  // register 4 g + j <-> row 8 g + 4 h + j
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float dy = acc[rt][ft][i];
+                    const float dy = acc[rt][ft][i] * dsc[8 * (i >> 2) + (i & 3)];
                     md[i] = p1[i] > 0.f ? dy : 0.f;
                     s1 = fmaf(md[i], p1[i], s1);  // = dy relu(p)
                     s2 += dy;
@@ -1847,8 +1955,9 @@ struct DeltaP {
     int Ns, Np, H2, H1, n_sets;
     // the action gradient in the same kernel: dC[n][k] = sum_c dZ2[n][c] W2[H1 + k][c] (one more product, B = the dZ2 tile as it stands),
     // da[n] = sum_k [p1(mu)[n][k] > 0] inv[k] Wa[k] dC[n][k] -- linear in dC, so every wave adds its 128 columns' part (f32 atomics)
-    const bf16* Wn;     // [sets][..][H2]: bf16(W2), row = feature
+    const bf16* Wn;     // [sets][..][H2]: bf16(W2), row = feature -- or bf16(cf[c] W2[f][c]) (cf_in_wn: the rank-one backward's operand)
     long setWn;
+    int cf_in_wn;
     const float* inv;   // [sets][setTab] (index H1 + k)
     long setTab;
     const float* th;    // [sets][setTh] critic parameters (wa_off: Wa[k])
@@ -1856,6 +1965,8 @@ struct DeltaP {
     int wa_off, Ha;
     float* da;          // [sets][setDa], zeroed by the caller
     long setDa;
+    bf16* Mk;           // [sets][Np][H2] or NULL: the relu mask {1, 0} of the z2(a) read here (critic(s, a)'s mask: the rank-one backward's
+                        // operand) -- written by this pass, which reads every element anyway and is bound by neither memory nor VALU
 };
 constexpr int DL_ROWN = FC * 2 + 16;  // row stride of the 64 action rows of W2 in LDS (1040 B: conflict-free 16-byte reads down the rows)
 constexpr int DL_W = 0, DL_CF = DL_W + FC * 64 * 2, DL_ZS = DL_CF + FC * 4, DL_WN = DL_ZS + 4 * FR * 4, DL_MK = DL_WN + 64 * DL_ROWN,
@@ -1940,6 +2051,18 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             acc[ct][4 * (2 * gg + g2) + 2 * e + 1] = __uint_as_float(pk[g2][e] & 0xffff0000u);
                         }
                 }
+            if (p.Mk) {  // critic(s, a)'s relu mask: same pieces, same places as the z2(a) image; before the next request overwrites them.
+                // (Stores count in vmcnt like loads, so the wait for the next rows also waits for these: 1.20 -> 1.66 ms. Held in
+                //  registers and stored behind the next request they spill -- 256 B of scratch, 2.48 ms.)
+                bf16* md = p.Mk + (long)set * p.setZ + n * p.H2 + FC * cb + 128 * cq + 8 * h;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    wide::u32x4 v = raw[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = wide::sign_mask2(v[e]);
+                    *(wide::u32x4*)(md + 16 * i) = v;
+                }
+            }
             const bf16x8 xa = x_frag_action(av, live, h), xm = x_frag_action(mv, live, h);
             bf16x8 dfr[2][2];  // [action tile][k-step]: bf16 of relu(p1(mu)) - relu(p1(a))
             unsigned long long pos = 0;  // relu mask of p1(mu), bit 16 ta + register
@@ -1987,7 +2110,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int j = 0; j < 4; ++j) {
                         o[j] = (bf16)fmaxf(acc[ct][4 * g + j], 0.f);
                         zp = fmaf((float)o[j], cv[j], zp);
-                        o[j] = (bf16)((float)o[j] > 0.f ? drow * cv[j] : 0.f);
+                        o[j] = (bf16)((float)o[j] > 0.f ? (p.cf_in_wn ? drow : drow * cv[j]) : 0.f);
                     }
                     pk[g][0] = (unsigned)__builtin_bit_cast(unsigned short, o[0]) | ((unsigned)__builtin_bit_cast(unsigned short, o[1]) << 16);
                     pk[g][1] = (unsigned)__builtin_bit_cast(unsigned short, o[2]) | ((unsigned)__builtin_bit_cast(unsigned short, o[3]) << 16);
@@ -2038,7 +2161,7 @@ struct Plan {
     size_t WT[4], Wn[2], bias[4];                    // weights: 0 actor, 1 critic, 2 target actor, 3 target critic
     size_t tabs[4];                                  // per net: inv/sh/rs/mean tables of [KCp + H2] floats x 4
     size_t cf[4], c0[4];                             // output-layer coefficient vectors
-    size_t q, y, dq, a1, tt, da, zbuf;               // row vectors [sets][Np]
+    size_t q, y, dq, a1, tt, da, zbuf, dcl;          // row vectors [sets][Np] (dcl: the current backward pass's seed, zero padding rows)
     size_t u, cs, acc;                               // [sets][H2] x 2, [sets][4]
     size_t bnacc;                                    // first-layer dgamma | dbeta partial tables [2][NSLICE][sets][ldT]
     size_t wf1[4];                                   // fused forward: first-layer fragments [sets][KCp / 32][64] x 16 B per net
@@ -2069,7 +2192,7 @@ static Plan make_plan(const avd_mlp_layout& L, int n_agents, int n_sets, int row
     p.ldT = KCp + d.H2;
     for (int i = 0; i < 4; ++i) p.tabs[i] = take(sets * p.ldT * 4 * 4), p.cf[i] = take(sets * d.H2 * 4), p.c0[i] = take(sets * 4);
     p.q = take(sets * Np * 4), p.y = take(sets * Np * 4), p.dq = take(sets * Np * 4), p.a1 = take(sets * Np * 4);
-    p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4), p.zbuf = take(sets * Np * 4);
+    p.tt = take(sets * Np * 4), p.da = take(sets * Np * 4), p.zbuf = take(sets * Np * 4), p.dcl = take(sets * Np * 4);
     p.u = take(sets * d.H2 * 4), p.cs = take(sets * d.H2 * 4), p.acc = take(sets * 4 * 4);
     p.bnacc = take(2 * (size_t)NSLICE * sets * p.ldT * 4);
     for (int i = 0; i < 4; ++i) p.wf1[i] = take(sets * (KCp / 32 + 1) * 64 * 16);
@@ -2149,12 +2272,15 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     static const char* ff_env = AVD_DIAG_ENV("WIDE_FUSED_FWD");
     const bool fused_fwd = L.S == 4 && H2 % fw::FC == 0 && H1 % 32 == 0 && KCp % 32 == 0 && KCp / 32 >= fw::FSTG && !(ff_env && ff_env[0] == '0');
     static const char* fd_env = AVD_DIAG_ENV("WIDE_FUSED_DW");
-    const bool fused_dw = fused_fwd && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
-                          !(fd_env && fd_env[0] == '0');
     static const char* fx_env = AVD_DIAG_ENV("WIDE_FUSED_DX");
-    const bool fused_dx = fused_dw && Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fx_env && fx_env[0] == '0');
     static const char* fl_env = AVD_DIAG_ENV("WIDE_FUSED_DELTA");
     const bool fused_delta = fused_fwd && H1 % 32 == 0 && KCp - H1 == 64 && !(fl_env && fl_env[0] == '0');
+    // The fused backward kernels exist in the rank-one form only (r06: dZ2 = d (x) cf (.) mask is never materialised; the forward
+    // kernels store the relu mask, fw::dw_gen_kernel / fw::dx_gen_kernel / fw::fwd_delta_kernel take d and cf on their other operands):
+    // all of them or none -- without one of them the backward pass runs layer-wise from out_bwd_kernel's dZ2.
+    const bool r1 = fused_fwd && fused_delta && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
+                    Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fd_env && fd_env[0] == '0') && !(fx_env && fx_env[0] == '0');
+    const bool fused_dw = r1, fused_dx = r1;
     constexpr size_t fw_lds = fw::L_TOTAL;
     if (fused_fwd) {
         // the > 64 KB dynamic-LDS opt-in, once per DEVICE of this process (the attribute belongs to the device's copy of the function)
@@ -2202,8 +2328,11 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
         }
         const int w2 = critic ? L.cW2 : L.aW2, b2 = critic ? L.cb2 : L.ab2, w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3;
+        hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3, b3, H2, n.inv + KCp,
+                           n.sh + KCp, ldT, n.cf, n.c0, (long)H2);
         hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, n.th,
-                           (long)L.theta_size, w2, K, H2, KCp, n.inv, ldT, n.WT, setWT, n.Wn, setWn, fused_fwd ? 1 : 0);
+                           (long)L.theta_size, w2, K, H2, KCp, n.inv, ldT, n.WT, setWT, n.Wn, setWn, fused_fwd ? 1 : 0,
+                           (r1 && n.Wn) ? n.cf : (const float*)nullptr);
         if (fused_fwd) {
             const int nfs = H1 / 32, nft = critic ? KCp / 32 : nfs;
             hipLaunchKernelGGL(fw::prep_wf1_kernel, dim3((unsigned)nft, sets), dim3(64), 0, st, n.th, (long)L.theta_size, L.S,
@@ -2212,8 +2341,6 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         }
         hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, n.th, (long)L.theta_size, w2, b2, K,
                            H2, n.sh, ldT, n.bias, (long)H2);
-        hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3, b3, H2, n.inv + KCp,
-                           n.sh + KCp, ldT, n.cf, n.c0, (long)H2);
     }
     WIDE_CHECK(check_launch("avd_learn_shared_bf16: operand preparation"));
 
@@ -2254,6 +2381,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
         f.P2 = keep_p2 ? (dz_out ? dZ2 : P2) : nullptr, f.setP2 = setP2, f.z = critic ? q : zbuf, f.setZ = Np, f.Ns = Ns, f.Np = Np, f.H2 = H2, f.n_sets = sets;
         f.dz_scale = dz_out ? -1.0f / (float)Ns : 0.f, f.rw = row_weight, f.store_pre = store_pre ? 1 : 0;
+        f.mask_out = (r1 && !critic && keep_p2) ? 1 : 0;  // (rank-one backward: the actor's pass leaves its relu mask, nothing reads its activations)
         static const char* dbg_env = AVD_DIAG_ENV("FW_DBG");
         f.dbg = dbg_env ? atoi(dbg_env) : 0;
         f.stamp = nullptr;
@@ -2331,20 +2459,29 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                         const float* bAct = nullptr, long bSetAct = 0) {
         (void)hipMemsetAsync(u, 0, sizeof(float) * sets * H2, st);
         (void)hipMemsetAsync(cs, 0, sizeof(float) * sets * H2, st);
-        hipLaunchKernelGGL(out_bwd_kernel, dim3((unsigned)rup(H2, 64) / 64, g64.y, sets), dim3(256), 0, st, P2, (long)H2, setP2, dvec,
-                           (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, (wg && !fused_dw) ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2, 0);
         const int K = critic ? KC : H1;
+        const int w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3, gg = critic ? L.cg3 : L.ag2,
+                  gbe = critic ? L.cbe3 : L.abe2, gb2 = critic ? L.cb2 : L.ab2;
+        if (!fused_dw)
+            hipLaunchKernelGGL(out_bwd_kernel, dim3((unsigned)rup(H2, 64) / 64, g64.y, sets), dim3(256), 0, st, P2, (long)H2, setP2, dvec,
+                               (long)Np, n.cf, (long)H2, H2, Ns, Np, dZ2, wg ? dZ2T : nullptr, (long)Np, setZT, u, cs, (long)H2, 0);
         if (wg) {
-            const int w3 = critic ? L.cW3 : L.aW3, b3 = critic ? L.cb3 : L.ab3, gg = critic ? L.cg3 : L.ag2,
-                      gbe = critic ? L.cbe3 : L.abe2, gb2 = critic ? L.cb2 : L.ab2;
-            hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,
-                               H2, n.inv + KCp, n.sh + KCp, n.rs + KCp, n.mean + KCp, ldT, u, cs, (long)H2, acc, acc_idx, gnet,
-                               (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
-            if (fused_dw) {  // the same from the raw inputs: first layer generated per 32-row chunk, dZ2^T streamed (fw::dw_gen_kernel)
+            if (!fused_dw)
+                hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,
+                                   H2, n.inv + KCp, n.sh + KCp, n.rs + KCp, n.mean + KCp, ldT, u, cs, (long)H2, acc, acc_idx, gnet,
+                                   (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
+            if (fused_dw) {
+                // rank-one form: the rows' records (|d| x, sign words, d), then G and S2 from the relu mask (critic: left in the dZ2 buffer
+                // by fw::fwd_delta_kernel; actor: stored by its forward pass in place of the activations) -- fw::dw_gen_kernel: first layer
+                // generated per 32-row chunk, mask streamed --, then u, db2 and the cf / sh terms of dW2
+                unsigned char* aux = ws + pl.dZ2T;  // (the transposed gradient matrix of the layer-wise path: free here)
+                const long setAux = (long)(Np / fw::FK + 1) * fw::AUX_REC;
+                hipLaunchKernelGGL(fw::aux_pack_kernel, dim3((unsigned)(Np / fw::FK + 1), sets), dim3(64), 0, st, bX, setX,
+                                   critic ? bAct : (const float*)nullptr, bSetAct, dvec, (long)Np, Ns, Np, aux, setAux, F32(pl.dcl));
                 fw::DwP d2;
-                d2.X = bX, d2.setX = setX, d2.act = critic ? bAct : nullptr, d2.setAct = bSetAct;
+                d2.aux = aux, d2.setAux = setAux;
                 d2.wf1 = (const bf16x8*)n.wf1, d2.nfs = H1 / 32, d2.nft = critic ? KCp / 32 : H1 / 32;
-                d2.ZT = dZ2, d2.setZT = setP2, d2.ldz = H2, d2.inv = n.inv, d2.sh = n.sh, d2.db = cs, d2.setTab = ldT;
+                d2.ZT = critic ? dZ2 : P2, d2.setZT = setP2, d2.ldz = H2, d2.inv = n.inv, d2.setTab = ldT, d2.s2 = cs;
                 d2.dW = gnet + (critic ? L.cW2 : L.aW2), d2.setW = L.theta_size;
                 d2.Ns = Ns, d2.Np = Np, d2.H2 = H2, d2.K = K, d2.n_sets = sets, d2.nsplit = 8;
                 {   // row ranges per (set, column block): the split whose items fill whole rounds of an XCD's workgroups best
@@ -2365,6 +2502,11 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                     hipLaunchKernelGGL((fw::dw_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, d2);
                 else
                     hipLaunchKernelGGL((fw::dw_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, d2);
+                hipLaunchKernelGGL(w2_post_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, n.th, (long)L.theta_size,
+                                   critic ? L.cW2 : L.aW2, K, H2, n.sh, ldT, n.bias, n.cf, gnet, (long)L.theta_size, u, cs, (long)H2);
+                hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,
+                                   H2, n.inv + KCp, n.sh + KCp, n.rs + KCp, n.mean + KCp, ldT, u, cs, (long)H2, acc, acc_idx, gnet,
+                                   (long)L.theta_size, w3, b3, gg, gbe, gb2, 1);
                 return check_launch("avd_learn_shared_bf16: fused weight gradient");
             }
             // dW2 = inv (.) (C^T dZ2) + sh (x) db2: reduction over the rows, split into chunks with f32 atomics
@@ -2378,8 +2520,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     // dX GEMM with the BN/ReLU backward of the first layer(s) over columns [c_begin, c_end)
     auto dx = [&](const NetOps& n, int c_begin, int c_end, bool wg, bool critic) {
+        // (rank-one form: the dZ2 buffer holds the relu mask, Wn carries cf -- the row factor d completes the product)
         GemmP p = {dZ2, n.Wn + (long)c_begin * H2, H2, H2, setP2, setWn, Ns, c_end - c_begin, H2, 1};
-        EpiDx e = {C, dZ1, KCp, setC, n.inv, n.rs, n.mean, nullptr, nullptr, ldT, (long)sets * ldT, c_begin};
+        EpiDx e = {C, dZ1, KCp, setC, n.inv, n.rs, n.mean, nullptr, nullptr, ldT, (long)sets * ldT, c_begin, r1 ? F32(pl.dcl) : (const float*)nullptr, (long)Np};
         (void)critic;
         if (wg) {  // dgamma / dbeta of the first layers accumulate in sliced table-shaped scratch, summed by flush_bn1
             (void)hipMemsetAsync(ws + pl.bnacc, 0, sizeof(float) * 2 * NSLICE * sets * ldT, st);
@@ -2406,7 +2549,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         fw::DxP d3;
         d3.X = X, d3.setX = setX, d3.act = critic ? act : nullptr, d3.setAct = set_act;
         d3.wf1 = (const bf16x8*)n.wf1, d3.nfs = H1 / 32, d3.nft = critic ? KCp / 32 : H1 / 32;
-        d3.dZ = dZ2, d3.setDZ = setP2, d3.Wn = n.Wn, d3.setWn = setWn, d3.inv = n.inv, d3.rs = n.rs, d3.mean = n.mean, d3.setTab = ldT;
+        d3.dZ = critic ? dZ2 : P2, d3.setDZ = setP2, d3.d = F32(pl.dcl), d3.setD = Np;  // (the pass's relu mask and seed)
+        d3.Wn = n.Wn, d3.setWn = setWn, d3.inv = n.inv, d3.rs = n.rs, d3.mean = n.mean, d3.setTab = ldT;
         d3.g = gnet, d3.setG = L.theta_size;
         d3.w_off[0] = critic ? L.cWs : L.aW1, d3.b_off[0] = critic ? L.cbs : L.ab1, d3.g_off[0] = critic ? L.cgs : L.ag1, d3.be_off[0] = critic ? L.cbes : L.abe1;
         d3.w_off[1] = L.cWa, d3.b_off[1] = L.cba, d3.g_off[1] = L.cga, d3.be_off[1] = L.cbea;
@@ -2443,24 +2587,32 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     float* gcrit = grads + asz;
     WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
     rows(1, q, y, nullptr, 0.f, dq);
-    WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
-    if (fused_dx) {
-        WIDE_CHECK(dx_fused(net[1], true, gcrit, s, a, (long)Ns));
-        // the action branch (48 features): its activations, the small GEMM with the BN / ReLU epilogue, first-layer gradients
-        l1(net[1], true, true, a, (long)Ns, false);
-        WIDE_CHECK(dx(net[1], H1, KC, true, true));
-        l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
-        flush_bn1(true, gcrit, false);
-    } else {
-        WIDE_CHECK(dx(net[1], 0, KC, true, true));
-        l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
-        l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
-        flush_bn1(true, gcrit);
-    }
+    auto pass1_backward = [&]() {
+        WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
+        if (fused_dx) {
+            WIDE_CHECK(dx_fused(net[1], true, gcrit, s, a, (long)Ns));
+            // the action branch (48 features): its activations, the small GEMM with the BN / ReLU epilogue, first-layer gradients
+            l1(net[1], true, true, a, (long)Ns, false);
+            WIDE_CHECK(dx(net[1], H1, KC, true, true));
+            l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+            flush_bn1(true, gcrit, false);
+        } else {
+            WIDE_CHECK(dx(net[1], 0, KC, true, true));
+            l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);
+            l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+            flush_bn1(true, gcrit);
+        }
+        return AVD_OK;
+    };
+    // rank-one form: the forward half of pass 2 runs BEFORE the critic's backward pass (all gradients are taken at the same
+    // pre-update weights, trainer.py:492-506: the order is free) -- the delta kernel, which reads critic(s, a)'s signed activations
+    // anyway, leaves their relu mask for it. The critic's seed stays in `dq`; the seeds of passes 2 / 3 then go to `y` (free after rows(1)).
+    float* dq3 = r1 ? y : dq;
+    if (!r1) WIDE_CHECK(pass1_backward());
 
     // ---- pass 2: actor through the critic, gradient w.r.t. the action                       (trainer.py:502-506)
     use_actor_buffers(true);
-    WIDE_CHECK(actor_forward(net[0], s, true));  // activations and transposes stay for pass 3
+    WIDE_CHECK(actor_forward(net[0], s, true));  // activations (rank-one form: their relu mask) stay for pass 3
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
     if (!fused_delta) l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
@@ -2470,8 +2622,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         dl.Zin = P2, dl.setZ = setP2, dl.a = a, dl.mu = a1, dl.setA = Ns, dl.setMu = Np, dl.wf1 = (const bf16x8*)net[1].wf1, dl.nft = KCp / 32,
         dl.nfs = H1 / 32, dl.WT = net[1].WT, dl.setWT = setWT, dl.ldw = KCp, dl.cf = net[1].cf, dl.z = q, dl.setQ = Np;
         dl.dz_scale = -1.0f / (float)Ns, dl.rw = row_weight, dl.Ns = Ns, dl.Np = Np, dl.H2 = H2, dl.H1 = H1, dl.n_sets = sets;
-        dl.Wn = net[1].Wn, dl.setWn = setWn, dl.inv = net[1].inv, dl.setTab = ldT, dl.th = net[1].th, dl.setTh = L.theta_size, dl.wa_off = L.cWa, dl.Ha = Ha;
+        dl.Wn = net[1].Wn, dl.setWn = setWn, dl.cf_in_wn = r1 ? 1 : 0, dl.inv = net[1].inv, dl.setTab = ldT, dl.th = net[1].th, dl.setTh = L.theta_size, dl.wa_off = L.cWa, dl.Ha = Ha;
         dl.da = da, dl.setDa = Np;
+        dl.Mk = r1 ? dZ2 : nullptr;  // (critic(s, a)'s relu mask, for pass1_backward below)
         (void)hipMemsetAsync(da, 0, sizeof(float) * sets * Np, st);
         hipLaunchKernelGGL(fw::fwd_delta_kernel, dim3((unsigned)std::min<long>(2 * avd::fset::cu_count(), Np / fw::FR)), dim3(fw::FT),
                            (size_t)fw::DL_TOTAL, st, dl);
@@ -2481,19 +2634,20 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     else
         WIDE_CHECK(l2(net[1], true));
     out_layer(net[1], 0, q);
-    rows(2, q, nullptr, nullptr, 0.f, dq);
-    if (!fused_fwd) WIDE_CHECK(backward(net[1], true, dq, false, 0, nullptr));
+    rows(2, q, nullptr, nullptr, 0.f, dq3);
+    if (!fused_fwd) WIDE_CHECK(backward(net[1], true, dq3, false, 0, nullptr));
     if (!fused_delta) {
         WIDE_CHECK(dx(net[1], H1, KC, false, true));
         // da[n] = sum_k dZ1[n][H1 + k] * Wa[0][k]
         hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)rup(Ns, 4) / 4, sets), dim3(256), 0, st, dZ1, (long)KCp, setC, H1, Ha,
                            net[1].th + L.cWa, (long)L.theta_size, (const float*)nullptr, Ns, 0, 0.f, da, (float*)nullptr, (long)Np);
     }
+    if (r1) WIDE_CHECK(pass1_backward());
 
-    // ---- pass 3: actor gradient from the activations kept in pass 2
+    // ---- pass 3: actor gradient from the activations (rank-one form: the mask) kept in pass 2
     use_actor_buffers(true);
-    rows(3, nullptr, tt, da, high, dq);
-    WIDE_CHECK(backward(net[0], false, dq, true, 3, grads, s));
+    rows(3, nullptr, tt, da, high, dq3);
+    WIDE_CHECK(backward(net[0], false, dq3, true, 3, grads, s));
     if (fused_dx) {
         WIDE_CHECK(dx_fused(net[0], false, grads, s, nullptr, 0));
     } else {
@@ -2539,7 +2693,7 @@ extern "C" int avd_actor_forward_shared_bf16(const avd_mlp_layout* lay, int n_ag
     tables(L.ag1, L.abe1, L.amm1, L.amv1, H1, 0, KCp);
     tables(L.ag2, L.abe2, L.amm2, L.amv2, H2, KCp, H2);
     hipLaunchKernelGGL(prep_w2_kernel, dim3((unsigned)rup(H2, 32) / 32, (unsigned)rup(KCp, 32) / 32, sets), dim3(256), 0, st, theta,
-                       (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L, 0);
+                       (long)L.theta_size, L.aW2, H1, H2, KCp, inv, ldT, WT, setWT, (bf16*)nullptr, 0L, 0, (const float*)nullptr);
     hipLaunchKernelGGL(bias2_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, theta, (long)L.theta_size, L.aW2, L.ab2,
                        H1, H2, sh, ldT, bias, (long)H2);
     hipLaunchKernelGGL(out_coefs_kernel, dim3(sets), dim3(256), 0, st, theta, (long)L.theta_size, L.aW3, L.ab3, H2, inv + KCp, sh + KCp,
