@@ -1462,9 +1462,15 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(b + 8 * g * DW_ROWB + ct * 64));
+                // (inline asm, not __builtin_amdgcn_ds_read_tr16_b64: behind the builtin hipcc puts s_waitcnt vmcnt(0) -- it cannot tell
+                //  the read from the LDS-DMA writes in flight -- and the stream ran one chunk deep instead of three. The explicit
+                //  lgkmcnt(0) before the phase barrier covers these reads: their first use is behind it.)
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                u32x2_t t;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(b + 8 * g * DW_ROWB)), "i"(ct * 64));
+                const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[ct][4 * g + j] = t[j];
+                for (int j = 0; j < 4; ++j) a[ct][4 * g + j] = tb[j];
             }
     };
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -1668,13 +1674,20 @@ struct DxP {
 
 constexpr int DX_STG = 2 * 256 * FK * 2, DX_NS = 3;  // A tile + B tile; three stages (two chunks in flight)
 // raw inputs three tiles deep; the running sums of a wave's 128 features (7 per feature) live in LDS between tile epilogues
-// + the first-layer fragments of every wave's four feature tiles (per set: the epilogue read them from memory one after the other)
-constexpr int DXL_X = DX_NS * DX_STG, DXL_A = DXL_X + 3 * 256 * 16, DXL_S = DXL_A + 3 * 256 * 4, DXL_W = DXL_S + 8 * 28 * 32 * 4,
-              DXL_TOTAL = DXL_W + 2 * 4 * 64 * 16;
+// + the first-layer fragments of every wave's four feature tiles (per set: the epilogue read them from memory one after the other).
+// CRITIC (r06): a stage also carries 32 of the critic's 64 (padded) action features x 32 c (2 KiB), the raw buffers the actions.
+template <bool CRITIC>
+struct DxL {
+    static constexpr int STG = DX_STG + (CRITIC ? 32 * FK * 2 : 0);
+    static constexpr int X = DX_NS * STG, A = X + 3 * 256 * 16, ACT = A + 3 * 256 * 4, S = ACT + (CRITIC ? 3 * 256 * 4 : 0),
+                         W = S + 8 * 28 * 32 * 4, TOTAL = W + 2 * 4 * 64 * 16;
+};
 
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dx_gen_kernel(DxP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef DxL<CRITIC> LY;
+    constexpr int DXL_X = LY::X, DXL_A = LY::A, DXL_ACT = LY::ACT, DXL_S = LY::S, DXL_W = LY::W, STG_B = LY::STG;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int rq = wave & 3, fh = wave >> 2, grp = fh;  // 64-row quarter, 128-feature half = ping-pong group
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -1696,6 +1709,16 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int ra0 = ((64 * rq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, ra1 = ((64 * rq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
     const int rb0 = 256 * FK * 2 + ((128 * fh + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rb1 = 256 * FK * 2 + ((128 * fh + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
     const unsigned vo_a = (unsigned)(((lane >> 2) * p.H2 + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+    // CRITIC: the critic's 64 (48 + padding) action features ride along as ONE more MFMA per wave and step. A row group's four feature
+    // blocks x two feature halves are eight wave classes for the eight (action tile, 32-row tile, k-step) products of a 64-row quarter:
+    // class (fb, fh) takes action tile fb & 1, row tile fb >> 1 and k-step fh of EVERY chunk -- a partial product over half of c, which is
+    // all the epilogue needs: everything behind dy is linear in dy (the mask comes from the regenerated first layer), so the two
+    // partial sums of a (rows, feature) pair are folded independently and meet in the gradient slab. (Replaces, for H1 = 1024, the
+    // 64-column GEMM over the mask with its activation / gradient matrices: l1_fwd, gemm_bt<EpiDx>, l1_grads, bn1_flush: 0.93 ms.)
+    const int at = fb & 1, rtx = (fb >> 1) & 1;
+    const int rax = (fh ? ra1 : ra0) + rtx * 32 * FK * 2, rbx = 2 * 256 * FK * 2 + (r * FK + (((2 * fh + h) ^ sw) << 3)) * 2;
+    float asum[4] = {0.f, 0.f, 0.f, 0.f};  // the action tile's running sums S1, S2, S3, S4[0] (halves already added; lanes h == 0)
+    bf16x8 wfa;                            // its first-layer fragment
 
     // running sums per feature, halves already added: [wave][7 ft-major quantities x 4 ft][32 lanes] floats in LDS
     float* sums = (float*)(smem_raw + DXL_S) + wave * 28 * 32 + r;
@@ -1709,10 +1732,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool action = CRITIC && f0 >= p.H1;          // (H1 is a multiple of 128: a wave's features lie on one side)
     int set = t_begin / ntile;
     // per-set state: first-layer fragments (B operand of the regenerated first layer), stream bases
-    const char *ub_a = nullptr, *ub_b = nullptr;
+    const char *ub_a = nullptr, *ub_b = nullptr, *ub_x = nullptr;
     auto load_set = [&]() {
         ub_a = (const char*)(p.dZ + (long)set * p.setDZ + (long)(32 * wv) * p.H2);             // + row tile, chunk
         ub_b = (const char*)(p.Wn + (long)set * p.setWn + (long)(fb * 256 + 32 * wv) * p.H2);  // + chunk
+        if constexpr (CRITIC) {  // rows H1 + 32 at .. + 32 of Wn, 16 per instruction: waves 2..7 repeat waves 0 and 1 (uniform counts)
+            ub_x = (const char*)(p.Wn + (long)set * p.setWn + (long)(p.H1 + 32 * at + 16 * (wv & 1)) * p.H2);
+            wfa = p.wf1[((long)set * p.nft + p.nfs + at) * 64 + lane];
+        }
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {  // the four first-layer fragments of the wave's feature half (its four row quarters write the same bytes)
             const bf16 zb = (bf16)0.f;
@@ -1724,7 +1751,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     // chunk kc of row tile tl into stage stg: wave w fills image rows [32 w, 32 w + 32) of both tiles (2 + 2 instructions)
     auto dma = [&](int stg, int tl, int kc) {
-        unsigned char* l = smem_raw + stg * DX_STG;
+        unsigned char* l = smem_raw + stg * STG_B;
         unsigned vw = vo_a;
         asm volatile("" : "+v"(vw));
         const long ta = (long)tl * 256 * p.H2 * 2 + (long)kc * FK * 2;
@@ -1733,6 +1760,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_global_load_lds((gptr_t)(ub_a + ta + (long)i * 32 * p.H2 + vw), (lptr_t)(l + (32 * wv + 16 * i) * FK * 2), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(ub_b + (long)kc * FK * 2 + (long)i * 32 * p.H2 + vw), (lptr_t)(l + 256 * FK * 2 + (32 * wv + 16 * i) * FK * 2), 16, 0, 0);
         }
+        if constexpr (CRITIC)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub_x + (long)kc * FK * 2 + vw), (lptr_t)(l + 2 * 256 * FK * 2 + 16 * (wv & 1) * FK * 2), 16, 0, 0);
     };
     // raw inputs of row tile tl into buffer b: 64 rows per instruction, waves 4..7 repeat waves 0..3 (uniform counts)
     auto dma_x = [&](int tl, int b) {
@@ -1741,8 +1770,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + DXL_X + (b * 256 + 64 * (wv & 3)) * 16), 16, 0, 0);
         // (the seed comes unclamped: its padding rows hold zeros)
         __builtin_amdgcn_global_load_lds((gptr_t)(p.d + (long)set * p.setD + tl * 256 + 64 * (wv & 3) + lane), (lptr_t)(smem_raw + DXL_A + (b * 256 + 64 * (wv & 3)) * 4), 4, 0, 0);
+        if constexpr (CRITIC)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + DXL_ACT + (b * 256 + 64 * (wv & 3)) * 4), 4, 0, 0);
     };
-    constexpr int NDMA = 4;  // per chunk; the counted waits leave ONE chunk in flight (three stages)
+    constexpr int NDMA = CRITIC ? 5 : 4;  // per chunk; the counted waits leave ONE chunk in flight (three stages)
     // the sums of the finished set go to the gradient slab
     auto flush = [&]() {
 #pragma unroll
@@ -1761,6 +1792,19 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int sI = 0; sI < ns; ++sI) atomicAdd(g + p.w_off[br] + (long)sI * Hn + fl, iv * s4[sI]);
             }
         }
+        if constexpr (CRITIC) {
+            const int fl = 32 * at + r;
+            if (h == 0 && fl < p.Ha) {
+                const long tb = (long)set * p.setTab + p.H1 + fl;
+                const float iv = p.inv[tb], rsv = p.rs[tb], mv = p.mean[tb];
+                float* g = p.g + (long)set * p.setG;
+                atomicAdd(g + p.g_off[1] + fl, rsv * (asum[0] - mv * asum[1]));
+                atomicAdd(g + p.be_off[1] + fl, asum[1]);
+                atomicAdd(g + p.b_off[1] + fl, iv * asum[2]);
+                atomicAdd(g + p.w_off[1] + fl, iv * asum[3]);
+            }
+            asum[0] = asum[1] = asum[2] = asum[3] = 0.f;
+        }
         clear_sums();
     };
     load_set();
@@ -1774,7 +1818,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     int stg = 0, xb = 0;
-    f32x16 acc[2][4];
+    f32x16 acc[2][4], accx = zero16;
     for (int t = t_begin; t < t_end; ++t) {
         // The two groups run the K loop a phase apart and the tile epilogue level: group 1 drops a phase behind here and group 0
         // waits for it after the loop. (With the offset kept across tiles each group's epilogue ran beside the other's LAST or FIRST
@@ -1789,15 +1833,18 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) acc[rt][ft] = zero16;
+        if constexpr (CRITIC) accx = zero16;
         auto step = [&](int kt, auto wait_c, auto tail_c) {
             constexpr bool WAIT = decltype(wait_c)::value, TAIL = decltype(tail_c)::value;
             // ================= prepare(kt)
             bf16x8 A[2][2], B[2][4];
-            const unsigned char* l = smem_raw + stg * DX_STG;
+            const unsigned char* l = smem_raw + stg * STG_B;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) A[0][rt] = *(const bf16x8*)(l + ra0 + rt * 32 * FK * 2), A[1][rt] = *(const bf16x8*)(l + ra1 + rt * 32 * FK * 2);
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) B[0][ft] = *(const bf16x8*)(l + rb0 + ft * 32 * FK * 2), B[1][ft] = *(const bf16x8*)(l + rb1 + ft * 32 * FK * 2);
+            bf16x8 Ax, Bx;
+            if constexpr (CRITIC) Ax = *(const bf16x8*)(l + rax), Bx = *(const bf16x8*)(l + rbx);
             {   // refill: chunk kt + 3 of this tile, or the first chunks of the next tile (a new set only after the flush: see below)
                 const int kc = kt + DX_NS - 1, sd = (stg + DX_NS - 1) % DX_NS;
                 if (!TAIL)  // (the loop body proper carries no branch: the last two steps are peeled below)
@@ -1821,6 +1868,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) acc[rt][ft] = mfma(A[ks][rt], B[ks][ft], acc[rt][ft]);
+            if constexpr (CRITIC) accx = mfma(Ax, Bx, accx);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
@@ -1906,6 +1954,54 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int q = 0; q < 7; ++q) {
                 q7[q] += __shfl_xor(q7[q], 32);  // (the two halves hold different rows of the same feature; G: hi + lo products)
                 if (h == 0) sums[(7 * ft + q) * 32] += q7[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (CRITIC) {
+            // the wave's action tile: rows 64 rq + 32 rtx, features H1 + 32 at .. + 32, the partial dy over k-step fh of every chunk
+            const int rowb = 64 * rq + 32 * rtx;
+            auto raw_a = [&](int row) { return *(const float*)(smem_raw + DXL_ACT + (xb * 256 + row) * 4); };
+            bf16x8 xTa[2];  // lane m = 0: hi of the action, m = 4: lo, m = 8: ones (the state layout with one input)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16 zb = (bf16)0.f;
+                bf16x8 v = {zb, zb, zb, zb, zb, zb, zb, zb};
+                if (r == 0 || r == 4) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xs = raw_a(rowb + 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3));
+                        const bf16 hi = (bf16)xs;
+                        v[e] = r == 0 ? hi : (bf16)(xs - (float)hi);
+                    }
+                } else if (r == 8) {
+                    const bf16 ob = (bf16)1.f;
+                    v = (bf16x8){ob, ob, ob, ob, ob, ob, ob, ob};
+                }
+                xTa[ks] = v;
+            }
+            const f32x16 p1 = mfma(x_frag_action(raw_a(rowb + r), tl * 256 + rowb + r < p.Ns, h), wfa, zero16);
+            const float* dsc = (const float*)(smem_raw + DXL_A) + xb * 256 + rowb + 4 * h;
+            float md[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float dy = accx[i] * dsc[8 * (i >> 2) + (i & 3)];
+                md[i] = p1[i] > 0.f ? dy : 0.f;
+                s1 = fmaf(md[i], p1[i], s1);
+                s2 += dy;
+            }
+            f32x16 G = zero16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 mb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mb[e] = (bf16)md[8 * ks + e];
+                G = mfma(xTa[ks], mb, G);
+            }
+            float q4[4] = {s1, s2, G[4], G[0]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                q4[q] += __shfl_xor(q4[q], 32);
+                if (h == 0) asum[q] += q4[q];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2281,6 +2377,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     const bool r1 = fused_fwd && fused_delta && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
                     Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fd_env && fd_env[0] == '0') && !(fx_env && fx_env[0] == '0');
     const bool fused_dw = r1, fused_dx = r1;
+    static const char* fa_env = AVD_DIAG_ENV("WIDE_ACT_IN_DX");
+    const bool act_in_dx = fused_dx && H1 / 256 == 4 && Ha <= 64 && !(fa_env && fa_env[0] == '0');  // (fw::dx_gen_kernel<true>)
     constexpr size_t fw_lds = fw::L_TOTAL;
     if (fused_fwd) {
         // the > 64 KB dynamic-LDS opt-in, once per DEVICE of this process (the attribute belongs to the device's copy of the function)
@@ -2294,7 +2392,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             };
             opt_in((const void*)fw::fwd_gen_kernel<false>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true>, fw_lds);
-            opt_in((const void*)fw::dx_gen_kernel<false>, fw::DXL_TOTAL), opt_in((const void*)fw::fwd_delta_kernel, fw::DL_TOTAL);
+            opt_in((const void*)fw::dx_gen_kernel<false>, fw::DxL<false>::TOTAL), opt_in((const void*)fw::dx_gen_kernel<true>, fw::DxL<true>::TOTAL);
+            opt_in((const void*)fw::fwd_delta_kernel, fw::DL_TOTAL);
             if (e != hipSuccess) {
                 set_error("avd_learn_shared_bf16: hipFuncSetAttribute(dynamic LDS %zu B) on device %d: %s", fw_lds, dev, hipGetErrorString(e));
                 return AVD_E_LAUNCH;
@@ -2558,8 +2657,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         // one workgroup per CU, dealt round-robin over the 8 XCDs: slots per XCD = CUs / 8 (32 on MI355X), each row group = nfb slots
         const int slots = std::max(1, avd::fset::cu_count() / 8);
         d3.nfb = H1 / 256, d3.groups_per_xcd = std::max(1, slots / d3.nfb);  // (the state features; the critic's 48 action features go the GEMM way)
-        // (state features only: the <false> form -- no action inputs -- serves both nets)
-        hipLaunchKernelGGL((fw::dx_gen_kernel<false>), dim3((unsigned)(8 * d3.groups_per_xcd * d3.nfb)), dim3(fw::FT), (size_t)fw::DXL_TOTAL, st, d3);
+        // the <false> form serves the state features of both nets; the <true> form also carries the critic's action features (one more
+        // MFMA per wave and step, dealt over a row group's FOUR feature blocks: H1 = 1024) -- elsewhere they go the GEMM way
+        const dim3 grid((unsigned)(8 * d3.groups_per_xcd * d3.nfb));
+        if (critic && act_in_dx)
+            hipLaunchKernelGGL((fw::dx_gen_kernel<true>), grid, dim3(fw::FT), (size_t)fw::DxL<true>::TOTAL, st, d3);
+        else
+            hipLaunchKernelGGL((fw::dx_gen_kernel<false>), grid, dim3(fw::FT), (size_t)fw::DxL<false>::TOTAL, st, d3);
         return check_launch("avd_learn_shared_bf16: fused input gradient");
     };
     auto flush_bn1 = [&](bool critic, float* gnet, bool state_part = true) {
@@ -2591,11 +2695,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
         if (fused_dx) {
             WIDE_CHECK(dx_fused(net[1], true, gcrit, s, a, (long)Ns));
-            // the action branch (48 features): its activations, the small GEMM with the BN / ReLU epilogue, first-layer gradients
-            l1(net[1], true, true, a, (long)Ns, false);
-            WIDE_CHECK(dx(net[1], H1, KC, true, true));
-            l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
-            flush_bn1(true, gcrit, false);
+            if (!act_in_dx) {
+                // the action branch (48 features): its activations, the small GEMM with the BN / ReLU epilogue, first-layer gradients
+                l1(net[1], true, true, a, (long)Ns, false);
+                WIDE_CHECK(dx(net[1], H1, KC, true, true));
+                l1_grads(a, (long)Ns, 1, H1, Ha, gcrit, L.cWa, L.cba);
+                flush_bn1(true, gcrit, false);
+            }
         } else {
             WIDE_CHECK(dx(net[1], 0, KC, true, true));
             l1_grads(s, setX, L.S, 0, H1, gcrit, L.cWs, L.cbs);

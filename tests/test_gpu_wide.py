@@ -256,9 +256,11 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     """csrc/wide.hip, fw::fwd_gen_kernel (first layer generated on the matrix cores as the GEMM operand, W2 streamed through
     LDS, output layer in the kernel, the mu pass's dZ2 written by the forward kernel) and fw::dw_gen_kernel (the weight gradient
     in the same style) against the layer-wise l1_fwd + GEMM + bias + out_bwd kernels they replace (AVD_WIDE_FUSED_FWD=0),
-    the whole learn chain on the same inputs in two processes (the switch is read once per process). The two differ by the
-    first layer's rounding before its bf16 cast (2^-16 against exact f32) and by summation order: 3e-3 of each block's max,
-    where the bf16 operands themselves cost 8e-2 against the float64 oracle."""
+    the whole learn chain on the same inputs in two processes (the switch is read once per process). Since r06 the fused backward
+    is the rank-one form (dZ2 = d (x) cf (.) mask never materialised: the operands are the exact mask and bf16(d y1), bf16(cf W2),
+    where the layer-wise path rounds bf16(d cf) and bf16(y1) separately): independent 2^-9 roundings per term of a 768-row sum,
+    measured 4.3e-3 of a block's max in the weighted case -- 6e-3 allowed, where the bf16 operands themselves cost 8e-2 against the
+    float64 oracle (tests above and tests/test_gpu_configs_full.py hold BOTH paths to the oracle)."""
     import os
     import subprocess
     import sys
@@ -282,7 +284,7 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     gf, gl = fused[:n].reshape(2, -1), layerwise[:n].reshape(2, -1)
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = np.abs(gl[:, lo:hi]).max()
-        assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 3e-3 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
+        assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 6e-3 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
     assert np.allclose(fused[n:], layerwise[n:], rtol=2e-3, atol=1e-6)
 
 
@@ -291,7 +293,9 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
     stored, the action gradient from the same kernel (the dZ2 tile as the next product's operand) -- against the full fused forward
     pass + the input-gradient GEMM of the action columns + the row dot it replaces (AVD_WIDE_FUSED_DELTA=0), same inputs, two
     processes. Only the actor gradient and the two losses depend on the pass (`workers/trainer.py:502-506`); the stored
-    activations cost one more bf16 rounding of z2(a) before the delta is added: 3e-3 of the block's max as for the forward pair."""
+    activations cost one more bf16 rounding of z2(a) before the delta is added. Since r06 switching the delta pass off also switches
+    the rank-one backward off (the delta pass leaves critic(s, a)'s relu mask for it), so the pair differs like the forward pair
+    above: 6e-3 of a block's max (measured 4.3e-3)."""
     import os
     import subprocess
     import sys
@@ -316,5 +320,5 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
     assert np.abs(gd[:, :lay.actor_size] - gf[:, :lay.actor_size]).max() > 0  # (the switch did switch)
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = np.abs(gf[:, lo:hi]).max()
-        assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 3e-3 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
+        assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 6e-3 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
     assert np.allclose(delta[n:], full[n:], rtol=2e-3, atol=1e-6)
