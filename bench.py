@@ -13,6 +13,11 @@ Launch: python bench.py --gpus N --steps K --warmup W. N > 1: one rank per GPU, 
 (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when WORLD_SIZE is not set, started BY this script as N child
 processes before anything touches the GPU (the parent only waits and never imports torch). Rank 0 prints ONE JSON line.
 
+On one GPU, without flags that select a workload, the same run then also times the other single-GPU BASELINE configs --
+configs[2] (4096 x 10, interfrl and nofrl at replay capacity 100000) and configs[4] (hidden 1024, bf16 batched engine) -- each
+with its own prewarm, warm-up and timed region of the same --steps (capped at 300), under also_measured.{config3_interfrl,
+config3_nofrl, config5}; `value` stays configs[1] interfrl (--no-extra-configs skips them).
+
 Without --mode the line carries BOTH workloads of the 4096 x 5 shape, measured one after the other in the same run:
 the primary one (PRIMARY_MODE) as `value`, the other under `also_measured`:
   * nofrl    -- the reference's default `fed_method` (src/config.py:25): 20480 independent agents, HBM-bound, no
@@ -88,6 +93,9 @@ def parse():
                          "a chip coming out of idle (trainer construction, ring fill) runs its first ~0.5 s 3-5 %% slow (clocks and power "
                          "state), so a short run -- --steps 20 --warmup 5 is 55 ms -- would time the ramp, not the workload; the line "
                          "records what was added (prewarm)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="default 1-GPU run: do not also time BASELINE configs[2] (4096 x 10) and configs[4] (hidden 1024) after the two "
+                         "4096 x 5 workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time N independent single-thread copies of the CPU loop on all host cores (side figure, opt-in)")
@@ -179,6 +187,12 @@ def cpu_baseline_all_cores(seconds, pl_size, max_workers=None, mode="nofrl"):
 # (csrc/fsplit.hip, 1e-4 of max against the float64 oracle like the f32 kernels). nofrl = the reference's default
 # `fed_method` (one independent weight / Adam set per agent): HBM-bound at 2.47 MB per agent-update, the r01/r02 headline.
 PRIMARY_MODE = "interfrl"
+# what the plain 1-GPU default run measures besides the two 4096 x 5 workloads (keys of also_measured; tests/test_abi_cpu.py)
+EXTRA_CONFIGS = {
+    "config3_interfrl": "BASELINE configs[2]: 4096 platoons x 10 vehicles, 1x MI355X -- interfrl, split engine",
+    "config3_nofrl": "BASELINE configs[2]: 4096 platoons x 10 vehicles, 1x MI355X -- nofrl (the reference's default fed_method)",
+    "config5": "BASELINE configs[4]: 4096 platoons, actor/critic hidden = 1024, bf16, 1x MI355X -- interfrl, batched engine",
+}
 
 
 def env_overrides():
@@ -352,7 +366,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     elapsed, stage_ms = timed_run(args.warmup, args.steps)
     # N > 1, split engine: time the OTHER collective form too (same trainer, same state), so that one multi-GPU run shows what the
     # overlap hides: forms.single = one all-reduce of the whole slab between learn and Adam; forms.overlapped = critic block on a side
-    # stream under the actor phase + actor block on the main stream. `value` is the form the trainer chose (overlapped on RCCL).
+    # stream under the actor phase + actor block on the main stream. `value` is the form the trainer runs: the single collective
+    # unless --overlap (on a one-rank RCCL communicator the overlapped form measured slower).
     forms = None
     if (world > 1 or group is not None) and mode == "interfrl" and split3 and not args.no_collective_ab:
         chosen = "overlapped" if vt.overlap_allreduce else "single"
@@ -418,9 +433,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
                                  "matrix work is 2.2x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
-                                 ("avd_learn_shared_bf16 (wide.hip, hidden >= 512: fwd_gen x4, fwd_delta, out_bwd x2, dw_gen x2, dx_gen x2 + "
-                                  "row / table kernels; FLOPs priced = the chain's algorithmic GEMMs, forward x5 incl. the pass the delta kernel "
-                                  "replaces)" if lay.H2 >= 512 else "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)")), "bound": "mfma",
+                                 ("avd_learn_shared_bf16 (wide.hip, hidden >= 512, rank-one backward: fwd_gen x4, fwd_delta, aux_pack x2, dw_gen x2, "
+                                  "w2_post x2, dx_gen x2 + row / table kernels; FLOPs priced = the chain's algorithmic GEMMs, forward x5 incl. the pass "
+                                  "the delta kernel replaces)" if lay.H2 >= 512 else "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)")), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})
     else:
@@ -436,7 +451,7 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
     # kernel of the same pass: tools/pmc_traffic.py; measured factors 2.000 / 1.000). One file per (workload, L, hidden); a line whose
     # shape has no committed pass carries traffic = null.
     def pmc(name):
-        for rnd in ("r05", "r04"):
+        for rnd in ("r06", "r05", "r04"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
             if os.path.exists(path):
                 return json.load(open(path)), f"profiles/{rnd}_{name}"
@@ -518,9 +533,10 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         ratio = executed / (flop_per_sample * 64 * n_agents)
         split_extra = {"executed_mfma_32x32x16_per_learn": cnt.value, "executed_over_algorithmic": ratio,
                        "executed_frac": ratio * dominant["frac"],
-                       "power": "the chain runs at the 1400 W package cap (rocm-smi 1398-1399 W at ~2.16 GHz, in-kernel clock 1.8-1.9 GHz); "
-                                "dense fp16 MFMA holds 2.3 PFLOP/s under that cap with one operand static, 1.30-1.35 PFLOP/s with both "
-                                "operands fresh from LDS on every MFMA, ~1.35 with the heads' VALU + LDS mix in either MFMA shape "
+                       "power": "the chain is paced by the clock governor, not by idle cycles: rocm-smi during 2500 back-to-back learns reads "
+                                "2.10-2.12 GHz at 1.34-1.36 kW on one box (below the 1400 W cap; an r04 box sat at 1398-1399 W), and a build whose dx "
+                                "idles less is clocked 4.4 % lower (profiles/r05_power_clock_ab_product_vs_two_tile_dx.txt); dense fp16 MFMA holds "
+                                "2.3 PFLOP/s with one operand static, 1.30-1.35 PFLOP/s with both operands fresh from LDS on every MFMA "
                                 "(profiles/r03_power_*.txt, r04_mfma_shape_probe.txt)"}
     rccl = mode == "interfrl" and (world > 1 or group is not None)
 
@@ -692,6 +708,36 @@ def main():
     if os.environ.get("AVD_BENCH_ORDER") == "rev":
         results = results[::-1]
 
+    # The other single-GPU BASELINE configs under the same clock: configs[2] = 4096 x 10 (interfrl with the split
+    # engine + the reference's default nofrl, replay capacity 100000) and configs[4] = hidden 1024 (bf16 batched engine), each with its
+    # own trainer, prewarm, warm-up and timed region; only in the plain default run on one GPU (no --mode / --hidden / --engine /
+    # shape flags), after the two 4096 x 5 workloads have been freed.
+    extras = {}
+    default_run = (world == 1 and group is None and not args.mode and not args.hidden and not args.engine and not args.no_secondary
+                   and args.framework == "decentralized" and args.platoons == 4096 and args.pl_size == 5 and args.chunks == 1
+                   and not args.no_fused and not args.no_extra_configs)
+    if default_run:
+        import gc
+        del trainers
+        gc.collect()
+        torch.cuda.empty_cache()
+        sub = lambda **kw: argparse.Namespace(**{**vars(args), "steps": min(args.steps, 300), "warmup": min(args.warmup, 50), **kw})
+        a3 = sub(pl_size=10)
+        t_nofrl = build_trainer(a3, "nofrl", None, rank, None)  # (per-agent slabs + the 164 GB ring first, on a clean heap)
+        t_inter = build_trainer(a3, "interfrl", "fused3", rank, None, ring=t_nofrl.replay.ring)
+        extras["config3_interfrl"] = run_workload(a3, "interfrl", "fused3", rank, world, None, vt=t_inter)
+        del t_inter
+        extras["config3_nofrl"] = run_workload(a3, "nofrl", None, rank, world, None, vt=t_nofrl)
+        del t_nofrl
+        gc.collect()
+        torch.cuda.empty_cache()
+        a5 = sub(hidden=1024)
+        extras["config5"] = run_workload(a5, "interfrl", None, rank, world, None)
+        assert set(extras) == set(EXTRA_CONFIGS)
+        for k, name in EXTRA_CONFIGS.items():
+            extras[k]["config"]["baseline_config"] = name
+            extras[k]["steps"], extras[k]["warmup"] = a3.steps, a3.warmup
+
     if rank == 0:
         first = results[0]
         out = {"metric": "env-steps/sec + DDPG updates/sec, 4096x5-vehicle platoons", "value": first["value"],
@@ -707,6 +753,10 @@ def main():
                                                                           "config", "roofline", "stages_ms", "pipeline")
                                                           + (("rccl_ranks", "collective_backend", "collective") if "rccl_ranks" in r else ())}
                                     for r in results[1:]}
+        if extras:
+            out.setdefault("also_measured", {}).update(
+                {k: {f: r[f] for f in ("value", "unit", "updates_per_s", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline",
+                                       "stages_ms", "prewarm", "pipeline")} for k, r in extras.items()})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.pl_size, first["config"]["mode"])
             if args.cpu_all_cores:  # the whole host beside the reference's own 1-thread setting (opt-in side figure)

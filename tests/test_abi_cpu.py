@@ -227,3 +227,25 @@ def test_learn_update_plan_describes_the_centralized_pipeline_and_single_launch_
     assert (ch.value, n.value, g.value) == (20480, 1, 0)
     with pytest.raises(_hip.AvdError):
         _hip.call("avd_learn_update_plan", C.byref(dec), 0, C.byref(ch), C.byref(n), C.byref(g))
+
+
+def test_bench_default_run_declares_every_single_gpu_baseline_config():
+    """bench.py's plain 1-GPU run must carry BASELINE configs[2] (both federated modes) and configs[4] beside the two configs[1]
+    workloads: the keys of also_measured are a module constant, each naming the BASELINE.json entry it measures,
+    and the run that emits them is the flag-less one (tests/test_gpu_bench_ranks.py runs it on the GPU). No GPU, no torch here."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.EXTRA_CONFIGS) == {"config3_interfrl", "config3_nofrl", "config5"}
+    configs = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    assert "4096 platoons × 10 vehicles" in configs[2] and "hidden=1024" in configs[4]
+    assert all("configs[2]" in bench.EXTRA_CONFIGS[k] and "10 vehicles" in bench.EXTRA_CONFIGS[k] for k in ("config3_interfrl", "config3_nofrl"))
+    assert "configs[4]" in bench.EXTRA_CONFIGS["config5"] and "1024" in bench.EXTRA_CONFIGS["config5"]
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "default_run" in src and "--no-extra-configs" in src and 'out.setdefault("also_measured", {}).update(' in src
+    assert bench.PRIMARY_MODE == "interfrl"
