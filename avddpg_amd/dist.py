@@ -7,7 +7,9 @@ followers), so platoons are sharded contiguously over ranks, one process per GPU
                          [M, theta_size] float32 (+ [M] weight sums when weighted), i.e. the cross-platoon
                          mean of reference src/server/federated.py:47-63 / :99-118 with the list-of-platoons
                          axis spread over ranks;
-  * parity mode       -- a 1-int all-reduce(max) of the any-terminal flag (workers/trainer.py:268-269).
+  * any-terminal rule -- the reference ends the episode of ALL platoons when any platoon is terminal (workers/trainer.py:268-269):
+                         in the throughput mode the rank's flag rides in the gradient all-reduce (exchange_set_slab), in parity mode
+                         (host episode loop) and on steps without an exchange it is a 1-int all-reduce(max).
 These helpers contain no device code: they work on CUDA tensors over RCCL ("nccl" backend) and on CPU
 tensors over gloo (tests/test_dist_cpu.py)."""
 import torch
@@ -53,7 +55,50 @@ def exchange_fed_sums(out_sum, wsum, n_local, group, total=None):
     return total_platoons(n_local, group, out_sum.device) if total is None else float(total)
 
 
-def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, actor_phase, timers=None):
+def set_exchange_buffer(M, theta_size, device):
+    """The flat float32 buffer the shared-set learners' gradients are exchanged in: [M * theta] slab | 1 any-terminal flag |
+    [M] weight sums -- one allocation for the life of the trainer (the slab view is what the learn call writes), so a federated
+    step neither allocates nor copies the slab. Returns (buffer, slab view [M, theta])."""
+    buf = torch.zeros(M * theta_size + 1 + M, dtype=torch.float32, device=device)
+    return buf, buf[:M * theta_size].view(M, theta_size)
+
+
+def exchange_set_slab(buf, M, theta_size, wsum, n_local, total, group, flag=None, equal_shards=False):
+    """The ONE collective of an interfrl step with shared weight sets (workers/trainer.py:400-431 over platoon shards): all-reduce(sum)
+    of `buf` from set_exchange_buffer(), whose slab holds this rank's MEAN gradient per set (what the set learners write).
+      * unweighted, every rank holding the same number of platoons (`equal_shards`): the means are summed and scaled by
+        n_local / total = 1 / ranks afterwards -- one elementwise launch; otherwise local mean x n_local -> sum -> / total;
+      * weighted (`wsum` [M] = this rank's sum of weights per set, src/server/federated.py:99-118): local weighted mean x wsum,
+        the [M] sums in the same buffer, divided by the reduced sums afterwards (`wsum` receives them);
+      * `flag` (int32[1], this rank's any-terminal flag of the step): rides in the same buffer; afterwards it is non-zero on EVERY
+        rank if any rank's was -- the reference ends the episode of ALL platoons when any platoon is terminal
+        (workers/trainer.py:268-269), and the conditional reset of the throughput mode reads this flag on the device. No extra
+        collective, no host synchronisation.
+    Works on CUDA tensors over RCCL and on CPU tensors over gloo."""
+    import torch.distributed as dist
+
+    n = M * theta_size
+    g = buf[:n].view(M, theta_size)
+    if flag is not None:
+        buf[n:n + 1].copy_(flag)
+    else:
+        buf[n:n + 1].zero_()
+    if wsum is None:
+        if not equal_shards:
+            g.mul_(float(n_local))
+        dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=group)
+        g.mul_(float(n_local) / float(total) if equal_shards else 1.0 / float(total))
+    else:
+        g.mul_(wsum.view(M, 1))
+        buf[n + 1:n + 1 + M].copy_(wsum)
+        dist.all_reduce(buf[:n + 1 + M], op=dist.ReduceOp.SUM, group=group)
+        wsum.copy_(buf[n + 1:n + 1 + M])
+        g.div_(wsum.view(M, 1))
+    if flag is not None:
+        flag.copy_(buf[n:n + 1] > 0)
+
+
+def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, actor_phase, timers=None, flag=None):
     """The interfrl exchange of a learn call that runs in two phases (avd_learn_set_split_critic / _actor): the CRITIC block
     set_grads[:, actor_size:] is final when this is called and is all-reduced (as the local sum: x `scale`) while
     ``actor_phase()`` -- which must leave the actor block set_grads[:, :actor_size] final -- computes; the actor block (with the
@@ -66,7 +111,8 @@ def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, a
     one communicator must be issued in the same order everywhere); waited for in that order too. On CUDA tensors the critic
     block's scaling and collective are queued on bufs["stream"] (a side stream) behind bufs["ready"], so they run under the
     actor phase on the caller's stream; on CPU tensors (gloo tests) the same calls run without streams.
-    bufs: dict(crit=[M, T - A] buffer, act=flat [M * A + M] buffer[, stream, ready])."""
+    bufs: dict(crit=[M, T - A] buffer, act=flat [M * A + M + 1] buffer[, stream, ready]). `flag` (int32[1]): this rank's any-terminal
+    flag rides behind the actor block (and the weight sums) and comes back non-zero everywhere if any rank's was (exchange_set_slab)."""
     import torch.distributed as dist
 
     M, A = set_grads.shape[0], actor_size
@@ -95,6 +141,9 @@ def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, a
     if wsum is not None:
         actbuf[M * A:M * A + M].copy_(wsum)
     n = M * A + (M if wsum is not None else 0)
+    if flag is not None:
+        actbuf[n:n + 1].copy_(flag)
+        n += 1
     if ev:
         ev[2].record()
     work_a = dist.all_reduce(actbuf[:n], op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -114,6 +163,8 @@ def exchange_two_phase(set_grads, actor_size, scale, wsum, total, group, bufs, a
     div = float(total) if wsum is None else actbuf[M * A:M * A + M].view(M, 1)
     set_grads[:, A:].copy_(crit.div_(div))
     set_grads[:, :A].copy_(act.div_(div))
+    if flag is not None:
+        flag.copy_(actbuf[n - 1:n] > 0)
 
 
 def broadcast_agents(agents, group, src=0):

@@ -176,6 +176,15 @@ class VecTrainer:
         if self.overlap_allreduce and not can_overlap:
             raise ValueError("overlap_allreduce needs a process group and shared_engine='fused3' (the two-phase learn call)")
         self._side = None  # side stream + buffers of the overlapped exchange, made on first use
+        # the exchange buffer of the shared-set learners ([M, theta] slab | flag | [M] weight sums: dist.set_exchange_buffer) and whether
+        # this step's any-terminal flag has already travelled with it
+        self._xbuf = None
+        self._flag_exchanged = False
+        ws = 1
+        if group is not None:
+            import torch.distributed as _td
+            ws = _td.get_world_size(group)
+        self._equal_shards = abs(self.total_platoons - self.P * ws) < 0.5
         self._step_parity = 0
         self._added = False
         self.fused_update = bool(fused_update)  # nofrl (any framework / widths the learn kernels serve): avd_learn_update_f32
@@ -347,15 +356,20 @@ class VecTrainer:
         P, M, B = self.P, self.M, self.conf.batch_size
         sm = lambda x: x.view(P, M, *x.shape[1:]).transpose(0, 1).reshape(M, P * B, *x.shape[2:]).contiguous()
         if getattr(self, "set_grads", None) is None:
-            self.set_grads = torch.empty(M, self.agents.lay.theta_size, dtype=torch.float32, device=self.device)
+            from .dist import set_exchange_buffer
+            self._xbuf, self.set_grads = set_exchange_buffer(M, self.agents.lay.theta_size, self.device)
             self.set_losses = torch.zeros(M, 2, dtype=torch.float32, device=self.device)
+        # the reference's any-terminal rule across ranks (workers/trainer.py:268-269): with device-side episodes the rank's flag of
+        # this step travels in the gradient exchange and comes back as the global one, which the conditional reset then reads
+        carry = self.env.any_done if (self.group is not None and self.auto_reset is True) else None
         rw = wsum = None
         if weights is not None:  # [P, M] -> factors w_p * P / sum_p w_p (federated.py:99-118)
             wsum = weights.sum(dim=0)  # [M]
         if self.shared_engine in ("fused", "fused3"):  # agent-major batches as sampled, one factor per agent
             aw = None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous()
             if self.overlap_allreduce:
-                self._learn_split_overlapped(s, a, r, s2, aw, wsum)
+                self._learn_split_overlapped(s, a, r, s2, aw, wsum, carry)
+                self._flag_exchanged = carry is not None
                 return
             self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw,
                                         split=self.shared_engine == "fused3")
@@ -365,13 +379,14 @@ class VecTrainer:
             self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses,
                                      row_weight=rw)
         if self.group is not None:
-            from .dist import exchange_fed_sums
-            # local (weighted) mean -> local (weighted) sum over platoons, all-reduce, divide by the global count / weight
-            self.set_grads.mul_(float(P) if wsum is None else wsum.view(M, 1))
-            total = self._timed("allreduce", exchange_fed_sums, self.set_grads, wsum, P, self.group, total=self.total_platoons)
-            self.set_grads.div_(total if wsum is None else wsum.view(M, 1))
+            from .dist import exchange_set_slab
+            # ONE all-reduce(sum) of [slab | flag | weight sums]; local (weighted) mean <-> sum scaling around it (one launch after it
+            # when every rank holds the same number of platoons)
+            self._timed("allreduce", exchange_set_slab, self._xbuf, M, self.agents.lay.theta_size, wsum, P, self.total_platoons,
+                        self.group, flag=carry, equal_shards=self._equal_shards)
+            self._flag_exchanged = carry is not None
 
-    def _learn_split_overlapped(self, s, a, r, s2, aw, wsum):
+    def _learn_split_overlapped(self, s, a, r, s2, aw, wsum, flag=None):
         """The split-operand learner in its two phases (avd_learn_set_split_critic / _actor) with the exchange of the critic block
         overlapped: as soon as the critic phase has written its block of the [M, theta] slab, a side stream turns it into the
         local sum and all-reduces it while the actor phase -- a third of the learn call -- still computes on the main stream; the
@@ -387,13 +402,13 @@ class VecTrainer:
         if self._side is None:
             f32 = dict(dtype=torch.float32, device=self.device)
             self._side = dict(stream=torch.cuda.Stream(device=self.device), ready=torch.cuda.Event(),
-                              crit=torch.empty(M, T - A, **f32), act=torch.empty(M * A + M, **f32))
+                              crit=torch.empty(M, T - A, **f32), act=torch.empty(M * A + M + 1, **f32))
         scale = float(P) if wsum is None else wsum.view(M, 1)
         learn = lambda phase: self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses,
                                                           agent_weight=aw, split=True, phase=phase)
         learn("critic")
         exchange_two_phase(self.set_grads, A, scale, wsum, self.total_platoons, self.group, self._side,
-                           lambda: learn("actor"), timers=self.timers)
+                           lambda: learn("actor"), timers=self.timers, flag=flag)
 
     def _update(self, ep, i, fed):
         conf, P, M = self.conf, self.P, self.M
@@ -451,10 +466,16 @@ class VecTrainer:
         when ``sync`` (parity mode); with auto_reset the episode bookkeeping stays on the device."""
         ep = self.episode if ep is None else ep
         i = self.ep_step if i is None else i
+        self._flag_exchanged = False
         self._timed("act+env", self._act)
         self._train(ep, i)
         self.env_steps += self.P
         self.ep_step += 1
+        if self.group is not None and self.auto_reset is True and not self._flag_exchanged:
+            # a step whose flag did not travel with a gradient exchange (the replay gate is still closed, or an engine without the
+            # slab exchange): its own 1-int all-reduce(max), still without a host synchronisation
+            import torch.distributed as _td
+            _td.all_reduce(self.env.any_done, op=_td.ReduceOp.MAX, group=self.group)
         if self.auto_reset == "platoon":
             # per-platoon episodes: no global episode counter; the schedule predicates see episode 0 and the running step
             self.env.episode_end(self.ep_reward, self.M, self.conf.steps_per_episode, any_reset=self.env.any_done)

@@ -243,3 +243,65 @@ def test_two_phase_exchange_issues_its_collectives_in_the_same_order_on_every_ra
         assert crit_before_actor  # the critic block's collective is in flight before the actor phase starts
         assert same_bits
     assert np.array_equal(res[0][4], res[1][4])  # every rank ends with the identical average
+
+
+def _slab_worker(rank, world, port, P_total, M, T, weighted, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(5)
+        g = rs.normal(size=(P_total, M, T)).astype(np.float32)
+        w = rs.uniform(0.5, 6.0, size=(P_total, M)).astype(np.float32)
+        lo, hi = adist.shard_platoons(P_total, world, rank)
+        gl, wl = g[lo:hi], w[lo:hi]
+        total = adist.total_platoons(hi - lo, dist.group.WORLD)
+        equal = abs(total - (hi - lo) * world) < 0.5
+        buf, slab = adist.set_exchange_buffer(M, T, "cpu")
+        assert slab.data_ptr() == buf.data_ptr() and buf.numel() == M * T + 1 + M
+        out = []
+        for step in range(3):  # the flag is this rank's any-terminal flag of the step: held by rank 1 only, at step 1 only
+            if weighted:  # what the set learners leave: the LOCAL weighted mean per set
+                ws = torch.from_numpy(wl.sum(axis=0, dtype=np.float32))
+                slab.copy_(torch.from_numpy((gl * wl[..., None]).sum(axis=0, dtype=np.float32)) / ws[:, None])
+            else:
+                ws = None
+                slab.copy_(torch.from_numpy(gl.mean(axis=0, dtype=np.float32)))
+            flag = torch.tensor([1 if (rank == 1 and step == 1) else 0], dtype=torch.int32)
+            adist.exchange_set_slab(buf, M, T, ws, hi - lo, total, dist.group.WORLD, flag=flag, equal_shards=equal)
+            out.append((int(flag.item()), slab.clone().numpy(), None if ws is None else ws.numpy()))
+        q.put((rank, equal, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("weighted,P_total", [(False, 8), (False, 7), (True, 7)])
+def test_set_slab_exchange_carries_the_any_terminal_flag_to_every_rank(weighted, P_total):
+    """the reference ends the episode of ALL platoons when any platoon is terminal (workers/trainer.py:268-269). In
+    the throughput mode the rank's flag rides in the ONE gradient all-reduce of the step (dist.exchange_set_slab: slab | flag |
+    weight sums) and comes back non-zero on every rank -- here only rank 1 holds a terminal platoon, at step 1 only, and BOTH ranks
+    see the flag at that step and at no other; the slab comes back as the (weighted) mean over all platoons (equal shards: one
+    scaling after the collective; unequal: mean -> sum -> mean), identical bits on both ranks."""
+    world, M, T = 2, 3, 257
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, P_total, M, T, weighted, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(5)
+    g = rs.normal(size=(P_total, M, T)).astype(np.float32)
+    w = rs.uniform(0.5, 6.0, size=(P_total, M)).astype(np.float32)
+    ref = ((g * w[..., None]).sum(axis=0) / w.sum(axis=0)[:, None]) if weighted else g.mean(axis=0)
+    for rank, equal, out in res:
+        assert equal == (P_total % world == 0)
+        assert [f for f, _, _ in out] == [0, 1, 0]  # both ranks end the episode at step 1 -- and only there
+        for _, slab, ws in out:
+            assert np.allclose(slab, ref, rtol=1e-5, atol=1e-6)
+            assert ws is None or np.allclose(ws, w.sum(axis=0), rtol=1e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a[1], b[1])  # identical bits on both ranks: the weight sets stay bit-identical

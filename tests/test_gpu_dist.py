@@ -284,3 +284,63 @@ def test_interfrl_over_a_one_rank_rccl_communicator_equals_the_groupless_run(ove
         assert np.abs(x_g - x_0).max() <= 1e-3 and np.abs(th_g - th_0).max() <= 5e-4
     else:
         assert np.array_equal(x_g, x_0) and np.array_equal(th_g, th_0)
+
+
+def _flag_worker(rank, world, port, q, engine):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from avddpg_amd import config, trainer
+
+        conf = config.Config(num_platoons=6, pl_size=3, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False)
+        vt = trainer.VecTrainer(conf, rng="device", group=dist.group.WORLD, auto_reset=True, seed=1 + rank, shared_engine=engine)
+        twin = trainer.VecTrainer(conf, rng="device", group=None, auto_reset=True, seed=1 + rank, shared_engine=engine)  # the same rank alone
+        vt.reset_episode(), twin.reset_episode()
+        flags, same = [], []
+        for i in range(76):
+            if rank == 1 and i in (10, 70):  # a terminal platoon on rank 1 ONLY: gap error far outside the limits (environment.py:505-509)
+                vt.env.x[2, 1, 0] = 25.0
+            vt.step()
+            flags.append(int(vt.env.any_done.item()))
+            if i < 14:  # before the replay gate opens nothing is learnt: the twin lives the same life until a reset parts them
+                twin.step()
+                same.append(bool(torch.equal(twin.env.x, vt.env.x)))
+        torch.cuda.synchronize()
+        q.put((rank, flags, same, int(vt.agents.step[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("engine", ["fused3", "per_agent"])
+def test_a_terminal_platoon_on_one_rank_ends_the_episode_on_every_rank(engine):
+    """VERDICT r05 #3 at trainer level: `VecTrainer(auto_reset=True)` over two ranks keeps the reference's episode rule -- any terminal
+    platoon ends the episode of ALL platoons (workers/trainer.py:268-269), on every rank. Only rank 1 is given a terminal platoon,
+    at step 10 (replay gate still closed: the flag's own 1-int all-reduce) and at step 70 (the flag rides in the gradient exchange of
+    the split engine: dist.exchange_set_slab; per_agent engine: its own all-reduce). Both ranks hold the same flag at every step, set
+    at those two, and rank 0 -- which has no terminal platoon of its own -- is reset there: until step 10 it lives the life of the same trainer
+    run alone, from step 10 on it does not."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flag_worker, args=(r, world, port, q, engine)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, f0, same0, st0), (_, f1, same1, st1) = res
+    # (an untrained policy also produces terminal platoons of its own a few dozen steps after a reset: whatever the flags are, both
+    #  ranks must hold the SAME ones at every step, and the two forced ones must be among them)
+    assert f0 == f1 and f0[10] == 1 and f0[70] == 1 and sum(f0[:10]) == 0, (f0, f1)
+    assert same0[:10] == [True] * 10 and same0[10:] == [False] * 4  # rank 0 was reset at step 10 by rank 1's terminal platoon
+    assert st0 == st1 >= 9
