@@ -80,6 +80,8 @@ _PROTOS = {
     "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],
     "avd_fed_finalize_f32": [_i, _i, _P, _f, _P, _P],
     "avd_fed_scatter_f32": [_i, _i, _i, _i, _i, _i, _P, _P, _P],
+    "avd_fed_history_push_f32": [_i, _i, _i, _P, _P, _P, _i, _P, _i, _i, _P, _P, _P],
+    "avd_fed_weights_f32": [_i, _i, _i, _P, _P, _i, _P, _P, _P, _P],
     "avd_learn_shared_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],
     "avd_learn_shared_bf16": [_LP, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, C.c_size_t, _P],
     "avd_learn_set_fused_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],
@@ -104,12 +106,18 @@ def _load(path):
         raise AvdError(f"{path} not found: build the HIP extension first (__graft_entry__.build()); "
                        "avddpg_amd has no CPU fallback")
     l = C.CDLL(path)
+    missing = []
     for name, args in _PROTOS.items():
         fn = getattr(l, name, None)
         if fn is None:
-            continue  # an older build (A/B tooling loads one through AVDDPG_HIP_LIB): call() raises when the name is used
+            missing.append(name)
+            continue
         fn.argtypes = args
         fn.restype = C.c_int
+    if missing and not os.environ.get("AVDDPG_HIP_LIB"):
+        # the product / diagnostic build of THIS tree must export every entry point (a stale or partial build, or a typo above);
+        # only an older build loaded on purpose through AVDDPG_HIP_LIB (A/B tooling) may lack some: call() raises when one is used
+        raise AvdError(f"{path} does not export {', '.join(missing)}: rebuild it (make -C avddpg_amd/csrc)")
     l.avd_last_error.restype = C.c_char_p
     l.avd_last_error.argtypes = []
     l.avd_version.restype, l.avd_version.argtypes = C.c_int, []

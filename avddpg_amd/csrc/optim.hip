@@ -300,6 +300,79 @@ static int adam_polyak_launch(const char* who, bool guard, const avd_mlp_layout*
     return check_launch(who);
 }
 
+// ---- federated weights on the device (workers/trainer.py:385-398; src/server/federated.py:99-118) ----------------------
+// The reference weights agent (p, m) by |1 / mean(its last `weighted_window` episodic rewards)|. In the throughput modes no
+// episodic reward ever reaches the host, so the history lives here: ring[P*M][W] of closed-episode rewards + hist_cnt[P].
+// fed_history_push_kernel: one thread per platoon, once per step; the platoon's episode closes when
+//   force != 0 (the caller's step limit), or *cond != 0 (the any-terminal flag: ALL platoons close, trainer.py:268-269), or
+//   done[p] / ep_len[p] + 1 >= limit (per-platoon episodes: the condition avd_episode_end_f32 is about to apply).
+__global__ void fed_history_push_kernel(int P, int M, int W, float* __restrict__ ep_reward, const uint8_t* __restrict__ done,
+                                        const int32_t* __restrict__ ep_len, int limit, const int32_t* __restrict__ cond, int force,
+                                        int zero_after, float* __restrict__ ring, int32_t* __restrict__ hist_cnt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    bool end = force != 0 || (cond && *cond != 0);
+    if (!end && done) end = done[p] != 0 || (ep_len && ep_len[p] + 1 >= limit);
+    if (!end) return;
+    const int c = hist_cnt[p], slot = c % W;
+    for (int m = 0; m < M; ++m) {
+        const long v = (long)p * M + m;
+        ring[v * W + slot] = ep_reward[v];
+        if (zero_after) ep_reward[v] = 0.f;
+    }
+    hist_cnt[p] = c + 1;
+}
+
+// fed_weights_kernel: one block per vehicle index m. enabled = host_enabled (0 / 1), or, when host_enabled < 0, "every platoon has
+// closed at least W episodes" (the reference's `training_episode >= weighted_window`, trainer.py:694: with the all-platoons episode
+// rule every count is the episode number). Enabled: w = |1 / mean(ring row)| (the W entries summed in slot order, float32),
+// wsum[m] = sum_p w, agent_weight = w P / wsum[m] (the factor the set learners take); disabled: w = agent_weight = 1, wsum[m] = P
+// -- the weighted formulas then give the plain mean.
+__global__ __launch_bounds__(256) void fed_weights_kernel(int P, int M, int W, const float* __restrict__ ring,
+                                                          const int32_t* __restrict__ hist_cnt, int host_enabled,
+                                                          float* __restrict__ w_raw, float* __restrict__ aw, float* __restrict__ wsum) {
+    __shared__ float part[256];
+    __shared__ int cmin[256];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    int enabled = host_enabled;
+    if (host_enabled < 0) {
+        int c = 0x7fffffff;
+        for (int p = tid; p < P; p += 256) c = min(c, hist_cnt[p]);
+        cmin[tid] = c;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) cmin[tid] = min(cmin[tid], cmin[tid + o]);
+            __syncthreads();
+        }
+        enabled = cmin[0] >= W ? 1 : 0;
+    }
+    float s = 0.f;
+    for (int p = tid; p < P; p += 256) {
+        const long v = (long)p * M + m;
+        float w = 1.0f;
+        if (enabled) {
+            float acc = 0.f;
+            for (int k = 0; k < W; ++k) acc += ring[v * W + k];
+            w = fabsf(1.0f / (acc / (float)W));
+        }
+        w_raw[v] = w;
+        s += w;
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {  // fixed tree: the same bits on every launch
+        if (tid < o) part[tid] += part[tid + o];
+        __syncthreads();
+    }
+    const float total = part[0];
+    if (tid == 0) wsum[m] = total;
+    const float f = (float)P / total;
+    for (int p = tid; p < P; p += 256) {
+        const long v = (long)p * M + m;
+        aw[v] = enabled ? w_raw[v] * f : 1.0f;
+    }
+}
+
 extern "C" int avd_adam_polyak_f32(const avd_mlp_layout* lay, int n_sets, float* theta, float* stats, float* theta_t,
                                    float* stats_t, float* m, float* v, const float* grads, const int32_t* step,
                                    float actor_lr, float critic_lr, double tau, void* stream) {
@@ -379,4 +452,22 @@ extern "C" int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stri
     hipLaunchKernelGGL(fed_scatter_kernel, dim3(gx, n_in - i_begin, n_out), dim3(256), 0, (hipStream_t)stream,
                        stride_out, stride_in, i_begin, n, (const float4*)src, (float4*)dst);
     return check_launch("avd_fed_scatter_f32");
+}
+
+extern "C" int avd_fed_history_push_f32(int P, int M, int W, float* ep_reward, const uint8_t* done, const int32_t* ep_len, int limit,
+                                        const int32_t* cond, int force, int zero_after, float* ring, int32_t* hist_cnt, void* stream) {
+    AVD_REQUIRE(P > 0 && M > 0 && W > 0 && ep_reward && ring && hist_cnt, "avd_fed_history_push_f32: P=%d M=%d W=%d", P, M, W);
+    AVD_REQUIRE(force || cond || (done && (!ep_len || limit >= 1)), "avd_fed_history_push_f32: no closing condition given");
+    hipLaunchKernelGGL(fed_history_push_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, W, ep_reward, done,
+                       ep_len, limit, cond, force, zero_after, ring, hist_cnt);
+    return check_launch("avd_fed_history_push_f32");
+}
+
+extern "C" int avd_fed_weights_f32(int P, int M, int W, const float* ring, const int32_t* hist_cnt, int host_enabled, float* w_raw,
+                                   float* agent_weight, float* wsum, void* stream) {
+    AVD_REQUIRE(P > 0 && M > 0 && M <= 65535 && W > 0 && ring && hist_cnt && w_raw && agent_weight && wsum,
+                "avd_fed_weights_f32: P=%d M=%d W=%d", P, M, W);
+    hipLaunchKernelGGL(fed_weights_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, M, W, ring, hist_cnt, host_enabled, w_raw,
+                       agent_weight, wsum);
+    return check_launch("avd_fed_weights_f32");
 }

@@ -148,12 +148,21 @@ class VecTrainer:
         self.auto_reset = auto_reset
         if auto_reset and rng != "device":
             raise ValueError("auto_reset needs rng='device'")
-        if auto_reset and fed and conf.weighted_average_enabled:
-            # the federated weights are |1 / mean(last episodic rewards)| (trainer.py:385-398); auto_reset keeps no
-            # per-episode reward history on the host, so there is nothing to compute them from
-            raise ValueError("auto_reset (device-side episode bookkeeping) cannot be combined with a federated method and "
-                             "weighted_average_enabled: the weights need the per-episode reward lists; run the episode "
-                             "loop (VecTrainer.run) or set weighted_average_enabled=False")
+        # Weighted federated averaging with the episode bookkeeping on the device (r06): the weights |1 / mean(last
+        # `weighted_window` episodic rewards)| (trainer.py:385-398) come from a device ring of closed-episode rewards
+        # (avd_fed_history_push_f32, filled where episodes close) through avd_fed_weights_f32, once per step, no host synchronisation.
+        # Enabled like the reference (`training_episode >= weighted_window`, :694): under the all-platoons episode rule when every
+        # platoon has closed `weighted_window` episodes (all counts ARE the episode number); with per-platoon episodes from step
+        # weighted_window x steps_per_episode on, when every platoon has surely closed that many (a host-known moment, the same on
+        # every rank).
+        self._dev_weighted = bool(auto_reset and fed and conf.weighted_average_enabled)
+        if self._dev_weighted:
+            W = int(conf.weighted_window)
+            self._hist_ring = torch.zeros(n_agents, W, **f32)
+            self._hist_cnt = torch.zeros(self.P, dtype=torch.int32, device=self.device)
+            self._w_raw, self._aw = torch.ones(n_agents, **f32), torch.ones(n_agents, **f32)
+            self._wsum = torch.full((self.M,), float(self.P), **f32)
+        self.steps_total = 0  # training steps since construction (per-platoon episodes: the schedule's episode-equivalent clock)
         # fused_step: OU noise, policy clip, leader exog, platoon step, replay add and the reward counters in ONE launch
         # (avd_step_fused_f32; bit-identical to the separate kernels). Device-RNG mode, decentralized agents. Default: on
         # where it applies.
@@ -337,7 +346,9 @@ class VecTrainer:
             return
         if self.shared and self.shared_engine in ("batched", "fused", "fused3"):
             weights = None
-            if is_weighted_fed_enabled(conf, ep):
+            if self._dev_weighted:
+                weights = "device"  # (self._aw / self._wsum, refreshed at the end of every step)
+            elif is_weighted_fed_enabled(conf, ep):
                 if self.fed_weights is None or self.fed_weights[0] != ep:
                     self.fed_weights = (ep, self._weights_for_fed(ep))
                 weights = self.fed_weights[1]
@@ -362,11 +373,13 @@ class VecTrainer:
         # the reference's any-terminal rule across ranks (workers/trainer.py:268-269): with device-side episodes the rank's flag of
         # this step travels in the gradient exchange and comes back as the global one, which the conditional reset then reads
         carry = self.env.any_done if (self.group is not None and self.auto_reset is True) else None
-        rw = wsum = None
-        if weights is not None:  # [P, M] -> factors w_p * P / sum_p w_p (federated.py:99-118)
+        rw = wsum = aw_dev = None
+        if isinstance(weights, str):  # device weights: the factors and the per-set sums exist already (avd_fed_weights_f32)
+            aw_dev, wsum, weights = self._aw, self._wsum, None
+        elif weights is not None:  # [P, M] -> factors w_p * P / sum_p w_p (federated.py:99-118)
             wsum = weights.sum(dim=0)  # [M]
         if self.shared_engine in ("fused", "fused3"):  # agent-major batches as sampled, one factor per agent
-            aw = None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous()
+            aw = aw_dev if aw_dev is not None else (None if weights is None else (weights * (float(P) / wsum)).reshape(P * M).contiguous())
             if self.overlap_allreduce:
                 self._learn_split_overlapped(s, a, r, s2, aw, wsum, carry)
                 self._flag_exchanged = carry is not None
@@ -374,7 +387,9 @@ class VecTrainer:
             self.agents.learn_set_fused(s, a, r, s2, P * M, grads=self.set_grads, losses=self.set_losses, agent_weight=aw,
                                         split=self.shared_engine == "fused3")
         else:
-            if weights is not None:  # per-row factors, set-major
+            if aw_dev is not None:
+                rw = aw_dev.view(P, M).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()
+            elif weights is not None:  # per-row factors, set-major
                 rw = (weights * (float(P) / wsum)).transpose(0, 1).reshape(M, P, 1).expand(M, P, B).reshape(M, P * B).contiguous()
             self.agents.learn_shared(sm(s), sm(a), sm(r), sm(s2), P * M, grads=self.set_grads, losses=self.set_losses,
                                      row_weight=rw)
@@ -419,7 +434,9 @@ class VecTrainer:
             self.agents.apply(self.grads)
             return
         weights = None
-        if is_weighted_fed_enabled(conf, ep):
+        if self._dev_weighted:
+            weights = self._w_raw.view(P, M)  # (all ones until the weighting is enabled: the weighted formulas then give the plain mean)
+        elif is_weighted_fed_enabled(conf, ep):
             if self.fed_weights is None or self.fed_weights[0] != ep:
                 self.fed_weights = (ep, self._weights_for_fed(ep))
             weights = self.fed_weights[1]
@@ -476,24 +493,50 @@ class VecTrainer:
             # slab exchange): its own 1-int all-reduce(max), still without a host synchronisation
             import torch.distributed as _td
             _td.all_reduce(self.env.any_done, op=_td.ReduceOp.MAX, group=self.group)
+        self.steps_total += 1
+        limit = self.conf.steps_per_episode
         if self.auto_reset == "platoon":
-            # per-platoon episodes: no global episode counter; the schedule predicates see episode 0 and the running step
-            self.env.episode_end(self.ep_reward, self.M, self.conf.steps_per_episode, any_reset=self.env.any_done)
+            # per-platoon episodes: there is no global episode; the schedule predicates (fed_update_count, fed_cutoff_episode,
+            # trainer.py:631-695) see the episode-EQUIVALENT clock steps / steps_per_episode -- the episode number a platoon that
+            # never terminates would be in -- and the running step
+            if self._dev_weighted:
+                self.env.ensure_episode_state()
+                self._push_history(done=self.env.done, ep_len=self.env.ep_len, limit=limit, zero_after=0)
+            self.env.episode_end(self.ep_reward, self.M, limit, any_reset=self.env.any_done)
+            self.episode = self.steps_total // limit
+            if self._dev_weighted:
+                self._refresh_weights(1 if self.steps_total >= int(self.conf.weighted_window) * limit else 0)
             return None
         if self.auto_reset:
             # any platoon terminal ends the episode for ALL platoons (:268-269); so does the step limit
-            if self.ep_step >= self.conf.steps_per_episode:
+            if self.ep_step >= limit:
+                if self._dev_weighted:
+                    self._push_history(force=1, zero_after=1)
                 self.env.reset()
                 self._act_ready = False
                 self.ep_step = 0
                 self.episode += 1
             else:
+                if self._dev_weighted:
+                    self._push_history(cond=self.env.any_done, zero_after=1)
                 self.env.reset(cond=self.env.any_done)
+            if self._dev_weighted:
+                self._refresh_weights(-1)
             return None
         if not sync:
             return None
         from .dist import any_terminal
         return any_terminal(self.env.any_done, self.group)
+
+    def _push_history(self, done=None, ep_len=None, limit=0, cond=None, force=0, zero_after=0):
+        """Closed-episode rewards into the device ring (avd_fed_history_push_f32), BEFORE the episode end / conditional reset."""
+        call("avd_fed_history_push_f32", self.P, self.M, int(self.conf.weighted_window), ptr(self.ep_reward), ptr(done), ptr(ep_len),
+             int(limit), ptr(cond), int(force), int(zero_after), ptr(self._hist_ring), ptr(self._hist_cnt), stream_handle())
+
+    def _refresh_weights(self, host_enabled):
+        """trainer.py:385-398 on the device: w, the per-set sums and the learners' per-agent factors for the NEXT step's update."""
+        call("avd_fed_weights_f32", self.P, self.M, int(self.conf.weighted_window), ptr(self._hist_ring), ptr(self._hist_cnt),
+             int(host_enabled), ptr(self._w_raw), ptr(self._aw), ptr(self._wsum), stream_handle())
 
     def nonfinite_updates(self):
         """Weight-set updates skipped because the set learner returned a NaN gradient slab (host synchronisation: call it at

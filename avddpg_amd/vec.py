@@ -147,15 +147,19 @@ class VecPlatoon:
         from fresh reset states. ``any_reset`` (int32[1]) is set when any platoon was closed."""
         if self.rng != "device":
             raise ValueError("per-platoon episode ends need rng='device'")
-        if self.ep_len is None:
-            z = lambda dt: torch.zeros(self.P, dtype=dt, device=self.device)
-            self.ep_len = z(torch.int32)
-            self.ep_stats = dict(ret_sum=z(torch.float32), len_sum=z(torch.float32), count=z(torch.int32))
+        self.ensure_episode_state()
         st = self.ep_stats
         call("avd_episode_end_f32", ptr(self.d_consts), self.P, self.L, M, ptr(self.x), ptr(self.prev_a), ptr(self.cum_accel),
              ptr(self.done), ptr(self.ep_len), ptr(ep_reward), int(limit), ptr(st["ret_sum"]), ptr(st["len_sum"]),
              ptr(st["count"]), ptr(any_reset), self._mode(), self.seed, self.reset_count, stream_handle())
         self.reset_count += 1
+
+    def ensure_episode_state(self):
+        """The per-platoon episode counters of episode_end (made on first use)."""
+        if self.ep_len is None:
+            z = lambda dt: torch.zeros(self.P, dtype=dt, device=self.device)
+            self.ep_len = z(torch.int32)
+            self.ep_stats = dict(ret_sum=z(torch.float32), len_sum=z(torch.float32), count=z(torch.int32))
 
     def pop_episode_stats(self):
         """(mean platoon-mean episodic reward, mean episode length, episodes closed) since the last call; clears the sums.

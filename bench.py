@@ -93,6 +93,10 @@ def parse():
                          "a chip coming out of idle (trainer construction, ring fill) runs its first ~0.5 s 3-5 %% slow (clocks and power "
                          "state), so a short run -- --steps 20 --warmup 5 is 55 ms -- would time the ramp, not the workload; the line "
                          "records what was added (prewarm)")
+    ap.add_argument("--weighted", action="store_true",
+                    help="interfrl: weighted federated averaging (weighted_average_enabled, the Config default src/config.py:28; "
+                         "workers/trainer.py:385-398) with the weights computed on the device from a ring of closed-episode rewards "
+                         "(avd_fed_history_push_f32 + avd_fed_weights_f32: two small launches per step)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default 1-GPU run: do not also time BASELINE configs[2] (4096 x 10) and configs[4] (hidden 1024) after the two "
                          "4096 x 5 workloads")
@@ -284,7 +288,8 @@ def build_trainer(args, mode, engine, rank, group, ring=None):
     P, L = args.platoons, args.pl_size
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
                          fed_method="interfrl" if mode == "interfrl" else "normal",
-                         weighted_average_enabled=False, random_seed=1, framework=args.framework)  # random_seed: initial weights, the same on every rank
+                         weighted_average_enabled=bool(getattr(args, "weighted", False) and mode == "interfrl"), random_seed=1,
+                         framework=args.framework)  # random_seed: initial weights, the same on every rank
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     return trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
@@ -552,7 +557,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                                + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
                                   if mode == "nofrl" else
                                   "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
-                                  + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else "")))
+                                  + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else ""))
+                                  + (", WEIGHTED mean (|1 / mean of the last 10 episodic rewards| per agent, weights on the device)"
+                                     if getattr(vt, "_dev_weighted", False) else ""))
                                + f", B=64, replay capacity {args.buffer_size} (full), 1 update per env step",
                    "platoons_per_gpu": P, "pl_size": L, "agents_per_gpu": n_agents, "mode": mode,
                    "parallelism": f"platoon shards x{world}" + (f" + one {args.backend} all-reduce(sum) of the [M, theta] gradient slab per step"
@@ -714,6 +721,7 @@ def main():
     # shape flags), after the two 4096 x 5 workloads have been freed.
     extras = {}
     default_run = (world == 1 and group is None and not args.mode and not args.hidden and not args.engine and not args.no_secondary
+                   and not args.weighted
                    and args.framework == "decentralized" and args.platoons == 4096 and args.pl_size == 5 and args.chunks == 1
                    and not args.no_fused and not args.no_extra_configs)
     if default_run:

@@ -275,6 +275,25 @@ int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float*
 int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n, const float* src,
                         float* dst, void* stream);
 
+/* ---- federated weights in the throughput modes (workers/trainer.py:385-398, 694; src/server/federated.py:99-118) ----
+ * The reference weights agent (p, m) by |1 / mean(all_ep_reward_lists[p][m][-weighted_window:])| from `training_episode >=
+ * weighted_window` on. With the episode bookkeeping on the device the history lives there too:
+ *   ring [P*M][W] f32  the last W closed episodes' rewards of every agent (slot = episode number % W); hist_cnt [P] int32.
+ * avd_fed_history_push_f32, once per step BEFORE the episode end / conditional reset: platoon p closes when `force` (the caller's
+ * step limit), or *cond != 0 (the any-terminal flag: every platoon closes, :268-269), or -- `done` given -- done[p] or
+ * ep_len[p] + 1 >= limit (per-platoon episodes: what avd_episode_end_f32 is about to apply; ep_len may be NULL). A closing
+ * platoon's M counters ep_reward[p*M ..] go into its ring row (and are zeroed when zero_after: the all-platoons rule has no other
+ * kernel doing it). */
+int avd_fed_history_push_f32(int P, int M, int W, float* ep_reward, const uint8_t* done, const int32_t* ep_len, int limit,
+                             const int32_t* cond, int force, int zero_after, float* ring, int32_t* hist_cnt, void* stream);
+/* avd_fed_weights_f32: w_raw [P*M] = |1 / mean(ring row)| (get_weight, trainer.py:385-398), wsum [M] = sum over platoons
+ * (fed_weight_sums), agent_weight [P*M] = w P / wsum -- the per-agent factor of avd_learn_set_split_f16x3 /
+ * avd_learn_set_fused_bf16 (federated.py:99-118 as a weighted mean). host_enabled 1 / 0: weighted / plain mean (all ones,
+ * wsum = P); < 0: decided here -- weighted once every platoon has closed W episodes (is_weighted_fed_enabled, :694). Deterministic
+ * (fixed reduction tree). A zero episodic-reward mean gives an infinite weight, as in the reference. */
+int avd_fed_weights_f32(int P, int M, int W, const float* ring, const int32_t* hist_cnt, int host_enabled, float* w_raw,
+                        float* agent_weight, float* wsum, void* stream);
+
 /* ---- one launch per training step (device-RNG mode, decentralized agents) ----------------------------------------
  * advance_environment + the replay add of train_all_models (workers/trainer.py:282-322) for all P platoons:
  *   noise  = OUActionNoise.__call__()                       src/noise.py:15-19        (= avd_ou_step_f32, Philox stream OU)

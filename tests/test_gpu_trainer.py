@@ -10,6 +10,7 @@ from avddpg_amd import config, ddpgagent, environment, model, noise, replaybuffe
 from oracle import mlp as omlp
 from oracle import platoon as oplatoon
 from oracle import trainer as otrainer
+from tests.gpu_util import need_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -483,14 +484,74 @@ def test_initial_weights_do_not_depend_on_the_stream_seed():
     assert not torch.equal(a.agents.theta, c.agents.theta)
 
 
-def test_auto_reset_refuses_weighted_federated_averaging():
-    """auto_reset keeps no per-episode reward history, which the federated weights |1 / mean(rewards)| need
-    (trainer.py:385-398): the combination must fail at construction, not poison the weights with NaN later."""
+@pytest.mark.parametrize("mode,engine", [(True, "fused3"), (True, "per_agent"), ("platoon", "fused3"), (True, "batched")])
+def test_weighted_federated_averaging_with_the_episode_bookkeeping_on_the_device(mode, engine):
+    """`weighted_average_enabled` -- the Config default (src/config.py:28) -- in the throughput modes. The weights
+    |1 / mean(last `weighted_window` episodic rewards)| (workers/trainer.py:385-398) come from a device ring of closed-episode
+    rewards (avd_fed_history_push_f32 + avd_fed_weights_f32), no host synchronisation per step. A host shadow follows the run step
+    by step -- float32 episodic counters as the reference's (:249, 321), closed where the device closes episodes -- and must find:
+    the ring holds exactly (bitwise) the last closed episodes' rewards; before `weighted_window` episodes the update is the plain
+    mean (all factors 1, like `training_episode < weighted_window`, :694); from then on w, the per-set sums and the learners'
+    factors w P / sum(w) equal the reference formula on the shadow's lists to float32 rounding (1e-6: the mean's summation order);
+    and the learn call fed from the device equals the one fed the host's weights (1e-5 of each block's max)."""
+    need_gpu()
+    P, L, W = 6, 3, 3
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=256, fed_method="interfrl", weighted_average_enabled=True,
+                         weighted_window=W, episode_sim_time=2.5)  # 25-step episodes
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=mode, shared_engine=engine, shared_sets=True)
+    assert vt._dev_weighted and vt.shared_engine == engine
+    vt.reset_episode()
+    acc = np.zeros((P, L), dtype=np.float32)
+    lists = [[[] for _ in range(L)] for _ in range(P)]
+    cnt_prev = np.zeros(P, dtype=np.int64)
+    checked = 0
+    for i in range(140):
+        vt.step()
+        acc += vt.env.reward.cpu().numpy()  # float32 adds in step order: what the fused step's counters do
+        cnt = vt._hist_cnt.cpu().numpy().astype(np.int64)
+        for p in np.nonzero(cnt != cnt_prev)[0]:
+            assert cnt[p] == cnt_prev[p] + 1
+            for m in range(L):
+                lists[p][m].append(acc[p, m])
+            acc[p] = 0.0
+        if mode is True:
+            assert len(set(cnt.tolist())) == 1  # the all-platoons rule: every platoon is in the same episode
+        cnt_prev = cnt
+        ring = vt._hist_ring.cpu().numpy().reshape(P, L, W)
+        for p in range(P):
+            for m in range(L):
+                for k, val in enumerate(lists[p][m][-W:]):
+                    e = len(lists[p][m]) - len(lists[p][m][-W:]) + k
+                    assert ring[p, m, e % W] == val, (i, p, m, e)
+        aw, ws, wr = vt._aw.cpu().numpy().reshape(P, L), vt._wsum.cpu().numpy(), vt._w_raw.cpu().numpy().reshape(P, L)
+        enabled = (cnt.min() >= W) if mode is True else (vt.steps_total >= W * conf.steps_per_episode)
+        if not enabled:
+            assert (aw == 1).all() and (ws == P).all() and (wr == 1).all()
+        else:
+            want = np.array([[abs(1 / np.mean(lists[p][m][-W:])) for m in range(L)] for p in range(P)], dtype=np.float32)
+            assert np.allclose(wr, want, rtol=2e-6) and np.allclose(ws, want.sum(axis=0), rtol=2e-6)
+            assert np.allclose(aw, want * (P / want.sum(axis=0)), rtol=3e-6)
+            checked += 1
+    assert checked >= 30 and cnt_prev.min() >= W + 1
+    assert torch.isfinite(vt.agents.theta).all() and int(vt.agents.step[0]) >= 70
+    if engine in ("fused3", "batched"):  # the same learn call from the device factors and from the host's weights
+        s_, a_, r_, s2_ = vt.replay.sample()
+        vt._learn_batched(s_, a_, r_, s2_, "device")
+        g_dev = vt.set_grads.clone()
+        vt._learn_batched(s_, a_, r_, s2_, vt._w_raw.view(P, L).clone())
+        A = vt.agents.lay.actor_size
+        for lo, hi in ((0, A), (A, vt.agents.lay.theta_size)):
+            d = (g_dev[:, lo:hi] - vt.set_grads[:, lo:hi]).abs().max().item()
+            assert d <= 1e-5 * vt.set_grads[:, lo:hi].abs().max().item(), (lo, d)
+
+
+def test_host_episode_loop_still_needs_recorded_episodes_for_its_weights():
+    """The host episode loop (auto_reset=False) computes the weights from its per-episode lists: without any recorded episode it
+    must fail loudly, not poison the weights with NaN."""
+    need_gpu()
     conf = config.Config(num_platoons=4, pl_size=2, buffer_size=128, fed_method="interfrl", weighted_average_enabled=True)
-    with pytest.raises(ValueError, match="weighted_average_enabled"):
-        trainer.VecTrainer(conf, rng="device", auto_reset=True)
-    vt = trainer.VecTrainer(conf, rng="device", auto_reset=False)  # the episode loop is fine ...
-    with pytest.raises(RuntimeError, match="episodic rewards"):       # ... but weights without any recorded episode are not
+    vt = trainer.VecTrainer(conf, rng="device", auto_reset=False)
+    with pytest.raises(RuntimeError, match="episodic rewards"):
         vt._weights_for_fed(conf.weighted_window)
 
 
