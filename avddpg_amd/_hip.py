@@ -80,6 +80,7 @@ _PROTOS = {
     "avd_fed_sum_f32": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P],
     "avd_fed_finalize_f32": [_i, _i, _P, _f, _P, _P],
     "avd_fed_scatter_f32": [_i, _i, _i, _i, _i, _i, _P, _P, _P],
+    "avd_adam_polyak_intra_f32": [_LP, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _d, _P],
     "avd_fed_history_push_f32": [_i, _i, _i, _P, _P, _P, _i, _P, _i, _i, _P, _P, _P],
     "avd_fed_weights_f32": [_i, _i, _i, _P, _P, _i, _P, _P, _P, _P],
     "avd_learn_shared_workspace": [_LP, _i, _i, C.POINTER(C.c_size_t)],

@@ -14,9 +14,12 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-7f;
 // A set whose gradient slab is not finite at the head of its actor block or of its critic block (the set learners of fset.hip /
 // fsplit.hip turn a non-finite input or an fp16 overflow into an ALL-NaN block: finalize_*) -- the guarded update leaves such a set
 // untouched.
+// CONTRACT (finalize_* of fset.hip / fsplit.hip): element 0 of a set's actor block and of its critic block is non-finite iff the
+// block is invalid -- every failure the learners detect goes through their `bad` flag, which makes finalize write NaN over the whole
+// slab. An Inf head (an overflow that reached the sums without tripping a watch) is treated the same.
 __device__ __forceinline__ bool slab_is_nan(const float* g, int actor_size) {
     const unsigned a = __float_as_uint(g[0]) & 0x7fffffffu, c = __float_as_uint(g[actor_size]) & 0x7fffffffu;
-    return a > 0x7f800000u || c > 0x7f800000u;
+    return a >= 0x7f800000u || c >= 0x7f800000u;
 }
 
 // grid: (blocks over theta_size/4, n_sets). GUARD: avd_adam_polyak_guarded_f32 -- a set with a NaN gradient slab takes no step at all
@@ -177,6 +180,88 @@ __global__ __launch_bounds__(256) void adam_polyak_rows_kernel(int theta_size, i
 
 #undef NTL
 #undef NTS
+
+// intrafrl (workers/trainer.py:189-190, 341-342, 417-431): the M agents of platoon p all step with the MEAN of their M gradients
+// (src/server/federated.py:47-63; weighted :99-118) -- averaged HERE, where the gradients are consumed: grid (blocks over theta_size / 4,
+// P); a thread loads its float4 group of the platoon's M gradient rows once, forms the mean in fed_sum_kernel's order (four partial
+// sums over the members i = ph, ph + 4, .., combined in phase order) and fed_finalize_kernel's scaling, and applies Adam + Polyak
+// to the M agents' weights with it. Replaces fed_sum + fed_finalize + fed_scatter + adam_polyak (r05: the 6.3 GB gradient slab of
+// 4096 x 5 agents was read twice and written twice; now it is read once). lead_skip: the lead vehicle of every platoon takes no
+// step at all under intra_directional_averaging (:417-418) -- a predicate, its gradient still enters the mean.
+constexpr int INTRA_MAX_M = 16;
+__global__ __launch_bounds__(256) void adam_polyak_intra_kernel(int theta_size, int actor_size, int M, int lead_skip,
+                                                                float4* __restrict__ theta, float4* __restrict__ theta_t,
+                                                                float4* __restrict__ m, float4* __restrict__ v,
+                                                                const float4* __restrict__ grads, const int32_t* __restrict__ step,
+                                                                const float* __restrict__ weights, float actor_lr, float critic_lr,
+                                                                float tau, float omt) {
+#pragma clang fp contract(off)
+    __shared__ float s_aa[INTRA_MAX_M], s_ac[INTRA_MAX_M], s_w[INTRA_MAX_M], s_scale;
+    const int p = blockIdx.y, n4 = theta_size / 4;
+    const long set0 = (long)p * M;
+    if (threadIdx.x < M) {
+        const int t = step[set0 + threadIdx.x];
+        const float b1p = (float)pow((double)ADAM_B1, (double)t), b2p = (float)pow((double)ADAM_B2, (double)t);
+        const float root = sqrtf(1.0f - b2p);
+        s_aa[threadIdx.x] = (actor_lr * root) / (1.0f - b1p);
+        s_ac[threadIdx.x] = (critic_lr * root) / (1.0f - b1p);
+        s_w[threadIdx.x] = weights ? weights[set0 + threadIdx.x] : 1.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ws = 0.f;
+        for (int i = 0; i < M; ++i) ws += s_w[i];  // (fed_sum_kernel's wsum: ascending)
+        s_scale = 1.0f / ws;
+    }
+    __syncthreads();
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+        float4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < M; ++i) {
+            const float4 g = grads[(set0 + i) * n4 + i4];
+            const float w = s_w[i];
+            float4& a = acc[i & 3];
+            a.x = __builtin_fmaf(w, g.x, a.x), a.y = __builtin_fmaf(w, g.y, a.y), a.z = __builtin_fmaf(w, g.z, a.z), a.w = __builtin_fmaf(w, g.w, a.w);
+        }
+        float4 r = acc[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) r.x += acc[k].x, r.y += acc[k].y, r.z += acc[k].z, r.w += acc[k].w;
+        float gm[4];
+        if (weights)
+            gm[0] = s_scale * r.x, gm[1] = s_scale * r.y, gm[2] = s_scale * r.z, gm[3] = s_scale * r.w;  // federated.py:110
+        else
+            gm[0] = r.x / (float)M, gm[1] = r.y / (float)M, gm[2] = r.z / (float)M, gm[3] = r.w / (float)M;  // reduce_mean (:62)
+        const bool actor = i4 * 4 < actor_size;  // blocks are 4-float aligned
+        for (int i = lead_skip ? 1 : 0; i < M; ++i) {
+            const long o = (set0 + i) * n4 + i4;
+            const float alpha = actor ? s_aa[i] : s_ac[i];
+            float4 w = theta[o], wt = theta_t[o], mm = m[o], vv = v[o];
+            float* wp = &w.x;
+            float* tp = &wt.x;
+            float* mp = &mm.x;
+            float* vp = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mp[k] = mp[k] + (gm[k] - mp[k]) * (1.0f - ADAM_B1);
+                vp[k] = vp[k] + (gm[k] * gm[k] - vp[k]) * (1.0f - ADAM_B2);
+                wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + ADAM_EPS);
+                tp[k] = wp[k] * tau + tp[k] * omt;
+            }
+            theta[o] = w, theta_t[o] = wt, m[o] = mm, v[o] = vv;
+        }
+    }
+}
+// the BN statistics' soft update for the same agents (set % M == 0 skipped under lead_skip)
+__global__ void polyak_intra_kernel(int stats_size, int M, int lead_skip, const float* __restrict__ w, float* __restrict__ t, float tau,
+                                    float omt) {
+#pragma clang fp contract(off)
+    const int set = blockIdx.y;
+    if (lead_skip && set % M == 0) return;
+    const long base = (long)set * stats_size;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stats_size; i += gridDim.x * blockDim.x)
+        t[base + i] = w[base + i] * tau + t[base + i] * omt;
+}
 
 __global__ void polyak_kernel(long n, const float* __restrict__ w, float* __restrict__ t, float tau, float omt) {
 #pragma clang fp contract(off)
@@ -470,4 +555,24 @@ extern "C" int avd_fed_weights_f32(int P, int M, int W, const float* ring, const
     hipLaunchKernelGGL(fed_weights_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, M, W, ring, hist_cnt, host_enabled, w_raw,
                        agent_weight, wsum);
     return check_launch("avd_fed_weights_f32");
+}
+
+extern "C" int avd_adam_polyak_intra_f32(const avd_mlp_layout* lay, int P, int M, int lead_skip, float* theta, float* stats, float* theta_t,
+                                         float* stats_t, float* m, float* v, const float* grads, const int32_t* step, const float* weights,
+                                         float actor_lr, float critic_lr, double tau, void* stream) {
+    AVD_REQUIRE(lay && P > 0 && M > 0 && M <= INTRA_MAX_M && P <= 65535, "avd_adam_polyak_intra_f32: P=%d M=%d (M <= %d)", P, M, INTRA_MAX_M);
+    AVD_REQUIRE(theta && stats && theta_t && stats_t && m && v && grads && step, "avd_adam_polyak_intra_f32: null pointer");
+    AVD_REQUIRE(lay->theta_size % 4 == 0 && lay->actor_size % 4 == 0, "avd_adam_polyak_intra_f32: layout not 4-float aligned");
+    const float tauf = (float)tau, omt = (float)(1.0 - tau);
+    const int n4 = lay->theta_size / 4;
+    int gx = (n4 + 255) / 256;
+    if (P >= 64 && gx > 8) gx = 8;  // many platoons: fewer, longer-lived blocks per platoon (as adam_polyak_launch)
+    hipLaunchKernelGGL(adam_polyak_intra_kernel, dim3(gx, P), dim3(256), 0, (hipStream_t)stream, lay->theta_size, lay->actor_size, M,
+                       lead_skip ? 1 : 0, (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v, (const float4*)grads, step, weights,
+                       actor_lr, critic_lr, tauf, omt);
+    int rc = check_launch("avd_adam_polyak_intra_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(polyak_intra_kernel, dim3((unsigned)((lay->stats_size + 255) / 256), (unsigned)(P * M)), dim3(256), 0,
+                       (hipStream_t)stream, lay->stats_size, M, lead_skip ? 1 : 0, stats, stats_t, tauf, omt);
+    return check_launch("avd_adam_polyak_intra_f32");
 }

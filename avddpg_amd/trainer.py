@@ -201,7 +201,10 @@ class VecTrainer:
         # (workers/trainer.py:287-289): self.actor_out then already holds the next step's actor outputs unless the states
         # were reset in between (device flag env.any_done / a host-side reset clears _act_ready)
         self._act_ready = False
-        self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl)
+        self.pipeline_chunks = int(pipeline_chunks)  # > 1: overlap Adam/Polyak with learn across agent slices (nofrl, intrafrl + gradients)
+        # intrafrl + gradients: the platoon mean formed inside the Adam pass (avd_adam_polyak_intra_f32) instead of fed_sum / finalize /
+        # scatter / apply over the gradient slab (same values; False keeps the four-kernel path for cross-checks)
+        self.intra_fused = True
         self.timers = None
         self.episode, self.ep_step = 0, 0
         self.updates = 0  # agent-updates (one agent's learn + Adam x2 + Polyak)
@@ -344,6 +347,20 @@ class VecTrainer:
             self.agents.learn_apply(s, a, r, s2, self.grads, self.losses, chunks=self.pipeline_chunks,
                                     timers=self.timers)
             return
+        if (fed and conf.fed_method == conf.intrafrl and not self.shared and self.pipeline_chunks > 1
+                and is_valid_update_step(conf, i) and is_valid_step_for_federated_training_with_gradients(conf, ep, i)):
+            # intrafrl + gradients, every agent stepping with its platoon's mean gradient (:417-431): learn || mean + Adam + Polyak over
+            # platoon chunks on two streams (vec.AgentGroup.learn_apply_intra)
+            w = self._intra_weights(ep)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if self.timers is not None:
+                e0.record()
+            self.agents.learn_apply_intra(s, a, r, s2, self.grads, P, M, losses=self.losses, chunks=self.pipeline_chunks, weights=w,
+                                          lead_skip=bool(conf.intra_directional_averaging), timers=self.timers)
+            if self.timers is not None:
+                e1.record()
+                self.timers.setdefault("learn+update", []).append((e0, e1))
+            return
         if self.shared and self.shared_engine in ("batched", "fused", "fused3"):
             weights = None
             if self._dev_weighted:
@@ -442,10 +459,16 @@ class VecTrainer:
             weights = self.fed_weights[1]
         method = conf.fed_method
         if is_valid_step_for_federated_training_with_gradients(conf, ep, i):
+            if method == conf.intrafrl and self.intra_fused and not self.shared:
+                # the platoon's mean formed where Adam consumes it: one pass over the gradient slab (avd_adam_polyak_intra_f32)
+                self.agents.apply_intra(self.grads, P, M, weights=weights, lead_skip=bool(conf.intra_directional_averaging))
+                return
             avg = vec.fed_mean(self.grads, P, M, weights=weights, group=self.group, method=method,
                                total=self.total_platoons)
             if self.shared:
                 self.agents.apply(avg)
+            elif method == conf.intrafrl and self.intra_fused:
+                pass  # (handled above: never reached)
             else:
                 directional = method == conf.intrafrl and conf.intra_directional_averaging
                 vec.fed_scatter(avg, self.grads, P, M, method)
@@ -527,6 +550,15 @@ class VecTrainer:
             return None
         from .dist import any_terminal
         return any_terminal(self.env.any_done, self.group)
+
+    def _intra_weights(self, ep):
+        if self._dev_weighted:
+            return self._w_raw.view(self.P, self.M)
+        if is_weighted_fed_enabled(self.conf, ep):
+            if self.fed_weights is None or self.fed_weights[0] != ep:
+                self.fed_weights = (ep, self._weights_for_fed(ep))
+            return self.fed_weights[1]
+        return None
 
     def _push_history(self, done=None, ep_len=None, limit=0, cond=None, force=0, zero_after=0):
         """Closed-episode rewards into the device ring (avd_fed_history_push_f32), BEFORE the episode end / conditional reset."""

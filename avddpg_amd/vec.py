@@ -469,6 +469,63 @@ class AgentGroup:
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())
 
+    def apply_intra(self, grads, P, M, weights=None, lead_skip=False, lo=0, hi=None, stream=None):
+        """intrafrl + gradients (workers/trainer.py:417-431) for platoons [lo, hi): every agent of a platoon steps with the (weighted)
+        mean of the platoon's M gradient rows, averaged where it is consumed (avd_adam_polyak_intra_f32: one pass over the slab;
+        same values as fed_mean + fed_scatter + apply). lead_skip: intra_directional_averaging -- vehicle 0 of every platoon takes
+        no step at all (:417-418). weights [P, M] or None."""
+        c = self.config
+        hi = P if hi is None else hi
+        if self.n_sets != P * M:
+            raise _hip.AvdError("apply_intra needs one weight set per agent (P * M sets)")
+        if stream is None:
+            self.step.view(P, M)[lo:hi, (1 if lead_skip else 0):] += 1
+        else:  # (on the stream the kernel runs on: it reads the counts)
+            with torch.cuda.stream(stream):
+                self.step.view(P, M)[lo:hi, (1 if lead_skip else 0):] += 1
+        a, b = lo * M, hi * M
+        call("avd_adam_polyak_intra_f32", self._layp, hi - lo, M, 1 if lead_skip else 0, ptr(self.theta[a:b]), ptr(self.stats[a:b]),
+             ptr(self.theta_t[a:b]), ptr(self.stats_t[a:b]), ptr(self.m[a:b]), ptr(self.v[a:b]), ptr(grads[a:b]), ptr(self.step[a:b]),
+             ptr(None if weights is None else weights.reshape(-1)[a:b]), c.actor_lr, c.critic_lr, float(c.tau),
+             stream_handle() if stream is None else _hip.C.c_void_p(stream.cuda_stream))
+
+    def learn_apply_intra(self, s, a, r, s2, grads, P, M, losses=None, chunks=8, weights=None, lead_skip=False, timers=None):
+        """intrafrl + gradients as a two-stream pipeline over PLATOON chunks (platoons are the unit of independence: the mean never
+        leaves a platoon): chunk c's learn kernel (matrix-core bound, gradients to the slab) runs on the caller's stream, its
+        mean + Adam + Polyak pass (an HBM stream, apply_intra) on a side stream under chunk c + 1's learn kernel. Same results as
+        learn() followed by apply_intra()."""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        c = self.config
+        chunks = max(1, min(chunks, P))
+        bounds = [(P * i) // chunks for i in range(chunks + 1)]
+        T = lambda: torch.cuda.Event(enable_timing=timers is not None)
+        for i in range(chunks):
+            lo, hi = bounds[i] * M, bounds[i + 1] * M
+            if hi == lo:
+                continue
+            t0, t1 = T(), T()
+            if timers is not None:
+                t0.record(main)
+            call("avd_learn_f32", self._layp, hi - lo, 0, ptr(self.theta[lo:hi]), ptr(self.stats[lo:hi]), ptr(self.theta_t[lo:hi]),
+                 ptr(self.stats_t[lo:hi]), ptr(s[lo:hi]), ptr(a[lo:hi]), ptr(r[lo:hi]), ptr(s2[lo:hi]), c.gamma, self.high,
+                 ptr(grads[lo:hi]), ptr(losses[lo:hi]) if losses is not None else None, _hip.C.c_void_p(main.cuda_stream))
+            t1.record(main)
+            side.wait_event(t1)
+            u0, u1 = T(), T()
+            if timers is not None:
+                u0.record(side)
+            self.apply_intra(grads, P, M, weights=weights, lead_skip=lead_skip, lo=bounds[i], hi=bounds[i + 1], stream=side)
+            if timers is not None:
+                u1.record(side)
+                timers.setdefault("learn", []).append((t0, t1))
+                timers.setdefault("update", []).append((u0, u1))
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+
     def learn_update(self, s, a, r, s2, grads, losses=None, next_states=None, x_stride=None, next_actions=None):
         """Fused Trainer.learn + Adam x2 + update_target for per-agent weight sets (reference nofrl,
         workers/trainer.py:325-356) in ONE kernel: every gradient is consumed where it is produced, the updated

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--platoons", type=int, default=4096, help="platoons per GPU")
     ap.add_argument("--pl-size", type=int, default=5)
     ap.add_argument("--buffer-size", type=int, default=100000)
-    ap.add_argument("--mode", choices=["nofrl", "interfrl"], default=None,
+    ap.add_argument("--mode", choices=["nofrl", "interfrl", "intrafrl"], default=None,
                     help="measure this workload only (default: both, PRIMARY_MODE as `value`, the other under `also_measured`)")
     ap.add_argument("--no-secondary", action="store_true", help="default run: skip the non-primary workload")
     ap.add_argument("--engine", choices=["per_agent", "batched", "fused", "fused3"], default=None,
@@ -67,7 +67,13 @@ def parse():
     ap.add_argument("--framework", choices=["decentralized", "centralized"], default="decentralized",
                     help="centralized: one model per platoon with S = 4L, A = L, widths x1.2 (SURVEY 8 f-3; cen.hip / general learn kernel)")
     ap.add_argument("--chunks", type=int, default=1,
-                    help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial)")
+                    help="nofrl: agent slices for the learn || Adam+Polyak two-stream pipeline (1 = serial). intrafrl: platoon chunks of the "
+                         "learn || mean + Adam + Polyak pipeline (--intra-chunks)")
+    ap.add_argument("--intra-chunks", type=int, default=16,
+                    help="intrafrl: platoon chunks of the learn || mean + Adam + Polyak two-stream pipeline (1 = learn, then one pass)")
+    ap.add_argument("--directional", action="store_true",
+                    help="intrafrl: intra_directional_averaging -- the lead vehicle of every platoon takes no federated step (the reference "
+                         "CLI's default, src/cmd/api.py:81; the Config default is off, src/config.py:37)")
     ap.add_argument("--no-fused", action="store_true",
                     help="nofrl: run learn and Adam+Polyak as two kernels instead of the fused avd_learn_update_f32")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -287,13 +293,14 @@ def build_trainer(args, mode, engine, rank, group, ring=None):
 
     P, L = args.platoons, args.pl_size
     conf = config.Config(num_platoons=P, pl_size=L, buffer_size=args.buffer_size,
-                         fed_method="interfrl" if mode == "interfrl" else "normal",
+                         fed_method={"interfrl": "interfrl", "intrafrl": "intrafrl"}.get(mode, "normal"),
+                         intra_directional_averaging=bool(getattr(args, "directional", False)),
                          weighted_average_enabled=bool(getattr(args, "weighted", False) and mode == "interfrl"), random_seed=1,
                          framework=args.framework)  # random_seed: initial weights, the same on every rank
     if args.hidden:
         conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = args.hidden
     return trainer.VecTrainer(conf, rng="device", group=group if mode == "interfrl" else None, auto_reset=True,
-                              seed=1 + rank, pipeline_chunks=args.chunks,
+                              seed=1 + rank, pipeline_chunks=(args.intra_chunks if mode == "intrafrl" else args.chunks),
                               fused_update=(mode == "nofrl" and not args.no_fused),
                               shared_engine=engine if mode == "interfrl" else None, replay_ring=ring,
                               overlap_allreduce=True if (args.overlap and mode == "interfrl" and group is not None and engine == "fused3") else None)
@@ -416,6 +423,16 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
             lk, fused_name = "cen::learn_kernel_c", "cen::learn_kernel_c in chunks || adam_polyak_rows_kernel (two streams)"
         else:
             lk, fused_name = "gen::learn_kernel_g", "gen::learn_kernel_g<fused> + adam_polyak_ranges_kernel"
+    intra = mode == "intrafrl"
+    if intra:
+        # learn_kernel_l (gradients to the slab) in platoon chunks || adam_polyak_intra_kernel (the platoon's mean formed where Adam
+        # consumes it) on a side stream: the whole region against both roofs, like the fused nofrl kernel
+        piped = stage_ms["learn+update"] > 0
+        fused_name = (f"learn_kernel_l (gradients out) in {vt.pipeline_chunks} platoon chunks || adam_polyak_intra_kernel (platoon mean + Adam x2 + "
+                      "Polyak, one pass over the gradient slab; side stream)") if piped else "learn_kernel_l, then adam_polyak_intra_kernel"
+        if not piped:
+            stage_ms["learn+update"] = stage_ms["learn"] + stage_ms["update"]
+        fused = True
     if fused:
         # one kernel does Trainer.learn AND Adam x2 + Polyak: price it against both roofs, the binding one is the
         # roof it sits closer to
@@ -556,6 +573,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                                + ("centralized " if args.framework == "centralized" else "")
                                + ("nofrl: one actor/critic/target/Adam/replay set per (platoon, vehicle)"
                                   if mode == "nofrl" else
+                                  ("intrafrl+gradients: one set per (platoon, vehicle), every agent stepping with the mean gradient of its platoon's "
+                                   "vehicles (workers/trainer.py:189-190, 417-431)" + (", directional (lead vehicle skipped)" if args.directional else ""))
+                                  if mode == "intrafrl" else
                                   "interfrl+gradients: one weight set per vehicle index, RCCL all-reduce of grads"
                                   + (f", engine={vt.shared_engine}" + (f", hidden={args.hidden}" if args.hidden else ""))
                                   + (", WEIGHTED mean (|1 / mean of the last 10 episodic rewards| per agent, weights on the device)"
@@ -576,7 +596,8 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
         "stages_ms": stage_ms,
         "prewarm": {"steps": prewarm_steps, "seconds": args.prewarm_seconds,
                     "note": "untimed steps of the same workload before the --warmup steps (steady clocks / power state); not in `steps`, `warmup` or the timed region"},
-        "pipeline": ((f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
+        "pipeline": (fused_name if intra else
+                     (f"fused learn+Adam+Polyak kernel (avd_learn_update_act_f32 -> {lk}); the NEXT step's actor forward is "
                       "evaluated in that kernel's epilogue on the weights it has just written (same values as the separate "
                       "actor launch, which now runs only after an episode reset): its time is inside learn+update, not act+env")
                      if (fused and getattr(vt, "_act_ready", False)) else

@@ -275,6 +275,17 @@ int avd_fed_finalize_f32(int n_out, int n, float* out, float count, const float*
 int avd_fed_scatter_f32(int n_out, int n_in, int stride_out, int stride_in, int i_begin, int n, const float* src,
                         float* dst, void* stream);
 
+/* intrafrl + gradients in ONE pass over the gradient slab (workers/trainer.py:189-190, 341-342, 417-431): the M agents of
+ * platoon p (rows p*M .. p*M + M - 1 of every slab) all take the Adam + Polyak step of avd_adam_polyak_f32 with the MEAN of
+ * their M gradient rows -- avd_fed_sum_f32 + avd_fed_finalize_f32 (same summation order and scaling) + avd_fed_scatter_f32 +
+ * avd_adam_polyak_f32 without the averaged slab and its copy back. weights [P*M] or NULL: the weighted mean
+ * (federated.py:99-118). lead_skip != 0: intra_directional_averaging -- vehicle 0 of every platoon takes no step (no Adam, no
+ * soft update, :417-418; the caller must not advance its step count either) while its gradient still enters the mean.
+ * step [P*M]: the agents' Adam iteration counts, already advanced by the caller for the agents that step. */
+int avd_adam_polyak_intra_f32(const avd_mlp_layout* lay, int P, int M, int lead_skip, float* theta, float* stats, float* theta_t,
+                              float* stats_t, float* m, float* v, const float* grads, const int32_t* step, const float* weights,
+                              float actor_lr, float critic_lr, double tau, void* stream);
+
 /* ---- federated weights in the throughput modes (workers/trainer.py:385-398, 694; src/server/federated.py:99-118) ----
  * The reference weights agent (p, m) by |1 / mean(all_ep_reward_lists[p][m][-weighted_window:])| from `training_episode >=
  * weighted_window` on. With the episode bookkeeping on the device the history lives there too:

@@ -305,7 +305,11 @@ def test_intrafrl_directional_and_weights_aggregation_semantics():
     assert int(vt.agents.step.view(P, M)[0, 0]) == 0 and int(vt.agents.step.view(P, M)[0, 1]) == 2
     assert torch.equal(th[0, 1], th[0, 2]) and not torch.equal(th[0, 1], th[1, 1])  # same mean grad inside a platoon
     g = vt.grads.view(P, M, -1)
-    assert torch.equal(g[1, 0], g[1, 2])  # the scattered intra-platoon mean
+    # (r06: the platoon's mean is formed inside the Adam pass, avd_adam_polyak_intra_f32 -- the slab keeps the agents' OWN gradients;
+    #  the followers' identical moments show that they stepped with one and the same mean)
+    assert not torch.equal(g[1, 0], g[1, 2])
+    mm = vt.agents.m.view(P, M, -1)
+    assert torch.equal(mm[1, 1], mm[1, 2]) and mm[1, 1].abs().max() > 0 and (mm[:, 0] == 0).all()
     # --- interfrl + weights aggregation with delay 2: odd steps train locally, even steps overwrite everything
     conf = config.Config(num_platoons=P, pl_size=M, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False,
                          aggregation_method="weights", fed_update_delay=0.2)
@@ -774,3 +778,35 @@ def test_cli_throughput_mode_with_per_platoon_episodes(tmp_path, capsys):
     assert "platoon 1:" in out and "platoon 2:" in out and "platoon 3:" not in out
     with pytest.raises(SystemExit):
         cli.main(["tr", "--episodes", "platoon", "--out", str(tmp_path)])  # host RNG: refused
+
+
+@pytest.mark.parametrize("weighted,directional", [(False, False), (False, True), (True, True)])
+def test_intrafrl_mean_inside_the_adam_pass_equals_the_four_kernel_path(weighted, directional):
+    """intrafrl + gradients (workers/trainer.py:189-190, 417-431) with the platoon's mean gradient formed where Adam
+    consumes it (avd_adam_polyak_intra_f32: the gradient slab is read once) against fed_sum + fed_finalize + fed_scatter + apply
+    with the lead vehicle's slabs saved and restored (the r05 path; VecTrainer.intra_fused = False), and the two-stream pipeline
+    over platoon chunks against both: 75 steps = 11 updates from identical Philox streams. Same summation order and scaling ->
+    the SAME BITS in every weight, moment, target and Adam step count (lead vehicles: untouched under directional averaging)."""
+    need_gpu()
+    P, L = 37, 5
+    conf = config.Config(num_platoons=P, pl_size=L, buffer_size=256, fed_method="intrafrl", weighted_average_enabled=weighted,
+                         weighted_window=2, intra_directional_averaging=directional, episode_sim_time=1.5)
+    runs = []
+    for fused, chunks in ((False, 1), (True, 1), (True, 6)):
+        vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=21, pipeline_chunks=chunks)
+        vt.intra_fused = fused
+        vt.reset_episode()
+        for _ in range(75):
+            vt.step()
+        torch.cuda.synchronize()
+        runs.append(vt)
+    ref = runs[0]
+    assert int(ref.agents.step.view(P, L)[0, 1]) == 11 and not torch.equal(ref.agents.theta, ref.agents.theta_t)
+    if directional:
+        assert int(ref.agents.step.view(P, L)[:, 0].max()) == 0  # lead vehicles never stepped
+    if weighted:
+        assert (ref._w_raw != 1).any()  # the weights did switch on (episode >= window)
+    for vt in runs[1:]:
+        for name in ("theta", "theta_t", "stats_t", "m", "v", "step"):
+            assert torch.equal(getattr(vt.agents, name), getattr(ref.agents, name)), name
+        assert torch.equal(vt.env.x, ref.env.x)
