@@ -286,7 +286,7 @@ class VecTrainer:
         env.x, env.x_prev = env.x_prev, env.x
         call("avd_step_fused_f32", ptr(env.d_consts), self.P, self.L, self.S, ptr(env.x_prev), ptr(env.x), ptr(env.prev_a),
              ptr(env.cum_accel), ptr(env.reward), ptr(env.term), ptr(env.done), ptr(env.any_done), ptr(other),
-             ptr(self.actor_out), ptr(ou.state), ptr(self.actions), ptr(self.leader_exog), conf.theta, 0.0, conf.ou_dt,
+             ptr(self.actor_out), ptr(ou.state), ptr(self.actions), ptr(self.leader_exog), conf.theta, ou.mean, conf.ou_dt,
              conf.std_dev, conf.action_low, conf.action_high, conf.reset_max_u, 1 if conf.rand_gen == conf.uniform else 0,
              self.seed, ou.calls, self.exog_calls, ptr(rp.ring), rp.cap, rp.buffer_counter, ptr(self.ep_reward), stream_handle())
         ou.calls += 1

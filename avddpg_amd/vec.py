@@ -189,9 +189,10 @@ class VecPlatoon:
 class VecOUNoise:
     """n independent scalar OU processes (reference src/noise.py)."""
 
-    def __init__(self, n, config, device=None, rng="host", seed=1):
+    def __init__(self, n, config, device=None, rng="host", seed=1, mean=0.0):
         self.n, self.config, self.device = int(n), config, _dev(device)
         self.rng, self.seed, self.calls = rng, int(seed), 0
+        self.mean = float(mean)  # the level every process reverts to (src/noise.py:7, 17; the reference trainer passes zeros)
         self.state = torch.zeros(self.n, dtype=torch.float32, device=self.device)  # x_prev = 0 (noise.py:29)
 
     def reset(self):
@@ -205,7 +206,7 @@ class VecOUNoise:
             if normals is None:
                 normals = np.random.normal(0, 1.0, size=self.n)
             d_n = torch.from_numpy(np.asarray(normals, dtype=np.float32).reshape(self.n)).to(self.device)
-        call("avd_ou_step_f32", self.n, ptr(self.state), ptr(d_n), c.theta, 0.0, c.ou_dt, c.std_dev, self.seed,
+        call("avd_ou_step_f32", self.n, ptr(self.state), ptr(d_n), c.theta, self.mean, c.ou_dt, c.std_dev, self.seed,
              self.calls, stream_handle())
         self.calls += 1
         return self.state

@@ -258,6 +258,37 @@ def test_ou_noise_matches_reference_sequence():
     assert not torch.equal(s1, s2)
 
 
+def test_ou_noise_with_a_non_zero_mean_follows_the_reference_recurrence():
+    """src/noise.py:15-19 with mean != 0 (the class refused it although avd_ou_step_f32 takes `mean`): the
+    reference-shaped OUActionNoise against the oracle's float64 restatement of the reference class on the same global RNG stream --
+    a scalar mean, a vector of equal means and a vector of DIFFERENT means (one process per element) with an x_init; bit-exact
+    against the float32 recurrence for the batched class."""
+    from avddpg_amd import noise
+
+    need_gpu()
+    conf, _ = conf_and_ep()
+    for mean, x_init in ((np.array([0.3]), None), (np.array([-0.7, -0.7, -0.7]), None), (np.array([0.5, -0.2]), np.array([1.0, 2.0]))):
+        a = noise.OUActionNoise(mean=mean, x_init=x_init, config=conf)
+        b = onoise.RefOUNoise(mean.astype(np.float64), std_dev=conf.std_dev, theta=conf.theta, dt=conf.ou_dt, x_init=x_init)
+        np.random.seed(31)
+        seq_a = [a() for _ in range(300)]
+        np.random.seed(31)  # (both draw from the global legacy stream: one after the other, from the same seed)
+        seq_b = [b() for _ in range(300)]
+        for k, (xa, xb) in enumerate(zip(seq_a, seq_b)):
+            assert xa.shape == mean.shape and np.allclose(xa, xb, rtol=1e-5, atol=1e-6), (k, xa, xb)
+        assert np.all(np.abs(xa - mean) < np.abs((x_init if x_init is not None else 0.0) - mean))  # it does revert towards the mean
+        a.reset()
+        assert np.array_equal(a.x_prev, x_init if x_init is not None else np.zeros_like(mean))
+    ou = vec.VecOUNoise(4, conf, mean=0.25)
+    x32 = np.zeros(4, np.float32)
+    rs = np.random.RandomState(3)
+    for k in range(64):
+        n = rs.normal(size=4).astype(np.float32)
+        out = ou(n)
+        x32 = onoise.batched_ou_step(x32, n, mean=0.25, dtype=np.float32)
+        assert np.array_equal(out.cpu().numpy(), x32)  # bit-exact vs the f32 oracle
+
+
 def test_policy_clip_and_noise():
     need_gpu()
     from avddpg_amd._hip import call, ptr, stream_handle

@@ -158,8 +158,28 @@ def test_reference_object_api_roundtrip():
         rb.add((prev[0], actions[0], rewards[0], states[0]))
         prev = states
     assert rb.buffer_counter == 70 > conf.batch_size
+    # the fused equivalents the north star names (avddpg_amd.ddpgagent.act / .learn): act == the per-model policy(actor(state), noise)
+    # loop of workers/trainer.py:286-289 -- one actor launch + one clip launch --, with and without noise, same draws in the same order
+    M_ = env.num_models
+    loop = np.array([ddpgagent.policy(actor(np.asarray(prev[m])[None]), None, conf.action_low, conf.action_high)[0] for m in range(M_)])
+    assert np.array_equal(ddpgagent.act([actor] * M_, prev, None, conf.action_low, conf.action_high), loop)
+    twins = [noise.OUActionNoise(mean=np.zeros(1), x_init=np.array([0.01 * (m % M_ + 1)]), config=conf) for m in range(2 * M_)]
+    st = np.random.get_state()
+    loop = np.array([ddpgagent.policy(actor(np.asarray(prev[m])[None]), twins[m], conf.action_low, conf.action_high)[0] for m in range(M_)])
+    np.random.set_state(st)
+    fused = ddpgagent.act([actor] * M_, prev, twins[M_:], conf.action_low, conf.action_high)
+    assert np.array_equal(fused, loop) and not np.array_equal(fused, ddpgagent.act([actor] * M_, prev, None, conf.action_low, conf.action_high))
+    others = [t_actor, actor, t_actor]  # different models per row: the per-set form of the same launch
+    t_actor.set_weights([w * 1.5 for w in actor.get_weights()])
+    mixed = ddpgagent.act(others[:M_], prev, None, conf.action_low, conf.action_high)
+    assert np.array_equal(mixed, np.array([ddpgagent.policy(others[m](np.asarray(prev[m])[None]), None, conf.action_low, conf.action_high)[0]
+                                           for m in range(M_)]))
+    t_actor.set_weights(actor.get_weights())
     np.random.seed(11)
     cg, ag = trainer.Trainer.learn(rb, actor, critic, t_actor, t_critic)
+    np.random.seed(11)
+    cg2, ag2 = ddpgagent.learn(rb, actor, critic, t_actor, t_critic)
+    assert all(np.array_equal(x, y) for x, y in zip(cg + ag, cg2 + ag2))
     np.random.seed(11)
     idx = np.random.choice(70, 64)
     ring = rb._v.ring.cpu().numpy()[0]
