@@ -42,7 +42,11 @@ def get_cmdl_args(argv, conf):
                          "all; per-episode reward CSVs in the reference's schema). platoon: THROUGHPUT mode (needs --rng device): "
                          "total_time_steps steps with every platoon running its own episodes on the device (avd_episode_end_f32), no "
                          "host synchronisation per step; writes curve.csv (episodes closed, mean episodic reward and length per "
-                         "reporting window, evaluator score) instead of the per-episode CSVs (not in the reference CLI)")
+                         "reporting window, evaluator score) instead of the per-episode CSVs (not in the reference CLI). The schedule "
+                         "flags keep their meaning on an episode-EQUIVALENT clock (step // steps_per_episode: --fed_update_count, "
+                         "--fed_cutoff_ratio); --fed_weight_enabled weights every agent by |1 / mean of its last fed_weight_window closed "
+                         "episodes' rewards| from a device-side history, from step fed_weight_window x steps_per_episode on; conf.json "
+                         "records the rule (episodes_mode, episode_clock)")
     tr.add_argument("--report_every", type=int, default=10000, help="--episodes platoon: steps per curve point")
     tr.add_argument("--save_platoons", type=int, default=None,
                     help="checkpoint the agents of the first N platoons only (default: all with --episodes reference, 4 with platoon)")
@@ -51,6 +55,8 @@ def get_cmdl_args(argv, conf):
     es.add_argument("exp_path", type=str)
     es.add_argument("--n_timesteps", type=int, default=100)
     args = ap.parse_args(argv)
+    if getattr(args, "save_platoons", None) is not None and args.save_platoons < 1:
+        ap.error("--save_platoons must be >= 1 (esim reloads platoon 1's actors)")
     return args, set_args_to_config(args, conf)
 
 
@@ -119,6 +125,14 @@ def main(argv=None, conf=None):
             artifacts.generate_csvs(base, conf, ep, avg)
         n_save = vt.P if args.save_platoons is None and args.episodes == "reference" else min(vt.P, 4 if args.save_platoons is None else args.save_platoons)
         artifacts.save_agents(base, vt.agents, n_save, vt.M, shared=vt.shared)
+        # what ran, beside the reference's fields: how many platoons' agents the directory holds (esim loops over exactly these),
+        # which episode rule applied and what the schedule predicates' `training_episode` was
+        conf.saved_platoons = int(n_save)
+        conf.episodes_mode = args.episodes
+        conf.episode_clock = ("workers/trainer.py:232-273: one episode loop for all platoons, any terminal platoon ends it" if args.episodes == "reference"
+                              else "per-platoon episodes on the device; schedule predicates on step // steps_per_episode; weighted averaging "
+                                   "(if enabled) from step weighted_window x steps_per_episode on, weights from each agent's last "
+                                   "weighted_window closed episodes")
         artifacts.config_writer(os.path.join(base, "conf.json"), conf)
         print(base)
     elif args.mode == "esim":
@@ -128,9 +142,12 @@ def main(argv=None, conf=None):
         # decentralized, ONE model of 4L states / L actions and widths x1.2 centralized (src/environment.py:35-52)
         shape = vec.VecPlatoon(1, conf.pl_size, conf, rng="device")  # device RNG: consumes no np.random draws
         M = shape.num_models
-        for p in range(1, conf.num_platoons + 1):
+        # a run saved with --save_platoons N holds the first N platoons' agents: conf.json says how many (older directories: all)
+        import json
+        saved = json.load(open(os.path.join(args.exp_path, "conf.json"))).get("saved_platoons", conf.num_platoons)
+        for p in range(1, int(saved) + 1):
             if not os.path.exists(os.path.join(args.exp_path, artifacts.FNAME["actor"] % (p, 1) + ".npz")):
-                break  # (a run saved with --save_platoons N holds the first N platoons' agents)
+                raise FileNotFoundError(f"{args.exp_path}: no checkpoint of platoon {p}'s actors (conf.json records {saved} saved platoons)")
             grp = vec.AgentGroup(M, shape.num_states, shape.num_actions, conf, hidd_mult=shape.hidden_multiplier)
             for m in range(M):
                 grp.set_weights(m, "actor", artifacts.load_actor_weights(args.exp_path, p, m + 1))

@@ -505,6 +505,17 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                 roofs[0]["traffic"] = t_
                 roofs[0]["traffic_note"] = ("HBM-side bytes per learn over all launches of the chain, PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (calibrated in "
                                             "the same pass), %s (matrix-core bound: reported, not the binding roof)" % (*cal(d), src))
+        if intra and not args.hidden:
+            d, src = pmc(f"pmc_traffic_intrafrl{shape_tag}.json")
+            if d:
+                n_steps = next((v["launches"] for n, v in d["kernels"].items() if "step_fused_kernel" in n), 0)
+                ks = [v for n, v in d["kernels"].items() if "learn_kernel_l" in n or "adam_polyak_intra" in n or "polyak_intra" in n]
+                if n_steps and ks:
+                    per_step = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks) / n_steps
+                    for r in roofs:
+                        r["traffic"] = per_step
+                        r["traffic_note"] = ("HBM-side bytes per step over the learn chunks and the mean + Adam + Polyak passes, PMC FETCH_SIZE x %.3f + "
+                                             "WRITE_SIZE x %.3f (calibrated in the same pass), %s" % (*cal(d), src))
         if mode == "interfrl" and batched and not fset and args.hidden:
             d, src = pmc(f"pmc_traffic_interfrl{shape_tag}.json")
             t_ = d and chain_bytes(d, lambda n: "fw::" in n or "wide::" in n, "losses_kernel")

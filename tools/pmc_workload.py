@@ -3,7 +3,7 @@
 16 bytes per lane -- whose FETCH_SIZE / WRITE_SIZE calibrate the counters IN THE SAME PASS (MI355X_MICROARCH.md, HBM: FETCH_SIZE
 reports 1/2 of wide coalesced reads on gfx950; VERDICT r03 weak #8 asked for a calibration that calibrates), then (2) a few steps of
 one bench workload at 4096 x L (L = 5; 10 = BASELINE configs[2]; hidden = 1024 = configs[4], interfrl only).
-usage: pmc_workload.py interfrl|nofrl|centralized [steps] [L] [hidden]"""
+usage: pmc_workload.py interfrl|nofrl|intrafrl|centralized [steps] [L] [hidden]"""
 import os
 import sys
 
@@ -23,11 +23,12 @@ for _ in range(3):
     torch.add(src, 1.0, out=dst)  # ONE vectorized elementwise kernel: reads 1 GiB, writes 1 GiB (a plain copy_ would be a DMA, not a kernel)
 torch.cuda.synchronize()
 del src, dst
-conf = config.Config(num_platoons=4096, pl_size=L, buffer_size=2048, fed_method="interfrl" if mode == "interfrl" else "normal",
+conf = config.Config(num_platoons=4096, pl_size=L, buffer_size=2048, fed_method={"interfrl": "interfrl", "intrafrl": "intrafrl"}.get(mode, "normal"),
                      weighted_average_enabled=False, framework="centralized" if mode == "centralized" else "decentralized")
 if hidden:
     conf.actor_layer1_size = conf.actor_layer2_size = conf.critic_layer1_size = conf.critic_layer2_size = hidden
-vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1, fused_update=(mode != "interfrl"),
+vt = trainer.VecTrainer(conf, rng="device", auto_reset=True, seed=1, fused_update=(mode not in ("interfrl", "intrafrl")),
+                        pipeline_chunks=16 if mode == "intrafrl" else 1,
                         shared_engine=("batched" if hidden else "fused3") if mode == "interfrl" else None)
 vt.replay.ring.normal_(0.0, 1.0)
 vt.replay.buffer_counter = conf.buffer_size
