@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libavddpg_hip.so")
-if os.environ.get("AVDDPG_HIP_LIB"):  # diagnostics: A/B another build of the same library (tools/ab.sh)
+if os.environ.get("AVDDPG_HIP_LIB"):  # diagnostics: A/B another build of the same library (tools/ab.sh @ tag r06-pre-prune)
     LIB_PATH = os.path.abspath(os.environ["AVDDPG_HIP_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avddpg_hip.h")
 AVD_MAX_L = 16

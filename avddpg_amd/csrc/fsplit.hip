@@ -905,7 +905,7 @@ __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {
 
     // Staging. sm (335 MB per pass, from HBM): 64 rows x 8 chunks of 32 bytes, one chunk per thread, TWO tiles ahead in two
     // register sets used alternately -- one tile of lookahead (~2.5 us) does not cover the tail of the HBM latency over 512
-    // threads and a barrier: measured, a third of the kernel was the wait for it (tools/fsplit_ablate.sh). The inputs
+    // threads and a barrier: measured, a third of the kernel was the wait for it (tools/fsplit_ablate.sh @ tag r06-pre-prune). The inputs
     // (states, g3, actions: 31 MB, L2 / Infinity-Cache resident): one tile ahead, threads 0..127 build the |g3|-scaled fragment
     // of (row, lane half) = (tid >> 1, tid & 1) once per tile.
     const int srow = tid >> 3, sch = tid & 7, frow = tid >> 1, fh = tid & 1;

@@ -21,7 +21,7 @@ constexpr float BN_EPS = 1e-3f;
 __host__ __device__ constexpr int ld_of(int k) { return ((k >> 2) & 1) ? k : k + 4; }
 
 #ifdef AVD_PHASE_TIMING
-// Diagnostic build only (tools/phase_profile.py): per-phase shader-cycle sums of workgroup thread 0.
+// Diagnostic build only (tools/phase_profile.py @ tag r06-pre-prune): per-phase shader-cycle sums of workgroup thread 0.
 static __device__ unsigned long long g_phase_cycles[32];  // per translation unit (mlp.hip reads its own)
 #define PH_INIT() unsigned long long ph_last = clock64()
 #define PH(id)                                                                  \

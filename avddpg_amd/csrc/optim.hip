@@ -360,7 +360,7 @@ static int adam_polyak_launch(const char* who, bool guard, const avd_mlp_layout*
     const int n4 = lay->theta_size / 4;
     int gx = (n4 + 255) / 256;
     if (n_sets >= 256 && gx > 8) gx = 8;  // many sets: fewer, longer-lived blocks per set
-    if (const char* e = AVD_DIAG_ENV("ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh)
+    if (const char* e = AVD_DIAG_ENV("ADAM_GX")) gx = atoi(e);  // tuning knob (tools/adam_sweep.sh @ tag r06-pre-prune)
     if (guard)
         hipLaunchKernelGGL(adam_polyak_kernel<true>, dim3(gx, n_sets), dim3(256), 0, (hipStream_t)stream, lay->theta_size, lay->actor_size,
                            (float4*)theta, (float4*)theta_t, (float4*)m, (float4*)v, (const float4*)grads, step, actor_lr, critic_lr, tauf,

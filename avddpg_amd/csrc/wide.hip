@@ -1066,7 +1066,7 @@ struct FwdP {
                              // 16 four of the 16 accumulating MFMAs, 32 no fragment reads): wrong results
 };
 
-// diagnostics build (-DAVD_FW_DBG): AVD_FW_DBG=<bits> switches pieces of the kernel off (tools/c5_dbg.sh; results wrong)
+// diagnostics build (-DAVD_FW_DBG): AVD_FW_DBG=<bits> switches pieces of the kernel off (tools/c5_dbg.sh @ tag r06-pre-prune; results wrong)
 #ifdef AVD_FW_DBG
 #define FW_DBG(bit) (p.dbg & (bit))
 #else

@@ -234,7 +234,7 @@ SPLIT_TOL = 2e-5  # tests/test_gpu_fsplit.py
 # (Nearly untrained networks -- 70 steps from the initialiser: critic output weights U(+-3e-4), actor gradients of 1e-8 -- were
 # the worst case of r03's bf16 operand pairs: 2.1e-5 on actor tensors, 2.07e-5 on cWa at 4096 x 10. With every operand an fp16
 # pair (r04) the same states measure <= 9e-6, one tensor 1.6e-5 where the exact-f32 engine shows the same 1.6e-5 -- a relu tie;
-# tools/r04_trainer_state_errors.py, profiles/r04_trainer_state_errors.txt. No looser constant is needed here.)
+# tools/r04_trainer_state_errors.py @ tag r06-pre-prune, profiles/r04_trainer_state_errors.txt. No looser constant is needed here.)
 
 
 @pytest.mark.parametrize("L", [5, 10])

@@ -5,7 +5,7 @@ workers/trainer.py:472-508), so the bar is float32's own, enforced here rather t
 
   SPLIT_TOL = 2e-5 of each gradient tensor's max against the float64 oracle (or 4 x the float32 ORACLE's own error on the same
   batch where that is larger) -- 5 x tighter than the 1e-4 the exact-f32 kernels are held to (tests/test_gpu_mlp.py GRAD_TOL).
-  Measured (tools/r04_precision_probe.py, profiles/r04_precision_probe.txt): <= 5e-7 at 64 ... 4480 rows per set (asserted at
+  Measured (tools/r04_precision_probe.py @ tag r06-pre-prune, profiles/r04_precision_probe.txt): <= 5e-7 at 64 ... 4480 rows per set (asserted at
   SPLIT_TOL_SMALL = 4e-6; the float32 NumPy oracle sits at 1e-6 there, r03's bf16 pairs sat at 5.6e-6), <= 1.1e-5 per tensor at
   4096 x 5 (262 144 rows per set; one relu-tie row is worth ~1e-5 there), where the exact-f32 per-agent engine + fed_mean sits at
   <= 1.5e-5 and the float32 NumPy oracle at <= 1.8e-4.
@@ -63,7 +63,7 @@ def _untie(grp, M, S, s, a, tie=1e-6):
     """The relu derivative is discontinuous at 0: a row with a pre-activation within float32 resolution of 0 in a layer that is
     differentiated has no defined float32 gradient -- the same arithmetic in another order decides the sign the other way, and
     ONE such row moves the actor's first-layer gradient of a 4480-row batch by 1e-3 of its max (seen: |z2| = 1.1e-8 at scale
-    0.8 in one row of 22400; tools/fsplit_both_debug.py). The CONDITIONED tests nudge such rows (in place, deterministically)
+    0.8 in one row of 22400; tools/fsplit_both_debug.py @ tag r06-pre-prune). The CONDITIONED tests nudge such rows (in place, deterministically)
     until none is left; the unconditioned test below runs the same inputs as they are and accounts for every tie. Returns the
     number of nudges."""
     nudged = 0
