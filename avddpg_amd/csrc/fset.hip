@@ -499,7 +499,7 @@ struct DwArgs {
 };
 // Wave w = (fg, wn): feature tiles fg*NFT/2 .. of column quarter wn. The first-layer tile is computed with the batch rows as
 // the M index (result: feature on the lane, rows in the registers) and used straight as the A operand of G = P1^T . dZ2
-// (k order permuted, tools/probes/mfma_layout.hip @ tag r06-pre-prune); the dZ2 tile goes through LDS (row stride 320 B: conflict-free for
+// (k order permuted, tools/probes/mfma_layout.hip); the dZ2 tile goes through LDS (row stride 320 B: conflict-free for
 // ds_read_b64_tr_b16, which delivers it reduction-contiguous in exactly that order). One barrier per tile.
 template <int S, class NET>
 __global__ __launch_bounds__(NT) void dw_kernel(const DwArgs p) {

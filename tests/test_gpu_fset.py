@@ -218,7 +218,7 @@ def test_trainer_fused_engine_weighted_federation_runs_model_a():
 def test_mfma_layout_probe_passes_on_this_gpu():
     """The three hardware layouts csrc/fset.hip is built on -- v_mfma_f32_32x32x16_bf16 lane maps, an accumulator tile as the
     next MFMA's A operand (permuted k order), ds_read_b64_tr_b16 as the B operand of that product -- checked with exact
-    small-integer data by tools/probes/mfma_layout.hip @ tag r06-pre-prune on the GPU the tests run on."""
+    small-integer data by tools/probes/mfma_layout.hip on the GPU the tests run on."""
     import os
     import subprocess
 
