@@ -408,51 +408,53 @@ __global__ void fed_history_push_kernel(int P, int M, int W, float* __restrict__
     hist_cnt[p] = c + 1;
 }
 
-// fed_weights_kernel: one block per vehicle index m. enabled = host_enabled (0 / 1), or, when host_enabled < 0, "every platoon has
-// closed at least W episodes" (the reference's `training_episode >= weighted_window`, trainer.py:694: with the all-platoons episode
-// rule every count is the episode number). Enabled: w = |1 / mean(ring row)| (the W entries summed in slot order, float32),
-// wsum[m] = sum_p w, agent_weight = w P / wsum[m] (the factor the set learners take); disabled: w = agent_weight = 1, wsum[m] = P
-// -- the weighted formulas then give the plain mean.
-__global__ __launch_bounds__(256) void fed_weights_kernel(int P, int M, int W, const float* __restrict__ ring,
-                                                          const int32_t* __restrict__ hist_cnt, int host_enabled,
-                                                          float* __restrict__ w_raw, float* __restrict__ aw, float* __restrict__ wsum) {
-    __shared__ float part[256];
-    __shared__ int cmin[256];
+// fed_weights: two launches. (1) fed_weights_w_kernel, one thread per agent: the candidate weight |1 / mean(ring row)| (the W entries
+// summed in slot order, float32). (2) fed_weights_kernel, one block of 1024 threads per vehicle index m: enabled = host_enabled (0 / 1),
+// or, when host_enabled < 0, "every platoon has closed at least W episodes" (the reference's `training_episode >= weighted_window`,
+// trainer.py:694: with the all-platoons episode rule every count is the episode number). Enabled: w = the candidate, wsum[m] = sum_p w,
+// agent_weight = w P / wsum[m] (the factor the set learners take); disabled: w = agent_weight = 1, wsum[m] = P -- the weighted formulas
+// then give the plain mean. (As ONE kernel of M blocks walking P x W ring entries per block it was latency-bound: 60 us per step.)
+__global__ void fed_weights_w_kernel(long n, int W, const float* __restrict__ ring, float* __restrict__ w_cand) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    float acc = 0.f;
+    for (int k = 0; k < W; ++k) acc += ring[v * W + k];
+    w_cand[v] = fabsf(1.0f / (acc / (float)W));
+}
+__global__ __launch_bounds__(1024) void fed_weights_kernel(int P, int M, int W, const int32_t* __restrict__ hist_cnt, int host_enabled,
+                                                           float* __restrict__ w_raw, float* __restrict__ aw, float* __restrict__ wsum) {
+    __shared__ float part[1024];
+    __shared__ int cmin[1024];
     const int m = blockIdx.x, tid = threadIdx.x;
     int enabled = host_enabled;
     if (host_enabled < 0) {
         int c = 0x7fffffff;
-        for (int p = tid; p < P; p += 256) c = min(c, hist_cnt[p]);
+        for (int p = tid; p < P; p += 1024) c = min(c, hist_cnt[p]);
         cmin[tid] = c;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = 512; o > 0; o >>= 1) {
             if (tid < o) cmin[tid] = min(cmin[tid], cmin[tid + o]);
             __syncthreads();
         }
         enabled = cmin[0] >= W ? 1 : 0;
     }
     float s = 0.f;
-    for (int p = tid; p < P; p += 256) {
+    for (int p = tid; p < P; p += 1024) {
         const long v = (long)p * M + m;
-        float w = 1.0f;
-        if (enabled) {
-            float acc = 0.f;
-            for (int k = 0; k < W; ++k) acc += ring[v * W + k];
-            w = fabsf(1.0f / (acc / (float)W));
-        }
+        const float w = enabled ? w_raw[v] : 1.0f;  // (w_raw holds the candidates)
         w_raw[v] = w;
         s += w;
     }
     part[tid] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {  // fixed tree: the same bits on every launch
+    for (int o = 512; o > 0; o >>= 1) {  // fixed tree: the same bits on every launch
         if (tid < o) part[tid] += part[tid + o];
         __syncthreads();
     }
     const float total = part[0];
     if (tid == 0) wsum[m] = total;
     const float f = (float)P / total;
-    for (int p = tid; p < P; p += 256) {
+    for (int p = tid; p < P; p += 1024) {
         const long v = (long)p * M + m;
         aw[v] = enabled ? w_raw[v] * f : 1.0f;
     }
@@ -552,7 +554,9 @@ extern "C" int avd_fed_weights_f32(int P, int M, int W, const float* ring, const
                                    float* agent_weight, float* wsum, void* stream) {
     AVD_REQUIRE(P > 0 && M > 0 && M <= 65535 && W > 0 && ring && hist_cnt && w_raw && agent_weight && wsum,
                 "avd_fed_weights_f32: P=%d M=%d W=%d", P, M, W);
-    hipLaunchKernelGGL(fed_weights_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, M, W, ring, hist_cnt, host_enabled, w_raw,
+    const long n = (long)P * M;
+    hipLaunchKernelGGL(fed_weights_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, W, ring, w_raw);
+    hipLaunchKernelGGL(fed_weights_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, P, M, W, hist_cnt, host_enabled, w_raw,
                        agent_weight, wsum);
     return check_launch("avd_fed_weights_f32");
 }

@@ -1539,7 +1539,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         int stg = 0;
         float s2acc = 0.f;  // sum_n d[n] mask[n][column tid] over this item's share of the rows
+        // (a ninth feature block -- the critic's -- has no rows left to sum: it goes through the same motions on rows 0..3 and keeps the
+        //  result to itself. Without them it ran a few per cent ahead of the stream's other blocks, out of the window in which they
+        //  share the chunks in L2: 8.2 GB fetched for 2.7)
         const bool s2on = fb < 8;
+        const int fbr = fb & 7;
         auto step = [&](int kt, auto wait_c) {
             constexpr bool WAIT = decltype(wait_c)::value;
             // ================= prepare(kt)
@@ -1550,11 +1554,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // fragment + sign words of chunk kt + 1 (its record rides in this stage)
             const bf16x8 xn = *(const bf16x8*)(l + fofs);
             const wide::u32x4 sg0 = *(const wide::u32x4*)(l + sofs), sg1 = *(const wide::u32x4*)(l + sofs + 16);
-            if (s2on) {  // (uniform per workgroup)
-                const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fb);
+            {
+                const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fbr);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned m = *(const unsigned short*)(l + (4 * fb + i) * DW_ROWB + tid * 2);
+                    const unsigned m = *(const unsigned short*)(l + (4 * fbr + i) * DW_ROWB + tid * 2);
                     s2acc = fmaf(__uint_as_float(m << 16), dv[i], s2acc);
                 }
             }
