@@ -426,6 +426,11 @@ def cmd_big(args):
         out["nofrl"] = big_run(f"nofrl_{args.nofrl_platoons}x{args.pl_size}_per_platoon_episodes", conf, args.nofrl_steps, args.out,
                                report=args.report, eval_every=args.eval_every, auto_reset="platoon", fused_update=True,
                                eval_platoons=tuple(range(min(8, args.nofrl_platoons))))
+    if "wide_bf16" in runs:  # the bf16 engine alone at BASELINE configs[4]'s full size (the float32 PyTorch reference is too slow there)
+        conf = config.Config(num_platoons=args.wide_platoons, fed_method="interfrl", actor_layer1_size=1024, actor_layer2_size=1024,
+                             critic_layer1_size=1024, critic_layer2_size=1024, **base)
+        out["wide_bf16"] = big_run(f"interfrl_{args.wide_platoons}x{args.pl_size}_hidden1024_bf16_engine", conf, args.wide_steps, args.out,
+                                   report=args.report, eval_every=args.eval_every, auto_reset="platoon", shared_engine="batched")
     if "wide" in runs:
         # BASELINE configs[4]'s width (hidden 1024): the bf16 layer-wise engine (csrc/wide.hip) against the float32 PyTorch reference
         # trainer on the same Philox streams (tie the 6 % gradient tolerance of the bf16 operands to an outcome)
