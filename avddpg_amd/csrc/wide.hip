@@ -996,7 +996,11 @@ __global__ void prep_wf1_kernel(const float* th, long set_th, int S, int ws_off,
 //   [2112, 2240)  d of the 32 rows of chunk j - 1 (the mask chunk that travels in the same stage), f32
 // Rows >= Ns give zero fragments and d = 0 (their mask rows are whatever the forward made of a zero input).
 // ------------------------------------------------------------------------------------------
-constexpr int AUX_REC = 2304, AUX_ACT = 1024, AUX_SGN = 2048, AUX_D = 2112, AUX_PIECE = AUX_REC / 8;
+constexpr int AUX_REC = 2304, AUX_ACT = 1024, AUX_SGN = 2048, AUX_D = 2112;
+// dw_gen_kernel streams a record as one UNMASKED wave instruction per wave: wave w moves bytes [256 w, 256 w + 1024) -- the eight
+// overlapping KiB cover the record and 512 B of the next one, overlaps carry identical bytes (an exec-masked instruction of 18 lanes per
+// wave put a branch into the prepare phase)
+constexpr int AUX_LDS = 7 * 256 + 1024;
 __global__ __launch_bounds__(64) void aux_pack_kernel(const float* X, long setX, const float* act, long setAct, const float* d, long setD,
                                                       int Ns, int Np, unsigned char* aux, long setAux, float* dclean) {
     __shared__ float sd[32];
@@ -1314,7 +1318,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
                 const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
                 const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
-                if (__builtin_expect(kt + 2 == nk && (wv >> 1) == 0, 0)) build_x(tile + gridDim.x, xb ^ 1);  // (scalar, out of line; read from the next prepare phase on)
+                // (scalar, out of line; read from the next prepare phase on. Peeling step nk - 2 out of the loop instead -- no branch in
+                //  the loop body -- made the kernel 7-9 % SLOWER, r06: three copies of the step, 100 B more scratch)
+                if (__builtin_expect(kt + 2 == nk && (wv >> 1) == 0, 0)) build_x(tile + gridDim.x, xb ^ 1);
                 if (!FW_DBG(1)) {
                     int kc = kt + FSTG - 1;
                     kc -= kc >= nk ? nk : 0;
@@ -1425,7 +1431,7 @@ struct DwP {
 
 // stage = the chunk's 32 mask rows (512 columns each, row stride 1088 B: the transposed reads below are conflict-free) + the record
 // of the NEXT chunk's fragments
-constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + AUX_REC;
+constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + AUX_LDS;
 template <bool CRITIC>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_gen_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1495,8 +1501,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             wf[ft] = (bf16x8){zb, zb, zb, zb, zb, zb, zb, zb};
             if (t0 + ft < p.nft) wf[ft] = p.wf1[((long)set * p.nft + t0 + ft) * 64 + lane];
         }
-        // stream: rows 4 w .. 4 w + 3 of the chunk's mask rows (512 columns = 1 KiB per instruction) + this wave's eighth of the
-        // record that holds the NEXT chunk's fragments (18 lanes x 16 B): 5 wave-instructions per chunk
+        // stream: rows 4 w .. 4 w + 3 of the chunk's mask rows (512 columns = 1 KiB per instruction) + this wave's KiB of the
+        // record that holds the NEXT chunk's fragments: 5 wave-instructions per chunk
         const char* ubw = (const char*)(p.ZT + (long)set * p.setZT + (long)(row_base + 4 * wv) * p.ldz + FC * cb);
         const unsigned char* rec0 = p.aux + (long)set * p.setAux + (long)(row_base / FK) * AUX_REC;  // record of the item's chunk 0
         const unsigned vow = (unsigned)lane * 16u;
@@ -1507,8 +1513,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ubw + ((long)kc * FK + i) * p.ldz * 2 + vw), (lptr_t)(l + (4 * wv + i) * DW_ROWB), 16, 0, 0);
-            if (lane < AUX_PIECE / 16)
-                __builtin_amdgcn_global_load_lds((gptr_t)(rec0 + (long)(kc + 1) * AUX_REC + AUX_PIECE * wv + vw), (lptr_t)(l + FK * DW_ROWB + AUX_PIECE * wv), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(rec0 + (long)(kc + 1) * AUX_REC + 256 * wv + vw), (lptr_t)(l + FK * DW_ROWB + 256 * wv), 16, 0, 0);
         };
         constexpr int NDMA = 5;
         const int fofs = FK * DW_ROWB + (action ? AUX_ACT : 0) + lane * 16, sofs = FK * DW_ROWB + AUX_SGN + h * 32;
@@ -1548,20 +1553,20 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             constexpr bool WAIT = decltype(wait_c)::value;
             // ================= prepare(kt)
             bf16x8 A[2][4];
-            read_frags(stg, 0, A[0]);
-            read_frags(stg, 1, A[1]);
             const unsigned char* l = smem_raw + stg * DW_STG;
-            // fragment + sign words of chunk kt + 1 (its record rides in this stage)
+            // fragment + sign words of chunk kt + 1 (its record rides in this stage); the four mask elements and seeds of the S2 sum.
+            // (All requested BEFORE the transposed fragment reads -- inline asm the compiler cannot count: behind them, every one of
+            //  these reads got its own lgkmcnt(0).)
             const bf16x8 xn = *(const bf16x8*)(l + fofs);
             const wide::u32x4 sg0 = *(const wide::u32x4*)(l + sofs), sg1 = *(const wide::u32x4*)(l + sofs + 16);
-            {
-                const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fbr);
+            const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fbr);
+            unsigned mrow[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned m = *(const unsigned short*)(l + (4 * fbr + i) * DW_ROWB + tid * 2);
-                    s2acc = fmaf(__uint_as_float(m << 16), dv[i], s2acc);
-                }
-            }
+            for (int i = 0; i < 4; ++i) mrow[i] = *(const unsigned short*)(l + (4 * fbr + i) * DW_ROWB + tid * 2);
+            read_frags(stg, 0, A[0]);
+            read_frags(stg, 1, A[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s2acc = fmaf(__uint_as_float(mrow[i] << 16), dv[i], s2acc);
             {
                 int kc = kt + FSTG - 1;
                 kc = kc < nk ? kc : nk - 1;  // (tail: harmless re-loads keep the vmcnt arithmetic uniform)
@@ -2578,7 +2583,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 // by fw::fwd_delta_kernel; actor: stored by its forward pass in place of the activations) -- fw::dw_gen_kernel: first layer
                 // generated per 32-row chunk, mask streamed --, then u, db2 and the cf / sh terms of dW2
                 unsigned char* aux = ws + pl.dZ2T;  // (the transposed gradient matrix of the layer-wise path: free here)
-                const long setAux = (long)(Np / fw::FK + 1) * fw::AUX_REC;
+                const long setAux = (long)(Np / fw::FK + 2) * fw::AUX_REC;  // (+ one record of slack: the stream reads 512 B past the last)
                 hipLaunchKernelGGL(fw::aux_pack_kernel, dim3((unsigned)(Np / fw::FK + 1), sets), dim3(64), 0, st, bX, setX,
                                    critic ? bAct : (const float*)nullptr, bSetAct, dvec, (long)Np, Ns, Np, aux, setAux, F32(pl.dcl));
                 fw::DwP d2;
