@@ -1679,6 +1679,7 @@ struct DxP {
     long setG;
     int w_off[2], b_off[2], g_off[2], be_off[2];  // [0] state branch, [1] action branch
     int Ns, Np, H2, H1, Ha, n_sets, nfb, groups_per_xcd;
+    int abl;  // diagnostic build only (AVD_WIDE_DX_ABL, results wrong by design): 1 = every mask tile fetched from row tile 0 (served by L2)
 };
 
 constexpr int DX_STG = 2 * 256 * FK * 2, DX_NS = 3;  // A tile + B tile; three stages (two chunks in flight)
@@ -1763,6 +1764,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         unsigned char* l = smem_raw + stg * STG_B;
         unsigned vw = vo_a;
         asm volatile("" : "+v"(vw));
+#ifdef AVD_DIAG
+        if (p.abl & 1) tl = 0;
+#endif
         const long ta = (long)tl * 256 * p.H2 * 2 + (long)kc * FK * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -2663,6 +2667,8 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         d3.w_off[0] = critic ? L.cWs : L.aW1, d3.b_off[0] = critic ? L.cbs : L.ab1, d3.g_off[0] = critic ? L.cgs : L.ag1, d3.be_off[0] = critic ? L.cbes : L.abe1;
         d3.w_off[1] = L.cWa, d3.b_off[1] = L.cba, d3.g_off[1] = L.cga, d3.be_off[1] = L.cbea;
         d3.Ns = Ns, d3.Np = Np, d3.H2 = H2, d3.H1 = H1, d3.Ha = Ha, d3.n_sets = sets;
+        static const char* dxabl = AVD_DIAG_ENV("WIDE_DX_ABL");
+        d3.abl = dxabl ? atoi(dxabl) : 0;
         // one workgroup per CU, dealt round-robin over the 8 XCDs: slots per XCD = CUs / 8 (32 on MI355X), each row group = nfb slots
         const int slots = std::max(1, avd::fset::cu_count() / 8);
         d3.nfb = H1 / 256, d3.groups_per_xcd = std::max(1, slots / d3.nfb);  // (the state features; the critic's 48 action features go the GEMM way)
