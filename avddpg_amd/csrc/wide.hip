@@ -1776,6 +1776,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if constexpr (CRITIC)
             __builtin_amdgcn_global_load_lds((gptr_t)(ub_x + (long)kc * FK * 2 + vw), (lptr_t)(l + 2 * 256 * FK * 2 + 16 * (wv & 1) * FK * 2), 16, 0, 0);
     };
+    // (r06, measured and not kept: the mask rows come from HBM and three stages give a chunk about one step to arrive -- with every tile
+    //  fetch redirected to one tile, diagnostic build AVD_WIDE_DX_ABL=1, the kernel runs 8-12 % faster. An L2 prefetch of the chunk four
+    //  steps ahead as one more LDS-DMA instruction per wave and step -- 4 bytes per lane of its 32 rows into a scratch word, counted
+    //  behind the refills -- made it 23 % SLOWER: 32 distinct lines per instruction on the in-order vm queue. A fourth stage does not
+    //  fit the LDS beside the running sums.)
     // raw inputs of row tile tl into buffer b: 64 rows per instruction, waves 4..7 repeat waves 0..3 (uniform counts)
     auto dma_x = [&](int tl, int b) {
         int n = tl * 256 + 64 * (wv & 3) + lane;
