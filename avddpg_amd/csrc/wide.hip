@@ -1411,7 +1411,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // D[c][f] = sum_n mask[n][c] (d y1)[n][f]: A = mask fragments (LDS), B = relu'd first-layer tile (lane = feature, registers = rows).
 // A work item = 128 features x 512 columns x one eighth (or less) of a set's rows, dealt over the persistent workgroups so that
 // the feature blocks of a (set, column block, row range) run side by side on the same stream; f32 atomics at the end of an item.
-// S2[c] = sum_n d[n] mask[n][c] rides along: thread t of the item with feature block fb < 8 adds rows 4 fb .. 4 fb + 3 of every
+// S2[c] = sum_n d[n] mask[n][c] rides along: thread t of the item with feature block fb < 32 / RPB adds rows RPB fb .. + RPB of every
 // chunk for column t (the stream's feature blocks share the rows between them). Same ping-pong of the two wave groups as
 // fwd_gen_kernel.
 struct DwP {
@@ -1432,7 +1432,10 @@ struct DwP {
 // stage = the chunk's 32 mask rows (512 columns each, row stride 1088 B: the transposed reads below are conflict-free) + the record
 // of the NEXT chunk's fragments
 constexpr int DW_ROWB = FC * 2 + 64, DW_STG = FK * DW_ROWB + AUX_LDS;
-template <bool CRITIC>
+// RPB = mask rows of every 32-row chunk an S2-summing feature block takes: 32 / min(8, state feature blocks) -- 4 at H1 >= 1024,
+// 8 at H1 = 512, 16 at H1 = 256 (the first 32 / RPB blocks of a stream share the rows; a compile-time trip count: a runtime loop
+// would put a branch into the prepare phase)
+template <bool CRITIC, int RPB>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_gen_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -1547,8 +1550,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // (a ninth feature block -- the critic's -- has no rows left to sum: it goes through the same motions on rows 0..3 and keeps the
         //  result to itself. Without them it ran a few per cent ahead of the stream's other blocks, out of the window in which they
         //  share the chunks in L2: 8.2 GB fetched for 2.7)
-        const bool s2on = fb < 8;
-        const int fbr = fb & 7;
+        constexpr int NSH = 32 / RPB;
+        const bool s2on = fb < NSH;
+        const int fbr = fb & (NSH - 1);
         auto step = [&](int kt, auto wait_c) {
             constexpr bool WAIT = decltype(wait_c)::value;
             // ================= prepare(kt)
@@ -1559,14 +1563,16 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             //  these reads got its own lgkmcnt(0).)
             const bf16x8 xn = *(const bf16x8*)(l + fofs);
             const wide::u32x4 sg0 = *(const wide::u32x4*)(l + sofs), sg1 = *(const wide::u32x4*)(l + sofs + 16);
-            const wide::f32x4 dv = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 16 * fbr);
-            unsigned mrow[4];
+            wide::f32x4 dv[RPB / 4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mrow[i] = *(const unsigned short*)(l + (4 * fbr + i) * DW_ROWB + tid * 2);
+            for (int q = 0; q < RPB / 4; ++q) dv[q] = *(const wide::f32x4*)(l + FK * DW_ROWB + AUX_D + 4 * RPB * fbr + 16 * q);
+            unsigned mrow[RPB];
+#pragma unroll
+            for (int i = 0; i < RPB; ++i) mrow[i] = *(const unsigned short*)(l + (RPB * fbr + i) * DW_ROWB + tid * 2);
             read_frags(stg, 0, A[0]);
             read_frags(stg, 1, A[1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s2acc = fmaf(__uint_as_float(mrow[i] << 16), dv[i], s2acc);
+            for (int i = 0; i < RPB; ++i) s2acc = fmaf(__uint_as_float(mrow[i] << 16), dv[i >> 2][i & 3], s2acc);
             {
                 int kc = kt + FSTG - 1;
                 kc = kc < nk ? kc : nk - 1;  // (tail: harmless re-loads keep the vmcnt arithmetic uniform)
@@ -2409,7 +2415,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             };
             opt_in((const void*)fw::fwd_gen_kernel<false>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true>, fw_lds);
-            opt_in((const void*)fw::dw_gen_kernel<false>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true>, fw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 4>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 4>, fw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 8>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 8>, fw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 16>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 16>, fw_lds);
             opt_in((const void*)fw::dx_gen_kernel<false>, fw::DxL<false>::TOTAL), opt_in((const void*)fw::dx_gen_kernel<true>, fw::DxL<true>::TOTAL);
             opt_in((const void*)fw::fwd_delta_kernel, fw::DL_TOTAL);
             if (e != hipSuccess) {
@@ -2615,10 +2623,17 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 const int nfb = (d2.nft * 32 + 127) / 128, items = sets * (H2 / fw::FC) * d2.nsplit * nfb;
                 (void)items;
                 const dim3 grid((unsigned)(avd::fset::cu_count() / 8 * 8));  // (a multiple of the XCD count: see the kernel's item map)
-                if (critic)
-                    hipLaunchKernelGGL((fw::dw_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, d2);
-                else
-                    hipLaunchKernelGGL((fw::dw_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, d2);
+                // (the rows of a chunk are shared by the first min(8, H1 / 128) feature blocks of a stream for the S2 sum)
+                const int nshare = std::min(8, H1 / 128);
+#define AVD_DW_LAUNCH(C, R) hipLaunchKernelGGL((fw::dw_gen_kernel<C, R>), grid, dim3(fw::FT), fw_lds, st, d2)
+                if (nshare == 8) {
+                    if (critic) AVD_DW_LAUNCH(true, 4); else AVD_DW_LAUNCH(false, 4);
+                } else if (nshare == 4) {
+                    if (critic) AVD_DW_LAUNCH(true, 8); else AVD_DW_LAUNCH(false, 8);
+                } else {
+                    if (critic) AVD_DW_LAUNCH(true, 16); else AVD_DW_LAUNCH(false, 16);
+                }
+#undef AVD_DW_LAUNCH
                 hipLaunchKernelGGL(w2_post_kernel, dim3((unsigned)rup(H2, 64) / 64, sets), dim3(1024), 0, st, n.th, (long)L.theta_size,
                                    critic ? L.cW2 : L.aW2, K, H2, n.sh, ldT, n.bias, n.cf, gnet, (long)L.theta_size, u, cs, (long)H2);
                 hipLaunchKernelGGL(out_grads_kernel, dim3((unsigned)rup(H2, 256) / 256, sets), dim3(256), 0, st, n.th, (long)L.theta_size, w3,

@@ -37,7 +37,11 @@ def test_bf16_gemm_matches_float64_on_the_same_bf16_operands(M, Nc, K):
 
 
 @pytest.mark.parametrize("S,P,widths,tol", [(4, 6, (256, 128, 48), 2e-2), (3, 4, (128, 64, 32), 2e-2), (3, 5, (64, 64, 16), 2e-2),
-                                            (4, 8, (1024, 1024, 48), 8e-2)])
+                                            (4, 8, (1024, 1024, 48), 8e-2),
+                                            # the rank-one backward (r06) with the critic's action features through the 64-column GEMM (its row
+                                            # factor in the epilogue; dx_gen_kernel<true> serves H1 = 1024 only), one and two 512-column blocks
+                                            # (H1 = 512 / 256: four / two state feature blocks share a chunk's rows for the S2 sum)
+                                            (4, 8, (512, 512, 48), 8e-2), (4, 8, (512, 1024, 32), 8e-2), (4, 8, (256, 512, 48), 8e-2)])
 def test_shared_learner_matches_oracle_on_concatenated_batch(S, P, widths, tol):
     """n_sets = 2 weight sets, P agents each: the mean of the agents' gradients == the gradient of the P*64-row batch."""
     need_gpu()
