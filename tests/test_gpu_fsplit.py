@@ -470,3 +470,36 @@ def test_guarded_update_skips_a_set_whose_slab_is_nan_and_is_bitwise_the_plain_u
     torch.cuda.synchronize()
     assert vt.nonfinite_updates() >= 1 and torch.isfinite(vt.agents.theta).all()
     assert torch.equal(vt.agents.theta[0], th[0])  # agent 0 = vehicle 0's set: skipped
+
+
+def test_guarded_update_covers_the_bf16_set_learner_and_an_infinite_head():
+    """the guard's contract -- element 0 of a set's actor block and of its critic block is non-finite iff the block is
+    invalid -- end to end for the OTHER 16-bit set learner too (csrc/fset.hip, shared_engine="fused": a non-finite input makes its
+    finalize write NaN over the whole slab), and for an Inf at a block's head (r05's guard tested for NaN only: an Inf went into
+    Adam's moments)."""
+    need_gpu()
+    from avddpg_amd import trainer as tr
+
+    vt = tr.VecTrainer(config.Config(num_platoons=8, pl_size=3, buffer_size=128, fed_method="interfrl", weighted_average_enabled=False),
+                       rng="device", auto_reset=True, seed=5, shared_engine="fused")
+    vt.reset_episode()
+    for _ in range(66):
+        vt.step()
+    assert vt.nonfinite_updates() == 0 and vt.updates > 0
+    vt.replay.ring[0, :, 0] = float("inf")  # every stored state of agent 0 non-finite
+    th, steps = vt.agents.theta.clone(), vt.agents.step.clone()
+    vt.step()
+    torch.cuda.synchronize()
+    assert vt.nonfinite_updates() >= 1 and torch.isfinite(vt.agents.theta).all() and torch.isfinite(vt.agents.m).all()
+    assert torch.equal(vt.agents.theta[0], th[0]) and int(vt.agents.step[0]) == int(steps[0])  # vehicle 0's set: skipped, count put back
+    # an infinite head of either block is a skipped set like a NaN one
+    M = 3
+    conf, grp = _perturbed_group(M, S=4, seed=91)
+    g = torch.zeros(M, grp.lay.theta_size, device="cuda")
+    g[0, 0] = float("inf")
+    g[2, grp.lay.actor_size] = float("-inf")
+    before = grp.theta.clone()
+    grp.apply(g, guarded=True)
+    torch.cuda.synchronize()
+    assert int(grp.nonfinite_skipped.item()) == 2 and grp.step.tolist() == [0, 1, 0]
+    assert torch.equal(grp.theta[0], before[0]) and torch.equal(grp.theta[2], before[2]) and torch.isfinite(grp.m).all()
