@@ -470,7 +470,7 @@ class AgentGroup:
              ptr(self.stats_t), ptr(self.m), ptr(self.v), ptr(grads), ptr(self.step), c.actor_lr, c.critic_lr,
              float(c.tau), stream_handle())
 
-    def apply_intra(self, grads, P, M, weights=None, lead_skip=False, lo=0, hi=None, stream=None):
+    def apply_intra(self, grads, P, M, weights=None, lead_skip=False, lo=0, hi=None, stream=None, advance=True):
         """intrafrl + gradients (workers/trainer.py:417-431) for platoons [lo, hi): every agent of a platoon steps with the (weighted)
         mean of the platoon's M gradient rows, averaged where it is consumed (avd_adam_polyak_intra_f32: one pass over the slab;
         same values as fed_mean + fed_scatter + apply). lead_skip: intra_directional_averaging -- vehicle 0 of every platoon takes
@@ -479,11 +479,12 @@ class AgentGroup:
         hi = P if hi is None else hi
         if self.n_sets != P * M:
             raise _hip.AvdError("apply_intra needs one weight set per agent (P * M sets)")
-        if stream is None:
-            self.step.view(P, M)[lo:hi, (1 if lead_skip else 0):] += 1
-        else:  # (on the stream the kernel runs on: it reads the counts)
-            with torch.cuda.stream(stream):
+        if advance:  # the Adam iteration counts of the agents that step (advance=False: the caller has done it for all platoons)
+            if stream is None:
                 self.step.view(P, M)[lo:hi, (1 if lead_skip else 0):] += 1
+            else:  # (on the stream the kernel runs on: it reads the counts)
+                with torch.cuda.stream(stream):
+                    self.step.view(P, M)[lo:hi, (1 if lead_skip else 0):] += 1
         a, b = lo * M, hi * M
         call("avd_adam_polyak_intra_f32", self._layp, hi - lo, M, 1 if lead_skip else 0, ptr(self.theta[a:b]), ptr(self.stats[a:b]),
              ptr(self.theta_t[a:b]), ptr(self.stats_t[a:b]), ptr(self.m[a:b]), ptr(self.v[a:b]), ptr(grads[a:b]), ptr(self.step[a:b]),
@@ -503,6 +504,9 @@ class AgentGroup:
         chunks = max(1, min(chunks, P))
         bounds = [(P * i) // chunks for i in range(chunks + 1)]
         T = lambda: torch.cuda.Event(enable_timing=timers is not None)
+        # the iteration counts of every stepping agent, ONCE, on the caller's stream: each chunk's pass on the side stream waits for an
+        # event recorded after this (one small launch per step instead of one per chunk)
+        self.step.view(P, M)[:, (1 if lead_skip else 0):] += 1
         for i in range(chunks):
             lo, hi = bounds[i] * M, bounds[i + 1] * M
             if hi == lo:
@@ -518,7 +522,7 @@ class AgentGroup:
             u0, u1 = T(), T()
             if timers is not None:
                 u0.record(side)
-            self.apply_intra(grads, P, M, weights=weights, lead_skip=lead_skip, lo=bounds[i], hi=bounds[i + 1], stream=side)
+            self.apply_intra(grads, P, M, weights=weights, lead_skip=lead_skip, lo=bounds[i], hi=bounds[i + 1], stream=side, advance=False)
             if timers is not None:
                 u1.record(side)
                 timers.setdefault("learn", []).append((t0, t1))

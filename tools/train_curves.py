@@ -426,6 +426,15 @@ def cmd_big(args):
         out["nofrl"] = big_run(f"nofrl_{args.nofrl_platoons}x{args.pl_size}_per_platoon_episodes", conf, args.nofrl_steps, args.out,
                                report=args.report, eval_every=args.eval_every, auto_reset="platoon", fused_update=True,
                                eval_platoons=tuple(range(min(8, args.nofrl_platoons))))
+    if "weighted" in runs:  # r06: the Config-default weighted federated mean with the weights computed on the device (per-platoon episodes)
+        conf = config.Config(num_platoons=args.platoons, fed_method="interfrl", **{**base, "weighted_average_enabled": True})
+        out["interfrl_weighted"] = big_run(f"interfrl_{args.platoons}x{args.pl_size}_fused3_weighted_per_platoon_episodes", conf, args.steps, args.out,
+                                           report=args.report, eval_every=args.eval_every, auto_reset="platoon", shared_engine="fused3")
+    if "intrafrl" in runs:  # r06: every agent stepping with its platoon's mean gradient (avd_adam_polyak_intra_f32, platoon-chunk pipeline)
+        conf = config.Config(num_platoons=args.platoons, fed_method="intrafrl", **base)
+        out["intrafrl"] = big_run(f"intrafrl_{args.platoons}x{args.pl_size}_per_platoon_episodes", conf, args.intra_steps, args.out,
+                                  report=args.report, eval_every=args.eval_every, auto_reset="platoon", pipeline_chunks=16,
+                                  eval_platoons=tuple(range(min(8, args.platoons))))
     if "wide_bf16" in runs:  # the bf16 engine alone at BASELINE configs[4]'s full size (the float32 PyTorch reference is too slow there)
         conf = config.Config(num_platoons=args.wide_platoons, fed_method="interfrl", actor_layer1_size=1024, actor_layer2_size=1024,
                              critic_layer1_size=1024, critic_layer2_size=1024, **base)
@@ -472,6 +481,7 @@ def main():
     b.add_argument("--parity-steps", type=int, default=20000)
     b.add_argument("--nofrl-platoons", type=int, default=512)
     b.add_argument("--nofrl-steps", type=int, default=50100)
+    b.add_argument("--intra-steps", type=int, default=30000)
     b.add_argument("--wide-platoons", type=int, default=256)
     b.add_argument("--wide-steps", type=int, default=30000)
     b.add_argument("--report", type=int, default=1000)
