@@ -1079,8 +1079,20 @@ struct FwdP {
 // One stage = the 32 k x 512 column chunk (32 KiB) + the first-layer fragments of that chunk's 32 features (1 KiB).
 constexpr int STG_BYTES = FC * FK * 2 + 1024;
 constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
-              L_XF = L_AR + FR * 4, L_TOTAL = L_XF + 2 * 8 * 1024;  // XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B
-template <bool CRITIC>
+              L_XF = L_AR + FR * 4, L_ZERO = L_XF + 2 * 8 * 1024, L_TOTAL = L_ZERO + 256;
+// XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B; ZERO: 256 B of zeros (the output-layer MFMA's idle A rows)
+//
+// EPI picks the tile epilogue at compile time (r06b; the r03 epilogue took every decision per group of four elements at run time --
+// uniform branches on p.dz_scale / p.store_pre / p.mask_out --, quieted every element with v_max_f32 x, x, converted one element per
+// v_cvt_pk_bf16_f32 and packed pairs with shifts: ~3400 instructions per wave and tile, with BOTH waves of a SIMD in their epilogues
+// at the same time and the matrix pipe idle):
+//   0  the r03 code, run-time flags: relu'd activations or dZ2 out (the layer-wise backward's operands; no BASELINE shape runs it)
+//   1  nothing stored (target networks)      2  bf16(z2) with its sign (critic(s, a): fwd_delta_kernel continues from it)
+//   3  the relu mask {1, 0} (actor(s): the rank-one backward's operand)
+// 1..3: one v_cvt_pk_bf16_f32 + one v_pk_max_i16 per PAIR, and the width-1 output layer on the matrix pipe: the packed relu'd tile is
+// the B operand (k = its 16 columns per k-step) of an MFMA whose A operand holds cf as a bf16 pair in rows 0 (hi) and 1 (lo) and zeros
+// below -- 16 MFMAs per wave and tile replace 128 shifts + 128 FMAs + a cross-lane add.
+template <bool CRITIC, int EPI>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_gen_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* zs = (float*)(smem_raw + L_ZS);      // [4 column quarters][FR]
@@ -1185,7 +1197,18 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         };
         __syncthreads();  // (the previous pair's LDS reads are done)
         sbias[tid] = p.bias[(long)set * p.H2 + FC * cb + tid];
-        scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+        if constexpr (EPI == 0) {
+            scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+        } else {
+            // cf as A fragments: [column quarter][hi, lo][32-column tile][k-step][lane half] x 16 B; slot i of lane half hh holds the
+            // column that register 8 ks + i of the accumulator tile holds there: 16 ks + 8 (i >> 2) + 4 hh + (i & 3)
+            bf16 chi, clo;
+            split_bf(p.cf[(long)set * p.H2 + FC * cb + tid], chi, clo);
+            const int c32 = tid & 31, slot = ((((tid >> 5) & 3) * 2 + (c32 >> 4)) * 2 + ((c32 >> 2) & 1)) * 8 + ((c32 >> 3) & 1) * 4 + (c32 & 3);
+            bf16* t = (bf16*)(smem_raw + L_CF) + (tid >> 7) * 256;
+            t[slot] = chi, t[128 + slot] = clo;
+            if (tid < 64) ((unsigned*)(smem_raw + L_ZERO))[tid] = 0u;
+        }
         dma_x(tile);
         // ---- start the stream: chunks 0 .. 2 into stages 0 .. 2 (a stage also carries the first-layer fragments of the NEXT chunk)
 #pragma unroll
@@ -1248,7 +1271,65 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
         };
         // relu, bf16, output-layer dot on the stored (rounded) activations, row-major store
+        const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;  // (EPI != 0) this lane's row of the cf fragments
         auto epilogue = [&](int pt) {
+            if constexpr (EPI != 0) {
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                    // (four lanes per row: lane (r, h) stores row r & 15 (+ 16 in the second instruction), columns 16 (r >> 4) + 8 h .. + 8 of every tile)
+                    bf16* dst4 = EPI >= 2 ? p.P2 + (long)set * p.setP2 + (n - (r & 16)) * p.H2 + FC * cb + 128 * cq + (r & 16) + 8 * h : nullptr;
+                    f32x16 E = zero16;  // rows 0 / 1 (registers 0 / 1 of the lower lane half): sum over this wave's columns of o . cf_hi / o . cf_lo
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        unsigned raw[4][2], rl[4][2];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const f32x2 f = {acc[rt][ct][4 * g + 2 * e], acc[rt][ct][4 * g + 2 * e + 1]};
+                                const s16x2 v = __builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2)), z = {0, 0};
+                                raw[g][e] = __builtin_bit_cast(unsigned, v);
+                                rl[g][e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, z));
+                            }
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            wide::u32x4 bw;
+                            bw[0] = rl[2 * ks][0], bw[1] = rl[2 * ks][1], bw[2] = rl[2 * ks + 1][0], bw[3] = rl[2 * ks + 1][1];
+                            E = mfma(*(const bf16x8*)(smem_raw + cfb + (ct * 2 + ks) * 32), __builtin_bit_cast(bf16x8, bw), E);
+                        }
+                        if constexpr (EPI >= 2) {
+                            // 16-byte row-major pieces: after the half swaps a row's two lanes hold 32 contiguous bytes twice (columns 0-15
+                            // and 16-31 of the tile); the 16-lane swaps then hand the second half of rows 0-15 to lanes 16-31 and the first
+                            // half of rows 16-31 to lanes 0-15: FOUR lanes per row, 64 contiguous bytes, 16 rows per store instruction (the
+                            // store tail is bound by the segments an instruction touches: 32 x 32 B took twice as long)
+                            wide::u32x4 ov[2];
+#pragma unroll
+                            for (int gg = 0; gg < 2; ++gg) {
+                                unsigned o[2][2];
+#pragma unroll
+                                for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) o[g2][e] = EPI == 2 ? raw[2 * gg + g2][e] : wide::relu_mask2(rl[2 * gg + g2][e]);
+                                const auto s0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
+                                const auto s1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
+                                ov[gg][0] = s0[0], ov[gg][1] = s1[0], ov[gg][2] = s0[1], ov[gg][3] = s1[1];
+                            }
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const auto t = __builtin_amdgcn_permlane16_swap(ov[0][d], ov[1][d], false, false);
+                                ov[0][d] = t[0], ov[1][d] = t[1];
+                            }
+                            *(wide::u32x4*)(dst4 + 32 * ct) = ov[0];
+                            *(wide::u32x4*)(dst4 + 16 * p.H2 + 32 * ct) = ov[1];
+                        }
+                    }
+                    if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = E[0] + E[1];
+                }
+            } else {
             float zp[2] = {0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -1291,6 +1372,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 zp[rt] += __shfl_xor(zp[rt], 32);
                 if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = zp[rt];
+            }
             }
         };
         init_acc();
@@ -1379,8 +1461,18 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunks 0 and 1 of the next period have landed; nothing older than the stores
             if (grp == 0) __builtin_amdgcn_s_barrier();  // level (pairs with group 1's last barrier of the loop)
             FW_STAMP(4);
+#ifdef AVD_FW_STAMP
+            // (when do the workgroups reach their tile boundaries? the 100 MHz real-time counter at the start of this workgroup's epilogues
+            //  of pair 0, and at their end: [256 workgroups][8 tiles][2])
+            if (p.stamp && pair == 0 && wave == 4 && lane == 0 && tile / (int)gridDim.x < 8)
+                p.stamp[64 + (blockIdx.x * 8 + tile / (int)gridDim.x) * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (!FW_DBG(8)) epilogue(tile);
             FW_STAMP(5);
+#ifdef AVD_FW_STAMP
+            if (p.stamp && pair == 0 && wave == 4 && lane == 0 && tile / (int)gridDim.x < 8)
+                p.stamp[64 + (blockIdx.x * 8 + tile / (int)gridDim.x) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
             z_flush(prev);
             prev = tile;
             init_acc();
@@ -2414,7 +2506,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             auto opt_in = [&](const void* fn, size_t bytes) {
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             };
-            opt_in((const void*)fw::fwd_gen_kernel<false>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true>, fw_lds);
+            opt_in((const void*)fw::fwd_gen_kernel<false, 0>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 0>, fw_lds);
+            opt_in((const void*)fw::fwd_gen_kernel<false, 1>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 1>, fw_lds);
+            opt_in((const void*)fw::fwd_gen_kernel<false, 3>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 2>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false, 4>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 4>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false, 8>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 8>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false, 16>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 16>, fw_lds);
@@ -2512,27 +2606,51 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         f.stamp = nullptr;
 #ifdef AVD_FW_STAMP
         static unsigned long long* d_fst = nullptr;
-        if (!d_fst) (void)hipMalloc(&d_fst, 64 * 8);
+        if (!d_fst) (void)hipMalloc(&d_fst, (64 + 256 * 16) * 8);
         f.stamp = d_fst;
 #endif
         if (H2 > fw::FC)
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, f.z, (long)Np, n.c0, Np);
         const dim3 grid((unsigned)std::min<long>(avd::fset::cu_count(), Np / fw::FR));
-        if (critic)
-            hipLaunchKernelGGL((fw::fwd_gen_kernel<true>), grid, dim3(fw::FT), fw_lds, st, f);
-        else
-            hipLaunchKernelGGL((fw::fwd_gen_kernel<false>), grid, dim3(fw::FT), fw_lds, st, f);
+        // the epilogue is a compile-time choice (fw::fwd_gen_kernel): nothing stored / signed bf16(z2) (critic) / relu mask (actor); the
+        // run-time-flag form for what is left (relu'd activations, dZ2 out: the layer-wise backward's operands)
+        static const char* epi_env = AVD_DIAG_ENV("WIDE_FWD_EPI0");  // diagnostics: =1 the r03 epilogue everywhere (A/B)
+        const bool epi0 = epi_env && epi_env[0] == '1';
+        if (!f.P2 && !epi0) {
+            if (critic)
+                hipLaunchKernelGGL((fw::fwd_gen_kernel<true, 1>), grid, dim3(fw::FT), fw_lds, st, f);
+            else
+                hipLaunchKernelGGL((fw::fwd_gen_kernel<false, 1>), grid, dim3(fw::FT), fw_lds, st, f);
+        } else if (critic && f.store_pre && f.dz_scale == 0.f && !epi0) {
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<true, 2>), grid, dim3(fw::FT), fw_lds, st, f);
+        } else if (!critic && f.mask_out && f.dz_scale == 0.f && !epi0) {
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<false, 3>), grid, dim3(fw::FT), fw_lds, st, f);
+        } else if (critic) {
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<true, 0>), grid, dim3(fw::FT), fw_lds, st, f);
+        } else {
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<false, 0>), grid, dim3(fw::FT), fw_lds, st, f);
+        }
 #ifdef AVD_FW_STAMP
         {
             static int printed = 0;
-            if (printed++ == 7) {
-                unsigned long long hst[64];
+            if (printed >= 4 && printed < 8) {  // (the second learn call's four forward passes)
+                static unsigned long long hst[64 + 256 * 16];
                 (void)hipStreamSynchronize(st);
                 (void)hipMemcpy(hst, f.stamp, sizeof(hst), hipMemcpyDeviceToHost);
                 for (int w_ = 0; w_ < 8; ++w_)
                     fprintf(stderr, "fwd_gen wave %d: prepare %llu barrier %llu multiply %llu barrier %llu | boundary: drain %llu epilogue %llu flush+init %llu  (P2 %d) cycles, pair 0\n", w_,
                             hst[w_ * 8], hst[w_ * 8 + 1], hst[w_ * 8 + 2], hst[w_ * 8 + 3], hst[w_ * 8 + 4], hst[w_ * 8 + 5], hst[w_ * 8 + 6], f.P2 != nullptr);
+                // tile boundaries of pair 0 on the real-time counter (10 ns units, relative to the first)
+                unsigned long long t0 = ~0ull;
+                const int nb = (int)grid.x;
+                for (int b = 0; b < nb; ++b) t0 = hst[64 + b * 16] < t0 ? hst[64 + b * 16] : t0;
+                for (int k = 2; k < 5; ++k) {
+                    fprintf(stderr, "fwd_gen tile %d epilogue start (end) per workgroup, x10 ns:", k);
+                    for (int b = 0; b < nb; b += 5) fprintf(stderr, " %llu(%llu)", hst[64 + (b * 8 + k) * 2] - t0, hst[64 + (b * 8 + k) * 2 + 1] - hst[64 + (b * 8 + k) * 2]);
+                    fprintf(stderr, "\n");
+                }
             }
+            ++printed;
         }
 #endif
         return check_launch("avd_learn_shared_bf16: fused forward");
