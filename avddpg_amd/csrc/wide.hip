@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <vector>
 #include <atomic>
 
 namespace avd {
@@ -53,6 +54,16 @@ __device__ __forceinline__ unsigned sign_mask2(unsigned x) {
     asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(m) : "v"(t), "s"(0x3F803F80));
     return m;
 }
+// a packed pair of relu'd bf16 activations -> the pair c where they are positive, 0 elsewhere: min(x, 1) is 0 / 1, times the bits of c
+__device__ __forceinline__ unsigned relu_select2(unsigned x, unsigned c) {
+    unsigned t, m;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "s"(0x00010001), "v"(x));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m) : "v"(t), "v"(c));
+    return m;
+}
+// relu as ONE instruction (fmaxf quiets its operand first: two). A builtin, not inline asm: the operand is an MFMA result, and only for
+// instructions it knows does hipcc keep the wait states between the MFMA and the first read of its result (asm here read stale registers)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 __device__ __forceinline__ unsigned relu_mask2(unsigned x) {
     unsigned t, m;
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "s"(0x00010001), "v"(x));
@@ -1065,6 +1076,15 @@ struct FwdP {
     float* z;            // [sets][setZ]; H2 > 512: pre-filled with c0, every 512-column block adds its part (f32 atomics)
     long setZ;
     int Ns, Np, H2, n_sets;  // Np: padded rows (multiple of 128); H2: multiple of 512
+    // EPI 4 (critic(s, a) and critic(s, mu) in one pass: see fwd_gen_kernel): the second action per row, its q sums, the action gradient
+    const float* mu;     // [sets][setMu]
+    long setMu;
+    float* z2;           // [sets][setZ], pre-filled with c0: q(s, mu), one f32 atomic per row, column block and wave
+    float* da;           // [sets][setDa], zeroed by the caller: dq(s, mu) / d mu per row (f32 atomics)
+    long setDa;
+    const float* wa;     // critic parameters + offset of the action layer's weights Wa[k]; set stride setTh
+    long setTh;
+    int Ha;
     unsigned long long* stamp;  // -DAVD_FW_STAMP: [8 waves][4] s_memtime sums of workgroup 16 (prepare, barrier, multiply, barrier)
     int dbg;                 // diagnostics build (AVD_FW_DBG bits: 1 no refill DMA, 2 no relu / pack, 4 no phase barriers, 8 no epilogue,
                              // 16 four of the 16 accumulating MFMAs, 32 no fragment reads): wrong results
@@ -1079,7 +1099,9 @@ struct FwdP {
 // One stage = the 32 k x 512 column chunk (32 KiB) + the first-layer fragments of that chunk's 32 features (1 KiB).
 constexpr int STG_BYTES = FC * FK * 2 + 1024;
 constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
-              L_XF = L_AR + FR * 4, L_ZERO = L_XF + 2 * 8 * 1024, L_TOTAL = L_ZERO + 256;
+              L_XF = L_AR + FR * 4, L_ZERO = L_XF + 2 * 8 * 1024, L_TOTAL = L_ZERO + 256,
+              L_MK = L_TOTAL, L_MU = L_MK + 256, L_TOTAL_DUAL = L_MU + 2 * FR * 4;  // (EPI 4: Wa[64]; the rows' second actions, two tiles deep)
+static_assert(L_TOTAL_DUAL <= 160 * 1024, "fwd_gen_kernel: LDS");
 // XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B; ZERO: 256 B of zeros (the output-layer MFMA's idle A rows)
 //
 // EPI picks the tile epilogue at compile time (r06b; the r03 epilogue took every decision per group of four elements at run time --
@@ -1092,6 +1114,16 @@ constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * 4 * FR * 4, L_CF = L_
 // 1..3: one v_cvt_pk_bf16_f32 + one v_pk_max_i16 per PAIR, and the width-1 output layer on the matrix pipe: the packed relu'd tile is
 // the B operand (k = its 16 columns per k-step) of an MFMA whose A operand holds cf as a bf16 pair in rows 0 (hi) and 1 (lo) and zeros
 // below -- 16 MFMAs per wave and tile replace 128 shifts + 128 FMAs + a cross-lane add.
+//   4  (critic) critic(s, a) AND critic(s, mu) of a learn step in one pass: the two share the states and the weights, so
+//      z2(mu) = z2(a) + W2[action features] . (f(mu) - f(a)), f = the relu'd first layer of the action branch (r05: fwd_delta_kernel, on
+//      the signed activations this kernel stored -- one matrix written, read and written again as a mask). Here the chunk order is
+//      rotated: the action branch's chunks are the FIRST of the period (physical chunk = (c + nfs) mod nk), so at a tile boundary,
+//      where chunks 0 and 1 of the next period have landed, the stages hold exactly the weights the second pass needs:
+//        epilogue A  q(s, a) sums; the relu mask of z2(a) stored (the rank-one backward's operand);
+//        delta       acc += W2[action chunk] . bf16(relu(p1(mu)) - relu(p1(a))) for both action tiles (8 + 32 MFMAs);
+//        epilogue B  q(s, mu) sums (atomics); the action gradient da[n] = drow sum_k [p1(mu) > 0] Wa[k] sum_c [z2(mu) > 0] cf[c] W2'[k][c]:
+//                    one more product over the columns, B = the mask tile times bf16(cf) as it stands, A = the action chunks read
+//                    TRANSPOSED from the same stages (ds_read_b64_tr_b16; the image rows are the contraction index here).
 template <bool CRITIC, int EPI>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_gen_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1101,6 +1133,11 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int rh = wave & 1, cq = wave >> 1;  // 64-row half, 128-column quarter
     const int nk = p.nft, ncb = p.H2 / FC, ntile = p.Np / FR;
+    constexpr bool DUAL = EPI == 4;
+    static_assert(!DUAL || CRITIC, "EPI 4 is the critic's pass");
+    // DUAL: the action branch's chunks lead the period (chunk c of the period = physical 32-feature chunk phys(c) of the image / fragments)
+    const int nact = DUAL ? nk - p.nfs : 0;
+    auto phys = [&](int c) { return DUAL ? (c < nact ? c + p.nfs : c - nact) : c; };
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1160,15 +1197,16 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if ((i >> 1) == part)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + kc * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + phys(kc) * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
             if (part == 1) {  // the first-layer fragments of the FOLLOWING chunk travel with this one
-                const int kf = kc + 1 == nk ? 0 : kc + 1;
+                const int kf = phys(kc + 1 == nk ? 0 : kc + 1);
                 __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kf * 1024 + (vw & 0u) + vof), (lptr_t)(l + FC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
             }
         };
         // raw inputs of a row tile into LDS buffer b (every wave issues the same 4 instructions: uniform counts). Rows beyond
         // Ns are clamped to row Ns - 1 here and zeroed when the fragments are built.
         auto dma_x = [&](int t) {
+            const int mub = t / (int)gridDim.x & 1;  // (of the tile asked for: a clamped request must not land in the running tile's buffer)
             if (t >= ntile) t = ntile - 1;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -1177,6 +1215,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + L_XR + (64 * half) * 16), 16, 0, 0);
                 if (CRITIC)
                     __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + L_AR + (64 * half) * 4), 4, 0, 0);
+                if (DUAL)  // (two tiles deep: the tile's epilogue reads its rows while the next tile's are already here)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p.mu + (long)set * p.setMu + n),
+                                                     (lptr_t)(smem_raw + L_MU + (mub * FR + 64 * half) * 4), 4, 0, 0);
             }
         };
         // fragments of row tile t from the raw rows, into fragment buffer b (the two waves with cq == 0 do it for their row half)
@@ -1208,6 +1249,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             bf16* t = (bf16*)(smem_raw + L_CF) + (tid >> 7) * 256;
             t[slot] = chi, t[128 + slot] = clo;
             if (tid < 64) ((unsigned*)(smem_raw + L_ZERO))[tid] = 0u;
+            if (DUAL && tid < 64) ((float*)(smem_raw + L_MK))[tid] = tid < p.Ha ? p.wa[(long)set * p.setTh + tid] : 0.f;
         }
         dma_x(tile);
         // ---- start the stream: chunks 0 .. 2 into stages 0 .. 2 (a stage also carries the first-layer fragments of the NEXT chunk)
@@ -1230,10 +1272,10 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int grp = wave >> 2;
         bf16x8 bfr[2][2];  // the chunk's B operand (k-step ks of row tile rt: bfr[rt][ks]): relu'd first layer, built one multiply phase ahead
         {
-            const bf16x8 wf0 = p.wf1[(long)set * nk * 64 + lane];  // (chunk 0's fragments travel with chunk nk - 1: not here yet)
+            const bf16x8 wf0 = p.wf1[((long)set * nk + phys(0)) * 64 + lane];  // (chunk 0's fragments travel with chunk nk - 1: not here yet)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const f32x16 p1 = mfma(wf0, x_frag(0, false, rt), zero16);
+                const f32x16 p1 = mfma(wf0, x_frag(0, DUAL, rt), zero16);
                 pack(p1, 0, bfr[rt][0]), pack(p1, 1, bfr[rt][1]);
             }
         }
@@ -1271,12 +1313,18 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
         };
         // relu, bf16, output-layer dot on the stored (rounded) activations, row-major store
-        const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;  // (EPI != 0) this lane's row of the cf fragments
         auto epilogue = [&](int pt) {
             if constexpr (EPI != 0) {
                 typedef short s16x2 __attribute__((ext_vector_type(2)));
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
+                // (lane-derived addresses from an OPAQUE copy of the lane id: hoisted out of the tile loop -- once per kernel -- they are state the
+                //  allocator spills over the K loop and reloads here, and a scratch reload issued behind the tile's stores waits for them)
+                int lane = tid & 63;
+                asm volatile("" : "+v"(lane));
+                const int r = lane & 31, h = lane >> 5;
+                const int rh = wv & 1, cq = wv >> 1;  // (the wave's tile from the SCALAR wave id: address parts in SGPRs, not hoisted vector registers)
+                const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;  // this lane's row of the cf fragments
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
@@ -1375,6 +1423,181 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             }
         };
+        // EPI 4: the tile's second pass -- critic(s, mu) on top of the accumulators of critic(s, a) (the kernel's header). `stg` is the stage
+        // of chunk 0 of the next period; rwv = the rows' weights, loaded before epilogue A's stores (a load behind them would wait for them)
+        auto dual_tail = [&](int pt, const float (&rwv)[2]) {
+            if constexpr (DUAL) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                // (every wave waited for vmcnt(0) on its way here: behind this barrier chunks 0 and 1 of the next period are complete)
+                __builtin_amdgcn_s_barrier();
+                // (lane-derived addresses from an OPAQUE copy of the lane id: hoisted out of the tile loop they are more loop state for the
+                //  allocator to spill -- and a scratch reload behind epilogue A's stores waits for those stores)
+                int lane = tid & 63;
+                asm volatile("" : "+v"(lane));
+                const int r = lane & 31, h = lane >> 5;
+                const int rh = wv & 1, cq = wv >> 1;
+                const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;
+                auto x_frag = [&](int b, bool action, int rt) {
+                    return *((const bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
+                };
+                auto wf_at = [&](int stg_) { return *(const bf16x8*)(smem_raw + stg_ * STG_BYTES + FC * FK * 2 + lane * 16); };
+                const int sw = (r >> 2) & 3;
+                const int rd0 = ((128 * cq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rd1 = ((128 * cq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
+                auto read_frags = [&](int stg_, int ks, bf16x8 (&a)[4]) {
+                    const unsigned char* b = smem_raw + stg_ * STG_BYTES + (ks ? rd1 : rd0);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
+                };
+                const int xbf = xb ^ 1;  // the finished tile's fragments (xb already points at the next tile's)
+                const float* mur = (const float*)(smem_raw + L_MU) + (pt / (int)gridDim.x & 1) * FR + rh * 64 + r;
+                // the action tiles' first-layer fragments: a stage carries those of the FOLLOWING chunk (tile 0: with chunk nk - 1, tile 1: with chunk 0)
+                const bf16x8 wfa[2] = {wf_at((stg + FSTG - 1) & (FSTG - 1)), wf_at(stg)};
+                unsigned pos[2] = {0u, 0u};  // [rt] bit 16 ta + i: p1(mu) > 0 in register i of action tile ta
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    bf16x8 dfr[2][2];  // [rt][ks]
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                        const f32x16 pa = mfma(wfa[ta], x_frag(xbf, true, rt), zero16);
+                        const f32x16 pm = mfma(wfa[ta], x_frag_action(mur[32 * rt], n < p.Ns, h), zero16);
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            wide::u32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const f32x2 f = {wide::relu1(pm[8 * ks + 2 * i]) - wide::relu1(pa[8 * ks + 2 * i]),
+                                                 wide::relu1(pm[8 * ks + 2 * i + 1]) - wide::relu1(pa[8 * ks + 2 * i + 1])};
+                                o[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+                            }
+                            dfr[rt][ks] = __builtin_bit_cast(bf16x8, o);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) pos[rt] |= pm[i] > 0.f ? 1u << (16 * ta + i) : 0u;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // (the first layers before the weight fragments: registers)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bf16x8 A2[4];
+                        read_frags((stg + ta) & (FSTG - 1), ks, A2);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(A2[ct], dfr[rt][ks], acc[rt][ct]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // (the masks are complete HERE. Left to the compiler, the 32 compares of row tile 1 were deferred to the start of its sweep,
+                //  with the first-layer tiles live across row tile 0's sweeps -- and that build returned wrong action gradients for part
+                //  of those rows: tests/test_gpu_wide.py's oracle comparison at hidden 1024 caught it, the dual-vs-delta row check pins it)
+                asm volatile("" : "+v"(pos[0]), "+v"(pos[1]));
+                // ---- epilogue B. Transposed reads of the action chunks (A = [feature][column] from image rows = columns): of a 16-lane group
+                // (mm = which 16 features, rows by lane half h) lane 4 q + pp addresses row c0 + q, features 16 mm + 4 pp .. + 3 -- image position
+                // 16 mm + 4 swap(pp) (bits 2 and 3 of k are swapped in the image), 16-byte piece XOR-swizzled by bits 2..3 of the row = (2 g + h) & 3;
+                // lane i of the group gets feature 16 mm + i of rows c0 .. c0 + 3 = slots 4 g .. 4 g + 3 with c0 = 16 ks + 8 g + 4 h of the tile
+                const int tq = (lane & 15) >> 2, tp = lane & 3, mm = (lane >> 4) & 1, sp = ((tp & 1) << 1) | (tp >> 1), lch = 2 * mm + (sp >> 1);
+                const int trow = (128 * cq + 4 * h + tq) * FK * 2 + (sp & 1) * 8;
+                const unsigned tr0 = (unsigned)(trow + ((lch ^ h) << 4)), tr1 = (unsigned)(trow + 8 * FK * 2 + ((lch ^ (2 + h)) << 4));
+                const unsigned sb0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_raw + stg * STG_BYTES),
+                               sb1 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem_raw + ((stg + 1) & (FSTG - 1)) * STG_BYTES);
+                const unsigned a00 = sb0 + tr0, a01 = sb0 + tr1, a10 = sb1 + tr0, a11 = sb1 + tr1;  // [action tile][g]
+                const int cfh = L_CF + cq * 2 * 256 + h * 16;  // bf16(cf) of this lane half's columns, in slot order (the hi row of the cf fragments)
+                const float* mk = (const float*)(smem_raw + L_MK);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                    const bool live = n < p.Ns;
+                    // the relu'd tile as packed bf16 first (32 registers for the row tile's 64 accumulators, dead from here on), then two sweeps
+                    // over it -- q(s, mu), then the action gradient: with the accumulators and both products' sums live at the same time the
+                    // allocator spilled the loop's state around the tail, and a scratch reload behind epilogue A's stores waits for them
+                    unsigned rla[4][4][2];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const f32x2 f = {acc[rt][ct][4 * g + 2 * e], acc[rt][ct][4 * g + 2 * e + 1]};
+                                const s16x2 v = __builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2)), z = {0, 0};
+                                rla[ct][g][e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, z));
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float qv;
+                    {
+                        f32x16 Q = zero16;
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            const unsigned (&rl)[4][2] = rla[ct];
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) {
+                                wide::u32x4 bw;
+                                bw[0] = rl[2 * ks][0], bw[1] = rl[2 * ks][1], bw[2] = rl[2 * ks + 1][0], bw[3] = rl[2 * ks + 1][1];
+                                Q = mfma(*(const bf16x8*)(smem_raw + cfb + (ct * 2 + ks) * 32), __builtin_bit_cast(bf16x8, bw), Q);
+                            }
+                        }
+                        qv = Q[0] + Q[1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 E[2] = {zero16, zero16};
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const unsigned (&rl)[4][2] = rla[ct];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                            u32x2_t t[2][2];  // [action tile][g]
+                            {   // (the builtin: here no LDS-DMA is outstanding by the compiler's count -- the boundary's explicit vmcnt(0) --, so it puts no
+                                //  vm wait in front of the reads; dw_gen_kernel's inline-asm form, consumed by MFMAs right behind its own
+                                //  lgkmcnt(0), gave wrong action gradients here)
+                                typedef short s16x4_t __attribute__((ext_vector_type(4)));
+                                typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+                                const int off = ct * 32 * FK * 2 + ks * 16 * FK * 2;
+                                t[0][0] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(a00 + off)));
+                                t[0][1] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(a01 + off)));
+                                t[1][0] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(a10 + off)));
+                                t[1][1] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(a11 + off)));
+                            }
+                            // cf as its bf16 pair, one product each: the rounding error of a single bf16(cf[c]) is the SAME for all 48 features, so
+                            // it adds up coherently over k -- a row-independent offset of 1-3 % of the action gradient with the hi part alone
+#pragma unroll
+                            for (int part = 0; part < 2; ++part) {
+                                wide::u32x4 bz;
+                                const wide::u32x4 cv = *(const wide::u32x4*)(smem_raw + cfh + part * 256 + (ct * 2 + ks) * 32);
+                                bz[0] = wide::relu_select2(rl[2 * ks][0], cv[0]), bz[1] = wide::relu_select2(rl[2 * ks][1], cv[1]);
+                                bz[2] = wide::relu_select2(rl[2 * ks + 1][0], cv[2]), bz[3] = wide::relu_select2(rl[2 * ks + 1][1], cv[3]);
+#pragma unroll
+                                for (int mt = 0; mt < 2; ++mt) {
+                                    wide::u32x4 af;
+                                    af[0] = t[mt][0][0], af[1] = t[mt][0][1], af[2] = t[mt][1][0], af[3] = t[mt][1][1];
+                                    E[mt] = mfma(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bz), E[mt]);
+                                }
+                            }
+                        }
+                    }
+                    // E[mt]: lane = row, register 4 g + j <-> action feature 32 mt + 8 g + 4 h + j (the layout of p1(mu) and of `pos`)
+                    float dap = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 mv = *(const f32x4*)(mk + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) dap += ((pos[rt] >> (16 * mt + 4 * g + j)) & 1u) ? mv[j] * E[mt][4 * g + j] : 0.f;
+                        }
+                    dap += __shfl_xor(dap, 32);
+                    if (h == 0) {
+                        atomicAdd(p.z2 + (long)set * p.setZ + n, qv);
+                        if (live) atomicAdd(p.da + (long)set * p.setDa + n, p.dz_scale * rwv[rt] * dap);
+                    }
+                }
+                // nobody is still reading this tile's second actions or the stages' fragments when the first wave of group 0 starts the next
+                // tile (its first requests -- the next second actions, chunk 3 into the stage chunk nk - 1 and action tile 0's fragments
+                // sit in -- are issued before its first phase barrier): without this barrier slow waves read the tile after next's actions
+                __builtin_amdgcn_s_barrier();
+            }
+        };
         init_acc();
         int prev = -1;  // tile whose partial output-layer sums were written in the previous epilogue
         for (; tile < ntile; tile += gridDim.x) {
@@ -1397,7 +1620,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int i = 0; i < 4; ++i) A[0][i] = A[1][i] = x_frag(0, false, 0);
                 }
                 const bf16x8 wfn = wf_at(stg);
-                const bool act_next = CRITIC && kt + 1 < nk && kt + 1 >= p.nfs;
+                const bool act_next = DUAL ? (kt + 1 == nk || kt + 1 < nact) : (CRITIC && kt + 1 < nk && kt + 1 >= p.nfs);
                 const int xbuf = kt + 1 == nk ? xb ^ 1 : xb;
                 const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
                 // (scalar, out of line; read from the next prepare phase on. Peeling step nk - 2 out of the loop instead -- no branch in
@@ -1435,6 +1658,8 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma(A[ks][ct], bfr[rt][ks], acc[rt][ct]);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) pack(p1n[rt], 0, bnx[rt][0]), pack(p1n[rt], 1, bnx[rt][1]);
+                // (r06b, measured and not kept: row tile 1's first layer half a phase behind row tile 0's -- the two tiles not live at the
+                //  same time, 16 registers -- took 30-50 B of scratch out of every variant and made every variant 4-9 % slower)
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #pragma unroll
                 for (int i = 0; i < 11; ++i) {
@@ -1467,7 +1692,26 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (p.stamp && pair == 0 && wave == 4 && lane == 0 && tile / (int)gridDim.x < 8)
                 p.stamp[64 + (blockIdx.x * 8 + tile / (int)gridDim.x) * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
+            float rwv[2] = {1.f, 1.f};
+            if (DUAL && p.rw) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                    rwv[rt] = p.rw[(long)set * p.Ns + (n < p.Ns ? n : p.Ns - 1)];
+                }
+            }
             if (!FW_DBG(8)) epilogue(tile);
+            dual_tail(tile, rwv);
+            if constexpr (DUAL) {
+                // the next tile's first B operand again (the last step built it too): recomputed here it is not live across the tail -- 16
+                // registers the allocator otherwise finds by spilling the loop's state. Chunk 0's fragments are still in the stage of chunk nk - 1.
+                const bf16x8 wf0 = wf_at((stg + FSTG - 1) & (FSTG - 1));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const f32x16 p1 = mfma(wf0, x_frag(xb, true, rt), zero16);
+                    pack(p1, 0, bfr[rt][0]), pack(p1, 1, bfr[rt][1]);
+                }
+            }
             FW_STAMP(5);
 #ifdef AVD_FW_STAMP
             if (p.stamp && pair == 0 && wave == 4 && lane == 0 && tile / (int)gridDim.x < 8)
@@ -2493,6 +2737,10 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     const bool r1 = fused_fwd && fused_delta && Np % (8 * fw::FK) == 0 && Np / (8 * fw::FK) >= 2 &&  // (>= 2 chunks per row range)
                     Np % 256 == 0 && H1 % 256 == 0 && 32 % (H1 / 256) == 0 && !(fd_env && fd_env[0] == '0') && !(fx_env && fx_env[0] == '0');
     const bool fused_dw = r1, fused_dx = r1;
+    // critic(s, a) and critic(s, mu) in ONE forward pass (fw::fwd_gen_kernel EPI 4) instead of a pass that stores its signed activations + the
+    // delta pass over them: whenever the rank-one chain runs (the action branch is two chunks: fused_delta)
+    static const char* du_env = AVD_DIAG_ENV("WIDE_DUAL");
+    const bool dual = r1 && KCp / 32 - H1 / 32 == 2 && !(du_env && du_env[0] == '0');
     static const char* fa_env = AVD_DIAG_ENV("WIDE_ACT_IN_DX");
     const bool act_in_dx = fused_dx && H1 / 256 == 4 && Ha <= 64 && !(fa_env && fa_env[0] == '0');  // (fw::dx_gen_kernel<true>)
     constexpr size_t fw_lds = fw::L_TOTAL;
@@ -2509,6 +2757,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             opt_in((const void*)fw::fwd_gen_kernel<false, 0>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 0>, fw_lds);
             opt_in((const void*)fw::fwd_gen_kernel<false, 1>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 1>, fw_lds);
             opt_in((const void*)fw::fwd_gen_kernel<false, 3>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 2>, fw_lds);
+            opt_in((const void*)fw::fwd_gen_kernel<true, 4>, fw::L_TOTAL_DUAL);
             opt_in((const void*)fw::dw_gen_kernel<false, 4>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 4>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false, 8>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 8>, fw_lds);
             opt_in((const void*)fw::dw_gen_kernel<false, 16>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 16>, fw_lds);
@@ -2592,9 +2841,12 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     };
     // second layer forward: P2 = relu(C @ WT^T + bias)
     // fused: first layer + second layer + output-layer dot from the raw inputs (X, act): C is not read
+    // mu2 != NULL (critic): critic(s, act) AND critic(s, mu2) in one pass (fw::fwd_gen_kernel EPI 4): q(s, act) -> q, its relu mask -> the
+    // dZ2 buffer; q(s, mu2) -> zbuf, the action gradient -> da
     auto l2f = [&](const NetOps& n, bool critic, const float* X, const float* act, long set_act, bool keep_p2, bool dz_out = false,
-                   bool store_pre = false) {
+                   bool store_pre = false, const float* mu2 = nullptr) {
         fw::FwdP f;
+        f.mu = mu2, f.setMu = Np, f.z2 = zbuf, f.da = da, f.setDa = Np, f.wa = n.th + L.cWa, f.setTh = L.theta_size, f.Ha = Ha;
         f.X = X, f.setX = setX, f.act = critic ? act : nullptr, f.setAct = set_act;
         f.wf1 = (const bf16x8*)n.wf1, f.nfs = H1 / 32, f.nft = critic ? KCp / 32 : H1 / 32;
         f.WT = n.WT, f.setWT = setWT, f.ldw = KCp, f.bias = n.bias, f.cf = n.cf, f.c0 = n.c0;
@@ -2616,7 +2868,12 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         // run-time-flag form for what is left (relu'd activations, dZ2 out: the layer-wise backward's operands)
         static const char* epi_env = AVD_DIAG_ENV("WIDE_FWD_EPI0");  // diagnostics: =1 the r03 epilogue everywhere (A/B)
         const bool epi0 = epi_env && epi_env[0] == '1';
-        if (!f.P2 && !epi0) {
+        if (mu2) {
+            f.P2 = dZ2, f.dz_scale = -1.0f / (float)Ns, f.store_pre = 0, f.mask_out = 1;
+            hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, f.z2, (long)Np, n.c0, Np);
+            (void)hipMemsetAsync(da, 0, sizeof(float) * sets * Np, st);
+            hipLaunchKernelGGL((fw::fwd_gen_kernel<true, 4>), grid, dim3(fw::FT), (size_t)fw::L_TOTAL_DUAL, st, f);
+        } else if (!f.P2 && !epi0) {
             if (critic)
                 hipLaunchKernelGGL((fw::fwd_gen_kernel<true, 1>), grid, dim3(fw::FT), fw_lds, st, f);
             else
@@ -2842,8 +3099,10 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
 
     // ---- pass 1: critic loss and gradient                                                   (trainer.py:495-498)
     float* gcrit = grads + asz;
-    WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
-    rows(1, q, y, nullptr, 0.f, dq);
+    if (!dual) {
+        WIDE_CHECK(critic_forward(net[1], s, a, (long)Ns, true));
+        rows(1, q, y, nullptr, 0.f, dq);
+    }
     auto pass1_backward = [&]() {
         WIDE_CHECK(backward(net[1], true, dq, true, 1, gcrit, s, a, (long)Ns));
         if (fused_dx) {
@@ -2874,8 +3133,13 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     WIDE_CHECK(actor_forward(net[0], s, true));  // activations (rank-one form: their relu mask) stay for pass 3
     use_actor_buffers(false);
     // same states, same critic as pass 1: the state columns of C are still valid, only the action branch changes
-    if (!fused_delta) l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
-    if (fused_delta) {  // z2(mu) = z2(a) + W2[action] (f(mu) - f(a)): 4 k-steps on top of the stored critic(s, a) activations
+    if (dual) {
+        // both critic passes at once: q(s, a) -> q and its relu mask -> dZ2 (pass 1's backward operand); q(s, mu) -> zbuf, dq / d mu -> da
+        WIDE_CHECK(l2f(net[1], true, s, a, (long)Ns, true, false, false, a1));
+        rows(1, q, y, nullptr, 0.f, dq);  // (the critic's seed; reads y before rows(2) below reuses it)
+    } else if (!fused_delta) l1(net[1], true, true, a1, (long)Np, false);  // (the input-gradient epilogue reads the action columns of C)
+    if (dual) {
+    } else if (fused_delta) {  // z2(mu) = z2(a) + W2[action] (f(mu) - f(a)): 4 k-steps on top of the stored critic(s, a) activations
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, q, (long)Np, net[1].c0, Np);
         fw::DeltaP dl;
         dl.Zin = P2, dl.setZ = setP2, dl.a = a, dl.mu = a1, dl.setA = Ns, dl.setMu = Np, dl.wf1 = (const bf16x8*)net[1].wf1, dl.nft = KCp / 32,
@@ -2893,7 +3157,17 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     else
         WIDE_CHECK(l2(net[1], true));
     out_layer(net[1], 0, q);
-    rows(2, q, nullptr, nullptr, 0.f, dq3);
+#ifdef AVD_DIAG
+    if (const char* dump = getenv("AVD_WIDE_DUMP")) {  // diagnostics: q(s, mu) and the action gradient of this call, [sets][Np] f32 each
+        std::vector<float> hb(3 * (size_t)sets * Np);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hb.data(), dual ? zbuf : q, sizeof(float) * sets * Np, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hb.data() + (size_t)sets * Np, da, sizeof(float) * sets * Np, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hb.data() + 2 * (size_t)sets * Np, a1, sizeof(float) * sets * Np, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(dump, "wb")) fwrite(hb.data(), sizeof(float), hb.size(), f), fclose(f);
+    }
+#endif
+    rows(2, dual ? zbuf : q, nullptr, nullptr, 0.f, dq3);
     if (!fused_fwd) WIDE_CHECK(backward(net[1], true, dq3, false, 0, nullptr));
     if (!fused_delta) {
         WIDE_CHECK(dx(net[1], H1, KC, false, true));

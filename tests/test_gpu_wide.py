@@ -263,8 +263,10 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     the whole learn chain on the same inputs in two processes (the switch is read once per process). Since r06 the fused backward
     is the rank-one form (dZ2 = d (x) cf (.) mask never materialised: the operands are the exact mask and bf16(d y1), bf16(cf W2),
     where the layer-wise path rounds bf16(d cf) and bf16(y1) separately): independent 2^-9 roundings per term of a 768-row sum,
-    measured 4.3e-3 of a block's max in the weighted case -- 6e-3 allowed, where the bf16 operands themselves cost 8e-2 against the
-    float64 oracle (tests above and tests/test_gpu_configs_full.py hold BOTH paths to the oracle)."""
+    measured 4.3e-3 of a block's max in the weighted case; since r06b critic(s, a) and critic(s, mu) are ONE forward pass whose action
+    gradient comes from the f32 accumulators (cf as a bf16 pair on the mask operand, inv (.) W2 on the other) where the layer-wise path
+    goes through a stored bf16 gradient matrix: 8.3e-3 measured (padded case), 1.2e-2 allowed -- where the bf16 operands themselves
+    cost 8e-2 against the float64 oracle (tests above and tests/test_gpu_configs_full.py hold BOTH paths to the oracle)."""
     import os
     import subprocess
     import sys
@@ -288,12 +290,17 @@ def test_fused_forward_passes_match_the_layerwise_forward_at_hidden_1024(tmp_pat
     gf, gl = fused[:n].reshape(2, -1), layerwise[:n].reshape(2, -1)
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = np.abs(gl[:, lo:hi]).max()
-        assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 6e-3 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
+        assert np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() <= 1.2e-2 * scale, (lo, np.abs(gf[:, lo:hi] - gl[:, lo:hi]).max() / scale)
     assert np.allclose(fused[n:], layerwise[n:], rtol=2e-3, atol=1e-6)
 
 
-def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
-    """csrc/wide.hip, fw::fwd_delta_kernel: critic(s, mu) = critic(s, a) + W2[action rows] (f(mu) - f(a)) on the activations pass 1
+@pytest.mark.parametrize("switch", ["AVD_WIDE_FUSED_DELTA", "AVD_WIDE_DUAL"])
+def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path, switch):
+    """AVD_WIDE_DUAL (r06b): the product path -- critic(s, a) and critic(s, mu) in ONE forward pass, fw::fwd_gen_kernel<true, 4>: the delta on
+    the f32 accumulators, the action gradient from transposed reads of the streamed action chunks -- against the two-kernel form it
+    replaced (=0: the forward pass that stores signed activations + fw::fwd_delta_kernel, still the path of shapes the one-pass form
+    does not take); the critic's gradients come from the same rank-one backward in both: only the mask's producer differs.
+    AVD_WIDE_FUSED_DELTA: csrc/wide.hip, fw::fwd_delta_kernel: critic(s, mu) = critic(s, a) + W2[action rows] (f(mu) - f(a)) on the activations pass 1
     stored, the action gradient from the same kernel (the dZ2 tile as the next product's operand) -- against the full fused forward
     pass + the input-gradient GEMM of the action columns + the row dot it replaces (AVD_WIDE_FUSED_DELTA=0), same inputs, two
     processes. Only the actor gradient and the two losses depend on the pass (`workers/trainer.py:502-506`); the stored
@@ -310,7 +317,7 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
     script.write_text(_FWD_AB_SCRIPT)
     outs = []
     for flag in ("1", "0"):
-        env = dict(os.environ, AVD_WIDE_FUSED_DELTA=flag, AVDDPG_HIP_LIB=_DIAG_LIB)
+        env = dict(os.environ, AVDDPG_HIP_LIB=_DIAG_LIB, **{switch: flag})
         out = tmp_path / f"d{flag}.npy"
         p = subprocess.run([sys.executable, str(script), root, str(out), "weighted"], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -324,5 +331,5 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path):
     assert np.abs(gd[:, :lay.actor_size] - gf[:, :lay.actor_size]).max() > 0  # (the switch did switch)
     for lo, hi in ((0, lay.actor_size), (lay.actor_size, lay.theta_size)):
         scale = np.abs(gf[:, lo:hi]).max()
-        assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 6e-3 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
+        assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 1.2e-2 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
     assert np.allclose(delta[n:], full[n:], rtol=2e-3, atol=1e-6)
