@@ -455,9 +455,9 @@ def run_workload(args, mode, engine, rank, world, group, vt=None):
                                  "pack, finalize; every operand a 16-bit pair: 2-3 MFMAs per algorithmic product, so the executed "
                                  "matrix work is 2.2x the algorithmic FLOPs priced here: roofline.executed_over_algorithmic)" if split3 else
                                  "avd_learn_set_fused_bf16 (fset.hip: head x6, dw x2, dx x2, dxa persistent kernels + prep, pack, finalize)" if fset else
-                                 ("avd_learn_shared_bf16 (wide.hip, hidden >= 512, rank-one backward: fwd_gen x4, fwd_delta, aux_pack x2, dw_gen x2, "
-                                  "w2_post x2, dx_gen x2 + row / table kernels; FLOPs priced = the chain's algorithmic GEMMs, forward x5 incl. the pass "
-                                  "the delta kernel replaces)" if lay.H2 >= 512 else "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)")), "bound": "mfma",
+                                 ("avd_learn_shared_bf16 (wide.hip, hidden >= 512, rank-one backward: fwd_gen x4 -- the critic's two passes of a learn step, "
+                                  "(s, a) and (s, mu), are ONE of them --, aux_pack x2, dw_gen x2, w2_post x2, dx_gen x2 + row / table kernels; FLOPs "
+                                  "priced = the chain's algorithmic GEMMs, forward x5 incl. the pass that now rides on critic(s, a)'s accumulators)" if lay.H2 >= 512 else "avd_learn_shared_bf16 (gemm_bt256_kernel x10 + row/column kernels)")), "bound": "mfma",
                       "achieved": flops / learn_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                       "_t": learn_s})
     else:
