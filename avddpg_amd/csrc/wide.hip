@@ -1097,12 +1097,16 @@ struct FwdP {
 #define FW_DBG(bit) false
 #endif
 // One stage = the 32 k x 512 column chunk (32 KiB) + the first-layer fragments of that chunk's 32 features (1 KiB).
-constexpr int STG_BYTES = FC * FK * 2 + 1024;
-constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * 4 * FR * 4, L_CF = L_BIAS + FC * 4, L_XR = L_CF + FC * 4, L_AR = L_XR + FR * 16,
-              L_XF = L_AR + FR * 4, L_ZERO = L_XF + 2 * 8 * 1024, L_TOTAL = L_ZERO + 256,
-              L_MK = L_TOTAL, L_MU = L_MK + 256, L_TOTAL_DUAL = L_MU + 2 * FR * 4;  // (EPI 4: Wa[64]; the rows' second actions, two tiles deep)
+// Tile of a workgroup: GR rows x GC columns (r06c: 256 x 256, was 128 x 512 -- same 64 x 128 per wave, same accumulators, HALF the
+// weight bytes streamed per row: the kernel is bound by that stream, not by the matrix pipe -- with the refill compiled out a pass took
+// 1.59 ms, with half its bytes 1.79, with all of them 2.46; the ablation libraries of docs/ENGINEERING_NOTES_r06.md)
+constexpr int GR = 256, GC = 256, NRQ = GR / 64, NCH = GC / 128;  // row quarters x column halves = the 8 waves
+constexpr int STG_BYTES = GC * FK * 2 + 1024;
+constexpr int L_ZS = FSTG * STG_BYTES, L_BIAS = L_ZS + 2 * NCH * GR * 4, L_CF = L_BIAS + GC * 4, L_XR = L_CF + GC * 4, L_AR = L_XR + GR * 16,
+              L_XF = L_AR + GR * 4, L_ZERO = L_XF + 2 * NRQ * 4 * 1024, L_TOTAL = L_ZERO + 256,
+              L_MK = L_TOTAL, L_MU = L_MK + 256, L_TOTAL_DUAL = L_MU + 2 * GR * 4;  // (EPI 4: Wa[64]; the rows' second actions, two tiles deep)
 static_assert(L_TOTAL_DUAL <= 160 * 1024, "fwd_gen_kernel: LDS");
-// XF: [2 buffers][2 row halves][state, action][2 row tiles][64 lanes] x 16 B; ZERO: 256 B of zeros (the output-layer MFMA's idle A rows)
+// XF: [2 buffers][4 row quarters][state, action][2 row tiles][64 lanes] x 16 B; ZERO: 256 B of zeros (the output-layer MFMA's idle A rows)
 //
 // EPI picks the tile epilogue at compile time (r06b; the r03 epilogue took every decision per group of four elements at run time --
 // uniform branches on p.dz_scale / p.store_pre / p.mask_out --, quieted every element with v_max_f32 x, x, converted one element per
@@ -1127,12 +1131,12 @@ static_assert(L_TOTAL_DUAL <= 160 * 1024, "fwd_gen_kernel: LDS");
 template <bool CRITIC, int EPI>
 __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_gen_kernel(FwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* zs = (float*)(smem_raw + L_ZS);      // [4 column quarters][FR]
-    float* sbias = (float*)(smem_raw + L_BIAS);  // [FC]
-    float* scf = (float*)(smem_raw + L_CF);      // [FC]
+    float* zs = (float*)(smem_raw + L_ZS);      // [2 tiles][NCH column halves][GR]
+    float* sbias = (float*)(smem_raw + L_BIAS);  // [GC]
+    float* scf = (float*)(smem_raw + L_CF);      // [GC] (EPI 0) or the cf fragments
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int rh = wave & 1, cq = wave >> 1;  // 64-row half, 128-column quarter
-    const int nk = p.nft, ncb = p.H2 / FC, ntile = p.Np / FR;
+    const int rh = wave & 3, cq = wave >> 2;  // 64-row quarter, 128-column half (cq = the wave's ping-pong group)
+    const int nk = p.nft, ncb = p.H2 / GC, ntile = p.Np / GR;
     constexpr bool DUAL = EPI == 4;
     static_assert(!DUAL || CRITIC, "EPI 4 is the critic's pass");
     // DUAL: the action branch's chunks lead the period (chunk c of the period = physical 32-feature chunk phys(c) of the image / fragments)
@@ -1168,7 +1172,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
     };
-    auto wf_at = [&](int stg) { return *(const bf16x8*)(smem_raw + stg * STG_BYTES + FC * FK * 2 + lane * 16); };
+    auto wf_at = [&](int stg) { return *(const bf16x8*)(smem_raw + stg * STG_BYTES + GC * FK * 2 + lane * 16); };
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     // Workgroups start up to one row tile apart (16 steps of ~2 us): in step, all 256 would write their 128 KiB of activations at
     // the same moment, every tile boundary a 32 MB burst that the stores sit out in the issue queue
@@ -1181,73 +1185,73 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int set = pair / ncb, cb = pair - set * ncb;
         int tile = blockIdx.x;
         if (tile >= ntile) continue;  // (uniform per workgroup)
-        // wave w fills image rows (= output columns) [64 w, 64 w + 64), 16 rows per instruction (lane -> row l / 4, slot l % 4),
+        // wave w fills image rows (= output columns) [32 w, 32 w + 32), 16 rows per instruction (lane -> row l / 4, slot l % 4),
         // and dwords [64 (w % 4), ..) of the chunk's first-layer fragments (waves 4..7 repeat what waves 0..3 write: one
         // instruction count for everybody). Addresses are wave-uniform base + one 32-bit lane offset (scalar-base form).
-        const char* ubw = (const char*)(p.WT + (long)set * p.setWT + (long)(FC * cb + 64 * wv) * p.ldw);
+        const char* ubw = (const char*)(p.WT + (long)set * p.setWT + (long)(GC * cb + 32 * wv) * p.ldw);
         const unsigned vow = (unsigned)(((lane >> 2) * p.ldw + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
         const long g16 = 32 * p.ldw;  // bytes between instructions (16 image rows)
         const char* ubf = (const char*)((const float*)(p.wf1 + (long)set * nk * 64) + 64 * (wv & 3));
         const unsigned vof = (unsigned)lane * 4u;
-        // one chunk = 5 wave-instructions, issued in two parts (0: 2 image instructions, 1: 2 + the fragments)
+        // one chunk = 3 wave-instructions, issued in two parts (0: one image instruction, 1: the other + the fragments)
         auto dma = [&](int stg, int kc, int part) {
             unsigned char* l = smem_raw + stg * STG_BYTES;
             unsigned vw = vow;
             asm volatile("" : "+v"(vw));  // (opaque per call: keeps the scalar-base + lane-offset address form)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((i >> 1) == part)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + phys(kc) * FK * 2 + vw), (lptr_t)(l + (64 * wv + 16 * i) * FK * 2), 16, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                if (i == part)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ubw + i * g16 + phys(kc) * FK * 2 + vw), (lptr_t)(l + (32 * wv + 16 * i) * FK * 2), 16, 0, 0);
             if (part == 1) {  // the first-layer fragments of the FOLLOWING chunk travel with this one
                 const int kf = phys(kc + 1 == nk ? 0 : kc + 1);
-                __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kf * 1024 + (vw & 0u) + vof), (lptr_t)(l + FC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(ubf + (long)kf * 1024 + (vw & 0u) + vof), (lptr_t)(l + GC * FK * 2 + 256 * (wv & 3)), 4, 0, 0);
             }
         };
-        // raw inputs of a row tile into LDS buffer b (every wave issues the same 4 instructions: uniform counts). Rows beyond
+        // raw inputs of a row tile into LDS buffer b (every wave issues the same 4 / 8 / 12 instructions: uniform counts). Rows beyond
         // Ns are clamped to row Ns - 1 here and zeroed when the fragments are built.
         auto dma_x = [&](int t) {
             const int mub = t / (int)gridDim.x & 1;  // (of the tile asked for: a clamped request must not land in the running tile's buffer)
             if (t >= ntile) t = ntile - 1;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                int n = t * FR + 64 * half + lane;
+            for (int half = 0; half < NRQ; ++half) {
+                int n = t * GR + 64 * half + lane;
                 n = n < p.Ns ? n : p.Ns - 1;
                 __builtin_amdgcn_global_load_lds((gptr_t)(p.X + (long)set * p.setX + (long)n * 4), (lptr_t)(smem_raw + L_XR + (64 * half) * 16), 16, 0, 0);
                 if (CRITIC)
                     __builtin_amdgcn_global_load_lds((gptr_t)(p.act + (long)set * p.setAct + n), (lptr_t)(smem_raw + L_AR + (64 * half) * 4), 4, 0, 0);
                 if (DUAL)  // (two tiles deep: the tile's epilogue reads its rows while the next tile's are already here)
                     __builtin_amdgcn_global_load_lds((gptr_t)(p.mu + (long)set * p.setMu + n),
-                                                     (lptr_t)(smem_raw + L_MU + (mub * FR + 64 * half) * 4), 4, 0, 0);
+                                                     (lptr_t)(smem_raw + L_MU + (mub * GR + 64 * half) * 4), 4, 0, 0);
             }
         };
-        // fragments of row tile t from the raw rows, into fragment buffer b (the two waves with cq == 0 do it for their row half)
+        // fragments of row tile t from the raw rows, into fragment buffer b (the four waves with cq == 0 do it for their row quarter)
         auto build_x = [&](int t, int b) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const int row = rh * 64 + 32 * rt + r, n = t * FR + row;
+                const int row = rh * 64 + 32 * rt + r, n = t * GR + row;
                 const bool live = t < ntile && n < p.Ns;
                 const f32x4 xv = *(const f32x4*)(smem_raw + L_XR + row * 16);
                 const float x[4] = {xv[0], xv[1], xv[2], xv[3]};
-                bf16x8* d = (bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + rt) * 1024) + lane;
+                bf16x8* d = (bf16x8*)(smem_raw + L_XF + ((b * NRQ + rh) * 4 + rt) * 1024) + lane;
                 d[0] = x_frag_state(x, live, h);
                 if (CRITIC) d[128] = x_frag_action(*(const float*)(smem_raw + L_AR + row * 4), live, h);
             }
         };
         auto x_frag = [&](int b, bool action, int rt) {
-            return *((const bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
+            return *((const bf16x8*)(smem_raw + L_XF + ((b * NRQ + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
         };
         __syncthreads();  // (the previous pair's LDS reads are done)
-        sbias[tid] = p.bias[(long)set * p.H2 + FC * cb + tid];
+        if (tid < GC) sbias[tid] = p.bias[(long)set * p.H2 + GC * cb + tid];
         if constexpr (EPI == 0) {
-            scf[tid] = p.cf[(long)set * p.H2 + FC * cb + tid];
+            if (tid < GC) scf[tid] = p.cf[(long)set * p.H2 + GC * cb + tid];
         } else {
             // cf as A fragments: [column quarter][hi, lo][32-column tile][k-step][lane half] x 16 B; slot i of lane half hh holds the
             // column that register 8 ks + i of the accumulator tile holds there: 16 ks + 8 (i >> 2) + 4 hh + (i & 3)
             bf16 chi, clo;
-            split_bf(p.cf[(long)set * p.H2 + FC * cb + tid], chi, clo);
+            split_bf(p.cf[(long)set * p.H2 + GC * cb + (tid & (GC - 1))], chi, clo);
             const int c32 = tid & 31, slot = ((((tid >> 5) & 3) * 2 + (c32 >> 4)) * 2 + ((c32 >> 2) & 1)) * 8 + ((c32 >> 3) & 1) * 4 + (c32 & 3);
             bf16* t = (bf16*)(smem_raw + L_CF) + (tid >> 7) * 256;
-            t[slot] = chi, t[128 + slot] = clo;
+            if (tid < GC) t[slot] = chi, t[128 + slot] = clo;
             if (tid < 64) ((unsigned*)(smem_raw + L_ZERO))[tid] = 0u;
             if (DUAL && tid < 64) ((float*)(smem_raw + L_MK))[tid] = tid < p.Ha ? p.wa[(long)set * p.setTh + tid] : 0.f;
         }
@@ -1267,7 +1271,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         //   prepare(k) : A <- stage of chunk k (both k-steps); wfn <- that stage's fragments of chunk k + 1; pack(p1n) -> bfr;
         //                request chunk k + 3 into the stage of chunk k - 1 (read by both groups two barriers ago)
         //   multiply(k): acc += A . bfr; p1n = first layer of chunk k + 1
-        // Every wave waits for vmcnt(10) before every barrier: its share of every chunk but the two youngest has landed, which
+        // Every wave waits for vmcnt(6) before every barrier: its share of every chunk but the two youngest has landed, which
         // covers whatever anybody reads in the next phase.
         const int grp = wave >> 2;
         bf16x8 bfr[2][2];  // the chunk's B operand (k-step ks of row tile rt: bfr[rt][ks]): relu'd first layer, built one multiply phase ahead
@@ -1281,14 +1285,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         int stg = 0;   // stage of the chunk being prepared / multiplied (the stream is periodic in nk, across row tiles)
         int xb = 0;    // fragment buffer of the current tile's inputs
-        // output-layer sums: every wave leaves its 128-column partial of tile t in zs[t & 1]; the two waves with cq == 2 add the
-        // four partials a whole tile later (both groups have written and passed barriers by then)
+        // output-layer sums: every wave leaves its 128-column partial of tile t in zs[t & 1]; the four waves with cq == 1 add the
+        // two partials a whole tile later (both groups have written and passed barriers by then)
         auto z_flush = [&](int zt_) {
-            if (zt_ >= 0 && cq == 2) {
+            if (zt_ >= 0 && cq == 1) {
                 const int row = rh * 64 + lane;
-                float* zd = p.z + (long)set * p.setZ + (long)zt_ * FR + row;
-                const float* zq = zs + (zt_ / (int)gridDim.x & 1) * 4 * FR;
-                const float zt = (zq[row] + zq[FR + row]) + (zq[2 * FR + row] + zq[3 * FR + row]);
+                float* zd = p.z + (long)set * p.setZ + (long)zt_ * GR + row;
+                const float* zq = zs + (zt_ / (int)gridDim.x & 1) * NCH * GR;
+                const float zt = zq[row] + zq[GR + row];
                 if (ncb == 1)
                     *zd = p.c0[set] + zt;
                 else
@@ -1323,13 +1327,13 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 int lane = tid & 63;
                 asm volatile("" : "+v"(lane));
                 const int r = lane & 31, h = lane >> 5;
-                const int rh = wv & 1, cq = wv >> 1;  // (the wave's tile from the SCALAR wave id: address parts in SGPRs, not hoisted vector registers)
+                const int rh = wv & 3, cq = wv >> 2;  // (the wave's tile from the SCALAR wave id: address parts in SGPRs, not hoisted vector registers)
                 const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;  // this lane's row of the cf fragments
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                    const long n = (long)pt * GR + rh * 64 + 32 * rt + r;
                     // (four lanes per row: lane (r, h) stores row r & 15 (+ 16 in the second instruction), columns 16 (r >> 4) + 8 h .. + 8 of every tile)
-                    bf16* dst4 = EPI >= 2 ? p.P2 + (long)set * p.setP2 + (n - (r & 16)) * p.H2 + FC * cb + 128 * cq + (r & 16) + 8 * h : nullptr;
+                    bf16* dst4 = EPI >= 2 ? p.P2 + (long)set * p.setP2 + (n - (r & 16)) * p.H2 + GC * cb + 128 * cq + (r & 16) + 8 * h : nullptr;
                     f32x16 E = zero16;  // rows 0 / 1 (registers 0 / 1 of the lower lane half): sum over this wave's columns of o . cf_hi / o . cf_lo
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
@@ -1375,14 +1379,14 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             *(wide::u32x4*)(dst4 + 16 * p.H2 + 32 * ct) = ov[1];
                         }
                     }
-                    if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = E[0] + E[1];
+                    if (h == 0) zs[((pt / (int)gridDim.x & 1) * NCH + cq) * GR + rh * 64 + 32 * rt + r] = E[0] + E[1];
                 }
             } else {
             float zp[2] = {0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
-                bf16* dst = p.P2 ? p.P2 + (long)set * p.setP2 + n * p.H2 + FC * cb + 128 * cq + 8 * h : nullptr;
+                const long n = (long)pt * GR + rh * 64 + 32 * rt + r;
+                bf16* dst = p.P2 ? p.P2 + (long)set * p.setP2 + n * p.H2 + GC * cb + 128 * cq + 8 * h : nullptr;
                 const float drow = (p.dz_scale != 0.f && n < p.Ns) ? p.dz_scale * (p.rw ? p.rw[(long)set * p.Ns + n] : 1.f) : 0.f;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
@@ -1419,7 +1423,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
                 zp[rt] += __shfl_xor(zp[rt], 32);
-                if (h == 0) zs[((pt / (int)gridDim.x & 1) * 4 + cq) * FR + rh * 64 + 32 * rt + r] = zp[rt];
+                if (h == 0) zs[((pt / (int)gridDim.x & 1) * NCH + cq) * GR + rh * 64 + 32 * rt + r] = zp[rt];
             }
             }
         };
@@ -1437,12 +1441,12 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 int lane = tid & 63;
                 asm volatile("" : "+v"(lane));
                 const int r = lane & 31, h = lane >> 5;
-                const int rh = wv & 1, cq = wv >> 1;
+                const int rh = wv & 3, cq = wv >> 2;
                 const int cfb = r < 2 ? L_CF + (cq * 2 + r) * 256 + h * 16 : L_ZERO + h * 16;
                 auto x_frag = [&](int b, bool action, int rt) {
-                    return *((const bf16x8*)(smem_raw + L_XF + ((b * 2 + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
+                    return *((const bf16x8*)(smem_raw + L_XF + ((b * NRQ + rh) * 4 + (action ? 2 : 0) + rt) * 1024) + lane);
                 };
-                auto wf_at = [&](int stg_) { return *(const bf16x8*)(smem_raw + stg_ * STG_BYTES + FC * FK * 2 + lane * 16); };
+                auto wf_at = [&](int stg_) { return *(const bf16x8*)(smem_raw + stg_ * STG_BYTES + GC * FK * 2 + lane * 16); };
                 const int sw = (r >> 2) & 3;
                 const int rd0 = ((128 * cq + r) * FK + (((0 + h) ^ sw) << 3)) * 2, rd1 = ((128 * cq + r) * FK + (((2 + h) ^ sw) << 3)) * 2;
                 auto read_frags = [&](int stg_, int ks, bf16x8 (&a)[4]) {
@@ -1451,7 +1455,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int ct = 0; ct < 4; ++ct) a[ct] = *(const bf16x8*)(b + ct * 32 * FK * 2);
                 };
                 const int xbf = xb ^ 1;  // the finished tile's fragments (xb already points at the next tile's)
-                const float* mur = (const float*)(smem_raw + L_MU) + (pt / (int)gridDim.x & 1) * FR + rh * 64 + r;
+                const float* mur = (const float*)(smem_raw + L_MU) + (pt / (int)gridDim.x & 1) * GR + rh * 64 + r;
                 // the action tiles' first-layer fragments: a stage carries those of the FOLLOWING chunk (tile 0: with chunk nk - 1, tile 1: with chunk 0)
                 const bf16x8 wfa[2] = {wf_at((stg + FSTG - 1) & (FSTG - 1)), wf_at(stg)};
                 unsigned pos[2] = {0u, 0u};  // [rt] bit 16 ta + i: p1(mu) > 0 in register i of action tile ta
@@ -1460,7 +1464,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     bf16x8 dfr[2][2];  // [rt][ks]
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
-                        const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                        const long n = (long)pt * GR + rh * 64 + 32 * rt + r;
                         const f32x16 pa = mfma(wfa[ta], x_frag(xbf, true, rt), zero16);
                         const f32x16 pm = mfma(wfa[ta], x_frag_action(mur[32 * rt], n < p.Ns, h), zero16);
 #pragma unroll
@@ -1507,7 +1511,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const float* mk = (const float*)(smem_raw + L_MK);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const long n = (long)pt * FR + rh * 64 + 32 * rt + r;
+                    const long n = (long)pt * GR + rh * 64 + 32 * rt + r;
                     const bool live = n < p.Ns;
                     // the relu'd tile as packed bf16 first (32 registers for the row tile's 64 accumulators, dead from here on), then two sweeps
                     // over it -- q(s, mu), then the action gradient: with the accumulators and both products' sums live at the same time the
@@ -1625,7 +1629,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const bf16x8 xf[2] = {x_frag(xbuf, act_next, 0), x_frag(xbuf, act_next, 1)};
                 // (scalar, out of line; read from the next prepare phase on. Peeling step nk - 2 out of the loop instead -- no branch in
                 //  the loop body -- made the kernel 7-9 % SLOWER, r06: three copies of the step, 100 B more scratch)
-                if (__builtin_expect(kt + 2 == nk && (wv >> 1) == 0, 0)) build_x(tile + gridDim.x, xb ^ 1);
+                if (__builtin_expect(kt + 2 == nk && wv < NRQ, 0)) build_x(tile + gridDim.x, xb ^ 1);
                 if (!FW_DBG(1)) {
                     int kc = kt + FSTG - 1;
                     kc -= kc >= nk ? nk : 0;
@@ -1636,7 +1640,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 // (vm operations complete in issue order per kind only: the tile boundary drains the stream before its stores, so
                 // the first two steps of a tile have nothing to wait for, and from step 2 on the counted wait also retires those stores)
                 if (WAIT)
-                    __builtin_amdgcn_s_waitcnt(0x007A);  // vmcnt(10) lgkmcnt(0)
+                    __builtin_amdgcn_s_waitcnt(0x0076);  // vmcnt(6) lgkmcnt(0)
                 else
                     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
                 FW_STAMP(0);
@@ -1671,7 +1675,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int rt = 0; rt < 2; ++rt) bfr[rt][0] = bnx[rt][0], bfr[rt][1] = bnx[rt][1];
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10)
+                if (WAIT) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
                 FW_STAMP(2);
                 if (!FW_DBG(4)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1696,7 +1700,7 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (DUAL && p.rw) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const long n = (long)tile * FR + rh * 64 + 32 * rt + r;
+                    const long n = (long)tile * GR + rh * 64 + 32 * rt + r;
                     rwv[rt] = p.rw[(long)set * p.Ns + (n < p.Ns ? n : p.Ns - 1)];
                 }
             }
@@ -2743,7 +2747,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
     const bool dual = r1 && KCp / 32 - H1 / 32 == 2 && !(du_env && du_env[0] == '0');
     static const char* fa_env = AVD_DIAG_ENV("WIDE_ACT_IN_DX");
     const bool act_in_dx = fused_dx && H1 / 256 == 4 && Ha <= 64 && !(fa_env && fa_env[0] == '0');  // (fw::dx_gen_kernel<true>)
-    constexpr size_t fw_lds = fw::L_TOTAL;
+    constexpr size_t fw_lds = fw::L_TOTAL, dw_lds = (size_t)fw::FSTG * fw::DW_STG;  // (forward; weight gradient: four stages, its epilogue's scratch inside them)
     if (fused_fwd) {
         // the > 64 KB dynamic-LDS opt-in, once per DEVICE of this process (the attribute belongs to the device's copy of the function)
         static unsigned long long fw_attr_done = 0;  // bit = device ordinal
@@ -2758,9 +2762,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
             opt_in((const void*)fw::fwd_gen_kernel<false, 1>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 1>, fw_lds);
             opt_in((const void*)fw::fwd_gen_kernel<false, 3>, fw_lds), opt_in((const void*)fw::fwd_gen_kernel<true, 2>, fw_lds);
             opt_in((const void*)fw::fwd_gen_kernel<true, 4>, fw::L_TOTAL_DUAL);
-            opt_in((const void*)fw::dw_gen_kernel<false, 4>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 4>, fw_lds);
-            opt_in((const void*)fw::dw_gen_kernel<false, 8>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 8>, fw_lds);
-            opt_in((const void*)fw::dw_gen_kernel<false, 16>, fw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 16>, fw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 4>, dw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 4>, dw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 8>, dw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 8>, dw_lds);
+            opt_in((const void*)fw::dw_gen_kernel<false, 16>, dw_lds), opt_in((const void*)fw::dw_gen_kernel<true, 16>, dw_lds);
             opt_in((const void*)fw::dx_gen_kernel<false>, fw::DxL<false>::TOTAL), opt_in((const void*)fw::dx_gen_kernel<true>, fw::DxL<true>::TOTAL);
             opt_in((const void*)fw::fwd_delta_kernel, fw::DL_TOTAL);
             if (e != hipSuccess) {
@@ -2861,9 +2865,9 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
         if (!d_fst) (void)hipMalloc(&d_fst, (64 + 256 * 16) * 8);
         f.stamp = d_fst;
 #endif
-        if (H2 > fw::FC)
+        if (H2 > fw::GC)
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rup(Np, 256) / 256, sets), dim3(256), 0, st, f.z, (long)Np, n.c0, Np);
-        const dim3 grid((unsigned)std::min<long>(avd::fset::cu_count(), Np / fw::FR));
+        const dim3 grid((unsigned)std::min<long>(avd::fset::cu_count(), Np / fw::GR));
         // the epilogue is a compile-time choice (fw::fwd_gen_kernel): nothing stored / signed bf16(z2) (critic) / relu mask (actor); the
         // run-time-flag form for what is left (relu'd activations, dZ2 out: the layer-wise backward's operands)
         static const char* epi_env = AVD_DIAG_ENV("WIDE_FWD_EPI0");  // diagnostics: =1 the r03 epilogue everywhere (A/B)
@@ -3000,7 +3004,7 @@ extern "C" int avd_learn_shared_bf16(const avd_mlp_layout* lay, int n_agents, in
                 const dim3 grid((unsigned)(avd::fset::cu_count() / 8 * 8));  // (a multiple of the XCD count: see the kernel's item map)
                 // (the rows of a chunk are shared by the first min(8, H1 / 128) feature blocks of a stream for the S2 sum)
                 const int nshare = std::min(8, H1 / 128);
-#define AVD_DW_LAUNCH(C, R) hipLaunchKernelGGL((fw::dw_gen_kernel<C, R>), grid, dim3(fw::FT), fw_lds, st, d2)
+#define AVD_DW_LAUNCH(C, R) hipLaunchKernelGGL((fw::dw_gen_kernel<C, R>), grid, dim3(fw::FT), dw_lds, st, d2)
                 if (nshare == 8) {
                     if (critic) AVD_DW_LAUNCH(true, 4); else AVD_DW_LAUNCH(false, 4);
                 } else if (nshare == 4) {
