@@ -41,7 +41,10 @@ def test_bf16_gemm_matches_float64_on_the_same_bf16_operands(M, Nc, K):
                                             # the rank-one backward (r06) with the critic's action features through the 64-column GEMM (its row
                                             # factor in the epilogue; dx_gen_kernel<true> serves H1 = 1024 only), one and two 512-column blocks
                                             # (H1 = 512 / 256: four / two state feature blocks share a chunk's rows for the S2 sum)
-                                            (4, 8, (512, 512, 48), 8e-2), (4, 8, (512, 1024, 32), 8e-2), (4, 8, (256, 512, 48), 8e-2)])
+                                            (4, 8, (512, 512, 48), 8e-2), (4, 8, (512, 1024, 32), 8e-2), (4, 8, (256, 512, 48), 8e-2),
+                                            # fused forward WITHOUT the rank-one backward (H1 = 128 is no multiple of 256): fwd_gen_kernel's run-time
+                                            # epilogue (relu'd / signed activations out), fwd_delta_kernel on stored activations, layer-wise backward
+                                            (4, 8, (128, 512, 32), 8e-2)])
 def test_shared_learner_matches_oracle_on_concatenated_batch(S, P, widths, tol):
     """n_sets = 2 weight sets, P agents each: the mean of the agents' gradients == the gradient of the P*64-row batch."""
     need_gpu()
