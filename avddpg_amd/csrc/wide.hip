@@ -1255,6 +1255,9 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (tid < 64) ((unsigned*)(smem_raw + L_ZERO))[tid] = 0u;
             if (DUAL && tid < 64) ((float*)(smem_raw + L_MK))[tid] = tid < p.Ha ? p.wa[(long)set * p.setTh + tid] : 0.f;
         }
+        // (chunk 0's first-layer fragments travel with chunk nk - 1: not in a stage yet. Requested HERE, ahead of the stream's first
+        //  chunks, the load's latency is covered by the wait below instead of standing alone behind it -- once per pair)
+        const bf16x8 wf0 = p.wf1[((long)set * nk + phys(0)) * 64 + lane];
         dma_x(tile);
         // ---- start the stream: chunks 0 .. 2 into stages 0 .. 2 (a stage also carries the first-layer fragments of the NEXT chunk)
 #pragma unroll
@@ -1276,7 +1279,6 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int grp = wave >> 2;
         bf16x8 bfr[2][2];  // the chunk's B operand (k-step ks of row tile rt: bfr[rt][ks]): relu'd first layer, built one multiply phase ahead
         {
-            const bf16x8 wf0 = p.wf1[((long)set * nk + phys(0)) * 64 + lane];  // (chunk 0's fragments travel with chunk nk - 1: not here yet)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const f32x16 p1 = mfma(wf0, x_frag(0, DUAL, rt), zero16);
