@@ -336,3 +336,40 @@ def test_critic_of_mu_as_a_delta_matches_the_full_forward_pass(tmp_path, switch)
         scale = np.abs(gf[:, lo:hi]).max()
         assert np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() <= 1.2e-2 * scale, (lo, np.abs(gd[:, lo:hi] - gf[:, lo:hi]).max() / scale)
     assert np.allclose(delta[n:], full[n:], rtol=2e-3, atol=1e-6)
+
+
+def test_one_pass_critic_action_gradient_agrees_with_the_two_kernel_form_row_by_row(tmp_path):
+    """csrc/wide.hip, fw::fwd_gen_kernel<true, 4> (critic(s, a) and critic(s, mu) in one forward pass): q(s, mu) and the action gradient
+    of EVERY row against the two-kernel form (AVD_WIDE_DUAL=0: stored signed activations + fw::fwd_delta_kernel), 4096 rows per set --
+    the check that caught, while the kernel was written, a missing barrier at the end of its tail, an inline-asm relu on an MFMA
+    result and first-layer masks the scheduler had deferred (whole row tiles wrong, tensor-level tolerances still met). Diagnostic
+    library: AVD_WIDE_DUMP writes q(s, mu), the action gradient and mu of the call. Both forms round differently (the one-pass form
+    continues from f32 accumulators, cf as a bf16 pair on the mask operand), so rows whose first-layer pre-activation sits on the relu
+    kink may flip either way: measured 11 / 12 rows of 4096 beyond 2 % of the largest gradient, median ratio 0.985 ... 0.997 -- allowed:
+    1 % of the rows, median within 3 %, q(s, mu) within 1.5 % of max |q|."""
+    import os
+    import subprocess
+    import sys
+
+    need_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rows.py"
+    script.write_text(_FWD_AB_SCRIPT.replace('{"small": 3, "padded": 15}.get(sys.argv[3] if len(sys.argv) > 3 else "", 12)', "64"))
+    dumps = []
+    for flag in ("0", "1"):
+        out, dump = tmp_path / f"g{flag}.npy", tmp_path / f"da{flag}.bin"
+        env = dict(os.environ, AVDDPG_HIP_LIB=_DIAG_LIB, AVD_WIDE_DUAL=flag, AVD_WIDE_DUMP=str(dump))
+        p = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        dumps.append(np.fromfile(dump, np.float32).reshape(3, 2, -1))  # [q(s, mu), da, mu][set][Np]
+    two, one = dumps
+    assert np.array_equal(two[2], one[2])  # the same mu went into both (the actor's pass is the same kernel)
+    for k in range(2):
+        q_max = np.abs(two[0, k]).max()  # (the two-kernel form continues from bf16(z2(a)): 2^-9 per element; measured 8e-3 of max |q|)
+        assert np.abs(one[0, k] - two[0, k]).max() <= 1.5e-2 * q_max, (k, np.abs(one[0, k] - two[0, k]).max() / q_max)
+        sc = np.abs(two[1, k]).max()
+        off = np.abs(one[1, k] - two[1, k]) > 2e-2 * sc
+        assert off.mean() <= 1e-2, (k, int(off.sum()), np.nonzero(off)[0][:32])
+        big = np.abs(two[1, k]) > 0.1 * sc
+        assert abs(np.median(one[1, k][big] / two[1, k][big]) - 1) <= 3e-2, (k, np.median(one[1, k][big] / two[1, k][big]))
+
